@@ -1,0 +1,171 @@
+"""oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+CPU checker for the BPR-MF hot path: ctypes doorway onto ``liboracle.so``
+(plain-C restatement, ``oracle/mf_oracle.c``) and, when it was built,
+``_ref/libref_eval.so`` (the reference's own ``func.h`` / ``holdout.h``).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this package; ``recsys_pytorch_amd`` never does.
+
+Parity status: pinned against golden vectors generated from the imported
+reference (``oracle/gen_golden.py`` -> ``tests/golden/*.npz``).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+
+
+def build(with_ref=True):
+    """Compile the checker (gcc).  Building the checker is not using it."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+    if with_ref:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build(with_ref=False)
+        L = C.CDLL(path)
+        L.orc_bpr_loss.restype = C.c_double
+        L.orc_bpr_loss.argtypes = [_f32p, _f32p, _i64p, _i64p, _i64p, C.c_int64, C.c_int]
+        L.orc_bpr_grad.restype = None
+        L.orc_bpr_grad.argtypes = [_f32p, _f32p, _i64p, _i64p, _i64p, C.c_int64, C.c_int,
+                                   _f32p, _f32p, C.POINTER(C.c_double)]
+        L.orc_bpr_step_sgd.restype = None
+        L.orc_bpr_step_sgd.argtypes = [_f32p, _f32p, C.c_int64, C.c_int64, _i64p, _i64p, _i64p,
+                                       C.c_int64, C.c_int, C.c_float, _f32p, _f32p,
+                                       C.POINTER(C.c_double)]
+        L.orc_bpr_step_adam.restype = None
+        L.orc_bpr_step_adam.argtypes = [_f32p, _f32p, C.c_int64, C.c_int64, _i64p, _i64p, _i64p,
+                                        C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float,
+                                        C.c_float, C.c_int64, _f32p, _f32p, _f32p, _f32p,
+                                        _f32p, _f32p, C.POINTER(C.c_double)]
+        L.orc_score.restype = None
+        L.orc_score.argtypes = [_f32p, _i64p, C.c_int64, _f32p, C.c_int64, C.c_int, _f32p]
+        L.orc_mask_seen.restype = None
+        L.orc_mask_seen.argtypes = [_f32p, _i64p, C.c_int64, C.c_int64, _i64p, _i32p]
+        L.orc_topk.restype = None
+        L.orc_topk.argtypes = [_f32p, C.c_int64, C.c_int64, C.c_int, _i32p]
+        L.orc_holdout.restype = None
+        L.orc_holdout.argtypes = [C.c_int64, _i32p, C.c_int, _i32p, C.c_int, _i64p, _i32p, _f32p]
+        _LIB = L
+    return _LIB
+
+
+def ref_lib():
+    """The reference's own native code (oracle/_ref), or None if it was not built."""
+    global _REF
+    if _REF is None:
+        path = os.path.join(_HERE, "_ref", "libref_eval.so")
+        if not os.path.exists(path):
+            return None
+        R = C.CDLL(path)
+        R.ref_top_k_array_index.restype = None
+        R.ref_top_k_array_index.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, _i32p]
+        R.ref_evaluate_holdout.restype = None
+        R.ref_evaluate_holdout.argtypes = [C.c_int, _i32p, C.c_int, _i32p, C.c_int, _i64p, _i32p, _f32p]
+        _REF = R
+    return _REF
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+class MFOracle:
+    """Stateful CPU model: two fp32 tables + optimizer state (models/MF.py:14-30)."""
+
+    def __init__(self, P0, Q0, optimizer="sgd", lr=0.05, betas=(0.9, 0.999), eps=1e-8):
+        self.P = np.array(P0, dtype=np.float32, order="C", copy=True)
+        self.Q = np.array(Q0, dtype=np.float32, order="C", copy=True)
+        self.U, self.d = self.P.shape
+        self.I = self.Q.shape[0]
+        self.optimizer, self.lr, self.betas, self.eps = optimizer, float(lr), betas, float(eps)
+        self._gP = np.zeros_like(self.P)
+        self._gQ = np.zeros_like(self.Q)
+        self.t = 0
+        if optimizer == "adam":
+            self.mP, self.vP = np.zeros_like(self.P), np.zeros_like(self.P)
+            self.mQ, self.vQ = np.zeros_like(self.Q), np.zeros_like(self.Q)
+
+    def grad(self, u, i, j):
+        gP, gQ = np.zeros_like(self.P), np.zeros_like(self.Q)
+        loss = C.c_double(0)
+        lib().orc_bpr_grad(self.P, self.Q, _i64(u), _i64(i), _i64(j), len(u), self.d,
+                           gP, gQ, C.byref(loss))
+        return gP, gQ, loss.value
+
+    def step(self, u, i, j):
+        loss = C.c_double(0)
+        self.t += 1
+        if self.optimizer == "sgd":
+            lib().orc_bpr_step_sgd(self.P, self.Q, self.U, self.I, _i64(u), _i64(i), _i64(j),
+                                   len(u), self.d, self.lr, self._gP, self._gQ, C.byref(loss))
+        else:
+            lib().orc_bpr_step_adam(self.P, self.Q, self.U, self.I, _i64(u), _i64(i), _i64(j),
+                                    len(u), self.d, self.lr, self.betas[0], self.betas[1],
+                                    self.eps, self.t, self.mP, self.vP, self.mQ, self.vQ,
+                                    self._gP, self._gQ, C.byref(loss))
+        return loss.value
+
+    def score(self, users):
+        users = _i64(users)
+        out = np.empty((len(users), self.I), dtype=np.float32)
+        lib().orc_score(self.P, users, len(users), self.Q, self.I, self.d, out)
+        return out
+
+
+def score(P, Q, users):
+    P = np.ascontiguousarray(P, np.float32)
+    Q = np.ascontiguousarray(Q, np.float32)
+    users = _i64(users)
+    out = np.empty((len(users), Q.shape[0]), dtype=np.float32)
+    lib().orc_score(P, users, len(users), Q, Q.shape[0], P.shape[1], out)
+    return out
+
+
+def mask_seen(scores, users, indptr, indices):
+    lib().orc_mask_seen(scores, _i64(users), scores.shape[0], scores.shape[1],
+                        _i64(indptr), np.ascontiguousarray(indices, np.int32))
+    return scores
+
+
+def topk(scores, K):
+    scores = np.ascontiguousarray(scores, np.float32)
+    out = np.empty((scores.shape[0], K), dtype=np.int32)
+    lib().orc_topk(scores, scores.shape[1], scores.shape[0], K, out)
+    return out
+
+
+def ref_topk(scores, K):
+    scores = np.ascontiguousarray(scores, np.float32)
+    out = np.zeros((scores.shape[0], K), dtype=np.int32)
+    ref_lib().ref_top_k_array_index(scores, scores.shape[1], scores.shape[0], K, out)
+    return out
+
+
+def holdout(rankings, Ks, t_indptr, t_indices, use_ref=False):
+    rankings = np.ascontiguousarray(rankings, np.int32)
+    Ks = np.ascontiguousarray(Ks, np.int32)
+    n = rankings.shape[0]
+    res = np.zeros((n, 3 * len(Ks)), dtype=np.float32)
+    ti = np.ascontiguousarray(t_indices, np.int32)
+    tp = _i64(t_indptr)
+    if use_ref:
+        ref_lib().ref_evaluate_holdout(n, rankings, rankings.shape[1], Ks, len(Ks), tp, ti, res)
+    else:
+        lib().orc_holdout(n, rankings, rankings.shape[1], Ks, len(Ks), tp, ti, res)
+    return res

@@ -1,0 +1,250 @@
+/*
+ * oracle/mf_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the reference's BPR-MF hot path
+ * (yoongi0428/RecSys_PyTorch).  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library, and only as the checker.
+ * The shipped path (recsys_pytorch_amd/csrc) never links or calls it.
+ *
+ * Parity status: PINNED -- every function here is checked against golden
+ * vectors produced by importing the reference itself in the build container
+ * (oracle/gen_golden.py -> tests/golden/ *.npz; tests/test_oracle_golden.py).
+ *
+ * Each function cites the reference file:line it follows (paths relative to
+ * the reference checkout).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_EXPORT __attribute__((visibility("default")))
+
+/* ---- forward: models/MF.py:32-42 ---------------------------------------
+ * embeddings(): gather P[u], Q[i]; forward(): sum(mul(user_emb,item_emb),1).
+ * torch's fp32 CPU reduction is a vectorised tree; a plain left-to-right fp32
+ * sum differs in the last ulps only, far inside the 1e-5 contract.           */
+static float orc_dot(const float *a, const float *b, int d)
+{
+    float s = 0.0f;
+    for (int k = 0; k < d; ++k) s += a[k] * b[k];
+    return s;
+}
+
+/* ---- BPR loss of one batch: models/MF.py:99-107 --------------------------
+ * x_b = r(u,i) - r(u,j);  loss = -mean_b log(sigmoid(x_b))                   */
+ORC_EXPORT double orc_bpr_loss(const float *P, const float *Q,
+                               const int64_t *u, const int64_t *i, const int64_t *j,
+                               int64_t B, int d)
+{
+    double acc = 0.0;
+    for (int64_t b = 0; b < B; ++b) {
+        const float *pu = P + u[b] * d;
+        float x = orc_dot(pu, Q + i[b] * d, d) - orc_dot(pu, Q + j[b] * d, d);
+        float s = 1.0f / (1.0f + expf(-x));          /* F.sigmoid, MF.py:105 */
+        acc += -(double)logf(s);                      /* .log()              */
+    }
+    return B > 0 ? acc / (double)B : 0.0;             /* .mean()             */
+}
+
+/* ---- dense gradients of that loss: models/MF.py:67 (loss.backward()) ------
+ * nn.Embedding(sparse=False) => dense [U x d] / [I x d] grads; duplicates are
+ * summed (index_add); every term carries 1/B from the mean (MF.py:105).
+ *   dL/dx_b = -(1 - sigmoid(x_b)) / B = -sigmoid(-x_b)/B
+ *   dP[u_b] += dL/dx_b * (Q[i_b] - Q[j_b])
+ *   dQ[i_b] += dL/dx_b * P[u_b];   dQ[j_b] -= dL/dx_b * P[u_b]
+ * gP / gQ must be zero-filled by the caller (optimizer.zero_grad, MF.py:64). */
+ORC_EXPORT void orc_bpr_grad(const float *P, const float *Q,
+                             const int64_t *u, const int64_t *i, const int64_t *j,
+                             int64_t B, int d, float *gP, float *gQ, double *loss_out)
+{
+    double acc = 0.0;
+    const float invB = 1.0f / (float)B;
+    for (int64_t b = 0; b < B; ++b) {
+        const float *pu = P + u[b] * d;
+        const float *qi = Q + i[b] * d;
+        const float *qj = Q + j[b] * d;
+        float x = orc_dot(pu, qi, d) - orc_dot(pu, qj, d);
+        float s = 1.0f / (1.0f + expf(-x));
+        acc += -(double)logf(s);
+        float g = -(1.0f - s) * invB;                 /* dL/dx_b             */
+        float *gpu = gP + u[b] * d;
+        float *gqi = gQ + i[b] * d;
+        float *gqj = gQ + j[b] * d;
+        for (int k = 0; k < d; ++k) {
+            /* autograd accumulates the pos-forward and neg-forward
+             * contributions separately (two embedding backward calls)       */
+            gpu[k] += g * qi[k];
+            gpu[k] += -g * qj[k];
+            gqi[k] += g * pu[k];
+            gqj[k] += -g * pu[k];
+        }
+    }
+    if (loss_out) *loss_out = B > 0 ? acc / (double)B : 0.0;
+}
+
+/* ---- one training step with SGD: models/MF.py:64-68 with the optimizer
+ * attribute swapped to torch.optim.SGD(lr) (north-star optimizer; the
+ * reference's loss/backward path is untouched).  theta -= lr * grad, applied
+ * to EVERY row (dense), all gradients taken at the pre-step tables.
+ * scratch gP [U*d], gQ [I*d] supplied by the caller.                         */
+ORC_EXPORT void orc_bpr_step_sgd(float *P, float *Q, int64_t U, int64_t I,
+                                 const int64_t *u, const int64_t *i, const int64_t *j,
+                                 int64_t B, int d, float lr,
+                                 float *gP, float *gQ, double *loss_out)
+{
+    memset(gP, 0, sizeof(float) * (size_t)U * d);
+    memset(gQ, 0, sizeof(float) * (size_t)I * d);
+    orc_bpr_grad(P, Q, u, i, j, B, d, gP, gQ, loss_out);
+    for (int64_t n = 0; n < U * d; ++n) P[n] -= lr * gP[n];
+    for (int64_t n = 0; n < I * d; ++n) Q[n] -= lr * gQ[n];
+}
+
+/* ---- one training step with the optimizer as shipped: models/MF.py:30
+ * torch.optim.Adam(lr=1e-3, betas=(0.9,0.999), eps=1e-8, weight_decay=0),
+ * dense over ALL rows: a row whose moments are non-zero keeps moving even
+ * when its gradient is zero this step.  t = step count AFTER increment.
+ * Follows torch's single-tensor Adam:
+ *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2
+ *   step = lr / (1 - b1^t);  denom = sqrt(v)/sqrt(1 - b2^t) + eps
+ *   theta -= step * m / denom                                               */
+static void orc_adam_apply(float *w, float *m, float *v, const float *g, int64_t n,
+                           float lr, float b1, float b2, float eps, int64_t t)
+{
+    double bc1 = 1.0 - pow((double)b1, (double)t);
+    double bc2 = 1.0 - pow((double)b2, (double)t);
+    float step_size = (float)((double)lr / bc1);
+    float bc2_sqrt = (float)sqrt(bc2);
+    for (int64_t k = 0; k < n; ++k) {
+        m[k] = m[k] + (1.0f - b1) * (g[k] - m[k]);            /* lerp_         */
+        v[k] = b2 * v[k] + (1.0f - b2) * g[k] * g[k];          /* addcmul_      */
+        float denom = sqrtf(v[k]) / bc2_sqrt + eps;
+        w[k] = w[k] - step_size * (m[k] / denom);              /* addcdiv_      */
+    }
+}
+
+ORC_EXPORT void orc_bpr_step_adam(float *P, float *Q, int64_t U, int64_t I,
+                                  const int64_t *u, const int64_t *i, const int64_t *j,
+                                  int64_t B, int d, float lr, float b1, float b2, float eps,
+                                  int64_t t,
+                                  float *mP, float *vP, float *mQ, float *vQ,
+                                  float *gP, float *gQ, double *loss_out)
+{
+    memset(gP, 0, sizeof(float) * (size_t)U * d);
+    memset(gQ, 0, sizeof(float) * (size_t)I * d);
+    orc_bpr_grad(P, Q, u, i, j, B, d, gP, gQ, loss_out);
+    orc_adam_apply(P, mP, vP, gP, U * d, lr, b1, b2, eps, t);
+    orc_adam_apply(Q, mQ, vQ, gQ, I * d, lr, b1, b2, eps, t);
+}
+
+/* ---- full-catalog scoring: models/MF.py:109-112 --------------------------
+ * S[r, :] = P[users[r]] @ Q.T  (fp32), out row-major [Bu x I].               */
+ORC_EXPORT void orc_score(const float *P, const int64_t *users, int64_t Bu,
+                          const float *Q, int64_t I, int d, float *out)
+{
+    for (int64_t r = 0; r < Bu; ++r) {
+        const float *pu = P + users[r] * d;
+        float *o = out + r * I;
+        for (int64_t c = 0; c < I; ++c) o[c] = orc_dot(pu, Q + c * d, d);
+    }
+}
+
+/* ---- seen-item masking: models/MF.py:130 ---------------------------------
+ * pred_matrix[eval_pos.nonzero()] = -inf ; rows are indexed by USER ID.
+ * Here: scores is [Bu x I] for users[r]; CSR (indptr int64, indices int32).  */
+ORC_EXPORT void orc_mask_seen(float *scores, const int64_t *users, int64_t Bu, int64_t I,
+                              const int64_t *indptr, const int32_t *indices)
+{
+    for (int64_t r = 0; r < Bu; ++r) {
+        int64_t uu = users[r];
+        for (int64_t p = indptr[uu]; p < indptr[uu + 1]; ++p)
+            scores[r * I + indices[p]] = -INFINITY;
+    }
+}
+
+/* ---- per-row top-k: evaluation/backend/cython/include/func.h:12-31 -------
+ * std::partial_sort_copy of an iota index vector with comparator
+ * ratings[x1] > ratings[x2]: the K largest scores, sorted descending.  The
+ * reference leaves the order among EXACTLY tied scores unspecified (heap
+ * order in C++, introselect+argsort in the numpy twin python/func.py:4-17);
+ * this restatement breaks ties by the lower item index, which is one of the
+ * admissible answers.  out: int32 [rows x K].                                */
+typedef struct { float s; int32_t i; } orc_pair;
+
+static int orc_better(orc_pair a, orc_pair b)   /* a ranks before b */
+{
+    if (a.s > b.s) return 1;
+    if (a.s < b.s) return 0;
+    return a.i < b.i;
+}
+
+static void orc_sift_down(orc_pair *h, int n, int k)
+{   /* min-heap on "rank": root = worst of the kept K */
+    for (;;) {
+        int l = 2 * k + 1, r = l + 1, w = k;
+        if (l < n && orc_better(h[w], h[l])) w = l;
+        if (r < n && orc_better(h[w], h[r])) w = r;
+        if (w == k) return;
+        orc_pair t = h[k]; h[k] = h[w]; h[w] = t; k = w;
+    }
+}
+
+static int orc_cmp_desc(const void *a, const void *b)
+{
+    orc_pair x = *(const orc_pair *)a, y = *(const orc_pair *)b;
+    return orc_better(x, y) ? -1 : (orc_better(y, x) ? 1 : 0);
+}
+
+ORC_EXPORT void orc_topk(const float *scores, int64_t I, int64_t rows, int K, int32_t *out)
+{
+    orc_pair *h = (orc_pair *)malloc(sizeof(orc_pair) * (size_t)K);
+    for (int64_t r = 0; r < rows; ++r) {
+        const float *s = scores + r * I;
+        int n = 0;
+        for (int64_t c = 0; c < I; ++c) {
+            orc_pair e = { s[c], (int32_t)c };
+            if (n < K) {
+                h[n++] = e;
+                if (n == K) for (int k = K / 2 - 1; k >= 0; --k) orc_sift_down(h, K, k);
+            } else if (orc_better(e, h[0])) {
+                h[0] = e; orc_sift_down(h, K, 0);
+            }
+        }
+        qsort(h, (size_t)n, sizeof(orc_pair), orc_cmp_desc);
+        for (int k = 0; k < n; ++k) out[r * K + k] = h[k].i;
+        for (int k = n; k < K; ++k) out[r * K + k] = -1;
+    }
+    free(h);
+}
+
+/* ---- holdout metrics: evaluation/backend/cython/include/holdout.h:20-103 -
+ * Prec@K = hits/K, Recall@K = hits/truth_len, NDCG@K = DCG/iDCG with
+ * 1/log2(i+2); float accumulators as in the header (hits, DCG, iDCG float).
+ * results layout [user][metric*K_len + k], metrics = Prec, Recall, NDCG.
+ * truth given as CSR (indptr int64, indices int32) instead of int**.         */
+ORC_EXPORT void orc_holdout(int64_t users_num, const int32_t *rankings, int max_k,
+                            const int32_t *Ks, int K_len,
+                            const int64_t *t_indptr, const int32_t *t_indices,
+                            float *results)
+{
+    for (int64_t uid = 0; uid < users_num; ++uid) {
+        const int32_t *rk = rankings + uid * max_k;
+        const int32_t *truth = t_indices + t_indptr[uid];
+        int truth_len = (int)(t_indptr[uid + 1] - t_indptr[uid]);
+        float *res = results + uid * 3 * K_len;
+        float hits = 0, iDCG = 0, DCG = 0;
+        for (int p = 0; p < max_k; ++p) {
+            int found = 0;
+            for (int t = 0; t < truth_len; ++t) if (truth[t] == rk[p]) { found = 1; break; }
+            if (found) { hits += 1; DCG += 1.0 / log2(p + 2); }
+            if (p < truth_len) iDCG += 1.0 / log2(p + 2);
+            for (int q = 0; q < K_len; ++q) {
+                if (Ks[q] == p + 1) {
+                    res[0 * K_len + q] = hits / (float)Ks[q];
+                    res[1 * K_len + q] = hits / truth_len;
+                    res[2 * K_len + q] = DCG / iDCG;
+                }
+            }
+        }
+    }
+}
