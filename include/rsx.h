@@ -1,0 +1,150 @@
+/*
+ * include/rsx.h -- C ABI of librsx.so: the MI355X (gfx950) BPR-MF hot path.
+ *
+ * Drop-in boundary for yoongi0428/RecSys_PyTorch's MF model.  The reference
+ * has no FFI for this path (its arithmetic is eager PyTorch); each entry point
+ * below names the reference code it replaces (paths relative to the reference
+ * checkout).  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types cross the ABI.
+ *   - every pointer named P, Q, G, *_dev, or documented "device" is a DEVICE
+ *     pointer borrowed from the caller (kept alive and contiguous by it).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all
+ *     launches are asynchronous on it.  Nothing here synchronises.
+ *   - return value: 0 = ok, <0 = error (RSX_E_*); text via rsx_last_error()
+ *     (thread-local).  No exceptions cross the ABI.
+ *   - tables are row-major fp32: P [U x d], Q [I x d]; d in {32, 64, 128};
+ *     row indices are int32.
+ */
+#ifndef RSX_H
+#define RSX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSX_ABI_VERSION 1
+
+#define RSX_OK 0
+#define RSX_E_INVALID (-1)   /* bad argument (null pointer, unsupported d, K ...) */
+#define RSX_E_HIP (-2)       /* a HIP runtime call failed                         */
+#define RSX_E_WORKSPACE (-3) /* caller-provided workspace too small               */
+
+/* flags for rsx_bpr_step */
+#define RSX_USERS_UNIQUE 1u /* caller guarantees no user id repeats inside the batch  */
+                            /* (true for rsx_bpr_sample output and for the reference's */
+                            /* PairwiseGenerator, data/generators.py:182-195)          */
+
+#define RSX_LOSS_SLOTS 64   /* loss accumulator is float[RSX_LOSS_SLOTS] (striped atomics) */
+
+typedef void *rsx_stream_t;
+
+typedef struct rsx_device_info {
+    int device;
+    int compute_units;
+    int wavefront_size;
+    int64_t total_mem_bytes;
+    int lds_bytes_per_cu;
+    int clock_khz;
+    char arch[64];
+} rsx_device_info;
+
+/* ---- library -------------------------------------------------------------- */
+int rsx_version(void);
+const char *rsx_last_error(void);
+int rsx_device_info_get(int device, rsx_device_info *out);
+
+/* ---- BPR triplet step -------------------------------------------------------
+ * Replaces, for the pairwise branch, one iteration of the reference loop
+ *   models/MF.py:64-68   zero_grad / process_one_batch / backward / step
+ *   models/MF.py:32-42   gather P[u], Q[i], Q[j]; r = sum(mul)
+ *   models/MF.py:99-107  loss = -mean(log(sigmoid(r_pos - r_neg)))
+ * with SGD as the optimizer.  Batch-synchronous like autograd: every gradient
+ * is taken at the PRE-step tables, duplicates are summed.
+ *
+ * rsx_bpr_step  (phase 1 of a step)
+ *   for each triplet b:  x = <P[u],Q[i]> - <P[u],Q[j]>,  g = -sigmoid(-x)*inv_batch
+ *     item gradients   G[i] += g*P[u];  G[j] -= g*P[u]     (fp32 atomics, G is [I x d])
+ *     user rows        P[u] -= lr * g * (Q[i]-Q[j])
+ *         RSX_USERS_UNIQUE set : written in place by the owning wavefront
+ *         otherwise            : summed per distinct user in `ws`, then applied
+ *                                (exact for repeated users)
+ *   loss_acc (nullable): float[RSX_LOSS_SLOTS]; sum_b softplus(-x_b) is ADDED,
+ *     striped over the slots (loss of the batch = sum(slots) * inv_batch).
+ *   inv_batch = 1 / (global batch size)  (the mean of MF.py:105; with user
+ *     sharding it is 1/(sum over ranks))
+ *   ws / ws_bytes: device scratch, needed only without RSX_USERS_UNIQUE;
+ *     size from rsx_bpr_step_workspace().  `ws` must be zero-filled once by
+ *     the caller before first use; the call leaves it zero-filled again.
+ *   Q is NOT modified here.  G must be zero before the first step; it is
+ *   consumed (and re-zeroed) by rsx_apply_item_grad.
+ *   Triplets with i < 0 are skipped (users without positives).
+ */
+int64_t rsx_bpr_step_workspace(int64_t num_users, int64_t max_batch, int d);
+
+int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, int64_t num_items,
+                 const int32_t *u_dev, const int32_t *i_dev, const int32_t *j_dev, int64_t batch,
+                 int d, float lr, float inv_batch, float *loss_acc, unsigned flags,
+                 void *ws, int64_t ws_bytes, rsx_stream_t stream);
+
+/* rsx_apply_item_grad  (phase 2 of a step; after the all-reduce of G when sharded)
+ *   Q -= lr * G ;  G = 0        for every row of the [num_items x d] tables.
+ *   Replaces the item-table half of optimizer.step() (models/MF.py:68) for SGD.
+ *   Rows whose gradient is entirely zero are not written.                       */
+int rsx_apply_item_grad(float *Q, float *G, int64_t num_items, int d, float lr,
+                        rsx_stream_t stream);
+
+/* ---- on-device triplet sampler ------------------------------------------------
+ * Replaces data/generators.py:151-224 (PairwiseGenerator: host-side numpy
+ * sampling + permutation + H2D copy).  Sampling semantics are BPR's, not the
+ * reference's quirks (SURVEY appendix A, Q1-Q3 documented in DESIGN.md):
+ *   user  : position (epoch_pos + b) of a keyed pseudo-random PERMUTATION of the
+ *           local users -> no user repeats while batch <= num_users
+ *           (the reference also visits each user once per epoch, generators.py:206-210)
+ *   pos i : uniform over the user's CSR row (indices[indptr[u]:indptr[u+1]])
+ *   neg j : uniform over [0,num_items) rejected while j is in that row
+ *           (generators.py:178-185: p = 0 on the user's positives)
+ * RNG: counter-based (seed, step, b) -> splitmix64 -> xorshift32 stream; the
+ * result does not depend on launch geometry.  Users with an empty row get i=-1.
+ * indptr: int64 [num_users+1], indices: int32, sorted within each row.          */
+int rsx_bpr_sample(const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users,
+                   int64_t num_items, int64_t batch, uint64_t seed, uint64_t step,
+                   int64_t epoch_pos, int32_t *u_out, int32_t *i_out, int32_t *j_out,
+                   rsx_stream_t stream);
+
+/* ---- full-catalog scoring + Top-K ----------------------------------------------
+ * Replaces
+ *   models/MF.py:109-112  predict_batch_users: S = P[users] @ Q.T   (fp32)
+ *   models/MF.py:130      pred[eval_pos.nonzero()] = -inf
+ *   evaluation/backend/cython/include/func.h:12-31  per-row partial sort, K best
+ *                         sorted by descending score (int32 indices)
+ * S is computed on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
+ *
+ * rsx_score  : scores_out [num_rows x num_items] = P[user_ids] @ Q^T, then -inf
+ *              at the CSR positions of each user's row when mask_indptr != NULL
+ *              (CSR is indexed by USER ID, as MF.py:128-130 does).
+ * rsx_topk   : per row of `scores` the K largest, descending; ties by lower index.
+ *              topk_val_out nullable.  K <= 1024 and K <= num_items.
+ * rsx_score_topk : both, tile by tile through `ws` without exposing the scores.
+ */
+int rsx_score(const float *P, const int32_t *user_ids_dev, int64_t num_rows, const float *Q,
+              int64_t num_items, int d, const int64_t *mask_indptr_dev,
+              const int32_t *mask_indices_dev, float *scores_out, rsx_stream_t stream);
+
+int rsx_topk(const float *scores_dev, int64_t num_rows, int64_t num_items, int K,
+             int32_t *topk_idx_out, float *topk_val_out, rsx_stream_t stream);
+
+int64_t rsx_score_topk_workspace(int64_t num_rows, int64_t num_items);
+
+int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t num_rows, const float *Q,
+                   int64_t num_items, int d, const int64_t *mask_indptr_dev,
+                   const int32_t *mask_indices_dev, int K, int32_t *topk_idx_out,
+                   float *topk_val_out, void *ws, int64_t ws_bytes, rsx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSX_H */

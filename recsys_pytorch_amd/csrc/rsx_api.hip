@@ -1,0 +1,52 @@
+// rsx_api.hip -- library plumbing of librsx: version, error text, device info.
+#include <stdarg.h>
+#include <string.h>
+
+#include "rsx_common.h"
+
+static thread_local char g_err[512] = "";
+
+void rsx_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int rsx_num_cus()
+{
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
+RSX_API int rsx_version(void) { return RSX_ABI_VERSION; }
+
+RSX_API const char *rsx_last_error(void) { return g_err; }
+
+RSX_API int rsx_device_info_get(int device, rsx_device_info *out)
+{
+    RSX_CHECK_ARG(out != nullptr, "null output");
+    hipDeviceProp_t p;
+    hipError_t e = hipGetDeviceProperties(&p, device);
+    if (e != hipSuccess) {
+        rsx_set_error("rsx_device_info_get: %s", hipGetErrorString(e));
+        return RSX_E_HIP;
+    }
+    memset(out, 0, sizeof(*out));
+    out->device = device;
+    out->compute_units = p.multiProcessorCount;
+    out->wavefront_size = p.warpSize;
+    out->total_mem_bytes = (int64_t)p.totalGlobalMem;
+    out->lds_bytes_per_cu = (int)p.maxSharedMemoryPerMultiProcessor;
+    out->clock_khz = p.clockRate;
+    strncpy(out->arch, p.gcnArchName, sizeof(out->arch) - 1);
+    return RSX_OK;
+}

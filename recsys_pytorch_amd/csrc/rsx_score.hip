@@ -1,0 +1,397 @@
+// rsx_score.hip -- full-catalog scoring on the matrix cores + seen-item mask +
+// per-row Top-K for gfx950 (MI355X).
+//
+// Restates (no kernel exists in the reference; eager PyTorch / C++ there):
+//   models/MF.py:109-112  S = P[users] @ Q.T                     -> score_tile_kernel
+//   models/MF.py:130      pred[eval_pos.nonzero()] = -inf        -> mask_seen_kernel
+//   evaluation/backend/cython/include/func.h:12-31  partial sort, K best by
+//                         descending score, int32 indices          -> topk_rows_kernel
+//
+// score_tile_kernel: a genuine dense contraction (K = d), so it runs on
+// v_mfma_f32_32x32x2_f32 (exact fp32, bitwise an fmaf chain).  128x128 output
+// tile per 256-thread workgroup, 2x2 wavefronts of 64x64, 2x2 MFMA tiles of
+// 32x32 per wavefront (64 accumulator registers), K staged through LDS in
+// chunks of 32 held K-MAJOR ([k][row], leading dimension 129) so that both the
+// transposing ds_write_b32 and the fragment ds_read_b32 are bank-conflict free.
+#include "rsx_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDT = BM + 1;   // K-major tile leading dimension (odd -> conflict-free transpose)
+
+// ---------------------------------------------------------------- scoring -------
+template <int D>
+__global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict__ P,
+                                                         const int32_t *__restrict__ user_ids,
+                                                         int64_t num_rows,
+                                                         const float *__restrict__ Q,
+                                                         int64_t num_items,
+                                                         float *__restrict__ out)
+{
+    __shared__ float As[BK * LDT];
+    __shared__ float Bs[BK * LDT];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int hi = lane >> 5, l31 = lane & 31;
+    // item tile varies fastest: the 8 XCDs each stream different item tiles of
+    // the SAME user tile, and a user tile's A panel (128 x d) stays L2 resident.
+    const int64_t item0 = (int64_t)blockIdx.x * BN;
+    const int64_t row0 = (int64_t)blockIdx.y * BM;
+
+    // staging assignment: thread -> (row = tid>>3 + 32 n, k-quad = tid&7)
+    const int kq = tid & 7;
+    const int srow = tid >> 3;
+    const float *a_src[4];
+    const float *b_src[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int64_t r = row0 + srow + 32 * n;
+        a_src[n] = (r < num_rows) ? P + (size_t)user_ids[r] * D + 4 * kq : nullptr;
+        const int64_t it = item0 + srow + 32 * n;
+        b_src[n] = (it < num_items) ? Q + (size_t)it * D + 4 * kq : nullptr;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    float4 ra[4], rb[4];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        ra[n] = a_src[n] ? *reinterpret_cast<const float4 *>(a_src[n]) : zero4;
+        rb[n] = b_src[n] ? *reinterpret_cast<const float4 *>(b_src[n]) : zero4;
+    }
+
+    for (int k0 = 0; k0 < D; k0 += BK) {
+        // registers -> LDS, transposed to K-major
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int r = srow + 32 * n;
+            As[(4 * kq + 0) * LDT + r] = ra[n].x; As[(4 * kq + 1) * LDT + r] = ra[n].y;
+            As[(4 * kq + 2) * LDT + r] = ra[n].z; As[(4 * kq + 3) * LDT + r] = ra[n].w;
+            Bs[(4 * kq + 0) * LDT + r] = rb[n].x; Bs[(4 * kq + 1) * LDT + r] = rb[n].y;
+            Bs[(4 * kq + 2) * LDT + r] = rb[n].z; Bs[(4 * kq + 3) * LDT + r] = rb[n].w;
+        }
+        __syncthreads();
+        // issue the next chunk's global loads; they fly under the MFMAs below
+        if (k0 + BK < D) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                ra[n] = a_src[n] ? *reinterpret_cast<const float4 *>(a_src[n] + k0 + BK) : zero4;
+                rb[n] = b_src[n] ? *reinterpret_cast<const float4 *>(b_src[n] + k0 + BK) : zero4;
+            }
+        }
+        const float *ap = As + hi * LDT + wr * 64 + l31;
+        const float *bp = Bs + hi * LDT + wc * 64 + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a0 = ap[kk * LDT], a1 = ap[kk * LDT + 32];
+            const float b0 = bp[kk * LDT], b1 = bp[kk * LDT + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (row >= num_rows) continue;
+            float *orow = out + (size_t)row * num_items;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int64_t col = item0 + wc * 64 + n * 32 + l31;
+                if (col < num_items) orow[col] = acc[m][n][r];
+            }
+        }
+    }
+}
+
+// scores[r, indices[p]] = -inf for p in the CSR row of user_ids[r]
+__global__ __launch_bounds__(256) void mask_seen_kernel(float *__restrict__ scores,
+                                                        const int32_t *__restrict__ user_ids,
+                                                        int64_t num_rows, int64_t num_items,
+                                                        const int64_t *__restrict__ indptr,
+                                                        const int32_t *__restrict__ indices)
+{
+    const int64_t r = blockIdx.x;
+    if (r >= num_rows) return;
+    const int32_t u = user_ids[r];
+    const int64_t lo = indptr[u], hi = indptr[u + 1];
+    float *row = scores + (size_t)r * num_items;
+    for (int64_t p = lo + threadIdx.x; p < hi; p += blockDim.x) row[indices[p]] = -INFINITY;
+}
+
+// ---------------------------------------------------------------- top-k ----------
+// order-preserving float -> uint32 (larger float <=> larger key; -inf smallest)
+__device__ __forceinline__ uint32_t f2key(float f)
+{
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+constexpr int TK_THREADS = 256;
+constexpr int TK_BINS = 4096;
+constexpr int TK_CAP = 2048;   // candidate list capacity (>= 2 * max K)
+
+// One workgroup per row.  Radix select on the key (12 + 12 + 8 bits) until the
+// candidates (everything not provably below the K-th key) fit the LDS list,
+// then a bitonic sort of that list by (key desc, index asc).
+__global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float *__restrict__ scores,
+                                                               int64_t num_items, int K,
+                                                               int32_t *__restrict__ out_idx,
+                                                               float *__restrict__ out_val)
+{
+    __shared__ uint32_t hist[TK_BINS];
+    __shared__ unsigned long long cand[TK_CAP];
+    __shared__ uint32_t s_wave[TK_THREADS / 64];
+    __shared__ uint32_t s_bin, s_need, s_count, s_ncand, s_run;
+
+    const int tid = threadIdx.x;
+    const float *row = scores + (size_t)blockIdx.x * num_items;
+    const int64_t n4 = (reinterpret_cast<uintptr_t>(row) % 16 == 0) ? num_items / 4 : 0;  // vector part
+
+    uint32_t prefix = 0;       // high bits of the K-th largest key fixed so far
+    uint32_t need = (uint32_t)K;  // rank still to resolve inside the prefix class
+    int shift = 32;
+    bool gathered = false;
+    const int level_bits[3] = {12, 12, 8};
+
+    for (int level = 0; level < 3 && !gathered; ++level) {
+        const int bits = level_bits[level];
+        const int nshift = shift - bits;
+        const uint32_t bmask = (1u << bits) - 1u;
+        for (int b = tid; b < TK_BINS; b += TK_THREADS) hist[b] = 0;
+        __syncthreads();
+        auto tally = [&](float f) {
+            const uint32_t key = f2key(f);
+            if (shift == 32 || (key >> shift) == (prefix >> shift)) atomicAdd(&hist[(key >> nshift) & bmask], 1u);
+        };
+        for (int64_t q = tid; q < n4; q += TK_THREADS) {
+            const float4 v = reinterpret_cast<const float4 *>(row)[q];
+            tally(v.x); tally(v.y); tally(v.z); tally(v.w);
+        }
+        for (int64_t c = n4 * 4 + tid; c < num_items; c += TK_THREADS) tally(row[c]);
+        __syncthreads();
+        // find the bin holding the need-th largest: suffix counts from the top bin down.
+        // thread t owns bins [t*16, t*16+16) (only the first (1<<bits)/16 threads have bins)
+        const int per = TK_BINS / TK_THREADS;
+        uint32_t mine = 0;
+        for (int b = 0; b < per; ++b) mine += hist[tid * per + b];
+        // inclusive suffix sum over threads (higher tid = higher bins)
+        uint32_t suf = mine;
+        {
+            const int lane = tid & 63;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_down(suf, o, 64);
+                if (lane + o < 64) suf += t;
+            }
+            if (lane == 0) s_wave[tid >> 6] = suf;
+            __syncthreads();
+            for (int w = (tid >> 6) + 1; w < TK_THREADS / 64; ++w) suf += s_wave[w];
+        }
+        const uint32_t above = suf - mine;   // elements in bins of higher threads
+        if (above < need && suf >= need) {   // the wanted bin is one of mine
+            uint32_t run = above;
+            for (int b = per - 1; b >= 0; --b) {
+                const uint32_t h = hist[tid * per + b];
+                if (run + h >= need) {
+                    s_bin = (uint32_t)(tid * per + b);
+                    s_need = need - run;     // rank inside that bin
+                    s_count = h;
+                    break;
+                }
+                run += h;
+            }
+        }
+        __syncthreads();
+        const uint32_t bin = s_bin, cnt = s_count;
+        const uint32_t sure = (uint32_t)K - s_need;   // strictly above the bin: certainly selected
+        need = s_need;
+        prefix |= bin << nshift;
+        shift = nshift;
+        if (sure + cnt <= (uint32_t)TK_CAP || level == 2) {
+            // gather every element whose high bits are >= prefix's (>, or == when the
+            // tie class fits; a too-large exact-tie class is resolved in index order below)
+            const bool take_ties = (sure + cnt <= (uint32_t)TK_CAP);
+            if (tid == 0) { s_ncand = 0; s_run = 0; }
+            __syncthreads();
+            auto consider = [&](float f, int64_t c) {
+                const uint32_t key = f2key(f);
+                const uint32_t hk = key >> shift, hp = prefix >> shift;
+                if (hk > hp || (take_ties && hk == hp)) {
+                    const uint32_t slot = atomicAdd(&s_ncand, 1u);
+                    cand[slot] = ((unsigned long long)key << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)c);
+                }
+            };
+            for (int64_t q = tid; q < n4; q += TK_THREADS) {
+                const float4 v = reinterpret_cast<const float4 *>(row)[q];
+                consider(v.x, 4 * q); consider(v.y, 4 * q + 1); consider(v.z, 4 * q + 2); consider(v.w, 4 * q + 3);
+            }
+            for (int64_t c = n4 * 4 + tid; c < num_items; c += TK_THREADS) consider(row[c], c);
+            __syncthreads();
+            if (!take_ties) {
+                // huge class of EXACTLY tied keys (shift == 0 here): take the `need`
+                // lowest indices, walking the row in index order.
+                for (int64_t base = 0; base < num_items && s_run < need; base += TK_THREADS) {
+                    const int64_t c = base + tid;
+                    const bool tie = (c < num_items) && (f2key(row[c]) == prefix);
+                    const unsigned long long bal = __ballot(tie);
+                    const int lane = tid & 63;
+                    if (lane == 0) s_wave[tid >> 6] = (uint32_t)__popcll(bal);
+                    __syncthreads();
+                    uint32_t before = s_run;
+                    for (int w = 0; w < (tid >> 6); ++w) before += s_wave[w];
+                    before += (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                    if (tie && before < need) {
+                        const uint32_t slot = atomicAdd(&s_ncand, 1u);
+                        cand[slot] = ((unsigned long long)prefix << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)c);
+                    }
+                    __syncthreads();
+                    if (tid == 0) {
+                        uint32_t tot = 0;
+                        for (int w = 0; w < TK_THREADS / 64; ++w) tot += s_wave[w];
+                        s_run += tot;
+                    }
+                    __syncthreads();
+                }
+            }
+            gathered = true;
+        }
+        __syncthreads();
+    }
+
+    // bitonic sort of the candidate list, descending on the 64-bit (key, ~index) word
+    const uint32_t ncand = s_ncand;
+    uint32_t n2 = 1;
+    while (n2 < ncand) n2 <<= 1;
+    for (uint32_t t = ncand + tid; t < n2; t += TK_THREADS) cand[t] = 0ull;   // sorts last
+    __syncthreads();
+    for (uint32_t size = 2; size <= n2; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = tid; t < n2 / 2; t += TK_THREADS) {
+                const uint32_t lo = 2 * t - (t & (stride - 1));
+                const uint32_t hi2 = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = cand[lo], b = cand[hi2];
+                if ((a < b) == desc) { cand[lo] = b; cand[hi2] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int t = tid; t < K; t += TK_THREADS) {
+        const unsigned long long e = cand[t];
+        out_idx[(size_t)blockIdx.x * K + t] = (t < (int)ncand) ? (int32_t)(0xFFFFFFFFu - (uint32_t)e) : -1;
+        if (out_val) out_val[(size_t)blockIdx.x * K + t] = (t < (int)ncand) ? key2f((uint32_t)(e >> 32)) : -INFINITY;
+    }
+}
+
+int launch_score(const float *P, const int32_t *users, int64_t rows, const float *Q, int64_t items,
+                 int d, float *out, hipStream_t st)
+{
+    dim3 grid((unsigned)((items + BN - 1) / BN), (unsigned)((rows + BM - 1) / BM));
+    switch (d) {
+    case 32: hipLaunchKernelGGL(score_tile_kernel<32>, grid, dim3(256), 0, st, P, users, rows, Q, items, out); break;
+    case 64: hipLaunchKernelGGL(score_tile_kernel<64>, grid, dim3(256), 0, st, P, users, rows, Q, items, out); break;
+    default: hipLaunchKernelGGL(score_tile_kernel<128>, grid, dim3(256), 0, st, P, users, rows, Q, items, out); break;
+    }
+    return 0;
+}
+
+constexpr int64_t kRowTile = 1024;   // rows scored per pass of rsx_score_topk (evaluator.py:11 batch)
+
+}  // namespace
+
+RSX_API int rsx_score(const float *P, const int32_t *user_ids_dev, int64_t num_rows, const float *Q,
+                      int64_t num_items, int d, const int64_t *mask_indptr_dev,
+                      const int32_t *mask_indices_dev, float *scores_out, rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(P && Q && user_ids_dev && scores_out, "null pointer");
+    RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64 or 128");
+    RSX_CHECK_ARG(num_rows >= 0 && num_items > 0, "bad shape");
+    RSX_CHECK_ARG((mask_indptr_dev == nullptr) == (mask_indices_dev == nullptr), "mask needs both CSR arrays");
+    if (num_rows == 0) return RSX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    for (int64_t r0 = 0; r0 < num_rows; r0 += 65535 * (int64_t)BM) {   // gridDim.y limit
+        const int64_t nr = (num_rows - r0 < 65535 * (int64_t)BM) ? num_rows - r0 : 65535 * (int64_t)BM;
+        launch_score(P, user_ids_dev + r0, nr, Q, num_items, d, scores_out + (size_t)r0 * num_items, st);
+    }
+    if (mask_indptr_dev) {
+        for (int64_t r0 = 0; r0 < num_rows; r0 += (1ll << 30)) {
+            const int64_t nr = (num_rows - r0 < (1ll << 30)) ? num_rows - r0 : (1ll << 30);
+            hipLaunchKernelGGL(mask_seen_kernel, dim3((unsigned)nr), dim3(256), 0, st,
+                               scores_out + (size_t)r0 * num_items, user_ids_dev + r0, nr, num_items,
+                               mask_indptr_dev, mask_indices_dev);
+        }
+    }
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+}
+
+RSX_API int rsx_topk(const float *scores_dev, int64_t num_rows, int64_t num_items, int K,
+                     int32_t *topk_idx_out, float *topk_val_out, rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(scores_dev && topk_idx_out, "null pointer");
+    RSX_CHECK_ARG(K >= 1 && K <= TK_CAP / 2 && K <= num_items, "K must be in [1, min(1024, num_items)]");
+    RSX_CHECK_ARG(num_rows >= 0 && num_rows < (1ll << 31) && num_items < (1ll << 32) - 1, "bad shape");
+    if (num_rows == 0) return RSX_OK;
+    hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)num_rows), dim3(TK_THREADS), 0,
+                       (hipStream_t)stream, scores_dev, num_items, K, topk_idx_out, topk_val_out);
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+}
+
+RSX_API int64_t rsx_score_topk_workspace(int64_t num_rows, int64_t num_items)
+{
+    if (num_rows < 0 || num_items <= 0) return RSX_E_INVALID;
+    const int64_t rows = num_rows < kRowTile ? num_rows : kRowTile;
+    return rows * num_items * 4;
+}
+
+RSX_API int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t num_rows,
+                           const float *Q, int64_t num_items, int d, const int64_t *mask_indptr_dev,
+                           const int32_t *mask_indices_dev, int K, int32_t *topk_idx_out,
+                           float *topk_val_out, void *ws, int64_t ws_bytes, rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(topk_idx_out != nullptr, "null output");
+    const int64_t need = rsx_score_topk_workspace(num_rows, num_items);
+    if (need < 0) { rsx_set_error("rsx_score_topk: bad shape"); return RSX_E_INVALID; }
+    if (num_rows == 0) return RSX_OK;
+    if (ws == nullptr || ws_bytes < need) {
+        rsx_set_error("rsx_score_topk: workspace of %lld bytes required, got %lld", (long long)need,
+                      (long long)ws_bytes);
+        return RSX_E_WORKSPACE;
+    }
+    float *tile = (float *)ws;
+    for (int64_t r0 = 0; r0 < num_rows; r0 += kRowTile) {
+        const int64_t nr = (num_rows - r0 < kRowTile) ? num_rows - r0 : kRowTile;
+        int rc = rsx_score(P, user_ids_dev + r0, nr, Q, num_items, d, mask_indptr_dev, mask_indices_dev,
+                           tile, stream);
+        if (rc != RSX_OK) return rc;
+        rc = rsx_topk(tile, nr, num_items, K, topk_idx_out + (size_t)r0 * K,
+                      topk_val_out ? topk_val_out + (size_t)r0 * K : nullptr, stream);
+        if (rc != RSX_OK) return rc;
+    }
+    return RSX_OK;
+}

@@ -1,0 +1,163 @@
+"""ctypes binding of librsx.so (include/rsx.h) for torch tensors.
+
+torch is storage and streams only: every function hands raw device pointers
+and torch's current HIP stream to the C ABI.  There is NO fallback: a missing
+library or a non-device tensor raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librsx.so")
+_lib = None
+
+RSX_USERS_UNIQUE = 1
+RSX_LOSS_SLOTS = 64
+SUPPORTED_DIMS = (32, 64, 128)
+
+# symbol -> (restype, argtypes); mirrors include/rsx.h one to one
+_P, _I64, _I32, _F, _U, _U64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint, C.c_uint64
+SIGNATURES = {
+    "rsx_version": (C.c_int, []),
+    "rsx_last_error": (C.c_char_p, []),
+    "rsx_device_info_get": (C.c_int, [C.c_int, _P]),
+    "rsx_bpr_step_workspace": (_I64, [_I64, _I64, _I32]),
+    "rsx_bpr_step": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _I64, _I32, _F, _F, _P, _U, _P, _I64, _P]),
+    "rsx_apply_item_grad": (C.c_int, [_P, _P, _I64, _I32, _F, _P]),
+    "rsx_bpr_sample": (C.c_int, [_P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _P, _P, _P, _P]),
+    "rsx_score": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P, _P, _P, _P]),
+    "rsx_topk": (C.c_int, [_P, _I64, _I64, _I32, _P, _P, _P]),
+    "rsx_score_topk_workspace": (_I64, [_I64, _I64]),
+    "rsx_score_topk": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P, _P, _I32, _P, _P, _P, _I64, _P]),
+}
+
+
+class RsxError(RuntimeError):
+    pass
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [("device", C.c_int), ("compute_units", C.c_int), ("wavefront_size", C.c_int),
+                ("total_mem_bytes", C.c_int64), ("lds_bytes_per_cu", C.c_int), ("clock_khz", C.c_int),
+                ("arch", C.c_char * 64)]
+
+
+def lib():
+    """Load librsx.so.  Raises if it has not been built (python -m recsys_pytorch_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RsxError(f"{LIB_PATH} not found: the HIP extension is not built "
+                           "(run `python -m recsys_pytorch_amd.build`); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RsxError(f"{what} failed ({rc}): {lib().rsx_last_error().decode()}")
+
+
+def _dev(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RsxError(f"{name} must be a device (HIP) tensor; the HIP path has no CPU fallback")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise RsxError(f"{name} must be contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def version():
+    return lib().rsx_version()
+
+
+def device_info(device=0):
+    info = DeviceInfo()
+    _check(lib().rsx_device_info_get(device, C.byref(info)), "rsx_device_info_get")
+    return {f: (getattr(info, f).decode() if f == "arch" else getattr(info, f)) for f, _ in DeviceInfo._fields_}
+
+
+def bpr_step_workspace(num_users, max_batch, d):
+    n = lib().rsx_bpr_step_workspace(num_users, max_batch, d)
+    if n < 0:
+        raise RsxError("rsx_bpr_step_workspace: invalid shape")
+    return n
+
+
+def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False, ws=None):
+    """One batch of include/rsx.h:rsx_bpr_step.  u, i, j: int32 device tensors."""
+    d = P.shape[1]
+    _check(lib().rsx_bpr_step(
+        _dev(P, torch.float32, "P"), _dev(Q, torch.float32, "Q"), _dev(G, torch.float32, "G"),
+        P.shape[0], Q.shape[0], _dev(u, torch.int32, "u"), _dev(i, torch.int32, "i"),
+        _dev(j, torch.int32, "j"), u.numel(), d, float(lr), float(inv_batch),
+        _dev(loss_acc, torch.float32, "loss_acc") if loss_acc is not None else None,
+        RSX_USERS_UNIQUE if users_unique else 0,
+        C.c_void_p(ws.data_ptr()) if ws is not None else None,
+        ws.numel() * ws.element_size() if ws is not None else 0, _stream()), "rsx_bpr_step")
+
+
+def apply_item_grad(Q, G, lr):
+    _check(lib().rsx_apply_item_grad(_dev(Q, torch.float32, "Q"), _dev(G, torch.float32, "G"),
+                                     Q.shape[0], Q.shape[1], float(lr), _stream()), "rsx_apply_item_grad")
+
+
+def bpr_sample(indptr, indices, num_items, batch, seed, step, epoch_pos, u_out, i_out, j_out):
+    _check(lib().rsx_bpr_sample(
+        _dev(indptr, torch.int64, "indptr"), _dev(indices, torch.int32, "indices"),
+        indptr.numel() - 1, num_items, batch, seed & (2**64 - 1), step, epoch_pos,
+        _dev(u_out, torch.int32, "u_out"), _dev(i_out, torch.int32, "i_out"),
+        _dev(j_out, torch.int32, "j_out"), _stream()), "rsx_bpr_sample")
+
+
+def _mask_ptrs(mask):
+    if mask is None:
+        return None, None
+    indptr, indices = mask
+    return _dev(indptr, torch.int64, "mask indptr"), _dev(indices, torch.int32, "mask indices")
+
+
+def score(P, Q, user_ids, mask=None, out=None):
+    """S = P[user_ids] @ Q.T on the matrix cores, -inf at mask CSR positions."""
+    rows, I = user_ids.numel(), Q.shape[0]
+    if out is None:
+        out = torch.empty((rows, I), dtype=torch.float32, device=P.device)
+    mp, mi = _mask_ptrs(mask)
+    _check(lib().rsx_score(_dev(P, torch.float32, "P"), _dev(user_ids, torch.int32, "user_ids"), rows,
+                           _dev(Q, torch.float32, "Q"), I, P.shape[1], mp, mi,
+                           _dev(out, torch.float32, "out"), _stream()), "rsx_score")
+    return out
+
+
+def topk(scores, K, want_values=False):
+    rows, I = scores.shape
+    idx = torch.empty((rows, K), dtype=torch.int32, device=scores.device)
+    val = torch.empty((rows, K), dtype=torch.float32, device=scores.device) if want_values else None
+    _check(lib().rsx_topk(_dev(scores, torch.float32, "scores"), rows, I, K, _dev(idx, torch.int32, "idx"),
+                          _dev(val, torch.float32, "val") if val is not None else None, _stream()), "rsx_topk")
+    return (idx, val) if want_values else idx
+
+
+def score_topk(P, Q, user_ids, K, mask=None, want_values=False, ws=None):
+    rows, I = user_ids.numel(), Q.shape[0]
+    need = lib().rsx_score_topk_workspace(rows, I)
+    if ws is None or ws.numel() * ws.element_size() < need:
+        ws = torch.empty(max(need, 4) // 4, dtype=torch.float32, device=P.device)
+    idx = torch.empty((rows, K), dtype=torch.int32, device=P.device)
+    val = torch.empty((rows, K), dtype=torch.float32, device=P.device) if want_values else None
+    mp, mi = _mask_ptrs(mask)
+    _check(lib().rsx_score_topk(
+        _dev(P, torch.float32, "P"), _dev(user_ids, torch.int32, "user_ids"), rows,
+        _dev(Q, torch.float32, "Q"), I, P.shape[1], mp, mi, K, _dev(idx, torch.int32, "idx"),
+        _dev(val, torch.float32, "val") if val is not None else None,
+        C.c_void_p(ws.data_ptr()), ws.numel() * ws.element_size(), _stream()), "rsx_score_topk")
+    return (idx, val) if want_values else idx

@@ -1,0 +1,59 @@
+"""The C-ABI library: builds for gfx950, loads, and exports every symbol that
+include/rsx.h declares (no compute calls: runs without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "rsx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rsx_[a-z_0-9]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    from recsys_pytorch_amd import build
+    return build.build()
+
+
+def test_header_declares_the_path():
+    names = declared_functions()
+    for must in ("rsx_bpr_step", "rsx_apply_item_grad", "rsx_bpr_sample", "rsx_score", "rsx_topk",
+                 "rsx_score_topk", "rsx_version", "rsx_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(libpath):
+    L = ctypes.CDLL(libpath)
+    for name in declared_functions():
+        assert hasattr(L, name), f"{name} declared in include/rsx.h but not exported"
+    L.rsx_version.restype = ctypes.c_int
+    assert L.rsx_version() == 1
+
+
+def test_binding_covers_every_declared_symbol(libpath):
+    from recsys_pytorch_amd import rsx
+    assert sorted(rsx.SIGNATURES) == declared_functions()
+    assert rsx.version() == 1
+
+
+def test_no_cpu_fallback():
+    """host tensors are refused loudly, never silently computed on the CPU"""
+    import torch
+    from recsys_pytorch_amd import rsx
+    P = torch.zeros(4, 32)
+    with pytest.raises(rsx.RsxError):
+        rsx.apply_item_grad(P, P.clone(), 0.1)
+
+
+def test_argument_errors_use_the_error_channel(libpath):
+    from recsys_pytorch_amd import rsx
+    L = rsx.lib()
+    assert L.rsx_bpr_step_workspace(10, 10, 48) < 0          # unsupported d
+    rc = L.rsx_apply_item_grad(None, None, 10, 32, 0.1, None)
+    assert rc == -1 and b"null" in L.rsx_last_error()

@@ -1,0 +1,215 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the
+golden vectors captured from the reference.  Run with `-m gpu` on an MI355X.
+
+Tolerances (north star): embeddings within 1e-5 relative; Top-K index sets
+identical wherever the K-th/K+1-th score gap is resolvable in fp32."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import G1_SGD, G23, golden, rel_err, split_batches
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def rsx():
+    from recsys_pytorch_amd import rsx as m
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    m.lib()
+    return m
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+def run_steps(rsx, P0, Q0, batches, lr, unique_flag, layout):
+    rsx.lib().rsx_debug_set_layout(layout)
+    P, Q = dev(P0), dev(Q0)
+    G = torch.zeros_like(Q)
+    U, d = P.shape
+    maxb = max(len(b[0]) for b in batches)
+    ws = torch.zeros(rsx.bpr_step_workspace(U, maxb, d), dtype=torch.uint8, device="cuda")
+    losses = []
+    for (u, i, j) in batches:
+        acc = torch.zeros(rsx.RSX_LOSS_SLOTS, dtype=torch.float32, device="cuda")
+        uniq = unique_flag and len(np.unique(u)) == len(u)
+        rsx.bpr_step(P, Q, G, dev(u, torch.int32), dev(i, torch.int32), dev(j, torch.int32), lr,
+                     1.0 / len(u), loss_acc=acc, users_unique=uniq, ws=ws)
+        rsx.apply_item_grad(Q, G, lr)
+        losses.append(float(acc.sum().item()) / len(u))
+    torch.cuda.synchronize()
+    assert float(G.abs().max()) == 0.0, "apply must leave the item-gradient buffer zeroed"
+    assert int(ws.max()) == 0, "the step must leave its workspace zero-filled"
+    return P.cpu().numpy(), Q.cpu().numpy(), losses
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("name", G1_SGD)
+def test_bpr_step_matches_reference_golden(rsx, name, layout):
+    """20 SGD steps on the reference's own triplets (duplicates inside batches)."""
+    g = golden(name)
+    batches = list(split_batches(g))
+    P, Q, losses = run_steps(rsx, g["P0"], g["Q0"], batches, float(g["lr"]), True, layout)
+    assert rel_err(P, g["PT"]) < REL_TOL
+    assert rel_err(Q, g["QT"]) < REL_TOL
+    assert np.allclose(losses, g["loss"], rtol=1e-5, atol=1e-6)
+
+
+def test_first_step_gradients(rsx):
+    """dense grads of step 1 (MF.py:67): G holds dQ; dP recovered from the P update."""
+    g = golden(G1_SGD[3])
+    u, i, j = next(split_batches(g))
+    P, Q = dev(g["P0"]), dev(g["Q0"])
+    G = torch.zeros_like(Q)
+    ws = torch.zeros(rsx.bpr_step_workspace(P.shape[0], len(u), P.shape[1]), dtype=torch.uint8, device="cuda")
+    lr = float(g["lr"])
+    rsx.bpr_step(P, Q, G, dev(u, torch.int32), dev(i, torch.int32), dev(j, torch.int32), lr, 1.0 / len(u), ws=ws)
+    assert rel_err(G.cpu().numpy(), g["gQ1"]) < REL_TOL
+    gP = (g["P0"] - P.cpu().numpy()) / lr
+    assert np.max(np.abs(gP - g["gP1"])) < 1e-5 * np.max(np.abs(g["gP1"])) + 2e-7 / lr * np.max(np.abs(g["P0"]))
+    assert torch.equal(Q.cpu(), torch.from_numpy(g["Q0"])), "Q must not change before apply"
+
+
+@pytest.mark.parametrize("d", [32, 64, 128])
+@pytest.mark.parametrize("B", [1, 63, 257, 4096])
+def test_bpr_step_random_vs_oracle(rsx, oracle_mod, d, B):
+    """ragged batch sizes (not multiples of 64), heavy duplicate users AND items"""
+    rng = np.random.default_rng(100 + d + B)
+    U, I = 300, 50
+    P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+    batches = [(rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)) for _ in range(3)]
+    orc = oracle_mod.MFOracle(P0, Q0, "sgd", 0.05)
+    ol = [orc.step(*b) for b in batches]
+    P, Q, losses = run_steps(rsx, P0, Q0, batches, 0.05, False, 0)
+    assert rel_err(P, orc.P) < REL_TOL and rel_err(Q, orc.Q) < REL_TOL
+    assert np.allclose(losses, ol, rtol=1e-5, atol=1e-6)
+
+
+def test_bpr_step_unique_users_fast_path_equals_general_path(rsx, oracle_mod):
+    rng = np.random.default_rng(5)
+    U, I, d, B = 5000, 700, 128, 3001
+    P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+    batches = [(rng.permutation(U)[:B], rng.integers(0, I, B), rng.integers(0, I, B)) for _ in range(4)]
+    orc = oracle_mod.MFOracle(P0, Q0, "sgd", 0.05)
+    for b in batches:
+        orc.step(*b)
+    for layout in (0, 1):
+        Pf, Qf, _ = run_steps(rsx, P0, Q0, batches, 0.05, True, layout)
+        Pg, Qg, _ = run_steps(rsx, P0, Q0, batches, 0.05, False, layout)
+        assert rel_err(Pf, orc.P) < REL_TOL and rel_err(Qf, orc.Q) < REL_TOL
+        assert rel_err(Pg, orc.P) < REL_TOL and rel_err(Qg, orc.Q) < REL_TOL
+
+
+def test_bpr_step_empty_and_skipped_triplets(rsx):
+    P = torch.randn(10, 32, device="cuda")
+    Q = torch.randn(7, 32, device="cuda")
+    G = torch.zeros_like(Q)
+    P0, Q0 = P.clone(), Q.clone()
+    e = torch.zeros(0, dtype=torch.int32, device="cuda")
+    rsx.bpr_step(P, Q, G, e, e, e, 0.1, 1.0, users_unique=True)           # empty batch
+    u = torch.tensor([1, 2, 3], dtype=torch.int32, device="cuda")
+    i = torch.tensor([-1, -1, -1], dtype=torch.int32, device="cuda")        # users without positives
+    rsx.bpr_step(P, Q, G, u, i, i, 0.1, 1.0 / 3, users_unique=True)
+    rsx.apply_item_grad(Q, G, 0.1)
+    torch.cuda.synchronize()
+    assert torch.equal(P, P0) and torch.equal(Q, Q0)
+
+
+def test_linearity_of_item_gradient_full_size(rsx):
+    """size-independent property at the bench shape: G is linear in inv_batch and
+    sum(G) over items is ~0 (every triplet adds +g p to i and -g p to j)."""
+    torch.manual_seed(0)
+    U, I, d, B = 1_000_000, 100_000, 128, 65_536
+    P = torch.randn(U, d, device="cuda") * 0.1
+    Q = torch.randn(I, d, device="cuda") * 0.1
+    u = torch.randperm(U, device="cuda")[:B].to(torch.int32)
+    i = torch.randint(0, I, (B,), device="cuda", dtype=torch.int32)
+    j = torch.randint(0, I, (B,), device="cuda", dtype=torch.int32)
+    G1, G2 = torch.zeros_like(Q), torch.zeros_like(Q)
+    Pa, Pb = P.clone(), P.clone()
+    rsx.bpr_step(Pa, Q, G1, u, i, j, 0.05, 1.0 / B, users_unique=True)
+    rsx.bpr_step(Pb, Q, G2, u, i, j, 0.05, 2.0 / B, users_unique=True)
+    torch.cuda.synchronize()
+    assert torch.allclose(G2, 2 * G1, rtol=1e-4, atol=1e-9)
+    col = G1.double().sum(0)
+    assert float(col.abs().max()) < 1e-6 * float(G1.double().abs().sum(0).max() + 1e-30) + 1e-9
+    touched = torch.zeros(U, dtype=torch.bool, device="cuda")
+    touched[u.long()] = True
+    assert torch.equal(Pa[~touched], P[~touched]), "rows of users outside the batch must not move"
+    assert torch.allclose((Pb - P), 2 * (Pa - P), rtol=1e-3, atol=1e-8)
+
+
+# ------------------------------------------------------------------ scoring / top-k
+@pytest.mark.parametrize("g1,g23", list(zip(G1_SGD, G23)))
+def test_score_mask_topk_match_reference_golden(rsx, oracle_mod, g1, g23):
+    a, b = golden(g1), golden(g23)
+    P, Q = dev(a["PT"]), dev(a["QT"])
+    U, I = P.shape[0], Q.shape[0]
+    rows = b["score_rows"].astype(np.int32)
+    S = rsx.score(P, Q, dev(rows)).cpu().numpy()
+    assert rel_err(S, b["S"]) < 2e-6                       # predict_batch_users (MF.py:109-112)
+    mask = (dev(b["mask_indptr"]), dev(b["mask_indices"]))
+    allu = dev(np.arange(U, dtype=np.int32))
+    Sm = rsx.score(P, Q, allu, mask=mask).cpu().numpy()
+    ref = oracle_mod.mask_seen(oracle_mod.score(a["PT"], a["QT"], np.arange(U)), np.arange(U),
+                               b["mask_indptr"], b["mask_indices"])
+    assert np.array_equal(np.isneginf(Sm), np.isneginf(ref))   # -inf exactly at eval_pos (MF.py:130)
+    for K in (5, 10, 50):
+        idx, val = rsx.score_topk(P, Q, allu, K, mask=mask, want_values=True)
+        idx, val = idx.cpu().numpy(), val.cpu().numpy()
+        assert np.all(val[:, :-1] >= val[:, 1:])            # descending (func.h:19)
+        assert not np.isneginf(val).any()
+        assert np.array_equal(np.take_along_axis(Sm, idx.astype(np.int64), 1), val)
+        safe = b[f"gap_{K}"] > 1e-5
+        assert safe.mean() > 0.9
+        for r in np.nonzero(safe)[0]:                       # bit-identical index SETS
+            assert set(idx[r]) == set(b[f"topk_py_{K}"][r]) == set(b[f"topk_cy_{K}"][r]), (K, r)
+        # wherever the scores of the selected items are pairwise distinct, even the ORDER is the reference's
+        exact = safe & (np.min(-np.diff(val, axis=1), axis=1) > 1e-6)
+        assert np.array_equal(idx[exact], b[f"topk_cy_{K}"][exact])
+
+
+@pytest.mark.parametrize("rows,I,K", [(1, 5, 5), (3, 129, 1), (37, 1000, 50), (5, 4099, 1024), (2, 100_003, 50)])
+def test_topk_vs_oracle_shapes(rsx, oracle_mod, rows, I, K):
+    rng = np.random.default_rng(rows * 31 + I)
+    S = rng.standard_normal((rows, I)).astype(np.float32)
+    idx, val = rsx.topk(dev(S), K, want_values=True)
+    ref = oracle_mod.topk(S, K)
+    assert np.array_equal(np.take_along_axis(S, idx.cpu().numpy().astype(np.int64), 1), val.cpu().numpy())
+    assert np.array_equal(val.cpu().numpy(), np.take_along_axis(S, ref.astype(np.int64), 1))
+    uniq = np.array([len(np.unique(r)) == len(r) for r in S])
+    assert np.array_equal(idx.cpu().numpy()[uniq], ref[uniq])
+
+
+def test_topk_ties_and_masked_rows(rsx, oracle_mod):
+    """exact ties (oracle rule: lower index first), all-equal rows, rows mostly -inf"""
+    S = np.zeros((4, 5000), np.float32)
+    S[0, ::7] = 1.0                                   # 715 exact ties for the top
+    S[1, :] = 3.25                                    # everything tied
+    S[2, :] = -np.inf; S[2, [17, 4000, 42]] = [0.5, 0.25, 0.5]
+    S[3, :] = np.linspace(-1, 1, 5000, dtype=np.float32)
+    for K in (1, 10, 50, 1024):
+        got = rsx.topk(dev(S), K).cpu().numpy()
+        want = oracle_mod.topk(S, K)
+        assert np.array_equal(got, want), K
+
+
+def test_score_large_tile_vs_torch_fp64(rsx):
+    """ragged tile edges (rows, items not multiples of 128) against an fp64 product"""
+    torch.manual_seed(1)
+    U, I, d = 1000, 10_007, 128
+    P = torch.randn(U, d, device="cuda") * 0.1
+    Q = torch.randn(I, d, device="cuda") * 0.1
+    users = torch.randperm(U, device="cuda")[:333].to(torch.int32)
+    S = rsx.score(P, Q, users)
+    ref = (P[users.long()].double() @ Q.double().T)
+    err = (S.double() - ref).abs().max() / ref.abs().max()
+    assert float(err) < 2e-6
