@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- BPR triplet updates/s (+ full-catalog scores/s) on N MI355X of one node.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic triplets:
+  device sampling (rsx_bpr_sample) -> rsx_bpr_step -> [all-reduce of the item
+  gradients over RCCL when N > 1] -> rsx_apply_item_grad.
+Workload = BASELINE.json configs[2] (the d=128 shape the metric is quoted on):
+1M users x 100K items per GPU, d=128, Zipf item popularity, 20 positives/user,
+tables N(0, 0.1^2) resident in HBM before the timed region.  Weak scaling: every
+rank owns its own 1M-user block (user rows sharded, items replicated).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel
+(bpr_step_kernel): algorithmic bytes 24*d per triplet over the
+kernel's average launch duration measured with HIP events on the launch stream.
+`cpu_baseline` is the torch-CPU port of the reference path (oracle/torch_port.py)
+timed on this host on a bounded sample; it is test infrastructure and is used here
+only as the thing-compared-against.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: matrix FP32 peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--users", type=int, default=1_000_000, help="users PER GPU")
+    ap.add_argument("--items", type=int, default=100_000)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=262_144, help="triplets per step PER GPU")
+    ap.add_argument("--degree", type=int, default=20)
+    ap.add_argument("--popularity", default="zipf", choices=["zipf", "uniform"])
+    ap.add_argument("--lr", type=float, default=0.05)
+    ap.add_argument("--score-tiles", type=int, default=16, help="1024-user tiles scored for scores/s (0 = skip)")
+    ap.add_argument("--topk", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=65_536)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """reference path (dense autograd + optimizer sweep) as ported in oracle/torch_port.py,
+    SGD like the GPU path, same U/I/d, bounded to ~10-30 s of CPU work."""
+    from oracle.torch_port import TorchMFPort
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    U, I, d, B = args.users, args.items, args.dim, args.cpu_batch
+    g = torch.Generator().manual_seed(2020)
+    P0 = (torch.randn(U, d, generator=g) * 0.1).numpy()
+    Q0 = (torch.randn(I, d, generator=g) * 0.1).numpy()
+    m = TorchMFPort(P0, Q0, optimizer="sgd", lr=args.lr)
+    rng = np.random.default_rng(1)
+    mk = lambda: (rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B))
+    for _ in range(2):
+        m.step(*mk())
+    times, t_all = [], time.time()
+    while len(times) < 10 and time.time() - t_all < 25.0:
+        b = mk()
+        t0 = time.time()
+        m.step(*b)
+        times.append(time.time() - t0)
+    med = float(np.median(times))
+    return {"value": B / med, "unit": "triplets/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} SGD steps of B={B} on U={U} I={I} d={d} (torch CPU port of models/MF.py:64-68, "
+                      f"dense grads + full optimizer sweep), median {med*1e3:.0f} ms/step"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)      # "nccl" IS RCCL on ROCm
+
+    from recsys_pytorch_amd import rsx
+    from recsys_pytorch_amd.data import synthetic_csr
+    from recsys_pytorch_amd.sharded import BPREngine
+    rsx.lib()
+
+    U, I, d, B = args.users, args.items, args.dim, min(args.batch, args.users)
+    torch.manual_seed(2020 + rank)
+    P = (torch.randn(U, d, device=dev) * 0.1).contiguous()          # this rank's user block
+    torch.manual_seed(2020)
+    Q = (torch.randn(I, d, device=dev) * 0.1).contiguous()          # replicated item table
+    indptr, indices = synthetic_csr(U, I, args.degree, dev, seed=2020 + rank, popularity=args.popularity)
+    eng = BPREngine(P, Q, args.lr, user_begin=rank * U, seed=2020)
+    gb = B * world
+
+    def one_step(ev=None):
+        u, i, j = eng.sample(indptr, indices, B)
+        if ev is not None:
+            ev[0].record()
+        rsx.bpr_step(eng.P, eng.Q, eng.G, u, i, j, eng.lr, 1.0 / gb, users_unique=True)
+        if ev is not None:
+            ev[1].record()
+        if world > 1:
+            dist.all_reduce(eng.G, op=dist.ReduceOp.SUM)
+        rsx.apply_item_grad(eng.Q, eng.G, eng.lr)
+        eng.step_count += 1
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    fence()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        one_step(events[s])
+    fence()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))   # bpr_step_kernel, HIP events
+    assert torch.isfinite(P).all() and torch.isfinite(Q).all()
+
+    # ---- scoring leg (reported beside the headline; its own timed region) ---------------
+    scoring = None
+    if args.score_tiles > 0 and rank == 0:
+        tiles, K = args.score_tiles, args.topk
+        ws = torch.empty(1024 * I, dtype=torch.float32, device=dev)
+        users = torch.arange(1024 * tiles, device=dev, dtype=torch.int32) % U
+        mask = (indptr, indices)
+        rsx.score_topk(P, Q, users[:1024], K, mask=mask, ws=ws)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        top = rsx.score_topk(P, Q, users, K, mask=mask, ws=ws)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        n_scores = 1024 * tiles * I
+        scoring = {"metric": "full_catalog_scores_per_sec", "value": n_scores / dt, "unit": "scores/s",
+                   "sample": f"{tiles} tiles of 1024 users x {I} items, mask + top-{K} on device",
+                   "roofline": {"bound": "mfma", "achieved": n_scores * 2 * d / dt / 1e12,
+                                "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": n_scores * 2 * d / dt / 1e12 / MFMA_F32_PEAK_TFLOPS},
+                   "topk_rows": int(top.shape[0])}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        value = gb * args.steps / elapsed
+        alg_bytes = 24 * d * B                                     # per launch
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-measured HBM bytes per launch, if profiled
+        if os.path.exists(tpath):
+            try:
+                t = json.load(open(tpath))
+                key = f"U{U}_I{I}_d{d}_B{B}_{args.popularity}"
+                traffic = t.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "bpr_triplet_updates_per_sec", "value": value, "unit": "triplets/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2]: BPRMF synthetic {U} users/GPU x {I} items, d={d}, "
+                                   "on-device negative sampling, SGD",
+                       "users_per_gpu": U, "items": I, "d": d, "batch_per_gpu": B, "global_batch": gb,
+                       "positives_per_user": args.degree, "item_popularity": args.popularity, "lr": args.lr,
+                       "parallelism": f"user-sharded x{world}, items replicated, 1 all-reduce(G)/step" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "bpr_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},
+        }
+        if scoring is not None:
+            out["scoring"] = scoring
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

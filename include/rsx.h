@@ -38,6 +38,9 @@ extern "C" {
                             /* (true for rsx_bpr_sample output and for the reference's */
                             /* PairwiseGenerator, data/generators.py:182-195)          */
 
+#define RSX_NO_UPDATE 2u    /* evaluate the loss only: P and G are not written             */
+                            /* (models/MF.py:99-107 process_one_batch without backward)    */
+
 #define RSX_LOSS_SLOTS 64   /* loss accumulator is float[RSX_LOSS_SLOTS] (striped atomics) */
 
 typedef void *rsx_stream_t;
@@ -97,6 +100,10 @@ int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, int64_t 
 int rsx_apply_item_grad(float *Q, float *G, int64_t num_items, int d, float lr,
                         rsx_stream_t stream);
 
+/* rsx_pair_score: r[b] = <P[u[b]], Q[i[b]]>   (models/MF.py:38-42, MF.forward)            */
+int rsx_pair_score(const float *P, const float *Q, const int32_t *u_dev, const int32_t *i_dev,
+                   int64_t n, int d, float *r_out, rsx_stream_t stream);
+
 /* ---- on-device triplet sampler ------------------------------------------------
  * Replaces data/generators.py:151-224 (PairwiseGenerator: host-side numpy
  * sampling + permutation + H2D copy).  Sampling semantics are BPR's, not the
@@ -143,6 +150,19 @@ int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t num_rows
                    int64_t num_items, int d, const int64_t *mask_indptr_dev,
                    const int32_t *mask_indices_dev, int K, int32_t *topk_idx_out,
                    float *topk_val_out, void *ws, int64_t ws_bytes, rsx_stream_t stream);
+
+/* ---- holdout metrics (HOST function, host pointers) --------------------------------
+ * Replaces evaluation/backend/cython/include/holdout.h:20-103 (evaluate_holdout) and its
+ * wrapper holdout_func.pyx: Prec@K = hits/K, Recall@K = hits/truth_len,
+ * NDCG@K = DCG/iDCG with 1/log2(rank+2).  O(users * max_k * log truth): stays on the CPU
+ * as in the reference.  rankings: int32 [users_num x max_k] (rsx_topk output copied to
+ * the host); truth as CSR (indptr int64 [users_num+1], indices int32, any order);
+ * results: float [users_num x 3*K_len], layout [user][metric*K_len + k] with metrics
+ * Prec, Recall, NDCG (holdout.h:72-102).  Users with an empty truth row get NaN for
+ * Recall/NDCG exactly like the reference header (0/0).                                  */
+int rsx_eval_holdout(int64_t users_num, const int32_t *rankings, int max_k, const int32_t *Ks,
+                     int K_len, const int64_t *truth_indptr, const int32_t *truth_indices,
+                     float *results);
 
 #ifdef __cplusplus
 }

@@ -41,6 +41,23 @@ struct Row {
             for (int c = 0; c < 4; ++c) v[c] = row[k + c * LPR];
         }
     }
+    // streaming (non-temporal) variants for rows nobody re-reads: keep them out of L2 / MALL
+    __device__ __forceinline__ void load_nt(const float *row, int k)
+    {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int e = VEC ? 4 * k + c : k + c * LPR;
+            v[c] = __builtin_nontemporal_load(row + e);
+        }
+    }
+    __device__ __forceinline__ void store_nt(float *row, int k) const
+    {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int e = VEC ? 4 * k + c : k + c * LPR;
+            __builtin_nontemporal_store(v[c], row + e);
+        }
+    }
     __device__ __forceinline__ void store(float *row, int k) const
     {
         if constexpr (VEC) {
@@ -90,7 +107,8 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
     float *__restrict__ P, const float *__restrict__ Q, float *__restrict__ G,
     const int32_t *__restrict__ U_idx, const int32_t *__restrict__ I_idx,
     const int32_t *__restrict__ J_idx, int64_t B, float lr, float inv_batch,
-    float *__restrict__ loss_acc, const int32_t *__restrict__ owner, float *__restrict__ GU)
+    float *__restrict__ loss_acc, const int32_t *__restrict__ owner, float *__restrict__ GU,
+    int ablate)
 {
     constexpr int LPR = D / 4;
     constexpr int TPW = 64 / LPR;  // triplets per wavefront
@@ -116,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
             const float *qi_row = Q + (size_t)i * D;
             const float *qj_row = Q + (size_t)j * D;
             Row<D, VEC> p, qi, qj;
-            p.load(prow, k);
+            if (ablate & 8) p.load_nt(prow, k); else p.load(prow, k);
             qi.load(qi_row, k);
             qj.load(qj_row, k);
             float dpos = 0.0f, dneg = 0.0f;
@@ -134,14 +152,14 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
             const float g = -sneg * inv_batch;                 // dL/dx
             if (k == 0) loss_local += softplus_neg(x);
             // item gradients (shared rows): G[i] += g p ; G[j] -= g p
-            p.atomic_axpy(G + (size_t)i * D, k, g);
-            p.atomic_axpy(G + (size_t)j * D, k, -g);
+            if (!(ablate & 1)) p.atomic_axpy(G + (size_t)i * D, k, g);
+            if (!(ablate & 2)) p.atomic_axpy(G + (size_t)j * D, k, -g);
             // user row: P[u] -= lr * g * (qi - qj)
             const float s = -lr * g;
             if constexpr (MODE == 0) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) p.v[c] = fmaf(s, qi.v[c] - qj.v[c], p.v[c]);
-                p.store(prow, k);
+                if (!(ablate & 4)) { if (ablate & 16) p.store_nt(prow, k); else p.store(prow, k); }
             } else {
                 Row<D, VEC> dq;
 #pragma unroll
@@ -205,6 +223,35 @@ __global__ __launch_bounds__(kBlock) void bpr_release_kernel(const int32_t *__re
     for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < B; b += (int64_t)gridDim.x * kBlock) {
         if (I_idx[b] < 0) continue;
         owner[U_idx[b]] = 0;   // benign same-value race between duplicates
+    }
+}
+
+// r[b] = <P[u_b], Q[i_b]>  (MF.forward); one lane group per pair
+template <int D>
+__global__ __launch_bounds__(kBlock) void pair_score_kernel(const float *__restrict__ P,
+                                                            const float *__restrict__ Q,
+                                                            const int32_t *__restrict__ U_idx,
+                                                            const int32_t *__restrict__ I_idx,
+                                                            int64_t n, float *__restrict__ out)
+{
+    constexpr int LPR = D / 4;
+    constexpr int TPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR;
+    const int k = lane % LPR;
+    const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock * TPW;
+    for (int64_t b = wave * TPW + sub; b - sub < n; b += stride) {
+        float acc = 0.0f;
+        if (b < n) {
+            Row<D, false> p, q;
+            p.load(P + (size_t)U_idx[b] * D, k);
+            q.load(Q + (size_t)I_idx[b] * D, k);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc = fmaf(p.v[c], q.v[c], acc);
+        }
+        acc = group_sum<LPR>(acc);
+        if (b < n && k == 0) out[b] = acc;
     }
 }
 
@@ -289,11 +336,12 @@ __global__ __launch_bounds__(kBlock) void bpr_sample_kernel(
 }
 
 int g_layout_vec = 0;   // row layout used by bpr_step (0 = strided dwords, 1 = dwordx4); tuning knob
+int g_ablate = 0;       // development only: 1 = skip pos-item atomics, 2 = skip neg-item atomics, 4 = skip P store
 
 template <int D, bool VEC, int MODE>
 void launch_step(float *P, const float *Q, float *G, const int32_t *u, const int32_t *i,
                  const int32_t *j, int64_t B, float lr, float inv_batch, float *loss_acc,
-                 const int32_t *owner, float *GU, hipStream_t st)
+                 const int32_t *owner, float *GU, int ablate, hipStream_t st)
 {
     constexpr int TPW = 64 / (D / 4);
     const int64_t waves = (B + TPW - 1) / TPW;
@@ -302,18 +350,18 @@ void launch_step(float *P, const float *Q, float *G, const int32_t *u, const int
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((bpr_step_kernel<D, VEC, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, P, Q,
-                       G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU);
+                       G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, ablate);
 }
 
 template <int MODE>
 void dispatch_step(int d, bool vec, float *P, const float *Q, float *G, const int32_t *u,
                    const int32_t *i, const int32_t *j, int64_t B, float lr, float inv_batch,
-                   float *loss_acc, const int32_t *owner, float *GU, hipStream_t st)
+                   float *loss_acc, const int32_t *owner, float *GU, int ablate, hipStream_t st)
 {
 #define RSX_CASE(DD)                                                                                   \
     case DD:                                                                                           \
-        if (vec) launch_step<DD, true, MODE>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, st); \
-        else launch_step<DD, false, MODE>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, st);    \
+        if (vec) launch_step<DD, true, MODE>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, ablate, st); \
+        else launch_step<DD, false, MODE>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, ablate, st);    \
         break;
     switch (d) { RSX_CASE(32) RSX_CASE(64) RSX_CASE(128) }
 #undef RSX_CASE
@@ -331,6 +379,7 @@ int64_t grid_1d(int64_t n)
 
 // undocumented tuning hook (bench / tests): select the row layout of bpr_step
 RSX_API int rsx_debug_set_layout(int vec) { g_layout_vec = vec ? 1 : 0; return RSX_OK; }
+RSX_API int rsx_debug_set_ablation(int mask) { g_ablate = mask; return RSX_OK; }
 
 RSX_API int64_t rsx_bpr_step_workspace(int64_t num_users, int64_t max_batch, int d)
 {
@@ -344,15 +393,21 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
                          int64_t batch, int d, float lr, float inv_batch, float *loss_acc,
                          unsigned flags, void *ws, int64_t ws_bytes, rsx_stream_t stream)
 {
-    RSX_CHECK_ARG(P && Q && G, "null table pointer");
+    RSX_CHECK_ARG(P && Q && (G || (flags & RSX_NO_UPDATE)), "null table pointer");
     RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64 or 128");
     RSX_CHECK_ARG(batch >= 0 && num_users > 0 && num_items > 0, "negative size");
     if (batch == 0) return RSX_OK;
     RSX_CHECK_ARG(u_dev && i_dev && j_dev, "null index pointer");
     hipStream_t st = (hipStream_t)stream;
+    if (flags & RSX_NO_UPDATE) {   // loss only: the in-place kernel with every write suppressed
+        dispatch_step<0>(d, g_layout_vec != 0, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch,
+                         loss_acc, nullptr, nullptr, /*suppress every write*/ 7, st);
+        RSX_CHECK_LAUNCH();
+        return RSX_OK;
+    }
     if (flags & RSX_USERS_UNIQUE) {
         dispatch_step<0>(d, g_layout_vec != 0, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch,
-                         loss_acc, nullptr, nullptr, st);
+                         loss_acc, nullptr, nullptr, g_ablate, st);
         RSX_CHECK_LAUNCH();
         return RSX_OK;
     }
@@ -367,7 +422,7 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
     const unsigned g1 = (unsigned)grid_1d(batch);
     hipLaunchKernelGGL(bpr_claim_kernel, dim3(g1), dim3(kBlock), 0, st, u_dev, i_dev, batch, owner);
     dispatch_step<1>(d, g_layout_vec != 0, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch,
-                     loss_acc, owner, GU, st);
+                     loss_acc, owner, GU, g_ablate, st);
     const int64_t tpw = 64 / (d / 4);
     const unsigned g2 = (unsigned)grid_1d((batch + tpw - 1) / tpw * 64);
     switch (d) {
@@ -376,6 +431,25 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
     default: hipLaunchKernelGGL(bpr_apply_user_kernel<128>, dim3(g2), dim3(kBlock), 0, st, P, u_dev, i_dev, batch, owner, GU); break;
     }
     hipLaunchKernelGGL(bpr_release_kernel, dim3(g1), dim3(kBlock), 0, st, u_dev, i_dev, batch, owner);
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+}
+
+RSX_API int rsx_pair_score(const float *P, const float *Q, const int32_t *u_dev, const int32_t *i_dev,
+                           int64_t n, int d, float *r_out, rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(P && Q && r_out, "null pointer");
+    RSX_CHECK_ARG(rsx_dim_ok(d) && n >= 0, "bad shape");
+    if (n == 0) return RSX_OK;
+    RSX_CHECK_ARG(u_dev && i_dev, "null index pointer");
+    const int64_t tpw = 64 / (d / 4);
+    const unsigned g = (unsigned)grid_1d((n + tpw - 1) / tpw * 64);
+    hipStream_t st = (hipStream_t)stream;
+    switch (d) {
+    case 32: hipLaunchKernelGGL(pair_score_kernel<32>, dim3(g), dim3(kBlock), 0, st, P, Q, u_dev, i_dev, n, r_out); break;
+    case 64: hipLaunchKernelGGL(pair_score_kernel<64>, dim3(g), dim3(kBlock), 0, st, P, Q, u_dev, i_dev, n, r_out); break;
+    default: hipLaunchKernelGGL(pair_score_kernel<128>, dim3(g), dim3(kBlock), 0, st, P, Q, u_dev, i_dev, n, r_out); break;
+    }
     RSX_CHECK_LAUNCH();
     return RSX_OK;
 }

@@ -1,0 +1,44 @@
+// rsx_eval.hip -- host-side holdout metrics behind the C ABI (no device code).
+//
+// Restates evaluation/backend/cython/include/holdout.h:20-103 of the reference
+// (Prec / Recall / NDCG @K per user, float accumulators, result layout
+// [user][metric*K_len + k]).  Own implementation: the truth row is sorted once
+// and probed by binary search instead of building a std::set per user.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "rsx_common.h"
+
+RSX_API int rsx_eval_holdout(int64_t users_num, const int32_t *rankings, int max_k,
+                             const int32_t *Ks, int K_len, const int64_t *truth_indptr,
+                             const int32_t *truth_indices, float *results)
+{
+    RSX_CHECK_ARG(rankings && Ks && truth_indptr && truth_indices && results, "null pointer");
+    RSX_CHECK_ARG(users_num >= 0 && max_k > 0 && K_len > 0, "bad shape");
+    for (int q = 0; q < K_len; ++q) RSX_CHECK_ARG(Ks[q] >= 1 && Ks[q] <= max_k, "K outside [1, max_k]");
+    std::vector<float> discount(max_k);
+    for (int p = 0; p < max_k; ++p) discount[p] = (float)(1.0 / std::log2((double)p + 2.0));
+    std::vector<int32_t> truth;
+    for (int64_t uid = 0; uid < users_num; ++uid) {
+        const int32_t *rk = rankings + uid * max_k;
+        const int64_t lo = truth_indptr[uid], hi = truth_indptr[uid + 1];
+        const int truth_len = (int)(hi - lo);
+        truth.assign(truth_indices + lo, truth_indices + hi);
+        std::sort(truth.begin(), truth.end());
+        float *res = results + uid * 3 * K_len;
+        float hits = 0.f, dcg = 0.f, idcg = 0.f;
+        for (int p = 0; p < max_k; ++p) {
+            if (std::binary_search(truth.begin(), truth.end(), rk[p])) { hits += 1.f; dcg += discount[p]; }
+            if (p < truth_len) idcg += discount[p];
+            for (int q = 0; q < K_len; ++q) {
+                if (Ks[q] == p + 1) {
+                    res[0 * K_len + q] = hits / (float)Ks[q];
+                    res[1 * K_len + q] = hits / (float)truth_len;
+                    res[2 * K_len + q] = dcg / idcg;
+                }
+            }
+        }
+    }
+    return RSX_OK;
+}

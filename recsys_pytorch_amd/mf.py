@@ -1,0 +1,201 @@
+"""Host-side mirror of the reference's model interface for the BPR-MF path.
+
+    models/BaseModel.py:3-14   BaseModel(nn.Module): forward / fit / predict
+    models/MF.py:13-132        MF(dataset, hparams, device), fit(...), predict(...)
+    models/__init__.py:12      registry name `MF`  (main.py:46-47 getattr(models, name))
+
+Same constructor convention, same `fit(dataset, exp_config, evaluator, early_stop,
+loggers) -> {'scores': ...}` loop shape, same `predict(eval_users, eval_pos,
+test_batch_size) -> ndarray[U x I]` with -inf at seen items.  The arithmetic is NOT
+torch: every step/score goes through librsx.so (include/rsx.h).  torch tensors are
+storage.  There is no CPU fallback.
+
+Divergences from the reference, all documented in DESIGN.md:
+  * optimizer: SGD (north star) instead of dense Adam lr=1e-3 (MF.py:30);
+    hparams['lr'] (default 0.05), hparams['optimizer'] must be 'sgd'.
+  * triplets: sampled on the device every step (include/rsx.h:rsx_bpr_sample), true
+    BPR sampling, instead of PairwiseGenerator's once-per-fit host sampling with its
+    quirks (data/generators.py:165,182-185).  `train_step` replays explicit triplets.
+  * pointwise branch (MF.py:48-51,101-102) is outside the hot path: NotImplementedError.
+  * hidden_dim is padded to 32/64/128 columns of zeros internally (they stay zero).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .data import csr_to_device
+from .sharded import BPREngine
+
+
+class BaseModel(nn.Module):
+    def __init__(self):
+        super().__init__()
+
+    def forward(self, *input):
+        pass
+
+    def fit(self, *input):
+        pass
+
+    def predict(self, eval_users, eval_pos, test_batch_size):
+        pass
+
+
+def _pad_dim(d):
+    for p in (32, 64, 128):
+        if d <= p:
+            return p
+    raise ValueError(f"hidden_dim {d} > 128 is not supported by the HIP kernels")
+
+
+def _get(cfg, key, default=None):
+    try:
+        return cfg[key]
+    except (KeyError, TypeError, IndexError):
+        return getattr(cfg, key, default)
+
+
+class MF(BaseModel):
+    def __init__(self, dataset, hparams, device, kernels=None):
+        super().__init__()
+        self.num_users = dataset.num_users
+        self.num_items = dataset.num_items
+        self.hidden_dim = int(hparams["hidden_dim"])
+        self.pointwise = bool(hparams["pointwise"])
+        if self.pointwise:
+            raise NotImplementedError("pointwise MF (models/MF.py:48-51) is outside the BPR hot path")
+        opt = _get(hparams, "optimizer", "sgd")
+        if opt != "sgd":
+            raise NotImplementedError("only SGD runs on the HIP path; the reference's dense Adam "
+                                      "(models/MF.py:30) is the 'next' row f3 of SURVEY section 8")
+        self.lr = float(_get(hparams, "lr", 0.05))
+        self.seed = int(_get(hparams, "seed", 2020))
+        self.device = torch.device(device)
+        self._dpad = _pad_dim(self.hidden_dim)
+        d = self.hidden_dim
+        # storage: padded row-major fp32 tables; N(0,1) init like nn.Embedding (MF.py:23-24)
+        P = torch.zeros(self.num_users, self._dpad, dtype=torch.float32)
+        Q = torch.zeros(self.num_items, self._dpad, dtype=torch.float32)
+        P[:, :d].normal_()
+        Q[:, :d].normal_()
+        self._P = P.to(self.device).contiguous()
+        self._Q = Q.to(self.device).contiguous()
+        self.user_embedding = nn.Embedding(self.num_users, d, _weight=self._P[:, :d])
+        self.item_embedding = nn.Embedding(self.num_items, d, _weight=self._Q[:, :d])
+        self.user_embedding.weight.requires_grad_(False)
+        self.item_embedding.weight.requires_grad_(False)
+        self._kernels = kernels
+        self._engine = BPREngine(self._P, self._Q, self.lr, kernels=kernels, seed=self.seed)
+        self._k = self._engine.k
+
+    # -- tables ---------------------------------------------------------------------
+    def load_tables(self, P, Q):
+        """overwrite the embedding tables (numpy or tensor [U x d], [I x d])"""
+        d = self.hidden_dim
+        self._P.zero_(); self._Q.zero_()
+        self._P[:, :d] = torch.as_tensor(np.asarray(P), dtype=torch.float32).to(self.device)
+        self._Q[:, :d] = torch.as_tensor(np.asarray(Q), dtype=torch.float32).to(self.device)
+
+    def _idx(self, t):
+        return torch.as_tensor(t).to(device=self.device, dtype=torch.int32).contiguous()
+
+    # -- models/MF.py:32-42 ------------------------------------------------------------
+    def embeddings(self, user_ids, item_ids):
+        return self.user_embedding(torch.as_tensor(user_ids).long()), self.item_embedding(torch.as_tensor(item_ids).long())
+
+    def forward(self, user_ids, item_ids):
+        return self._k.pair_score(self._P, self._Q, self._idx(user_ids), self._idx(item_ids))
+
+    # -- models/MF.py:99-107: the loss of one batch (no update) ---------------------------
+    def process_one_batch(self, users, items, ratings):
+        u, i, j = self._idx(users), self._idx(items), self._idx(ratings)
+        acc = torch.zeros(self._k.RSX_LOSS_SLOTS, dtype=torch.float32, device=self.device)
+        self._k.bpr_step(self._P, self._Q, None, u, i, j, 0.0, 1.0, loss_acc=acc, no_update=True)
+        return acc.sum() / max(1, u.numel())
+
+    # -- models/MF.py:64-68: zero_grad + loss + backward + optimizer.step, fused ------------
+    def train_step(self, users, pos, neg, users_unique=False):
+        u, i, j = self._idx(users), self._idx(pos), self._idx(neg)
+        acc = self._engine.step(u, i, j, users_unique=users_unique)
+        return acc.sum() / max(1, u.numel())
+
+    # -- models/MF.py:44-97 ----------------------------------------------------------------
+    def fit(self, dataset, exp_config, evaluator=None, early_stop=None, loggers=None):
+        train_matrix = dataset.train_data
+        indptr, indices = csr_to_device(train_matrix, self.device)
+        batch_size = int(_get(exp_config, "batch_size"))
+        num_epochs = int(_get(exp_config, "num_epochs"))
+        verbose = _get(exp_config, "verbose", 0)
+        test_from = int(_get(exp_config, "test_from", 1))
+        test_step = int(_get(exp_config, "test_step", 1))
+        # one triplet per user per epoch, like PairwiseGenerator(num_positives_per_user=1)
+        # (data/generators.py:182-195); the last batch of an epoch is short, not dropped (:213)
+        n_data = self.num_users
+        num_batches = int(np.ceil(n_data / batch_size))
+        scores = None
+        for epoch in range(1, num_epochs + 1):
+            self.train()
+            epoch_loss = torch.zeros((), dtype=torch.float32, device=self.device)
+            self._engine.epoch_pos = (epoch - 1) * n_data
+            for b in range(num_batches):
+                bsz = min(batch_size, n_data - b * batch_size)
+                acc = self._engine.sampled_step(indptr, indices, bsz)
+                batch_loss = acc.sum() / bsz
+                epoch_loss += batch_loss
+                if verbose and b % 50 == 0:
+                    print('(%3d / %3d) loss = %.4f' % (b, num_batches, float(batch_loss)))
+            epoch_summary = {'loss': float(epoch_loss)}
+            if evaluator is not None and epoch >= test_from and epoch % test_step == 0:
+                scores = evaluator.evaluate(self)
+                epoch_summary.update(scores)
+                if loggers is not None:
+                    for logger in loggers:
+                        logger.log_metrics(epoch_summary, epoch=epoch)
+                if early_stop is not None:
+                    is_update, should_stop = early_stop.step(scores, epoch)
+                    if should_stop:
+                        break
+            else:
+                if loggers is not None:
+                    for logger in loggers:
+                        logger.log_metrics(epoch_summary, epoch=epoch)
+        best_score = early_stop.best_score if early_stop is not None else scores
+        return {'scores': best_score}
+
+    # -- models/MF.py:109-112 ----------------------------------------------------------------
+    def predict_batch_users(self, user_ids):
+        return self._k.score(self._P, self._Q, self._idx(user_ids))
+
+    # -- models/MF.py:114-132: dense [U x I] float64 with -inf at eval_pos (small problems) ------
+    def predict(self, eval_users, eval_pos, test_batch_size):
+        eval_users = np.asarray(eval_users)
+        n_bytes = eval_pos.shape[0] * eval_pos.shape[1] * 8
+        if n_bytes > 8 << 30:
+            raise MemoryError(f"predict() would materialise {n_bytes / 2**30:.0f} GiB on the host "
+                              "(models/MF.py:117); use predict_topk() for catalogs this large")
+        pred_matrix = np.zeros(eval_pos.shape)
+        mask = csr_to_device(eval_pos, self.device)
+        for s in range(0, len(eval_users), test_batch_size):
+            batch_users = eval_users[s:s + test_batch_size]
+            S = self._k.score(self._P, self._Q, self._idx(batch_users), mask=mask)
+            pred_matrix[batch_users] = S.cpu().numpy()       # rows indexed by USER ID (MF.py:128)
+        return pred_matrix
+
+    # -- the large-catalog twin: only [n x K] indices leave the device -----------------------------
+    def predict_topk(self, eval_users, eval_pos, K, test_batch_size=1024, want_values=False):
+        eval_users = np.asarray(eval_users)
+        mask = csr_to_device(eval_pos, self.device) if eval_pos is not None else None
+        out_i, out_v = [], []
+        ws = None
+        for s in range(0, len(eval_users), test_batch_size):
+            users = self._idx(eval_users[s:s + test_batch_size])
+            if ws is None:
+                ws = torch.empty(min(len(eval_users), test_batch_size, 1024) * self.num_items,
+                                 dtype=torch.float32, device=self.device)
+            r = self._k.score_topk(self._P, self._Q, users, K, mask=mask, want_values=want_values, ws=ws)
+            if want_values:
+                out_i.append(r[0].cpu().numpy()); out_v.append(r[1].cpu().numpy())
+            else:
+                out_i.append(r.cpu().numpy())
+        idx = np.concatenate(out_i) if out_i else np.zeros((0, K), np.int32)
+        return (idx, np.concatenate(out_v)) if want_values else idx

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "librsx.so")
 _lib = None
 
 RSX_USERS_UNIQUE = 1
+RSX_NO_UPDATE = 2
 RSX_LOSS_SLOTS = 64
 SUPPORTED_DIMS = (32, 64, 128)
 
@@ -26,6 +27,8 @@ SIGNATURES = {
     "rsx_bpr_step_workspace": (_I64, [_I64, _I64, _I32]),
     "rsx_bpr_step": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _I64, _I32, _F, _F, _P, _U, _P, _I64, _P]),
     "rsx_apply_item_grad": (C.c_int, [_P, _P, _I64, _I32, _F, _P]),
+    "rsx_pair_score": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P]),
+    "rsx_eval_holdout": (C.c_int, [_I64, _P, _I32, _P, _I32, _P, _P, _P]),
     "rsx_bpr_sample": (C.c_int, [_P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _P, _P, _P, _P]),
     "rsx_score": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P, _P, _P, _P]),
     "rsx_topk": (C.c_int, [_P, _I64, _I64, _I32, _P, _P, _P]),
@@ -93,15 +96,17 @@ def bpr_step_workspace(num_users, max_batch, d):
     return n
 
 
-def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False, ws=None):
+def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False, ws=None,
+             no_update=False):
     """One batch of include/rsx.h:rsx_bpr_step.  u, i, j: int32 device tensors."""
     d = P.shape[1]
     _check(lib().rsx_bpr_step(
-        _dev(P, torch.float32, "P"), _dev(Q, torch.float32, "Q"), _dev(G, torch.float32, "G"),
+        _dev(P, torch.float32, "P"), _dev(Q, torch.float32, "Q"),
+        _dev(G, torch.float32, "G") if G is not None else None,
         P.shape[0], Q.shape[0], _dev(u, torch.int32, "u"), _dev(i, torch.int32, "i"),
         _dev(j, torch.int32, "j"), u.numel(), d, float(lr), float(inv_batch),
         _dev(loss_acc, torch.float32, "loss_acc") if loss_acc is not None else None,
-        RSX_USERS_UNIQUE if users_unique else 0,
+        (RSX_USERS_UNIQUE if users_unique else 0) | (RSX_NO_UPDATE if no_update else 0),
         C.c_void_p(ws.data_ptr()) if ws is not None else None,
         ws.numel() * ws.element_size() if ws is not None else 0, _stream()), "rsx_bpr_step")
 
@@ -109,6 +114,31 @@ def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False,
 def apply_item_grad(Q, G, lr):
     _check(lib().rsx_apply_item_grad(_dev(Q, torch.float32, "Q"), _dev(G, torch.float32, "G"),
                                      Q.shape[0], Q.shape[1], float(lr), _stream()), "rsx_apply_item_grad")
+
+
+def pair_score(P, Q, u, i):
+    """r[b] = <P[u[b]], Q[i[b]]>  (MF.forward, models/MF.py:38-42)"""
+    out = torch.empty(u.numel(), dtype=torch.float32, device=P.device)
+    _check(lib().rsx_pair_score(_dev(P, torch.float32, "P"), _dev(Q, torch.float32, "Q"),
+                                _dev(u, torch.int32, "u"), _dev(i, torch.int32, "i"), u.numel(),
+                                P.shape[1], _dev(out, torch.float32, "out"), _stream()), "rsx_pair_score")
+    return out
+
+
+def eval_holdout(rankings, ks, truth_indptr, truth_indices):
+    """HOST function: numpy in, numpy out (include/rsx.h:rsx_eval_holdout)."""
+    import numpy as np
+    rankings = np.ascontiguousarray(rankings, dtype=np.int32)
+    ks = np.ascontiguousarray(ks, dtype=np.int32)
+    tp = np.ascontiguousarray(truth_indptr, dtype=np.int64)
+    ti = np.ascontiguousarray(truth_indices, dtype=np.int32)
+    n, max_k = rankings.shape
+    if len(tp) != n + 1:
+        raise RsxError("truth_indptr must have one entry per ranked user plus one")
+    res = np.zeros((n, 3 * len(ks)), dtype=np.float32)
+    _check(lib().rsx_eval_holdout(n, rankings.ctypes.data, max_k, ks.ctypes.data, len(ks),
+                                  tp.ctypes.data, ti.ctypes.data, res.ctypes.data), "rsx_eval_holdout")
+    return res
 
 
 def bpr_sample(indptr, indices, num_items, batch, seed, step, epoch_pos, u_out, i_out, j_out):

@@ -1,0 +1,62 @@
+"""TEST INFRASTRUCTURE: a CPU stand-in for the `kernels` argument of
+recsys_pytorch_amd.sharded.BPREngine, backed by the oracle (oracle/mf_oracle.c).
+It exists so the sharding / collective logic can run under gloo without a GPU.
+It is never importable from the product package."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+import oracle
+
+RSX_LOSS_SLOTS = 64
+
+
+def bpr_step_workspace(num_users, max_batch, d):
+    return 16
+
+
+def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False, ws=None, no_update=False):
+    """same contract as include/rsx.h:rsx_bpr_step, on host tensors: G += dQ (scaled by
+    inv_batch), P -= lr*dP, loss slots += sum softplus(-x)."""
+    Pn, Qn = P.numpy(), Q.numpy()
+    B = int(u.numel())
+    keep = (i.numpy() >= 0)
+    uu, ii, jj = (t.numpy().astype(np.int64)[keep] for t in (u, i, j))
+    gP, gQ = np.zeros_like(Pn), np.zeros_like(Qn)
+    loss = C.c_double(0)
+    if len(uu):
+        oracle.lib().orc_bpr_grad(Pn, Qn, uu, ii, jj, len(uu), Pn.shape[1], gP, gQ, C.byref(loss))
+    scale = float(inv_batch) * len(uu)      # orc_bpr_grad uses 1/len(batch); rescale to inv_batch
+    if loss_acc is not None:
+        loss_acc[0] += float(loss.value) * len(uu)
+    if no_update:
+        return
+    G += torch.from_numpy(gQ * np.float32(scale))
+    P -= torch.from_numpy(gP * np.float32(scale * lr))
+
+
+def apply_item_grad(Q, G, lr):
+    Q -= lr * G
+    G.zero_()
+
+
+def bpr_sample(indptr, indices, num_items, batch, seed, step, epoch_pos, u_out, i_out, j_out):
+    """simple host sampler with the same guarantees (unique users, true pos, true neg)"""
+    U = indptr.numel() - 1
+    rng = np.random.default_rng(seed + 1000003 * step)
+    perm = np.random.default_rng(seed + (epoch_pos // U)).permutation(U)
+    ip, ix = indptr.numpy(), indices.numpy()
+    for b in range(batch):
+        u = perm[(epoch_pos + b) % U]
+        row = ix[ip[u]:ip[u + 1]]
+        u_out[b] = int(u)
+        if len(row) == 0:
+            i_out[b] = -1; j_out[b] = -1
+            continue
+        i_out[b] = int(row[rng.integers(len(row))])
+        while True:
+            j = int(rng.integers(num_items))
+            if j not in row:
+                break
+        j_out[b] = j

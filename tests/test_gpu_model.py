@@ -1,0 +1,159 @@
+"""GPU: the MF model class behind the reference interface, the device sampler, and the
+engine on the HIP kernels.  Run with `-m gpu` on an MI355X."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import G1_SGD, GOLDEN, golden, rel_err, split_batches
+
+pytestmark = pytest.mark.gpu
+HP = {"hidden_dim": 32, "pointwise": False, "loss_func": "ce"}     # conf/MF.yaml keys
+
+
+@pytest.fixture(scope="module")
+def ml100k():
+    import recsys_pytorch_amd as pkg
+    return pkg.InteractionData.from_npz(os.path.join(GOLDEN, "ml100k_csr.npz"))
+
+
+def test_model_replay_matches_reference_golden(ml100k):
+    """MF.train_step on the reference PairwiseGenerator's own batches (config C1 shape)"""
+    import recsys_pytorch_amd as pkg
+    g = golden(G1_SGD[1])
+    m = pkg.MF(ml100k, dict(HP, lr=float(g["lr"])), "cuda")
+    m.load_tables(g["P0"], g["Q0"])
+    for t, (u, i, j) in enumerate(split_batches(g)):
+        loss = m.train_step(u, i, j, users_unique=True)        # one triplet per user (quirk Q3)
+        assert abs(float(loss) - g["loss"][t]) < 1e-5
+    assert rel_err(m.user_embedding.weight.cpu().numpy(), g["PT"]) < 1e-5
+    assert rel_err(m.item_embedding.weight.cpu().numpy(), g["QT"]) < 1e-5
+    # loss-only entry point (process_one_batch, MF.py:99-107) and forward (MF.py:38-42)
+    u, i, j = next(split_batches(g))
+    m.load_tables(g["P0"], g["Q0"])
+    assert abs(float(m.process_one_batch(u, i, j)) - g["loss"][0]) < 1e-5
+    r = m.forward(u, i).cpu().numpy()
+    assert np.allclose(r, np.sum(g["P0"][u] * g["Q0"][i], 1), atol=1e-6)
+    assert rel_err(m.user_embedding.weight.cpu().numpy(), g["P0"]) == 0.0   # nothing was updated
+
+
+def test_hidden_dim_padding_d50(oracle_mod):
+    """conf/MF.yaml ships hidden_dim 50: stored as 64 columns, the pad stays zero"""
+    import recsys_pytorch_amd as pkg
+    rng = np.random.default_rng(2)
+    ds = types.SimpleNamespace(num_users=120, num_items=80)
+    m = pkg.MF(ds, dict(HP, hidden_dim=50, lr=0.05), "cuda")
+    P0 = (rng.standard_normal((120, 50)) * 0.1).astype(np.float32)
+    Q0 = (rng.standard_normal((80, 50)) * 0.1).astype(np.float32)
+    m.load_tables(P0, Q0)
+    orc = oracle_mod.MFOracle(P0, Q0, "sgd", 0.05)
+    for _ in range(3):
+        u, i, j = rng.integers(0, 120, 77), rng.integers(0, 80, 77), rng.integers(0, 80, 77)
+        l = m.train_step(u, i, j)
+        assert abs(float(l) - orc.step(u, i, j)) < 1e-5
+    assert rel_err(m.user_embedding.weight.cpu().numpy(), orc.P) < 1e-5
+    assert rel_err(m.item_embedding.weight.cpu().numpy(), orc.Q) < 1e-5
+    assert float(m._P[:, 50:].abs().max()) == 0.0 and float(m._Q[:, 50:].abs().max()) == 0.0
+    S = m.predict_batch_users(np.arange(120)).cpu().numpy()
+    assert rel_err(S, orc.score(np.arange(120))) < 2e-6
+
+
+def test_predict_and_predict_topk_agree_with_oracle(ml100k, oracle_mod):
+    import recsys_pytorch_amd as pkg
+    g, b = golden(G1_SGD[1]), golden("g23_ml100k_d32_b256")
+    m = pkg.MF(ml100k, HP, "cuda")
+    m.load_tables(g["PT"], g["QT"])
+    users = np.arange(ml100k.num_users)
+    pred = m.predict(users, ml100k.train_data, 64)             # float64 [U x I], -inf at train positives
+    assert pred.dtype == np.float64 and pred.shape == ml100k.train_data.shape
+    ref = oracle_mod.score(g["PT"], g["QT"], users)
+    oracle_mod.mask_seen(ref, users, b["mask_indptr"], b["mask_indices"])
+    assert np.array_equal(np.isneginf(pred), np.isneginf(ref))
+    ok = ~np.isneginf(ref)
+    assert np.max(np.abs(pred[ok] - ref[ok])) < 2e-6 * np.max(np.abs(ref[ok]))
+    for K in (5, 50):
+        top = m.predict_topk(users, ml100k.train_data, K, 256)
+        safe = b[f"gap_{K}"] > 1e-5
+        for r in np.nonzero(safe)[0]:
+            assert set(top[r]) == set(b[f"topk_cy_{K}"][r])
+
+
+def test_fit_with_evaluator_end_to_end(ml100k):
+    """main.py:62-68 flow: Evaluator(valid_input, valid_target) + model.fit(...)"""
+    import recsys_pytorch_amd as pkg
+    torch.manual_seed(2020)
+    ev = pkg.Evaluator(ml100k.valid_input, ml100k.valid_target, "holdout", [5, 10])
+    m = pkg.MF(ml100k, dict(HP, lr=5.0), "cuda")
+    with torch.no_grad():
+        m._P.mul_(0.1); m._Q.mul_(0.1)
+    logged = []
+    logger = types.SimpleNamespace(log_metrics=lambda d, epoch: logged.append((epoch, dict(d))))
+    cfg = types.SimpleNamespace(batch_size=256, num_epochs=30, verbose=0, test_from=10, test_step=10)
+    before = ev.evaluate(m)
+    ret = m.fit(ml100k, cfg, evaluator=ev, loggers=[logger])
+    after = ret["scores"]
+    assert set(after) == {"Prec@5", "Prec@10", "Recall@5", "Recall@10", "NDCG@5", "NDCG@10"}
+    assert [e for e, _ in logged] == list(range(1, 31))
+    assert "NDCG@10" in logged[9][1] and "NDCG@10" not in logged[0][1]
+    assert logged[-1][1]["loss"] < logged[0][1]["loss"]          # BPR loss goes down
+    assert after["NDCG@10"] > 3 * before["NDCG@10"] + 0.01       # and ranking quality goes up
+
+
+def test_device_sampler_properties(ml100k):
+    from recsys_pytorch_amd import rsx
+    from recsys_pytorch_amd.data import csr_to_device
+    ip, ix = csr_to_device(ml100k.train_data, "cuda")
+    U, I = ml100k.num_users, ml100k.num_items
+    mk = lambda n: torch.empty(n, dtype=torch.int32, device="cuda")
+    u, i, j = mk(U), mk(U), mk(U)
+    rsx.bpr_sample(ip, ix, I, U, 2020, 3, 0, u, i, j)
+    un, inn, jn = u.cpu().numpy(), i.cpu().numpy(), j.cpu().numpy()
+    assert sorted(un) == list(range(U))                          # a permutation: every user exactly once
+    ipn, ixn = ip.cpu().numpy(), ix.cpu().numpy()
+    for a, b, c in zip(un, inn, jn):
+        row = ixn[ipn[a]:ipn[a + 1]]
+        assert b in row and c not in row and 0 <= c < I          # true positive, true negative
+    u2, i2, j2 = mk(U), mk(U), mk(U)
+    rsx.bpr_sample(ip, ix, I, U, 2020, 3, 0, u2, i2, j2)
+    assert torch.equal(u, u2) and torch.equal(i, i2) and torch.equal(j, j2)   # deterministic
+    rsx.bpr_sample(ip, ix, I, U, 2020, 4, U, u2, i2, j2)
+    assert not torch.equal(u, u2)                                # next epoch: another permutation
+    assert sorted(u2.cpu().numpy()) == list(range(U))
+    # negatives are ~uniform over non-positives: chi-square-ish sanity on 8 item buckets
+    big = 200_000
+    ub, ib, jb = mk(big), mk(big), mk(big)
+    for s in range(0, big, U):
+        n = min(U, big - s)
+        rsx.bpr_sample(ip, ix, I, n, 7, s, s // U * U, ub[s:s + n], ib[s:s + n], jb[s:s + n])
+    h = np.bincount(jb.cpu().numpy() * 8 // I, minlength=8)
+    assert h.min() > 0.5 * big / 8
+
+
+def test_sampled_triplets_replay_through_oracle(oracle_mod):
+    """parity of the sampled path: dump the device-sampled triplets, replay on the CPU oracle"""
+    from recsys_pytorch_amd.data import synthetic_csr
+    from recsys_pytorch_amd.sharded import BPREngine
+    U, I, d, B = 20_000, 3_000, 128, 4096
+    ip, ix = synthetic_csr(U, I, 20, "cuda", seed=1)
+    torch.manual_seed(3)
+    P = torch.randn(U, d, device="cuda") * 0.1
+    Q = torch.randn(I, d, device="cuda") * 0.1
+    orc = oracle_mod.MFOracle(P.cpu().numpy(), Q.cpu().numpy(), "sgd", 0.05)
+    eng = BPREngine(P, Q, 0.05)
+    for _ in range(6):
+        u, i, j = eng.sample(ip, ix, B)
+        lo = orc.step(u.cpu().numpy(), i.cpu().numpy(), j.cpu().numpy())
+        acc = eng.step(u, i, j, users_unique=True)
+        assert abs(float(acc.sum()) / B - lo) < 1e-5
+    assert rel_err(P.cpu().numpy(), orc.P) < 1e-5 and rel_err(Q.cpu().numpy(), orc.Q) < 1e-5
+
+
+def test_synthetic_csr_shape_and_popularity():
+    from recsys_pytorch_amd.data import synthetic_csr
+    ip, ix = synthetic_csr(50_000, 10_000, 20, "cuda", seed=2020)
+    rows = ix.view(50_000, 20).cpu().numpy()
+    assert np.all(np.diff(rows, axis=1) > 0)                     # sorted, no duplicates per user
+    cnt = np.bincount(rows.reshape(-1), minlength=10_000)
+    assert cnt[0] > 20 * cnt[1000:1100].mean()                   # head is much more popular than the tail

@@ -144,7 +144,13 @@ def test_linearity_of_item_gradient_full_size(rsx):
     touched = torch.zeros(U, dtype=torch.bool, device="cuda")
     touched[u.long()] = True
     assert torch.equal(Pa[~touched], P[~touched]), "rows of users outside the batch must not move"
-    assert torch.allclose((Pb - P), 2 * (Pa - P), rtol=1e-3, atol=1e-8)
+    # user-row update is linear in lr (inv_batch = 1 makes the deltas large against fp32 ulp of P)
+    Pc, Pd = P.clone(), P.clone()
+    G1.zero_(); G2.zero_()
+    rsx.bpr_step(Pc, Q, G1, u, i, j, 0.05, 1.0, users_unique=True)
+    rsx.bpr_step(Pd, Q, G2, u, i, j, 0.10, 1.0, users_unique=True)
+    torch.cuda.synchronize()
+    assert torch.allclose((Pd - P), 2 * (Pc - P), rtol=1e-3, atol=2e-7)
 
 
 # ------------------------------------------------------------------ scoring / top-k

@@ -1,0 +1,98 @@
+"""Host logic on the CPU: metrics behind the C ABI, shard arithmetic, the step engine
+(with the oracle-backed kernels stand-in), and the loud failure without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+import cpu_kernels
+from conftest import G1_SGD, golden, rel_err, split_batches
+
+
+def test_eval_holdout_matches_reference_golden():
+    from recsys_pytorch_amd import rsx
+    g, c = golden("g4_eval_ml100k"), golden("ml100k_csr")
+    res = rsx.eval_holdout(g["topk10"], [5, 10], c["valid_indptr"], c["valid_indices"].astype(np.int32))
+    assert np.allclose(res, g["per_user"], atol=1e-6)             # holdout.h:29-70
+    assert np.allclose(res.mean(0, dtype=np.float32), g["scores_py"], atol=1e-6)
+
+
+def test_eval_holdout_matches_reference_native(oracle_mod):
+    from recsys_pytorch_amd import rsx
+    if oracle_mod.ref_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(3)
+    n, I, mk = 200, 500, 20
+    rk = np.stack([rng.permutation(I)[:mk] for _ in range(n)]).astype(np.int32)
+    lens = rng.integers(1, 40, n)
+    ip = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    ix = np.concatenate([rng.permutation(I)[:l] for l in lens]).astype(np.int32)   # unsorted rows
+    a = rsx.eval_holdout(rk, [1, 5, 20], ip, ix)
+    b = oracle_mod.holdout(rk, [1, 5, 20], ip, ix, use_ref=True)
+    assert np.allclose(a, b, atol=1e-6)
+
+
+def test_eval_holdout_rejects_bad_k():
+    from recsys_pytorch_amd import rsx
+    with pytest.raises(rsx.RsxError):
+        rsx.eval_holdout(np.zeros((2, 5), np.int32), [6], np.array([0, 1, 2]), np.array([0, 1], np.int32))
+
+
+def test_user_block_partition():
+    from recsys_pytorch_amd.sharded import user_block
+    for U, W in ((10, 3), (1_000_000, 8), (7, 8), (943, 2)):
+        blocks = [user_block(U, r, W) for r in range(W)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == U
+        for (a, b), (c, d) in zip(blocks, blocks[1:]):
+            assert b == c and a <= b
+
+
+@pytest.mark.parametrize("name", [G1_SGD[0], G1_SGD[2]])
+def test_engine_replay_matches_reference_golden_on_cpu_kernels(name):
+    """the engine's step sequence (step -> apply) with the oracle-backed kernels"""
+    from recsys_pytorch_amd.sharded import BPREngine
+    g = golden(name)
+    P, Q = torch.from_numpy(g["P0"].copy()), torch.from_numpy(g["Q0"].copy())
+    eng = BPREngine(P, Q, float(g["lr"]), kernels=cpu_kernels)
+    for t, (u, i, j) in enumerate(split_batches(g)):
+        acc = eng.step(torch.from_numpy(u).int(), torch.from_numpy(i).int(), torch.from_numpy(j).int())
+        assert abs(float(acc.sum()) / len(u) - g["loss"][t]) < 1e-5
+    assert rel_err(P.numpy(), g["PT"]) < 1e-5 and rel_err(Q.numpy(), g["QT"]) < 1e-5
+
+
+def test_engine_sampler_epoch_logic():
+    from recsys_pytorch_amd.sharded import BPREngine
+    c = golden("ml100k_csr")
+    U, I = int(c["num_users"]), int(c["num_items"])
+    ip = torch.from_numpy(c["train_indptr"]); ix = torch.from_numpy(c["train_indices"].astype(np.int32))
+    eng = BPREngine(torch.zeros(U, 32), torch.zeros(I, 32), 0.05, kernels=cpu_kernels)
+    seen = []
+    for _ in range(4):   # 943 users, batch 256: 3 full batches then a restart (tail dropped)
+        u, i, j = eng.sample(ip, ix, 256)
+        assert len(torch.unique(u)) == 256
+        seen.append(u.clone())
+    assert eng.epoch_pos == 943 + 256          # 4th batch started a new pass
+    assert len(torch.unique(torch.cat(seen[:3]))) == 768
+
+
+def test_model_fails_loudly_without_gpu():
+    """no silent CPU path: the product model on a host device must raise, not compute"""
+    import recsys_pytorch_amd as pkg
+    from recsys_pytorch_amd import rsx
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ds = pkg.InteractionData.from_npz(__import__("os").path.join(__import__("conftest").GOLDEN, "ml100k_csr.npz"))
+    m = pkg.MF(ds, {"hidden_dim": 32, "pointwise": False, "loss_func": "ce"}, "cpu")
+    with pytest.raises(rsx.RsxError):
+        m.train_step(np.array([0, 1]), np.array([1, 2]), np.array([3, 4]))
+    with pytest.raises(rsx.RsxError):
+        m.predict_batch_users(np.array([0, 1]))
+
+
+def test_registry_and_interface_names():
+    import recsys_pytorch_amd as pkg
+    cls = getattr(pkg, "MF")                                   # main.py:46-47
+    for name in ("forward", "fit", "predict", "embeddings", "process_one_batch", "predict_batch_users"):
+        assert callable(getattr(cls, name))
+    assert issubclass(cls, pkg.BaseModel) and issubclass(pkg.BaseModel, torch.nn.Module)
+    with pytest.raises(NotImplementedError):
+        cls(type("D", (), {"num_users": 4, "num_items": 4})(), {"hidden_dim": 8, "pointwise": True, "loss_func": "ce"}, "cpu")

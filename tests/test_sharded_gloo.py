@@ -1,0 +1,61 @@
+"""world_size-2 gloo run of the user-sharded engine on CPU: two ranks on their own
+triplets must equal one process on the concatenated batch (fp32 summation tolerance),
+and the item replicas must stay identical (SURVEY section 8e parity check)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _worker(rank, world, port, P0, Q0, batches, lr, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cpu_kernels
+    from recsys_pytorch_amd.sharded import BPREngine, user_block
+    lo, hi = user_block(P0.shape[0], rank, world)
+    P = torch.from_numpy(P0[lo:hi].copy())
+    Q = torch.from_numpy(Q0.copy())
+    eng = BPREngine(P, Q, lr, kernels=cpu_kernels, user_begin=lo)
+    losses, sums = [], []
+    for (u, i, j) in batches:
+        ul, il, jl = eng.route(torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(j))
+        acc = eng.step(ul, il, jl)                      # global batch size found by all-reduce
+        losses.append(float(acc.sum()) / len(u))
+        sums.append(eng.item_checksum())
+    out[rank] = (lo, hi, P.numpy().copy(), Q.numpy().copy(), losses, sums)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_equal_one_process(oracle_mod):
+    rng = np.random.default_rng(9)
+    U, I, d, B, T, lr = 301, 97, 64, 200, 5, 0.05
+    P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+    batches = [(rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)) for _ in range(T)]
+    batches.append((rng.integers(0, 150, 64), rng.integers(0, I, 64), rng.integers(0, I, 64)))  # rank 1 idle
+    single = oracle_mod.MFOracle(P0, Q0, "sgd", lr)
+    ref_losses = [single.step(*b) for b in batches]
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(world, port, P0, Q0, batches, lr, out), nprocs=world, join=True)
+    P = np.zeros_like(P0)
+    for r in range(world):
+        lo, hi, Pr, Qr, losses, sums = out[r]
+        P[lo:hi] = Pr
+        assert np.allclose(losses, ref_losses, rtol=1e-5, atol=1e-6)
+    assert np.array_equal(out[0][3], out[1][3]), "item replicas diverged"
+    assert out[0][5] == out[1][5]
+    err = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
+    assert err(P, single.P) < 1e-5 and err(out[0][3], single.Q) < 1e-5

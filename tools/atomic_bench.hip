@@ -1,0 +1,60 @@
+// tools/atomic_bench.hip -- development probe: device-scope atomic throughput on MI355X
+// by operand type and access shape (random 512-B rows, 128 B per row per instruction).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <vector>
+#define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1;}}while(0)
+
+// each 32-lane half-wave owns one random row of 128 floats (512 B); MODE selects the op
+template <int MODE>
+__global__ __launch_bounds__(256) void k(float* G, const int* rows, int64_t n)
+{
+    const int lane = threadIdx.x & 63, sub = lane >> 5, kk = lane & 31;
+    int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t b = w * 2 + sub; b < n; b += nw * 2) {
+        float* row = G + (size_t)rows[b] * 128;
+        if (MODE == 0) {          // 4 x f32 atomics, 128 B contiguous per row per instr
+            for (int c = 0; c < 4; ++c) __hip_atomic_fetch_add(row + kk + 32 * c, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (MODE == 1) {   // 2 x u64 atomics, 256 B contiguous per row per instr
+            unsigned long long* r64 = (unsigned long long*)row;
+            for (int c = 0; c < 2; ++c) __hip_atomic_fetch_add(r64 + kk + 32 * c, 0x100000001ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (MODE == 2) {   // 4 x u32 atomics
+            unsigned* r32 = (unsigned*)row;
+            for (int c = 0; c < 4; ++c) __hip_atomic_fetch_add(r32 + kk + 32 * c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (MODE == 3) {   // 2 x f64 atomics
+            double* r64 = (double*)row;
+            for (int c = 0; c < 2; ++c) __hip_atomic_fetch_add(r64 + kk + 32 * c, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (MODE == 4) {   // plain RMW (non-atomic) for reference
+            for (int c = 0; c < 4; ++c) row[kk + 32 * c] += 1.0f;
+        } else if (MODE == 5) {   // f32 atomics, workgroup scope (XCD-local L2?)
+            for (int c = 0; c < 4; ++c) __hip_atomic_fetch_add(row + kk + 32 * c, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (MODE == 6) {   // plain stores only
+            for (int c = 0; c < 4; ++c) row[kk + 32 * c] = 1.0f;
+        } else if (MODE == 7) {   // packed bf16 atomics: 2 x (2 bf16 per dword)... use pk_add_f16 via builtin if available
+            for (int c = 0; c < 2; ++c) {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                h2 v = {(_Float16)1.0f, (_Float16)1.0f};
+                __builtin_amdgcn_global_atomic_fadd_v2f16((h2 __attribute__((address_space(1)))*)((h2*)row + kk + 32 * c), v);
+            }
+        }
+    }
+}
+
+int main()
+{
+    const int64_t I = 100000, n = 2000000;
+    float* G; int* rows;
+    CK(hipMalloc(&G, I * 128 * 4)); CK(hipMemset(G, 0, I * 128 * 4));
+    std::vector<int> h(n); uint64_t s = 88172645463325252ull;
+    for (auto& x : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; x = (int)(s % I); }
+    CK(hipMalloc(&rows, n * 4)); CK(hipMemcpy(rows, h.data(), n * 4, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const char* names[] = {"f32 atomic x4 (512B/row)", "u64 atomic x2 (512B/row)", "u32 atomic x4", "f64 atomic x2", "plain RMW x4", "f32 atomic wg-scope x4", "plain store x4", "pk f16 atomic x2 (256B/row)"};
+#define RUN(M) { for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(k<M>, dim3(2048), dim3(256), 0, 0, G, rows, n); \
+    hipEventRecord(e0); for (int it = 0; it < 10; ++it) hipLaunchKernelGGL(k<M>, dim3(2048), dim3(256), 0, 0, G, rows, n); hipEventRecord(e1); hipEventSynchronize(e1); \
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10; printf("%-32s %8.1f us  %7.1f M rows/s\n", names[M], ms * 1e3, n / ms / 1e3); }
+    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7)
+    return 0;
+}
