@@ -59,7 +59,7 @@ def cpu_baseline(args):
     """reference path (dense autograd + optimizer sweep) as ported in oracle/torch_port.py,
     SGD like the GPU path, same U/I/d, bounded to ~10-30 s of CPU work."""
     from oracle.torch_port import TorchMFPort
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)   # dense fp32 sweeps stop scaling (and regress) past ~64 threads
     torch.set_num_threads(cores)
     U, I, d, B = args.users, args.items, args.dim, args.cpu_batch
     g = torch.Generator().manual_seed(2020)

@@ -85,20 +85,20 @@ def test_fit_with_evaluator_end_to_end(ml100k):
     import recsys_pytorch_amd as pkg
     torch.manual_seed(2020)
     ev = pkg.Evaluator(ml100k.valid_input, ml100k.valid_target, "holdout", [5, 10])
-    m = pkg.MF(ml100k, dict(HP, lr=5.0), "cuda")
+    m = pkg.MF(ml100k, dict(HP, lr=20.0), "cuda")
     with torch.no_grad():
         m._P.mul_(0.1); m._Q.mul_(0.1)
     logged = []
     logger = types.SimpleNamespace(log_metrics=lambda d, epoch: logged.append((epoch, dict(d))))
-    cfg = types.SimpleNamespace(batch_size=256, num_epochs=30, verbose=0, test_from=10, test_step=10)
+    cfg = types.SimpleNamespace(batch_size=128, num_epochs=40, verbose=0, test_from=10, test_step=10)
     before = ev.evaluate(m)
     ret = m.fit(ml100k, cfg, evaluator=ev, loggers=[logger])
     after = ret["scores"]
     assert set(after) == {"Prec@5", "Prec@10", "Recall@5", "Recall@10", "NDCG@5", "NDCG@10"}
-    assert [e for e, _ in logged] == list(range(1, 31))
+    assert [e for e, _ in logged] == list(range(1, 41))
     assert "NDCG@10" in logged[9][1] and "NDCG@10" not in logged[0][1]
     assert logged[-1][1]["loss"] < logged[0][1]["loss"]          # BPR loss goes down
-    assert after["NDCG@10"] > 3 * before["NDCG@10"] + 0.01       # and ranking quality goes up
+    assert after["NDCG@10"] > before["NDCG@10"] + 0.05           # and ranking quality goes up (CPU oracle run: 0.013 -> 0.19)
 
 
 def test_device_sampler_properties(ml100k):
