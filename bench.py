@@ -5,8 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one batch of synthetic triplets:
-  device sampling (rsx_bpr_sample) -> rsx_bpr_step -> [all-reduce of the item
-  gradients over RCCL when N > 1] -> rsx_apply_item_grad.
+  device sampling (rsx_bpr_sample, on a second stream, one step ahead) -> rsx_bpr_step
+  -> [all-reduce of the item gradients over RCCL when N > 1] -> rsx_apply_item_grad.
 Workload = BASELINE.json configs[2] (the d=128 shape the metric is quoted on):
 1M users x 100K items per GPU, d=128, Zipf item popularity, 20 positives/user,
 tables N(0, 0.1^2) resident in HBM before the timed region.  Weak scaling: every
@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--lr", type=float, default=0.05)
     ap.add_argument("--score-tiles", type=int, default=16, help="1024-user tiles scored for scores/s (0 = skip)")
     ap.add_argument("--topk", type=int, default=50)
+    ap.add_argument("--hot", type=int, default=256, help="popular items whose gradient rows are replicated (0 = off)")
+    ap.add_argument("--hot-replicas", type=int, default=16)
+    ap.add_argument("--neg-block", type=int, default=8, help="item block of the stratified negatives (0 = independent uniform negatives)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=65_536)
     return ap.parse_args()
@@ -110,18 +113,52 @@ def main():
     indptr, indices = synthetic_csr(U, I, args.degree, dev, seed=2020 + rank, popularity=args.popularity)
     eng = BPREngine(P, Q, args.lr, user_begin=rank * U, seed=2020)
     gb = B * world
+    neg_block = eng.set_neg_block(B, args.neg_block) if args.neg_block > 0 else 0
+    if args.hot > 0:
+        eng.set_hot_items(torch.bincount(indices.long(), minlength=I), args.hot, args.hot_replicas)
+
+    # the sampler of step t+1 runs on a second HIP stream while step t computes (it reads only
+    # the CSR); both are inside the timed region
+    side = torch.cuda.Stream(device=dev)
+    bufs = [{"t": eng._triplet_buffers(B), "ready": None, "free": None, "key": 0} for _ in range(2)]
+    state = {"cur": 0, "next_step": 0}
+
+    def prefetch(slot):
+        buf = bufs[slot]
+        if buf["free"] is not None:
+            side.wait_event(buf["free"])
+        with torch.cuda.stream(side):
+            buf["key"] = eng._launch_sample(indptr, indices, B, buf["t"], state["next_step"])
+            buf["ready"] = torch.cuda.Event()
+            buf["ready"].record(side)
+        state["next_step"] += 1
+
+    side.wait_stream(torch.cuda.current_stream())
+    prefetch(0)
 
     def one_step(ev=None):
-        u, i, j = eng.sample(indptr, indices, B)
+        main = torch.cuda.current_stream()
+        cur = state["cur"]
+        buf = bufs[cur]
+        main.wait_event(buf["ready"])
+        prefetch(cur ^ 1)
+        u, i, j = buf["t"]
+        use_hot = eng.hot is not None and not neg_block
         if ev is not None:
             ev[0].record()
-        rsx.bpr_step(eng.P, eng.Q, eng.G, u, i, j, eng.lr, 1.0 / gb, users_unique=True)
+        rsx.bpr_step(eng.P, eng.Q, eng.G, u, i, j, eng.lr, 1.0 / gb, users_unique=True,
+                     hot=eng.hot if use_hot else None, neg_block=neg_block, neg_key=buf["key"])
         if ev is not None:
             ev[1].record()
+        buf["free"] = torch.cuda.Event()
+        buf["free"].record(main)
+        if use_hot:
+            rsx.fold_hot_grad(eng.G, eng.hot)
         if world > 1:
             dist.all_reduce(eng.G, op=dist.ReduceOp.SUM)
         rsx.apply_item_grad(eng.Q, eng.G, eng.lr)
         eng.step_count += 1
+        state["cur"] = cur ^ 1
 
     def fence():
         torch.cuda.synchronize()
@@ -190,6 +227,9 @@ def main():
                                    "on-device negative sampling, SGD",
                        "users_per_gpu": U, "items": I, "d": d, "batch_per_gpu": B, "global_batch": gb,
                        "positives_per_user": args.degree, "item_popularity": args.popularity, "lr": args.lr,
+                       "negatives": f"stratified by item block of {neg_block}, batch sorted by positive item" if neg_block else "independent uniform",
+                       "sampler": "on device, overlapped on a second HIP stream",
+                       "hot_items": args.hot, "hot_replicas": args.hot_replicas if args.hot > 0 else 0,
                        "parallelism": f"user-sharded x{world}, items replicated, 1 all-reduce(G)/step" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "bpr_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -41,6 +41,9 @@ extern "C" {
 #define RSX_NO_UPDATE 2u    /* evaluate the loss only: P and G are not written             */
                             /* (models/MF.py:99-107 process_one_batch without backward)    */
 
+/* flags for rsx_bpr_sample */
+#define RSX_SAMPLE_SORT_POS 1u /* order the batch by positive item (needs a workspace)       */
+
 #define RSX_LOSS_SLOTS 64   /* loss accumulator is float[RSX_LOSS_SLOTS] (striped atomics) */
 
 typedef void *rsx_stream_t;
@@ -85,13 +88,32 @@ int rsx_device_info_get(int device, rsx_device_info *out);
  *   Q is NOT modified here.  G must be zero before the first step; it is
  *   consumed (and re-zeroed) by rsx_apply_item_grad.
  *   Triplets with i < 0 are skipped (users without positives).
+ *   hot_slot_dev / G_hot / hot_replicas (all nullable/0): contention relief for very
+ *     popular items.  hot_slot_dev is int32 [num_items], the hot slot s of an item or -1;
+ *     the positive-item gradient of a hot item goes to one of `hot_replicas` (power of
+ *     two) private rows G_hot[(s*hot_replicas + r)*d ...] instead of G[i].  The caller
+ *     runs rsx_fold_hot_grad before G is all-reduced / applied.  Sums are unchanged.
+ *   neg_block (0 = off, <= 16; needs RSX_USERS_UNIQUE): the batch was drawn by
+ *     rsx_bpr_sample with the same neg_block, i.e. the negative of triplet b lies in the
+ *     item block floor(floor(b*I/B)/neg_block).  One wavefront then owns all triplets of
+ *     a block and sums their negative-side gradients in LDS before touching G (one row
+ *     update per item instead of one per triplet).  neg_key is the sampler's block
+ *     permutation key (0 = identity).  Consecutive triplets with the same positive item
+ *     (RSX_SAMPLE_SORT_POS) are summed in registers and reach G once per run.  Triplets
+ *     that do not honour either contract are still summed correctly (atomic path).
+ *     hot_slot_dev is ignored in this mode (runs replace the replicas).
  */
 int64_t rsx_bpr_step_workspace(int64_t num_users, int64_t max_batch, int d);
 
 int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, int64_t num_items,
                  const int32_t *u_dev, const int32_t *i_dev, const int32_t *j_dev, int64_t batch,
                  int d, float lr, float inv_batch, float *loss_acc, unsigned flags,
-                 void *ws, int64_t ws_bytes, rsx_stream_t stream);
+                 void *ws, int64_t ws_bytes, const int32_t *hot_slot_dev, float *G_hot,
+                 int hot_replicas, int neg_block, uint64_t neg_key, rsx_stream_t stream);
+
+/* G[hot_items[s]] += sum_r G_hot[s][r];  G_hot = 0.   hot_items_dev: int32 [n_hot].      */
+int rsx_fold_hot_grad(float *G, float *G_hot, const int32_t *hot_items_dev, int n_hot,
+                      int hot_replicas, int d, rsx_stream_t stream);
 
 /* rsx_apply_item_grad  (phase 2 of a step; after the all-reduce of G when sharded)
  *   Q -= lr * G ;  G = 0        for every row of the [num_items x d] tables.
@@ -116,10 +138,24 @@ int rsx_pair_score(const float *P, const float *Q, const int32_t *u_dev, const i
  *           (generators.py:178-185: p = 0 on the user's positives)
  * RNG: counter-based (seed, step, b) -> splitmix64 -> xorshift32 stream; the
  * result does not depend on launch geometry.  Users with an empty row get i=-1.
+ * neg_block = c > 0: the negative of batch position p is drawn uniformly from the item
+ *   block pi(w)*c .. pi(w)*c + c, w = floor(floor(p*I/B)/c), pi = permutation of the
+ *   blocks keyed by neg_key (0 = identity), instead of from all items.  A user's
+ *   position in the keyed user permutation is uniform, so each user still sees a
+ *   uniformly distributed negative (exactly so when c | I and I | B); what changes is
+ *   that the negatives of one step are stratified over the catalog (B/I per item on
+ *   average) rather than independent.  See rsx_bpr_step(neg_block).
+ * flags & RSX_SAMPLE_SORT_POS: the (user, positive) pairs are sorted by positive item
+ *   before negatives are drawn per sorted position (pass a fresh nonzero neg_key per
+ *   step so that a positive item's rank does not pin the negative block).  Needs
+ *   ws of rsx_bpr_sample_workspace() bytes (scratch, contents irrelevant).
  * indptr: int64 [num_users+1], indices: int32, sorted within each row.          */
+int64_t rsx_bpr_sample_workspace(int64_t batch, int64_t num_items);
+
 int rsx_bpr_sample(const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users,
                    int64_t num_items, int64_t batch, uint64_t seed, uint64_t step,
-                   int64_t epoch_pos, int32_t *u_out, int32_t *i_out, int32_t *j_out,
+                   int64_t epoch_pos, int neg_block, uint64_t neg_key, unsigned flags,
+                   void *ws, int64_t ws_bytes, int32_t *u_out, int32_t *i_out, int32_t *j_out,
                    rsx_stream_t stream);
 
 /* ---- full-catalog scoring + Top-K ----------------------------------------------

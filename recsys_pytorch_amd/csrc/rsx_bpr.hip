@@ -100,6 +100,16 @@ __device__ __forceinline__ float softplus_neg(float x)
     return fmaxf(-x, 0.0f) + log1pf(__expf(-fabsf(x)));
 }
 
+// Hot item rows (popular items hit by thousands of triplets per step) serialise at the
+// memory-side atomic unit (~40 same-line ops/us measured).  Their gradient is therefore
+// spread over `replicas` private copies, picked by wavefront id, and folded into G by
+// fold_hot_kernel before G is consumed.  slot == nullptr disables the indirection.
+struct HotMap {
+    const int32_t *slot;   // [num_items] hot slot of an item or -1
+    float *ghot;           // [n_hot x replicas x D], zero between steps
+    int replicas;          // power of two
+};
+
 // MODE 0: users unique in the batch -> P[u] updated in place by its owner group.
 // MODE 1: users may repeat          -> user deltas summed into GU[owner slot].
 template <int D, bool VEC, int MODE>
@@ -108,7 +118,7 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
     const int32_t *__restrict__ U_idx, const int32_t *__restrict__ I_idx,
     const int32_t *__restrict__ J_idx, int64_t B, float lr, float inv_batch,
     float *__restrict__ loss_acc, const int32_t *__restrict__ owner, float *__restrict__ GU,
-    int ablate)
+    HotMap hot, int ablate)
 {
     constexpr int LPR = D / 4;
     constexpr int TPW = 64 / LPR;  // triplets per wavefront
@@ -152,7 +162,13 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
             const float g = -sneg * inv_batch;                 // dL/dx
             if (k == 0) loss_local += softplus_neg(x);
             // item gradients (shared rows): G[i] += g p ; G[j] -= g p
-            if (!(ablate & 1)) p.atomic_axpy(G + (size_t)i * D, k, g);
+            float *gi_row = G + (size_t)i * D;
+            if (hot.slot != nullptr) {
+                const int32_t hs = hot.slot[i];
+                if (hs >= 0)
+                    gi_row = hot.ghot + ((size_t)hs * hot.replicas + (size_t)(wave & (hot.replicas - 1))) * D;
+            }
+            if (!(ablate & 1)) p.atomic_axpy(gi_row, k, g);
             if (!(ablate & 2)) p.atomic_axpy(G + (size_t)j * D, k, -g);
             // user row: P[u] -= lr * g * (qi - qj)
             const float s = -lr * g;
@@ -169,6 +185,154 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
             }
         }
         b = bn; u = un; i = in; j = jn;
+    }
+    if (loss_acc != nullptr) {
+        const float w = wave_sum(loss_local);
+        if (lane == 0) rsx_atomic_add(loss_acc + (wave & (RSX_LOSS_SLOTS - 1)), w);
+    }
+}
+
+// ---- blocked negatives + run-length positives ----------------------------------------------
+// When the batch is large against the catalog (B >= 2 I) every item row receives several
+// updates per step and the fp32 atomic unit is the bound.  The sampler can
+// order the batch so that almost all of those updates are summed on chip first:
+//  * rsx_bpr_sample(neg_block = c) draws the negative of batch position p from the item block
+//        pi(w),  w = floor(floor(p I / B) / c),   pi = keyed permutation of the blocks
+//    (a user's position is uniform, so each user still sees a uniformly distributed negative).
+//    Wavefront w of this kernel owns exactly the positions of block w, so ALL negative-side
+//    gradients of its c item rows are summed in a wave-private LDS tile (plain read-modify-write)
+//    and leave the CU once per row instead of once per triplet.
+//  * with RSX_SAMPLE_SORT_POS the positions are sorted by positive item; each lane group walks a
+//    CONTIGUOUS range and keeps the running sum of g*P[u] for the current positive item in
+//    registers, touching G once per run.
+// Neither is a correctness contract: a negative outside the wave's block and an unsorted batch
+// take the global-atomic path / runs of length one, and the sums are the same.
+template <int D>
+__global__ __launch_bounds__(kBlock) void bpr_step_blocked_kernel(
+    float *__restrict__ P, const float *__restrict__ Q, float *__restrict__ G,
+    const int32_t *__restrict__ U_idx, const int32_t *__restrict__ I_idx,
+    const int32_t *__restrict__ J_idx, int64_t B, int64_t num_items, int c, uint64_t neg_key, float lr,
+    float inv_batch, float *__restrict__ loss_acc, HotMap hot, int ablate)
+{
+    extern __shared__ __attribute__((aligned(16))) float neg_acc[];   // [4 waves][c][D]
+    constexpr int LPR = D / 4;
+    constexpr int TPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR;
+    const int k = lane % LPR;
+    const int wib = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wib;
+    const int64_t nblocks = ceil_div64(num_items, c);
+    if (wave >= nblocks) return;
+    float *acc = neg_acc + (size_t)wib * c * D;
+    for (int e = lane; e < c * D; e += 64) acc[e] = 0.0f;
+
+    // batch positions of this wavefront, and the item block its negatives come from
+    const int64_t nom_lo = wave * c;
+    const int64_t nom_hi = (nom_lo + c < num_items) ? nom_lo + c : num_items;
+    const int64_t b0 = ceil_div64(nom_lo * B, num_items);
+    const int64_t b1 = ceil_div64(nom_hi * B, num_items);
+    const int64_t item_lo = neg_block_of(wave, nblocks, neg_key) * c;
+    const int64_t item_hi = (item_lo + c < num_items) ? item_lo + c : num_items;
+    // each lane group walks a contiguous part of [b0, b1)
+    const int64_t len = ceil_div64(b1 - b0, TPW);
+    const int64_t g_lo = b0 + sub * len;
+    const int64_t g_hi = (g_lo + len < b1) ? g_lo + len : b1;
+
+    float loss_local = 0.0f;
+    int32_t run_item = -1;                       // positive item of the current run
+    float run[4] = {0.f, 0.f, 0.f, 0.f};         // sum of g*P[u] over the run
+    int32_t u = -1, i = -1, j = -1;
+    if (g_lo < g_hi) { u = U_idx[g_lo]; i = I_idx[g_lo]; j = J_idx[g_lo]; }
+    for (int64_t t = 0; t < len; ++t) {          // wave-uniform trip count
+        const int64_t b = g_lo + t;
+        const int64_t bn = b + 1;
+        int32_t un = -1, in = -1, jn = -1;
+        if (bn < g_hi) { un = U_idx[bn]; in = I_idx[bn]; jn = J_idx[bn]; }
+        bool neg_local = false;
+        float neg_g = 0.0f;
+        float pv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (b < g_hi && i >= 0) {
+            float *prow = P + (size_t)u * D;
+            Row<D, false> p, qi, qj;
+            p.load(prow, k);
+            qi.load(Q + (size_t)i * D, k);
+            qj.load(Q + (size_t)j * D, k);
+            float dpos = 0.0f, dneg = 0.0f;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                dpos = fmaf(p.v[cc], qi.v[cc], dpos);
+                dneg = fmaf(p.v[cc], qj.v[cc], dneg);
+            }
+            dpos = group_sum<LPR>(dpos);
+            dneg = group_sum<LPR>(dneg);
+            const float x = dpos - dneg;
+            const float sneg = 1.0f / (1.0f + __expf(x));
+            const float g = -sneg * inv_batch;
+            if (k == 0) loss_local += softplus_neg(x);
+            // positive item: extend the run, or flush it and start a new one
+            if (i != run_item) {
+                if (run_item >= 0 && !(ablate & 1)) {
+                    float *grow = G + (size_t)run_item * D;
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) rsx_atomic_add(grow + k + cc * LPR, run[cc]);
+                }
+                run_item = i;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) run[cc] = 0.0f;
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) run[cc] = fmaf(g, p.v[cc], run[cc]);
+            // negative item: the wave's own block goes to LDS, anything else to G
+            neg_local = ((int64_t)j >= item_lo && (int64_t)j < item_hi);
+            if (!neg_local && !(ablate & 2)) p.atomic_axpy(G + (size_t)j * D, k, -g);
+            neg_g = -g;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) pv[cc] = p.v[cc];
+            const float s = -lr * g;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) p.v[cc] = fmaf(s, qi.v[cc] - qj.v[cc], p.v[cc]);
+            if (!(ablate & 4)) p.store(prow, k);
+        }
+        // wave-private LDS tile, plain read-modify-write (ds_add_f32 measured ~120 clk per
+        // wave instruction).  The lane groups of one wavefront may hit the same row, so they
+        // take turns; LDS executes a wavefront's instructions in order.
+        if (!(ablate & 2)) {
+#pragma unroll
+            for (int tt = 0; tt < TPW; ++tt) {
+                if (sub == tt && neg_local) {
+                    float4 *cell = reinterpret_cast<float4 *>(acc) + (size_t)(j - item_lo) * LPR + k;
+                    float4 a = *cell;
+                    a.x = fmaf(neg_g, pv[0], a.x); a.y = fmaf(neg_g, pv[1], a.y);
+                    a.z = fmaf(neg_g, pv[2], a.z); a.w = fmaf(neg_g, pv[3], a.w);
+                    *cell = a;
+                }
+            }
+        }
+        u = un; i = in; j = jn;
+    }
+    if (run_item >= 0 && !(ablate & 1)) {        // last run of this lane group
+        float *grow = G + (size_t)run_item * D;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) rsx_atomic_add(grow + k + cc * LPR, run[cc]);
+    }
+    // flush the block's rows: one global atomic row per touched item
+    const int rows = (int)(item_hi - item_lo);
+    for (int m = sub; m - sub < rows; m += TPW) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        bool nz = false;
+        if (m < rows) {
+            const float4 a = reinterpret_cast<const float4 *>(acc)[(size_t)m * LPR + k];   // cell = lane k's 4 elements
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+            nz = (a.x != 0.0f) | (a.y != 0.0f) | (a.z != 0.0f) | (a.w != 0.0f);
+        }
+        const unsigned long long bal = __ballot(nz);
+        const unsigned long long gmask = (LPR == 64) ? ~0ull : (((1ull << LPR) - 1ull) << (sub * LPR));
+        if (m < rows && (bal & gmask) != 0ull) {
+            float *grow = G + (size_t)(item_lo + m) * D;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) rsx_atomic_add(grow + k + cc * LPR, v[cc]);
+        }
     }
     if (loss_acc != nullptr) {
         const float w = wave_sum(loss_local);
@@ -272,67 +436,26 @@ __global__ __launch_bounds__(kBlock) void apply_item_grad_kernel(float4 *__restr
     }
 }
 
-// ---------------------------------------------------------------- sampler ------
-__device__ __forceinline__ uint64_t splitmix64(uint64_t z)
+// G[hot_items[s]] += sum_r ghot[s][r] ; ghot = 0     (one lane group per hot row)
+template <int D>
+__global__ __launch_bounds__(kBlock) void fold_hot_kernel(float *__restrict__ G, float *__restrict__ ghot,
+                                                          const int32_t *__restrict__ hot_items, int n_hot,
+                                                          int replicas)
 {
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-
-__device__ __forceinline__ uint32_t xorshift32(uint32_t &s)
-{
-    s ^= s << 13; s ^= s >> 17; s ^= s << 5;
-    return s;
-}
-
-// keyed bijection of [0,n): 4-round Feistel over 2*hb bits with cycle walking
-__device__ __forceinline__ uint32_t feistel_perm(uint32_t x, uint32_t n, int hb, uint64_t key)
-{
-    const uint32_t mask = (1u << hb) - 1u;
-    do {
-        uint32_t l = x >> hb, r = x & mask;
-#pragma unroll
-        for (int round = 0; round < 4; ++round) {
-            const uint32_t f = (uint32_t)splitmix64(key ^ ((uint64_t)r << 8) ^ (uint64_t)round) & mask;
-            const uint32_t t = l ^ f;
-            l = r; r = t;
-        }
-        x = (l << hb) | r;
-    } while (x >= n);
-    return x;
-}
-
-__global__ __launch_bounds__(kBlock) void bpr_sample_kernel(
-    const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t U, int64_t I,
-    int64_t B, uint64_t seed, uint64_t step, int64_t epoch_pos, int hb,
-    int32_t *__restrict__ u_out, int32_t *__restrict__ i_out, int32_t *__restrict__ j_out)
-{
-    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < B; b += (int64_t)gridDim.x * kBlock) {
-        const int64_t gpos = epoch_pos + b;
-        const uint64_t epoch = (uint64_t)(gpos / U);
-        const uint32_t pos = (uint32_t)(gpos % U);
-        const uint32_t u = feistel_perm(pos, (uint32_t)U, hb, splitmix64(seed ^ (epoch * 0xD1B54A32D192ED03ull)));
-        uint32_t s = (uint32_t)splitmix64(seed ^ (step * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)b * 0xBF58476D1CE4E5B9ull));
-        s |= (s == 0);
-        const int64_t lo = indptr[u], hi = indptr[u + 1];
-        const uint32_t deg = (uint32_t)(hi - lo);
-        int32_t pi = -1, nj = -1;
-        if (deg > 0 && (int64_t)deg < I) {
-            pi = indices[lo + (int64_t)(((uint64_t)xorshift32(s) * deg) >> 32)];
-            for (;;) {
-                nj = (int32_t)(((uint64_t)xorshift32(s) * (uint64_t)I) >> 32);
-                int64_t a = lo, z = hi;     // binary search in the sorted row
-                while (a < z) {
-                    const int64_t m = (a + z) >> 1;
-                    if (indices[m] < nj) a = m + 1; else z = m;
-                }
-                if (!(a < hi && indices[a] == nj)) break;
-            }
-        }
-        u_out[b] = (int32_t)u; i_out[b] = pi; j_out[b] = nj;
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int s = t / (D / 4), k = t % (D / 4);
+    if (s >= n_hot) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 *src = reinterpret_cast<float4 *>(ghot + (size_t)s * replicas * D) + k;
+    for (int r = 0; r < replicas; ++r) {
+        const float4 v = src[(size_t)r * (D / 4)];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        src[(size_t)r * (D / 4)] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    float4 *dst = reinterpret_cast<float4 *>(G + (size_t)hot_items[s] * D) + k;
+    float4 g = *dst;
+    g.x += acc.x; g.y += acc.y; g.z += acc.z; g.w += acc.w;
+    *dst = g;
 }
 
 int g_layout_vec = 0;   // row layout used by bpr_step (0 = strided dwords, 1 = dwordx4); tuning knob
@@ -341,7 +464,7 @@ int g_ablate = 0;       // development only: 1 = skip pos-item atomics, 2 = skip
 template <int D, bool VEC, int MODE>
 void launch_step(float *P, const float *Q, float *G, const int32_t *u, const int32_t *i,
                  const int32_t *j, int64_t B, float lr, float inv_batch, float *loss_acc,
-                 const int32_t *owner, float *GU, int ablate, hipStream_t st)
+                 const int32_t *owner, float *GU, HotMap hot, int ablate, hipStream_t st)
 {
     constexpr int TPW = 64 / (D / 4);
     const int64_t waves = (B + TPW - 1) / TPW;
@@ -350,18 +473,18 @@ void launch_step(float *P, const float *Q, float *G, const int32_t *u, const int
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((bpr_step_kernel<D, VEC, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, P, Q,
-                       G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, ablate);
+                       G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot, ablate);
 }
 
 template <int MODE>
 void dispatch_step(int d, bool vec, float *P, const float *Q, float *G, const int32_t *u,
                    const int32_t *i, const int32_t *j, int64_t B, float lr, float inv_batch,
-                   float *loss_acc, const int32_t *owner, float *GU, int ablate, hipStream_t st)
+                   float *loss_acc, const int32_t *owner, float *GU, HotMap hot, int ablate, hipStream_t st)
 {
 #define RSX_CASE(DD)                                                                                   \
     case DD:                                                                                           \
-        if (vec) launch_step<DD, true, MODE>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, ablate, st); \
-        else launch_step<DD, false, MODE>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, ablate, st);    \
+        if (vec) launch_step<DD, true, MODE>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot, ablate, st); \
+        else launch_step<DD, false, MODE>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot, ablate, st);    \
         break;
     switch (d) { RSX_CASE(32) RSX_CASE(64) RSX_CASE(128) }
 #undef RSX_CASE
@@ -391,7 +514,8 @@ RSX_API int64_t rsx_bpr_step_workspace(int64_t num_users, int64_t max_batch, int
 RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, int64_t num_items,
                          const int32_t *u_dev, const int32_t *i_dev, const int32_t *j_dev,
                          int64_t batch, int d, float lr, float inv_batch, float *loss_acc,
-                         unsigned flags, void *ws, int64_t ws_bytes, rsx_stream_t stream)
+                         unsigned flags, void *ws, int64_t ws_bytes, const int32_t *hot_slot_dev,
+                         float *G_hot, int hot_replicas, int neg_block, uint64_t neg_key, rsx_stream_t stream)
 {
     RSX_CHECK_ARG(P && Q && (G || (flags & RSX_NO_UPDATE)), "null table pointer");
     RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64 or 128");
@@ -399,15 +523,34 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
     if (batch == 0) return RSX_OK;
     RSX_CHECK_ARG(u_dev && i_dev && j_dev, "null index pointer");
     hipStream_t st = (hipStream_t)stream;
+    HotMap hot{nullptr, nullptr, 1};
+    if (hot_slot_dev != nullptr) {
+        RSX_CHECK_ARG(G_hot != nullptr, "hot_slot_dev given without G_hot");
+        RSX_CHECK_ARG(hot_replicas >= 1 && (hot_replicas & (hot_replicas - 1)) == 0, "hot_replicas must be a power of two");
+        hot = HotMap{hot_slot_dev, G_hot, hot_replicas};
+    }
     if (flags & RSX_NO_UPDATE) {   // loss only: the in-place kernel with every write suppressed
         dispatch_step<0>(d, g_layout_vec != 0, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch,
-                         loss_acc, nullptr, nullptr, /*suppress every write*/ 7, st);
+                         loss_acc, nullptr, nullptr, HotMap{nullptr, nullptr, 1}, /*suppress every write*/ 7, st);
+        RSX_CHECK_LAUNCH();
+        return RSX_OK;
+    }
+    RSX_CHECK_ARG(neg_block >= 0 && neg_block <= kMaxNegBlock, "neg_block must be in [0, 16]");
+    if ((flags & RSX_USERS_UNIQUE) && neg_block > 0 && g_layout_vec == 0) {
+        const int64_t waves = ceil_div64(num_items, neg_block);
+        const unsigned blocks = (unsigned)ceil_div64(waves, kWavesPerBlock);
+        const size_t lds = (size_t)kWavesPerBlock * neg_block * d * sizeof(float);
+        switch (d) {
+        case 32: hipLaunchKernelGGL(bpr_step_blocked_kernel<32>, dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u_dev, i_dev, j_dev, batch, num_items, neg_block, neg_key, lr, inv_batch, loss_acc, hot, g_ablate); break;
+        case 64: hipLaunchKernelGGL(bpr_step_blocked_kernel<64>, dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u_dev, i_dev, j_dev, batch, num_items, neg_block, neg_key, lr, inv_batch, loss_acc, hot, g_ablate); break;
+        default: hipLaunchKernelGGL(bpr_step_blocked_kernel<128>, dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u_dev, i_dev, j_dev, batch, num_items, neg_block, neg_key, lr, inv_batch, loss_acc, hot, g_ablate); break;
+        }
         RSX_CHECK_LAUNCH();
         return RSX_OK;
     }
     if (flags & RSX_USERS_UNIQUE) {
         dispatch_step<0>(d, g_layout_vec != 0, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch,
-                         loss_acc, nullptr, nullptr, g_ablate, st);
+                         loss_acc, nullptr, nullptr, hot, g_ablate, st);
         RSX_CHECK_LAUNCH();
         return RSX_OK;
     }
@@ -422,7 +565,7 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
     const unsigned g1 = (unsigned)grid_1d(batch);
     hipLaunchKernelGGL(bpr_claim_kernel, dim3(g1), dim3(kBlock), 0, st, u_dev, i_dev, batch, owner);
     dispatch_step<1>(d, g_layout_vec != 0, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch,
-                     loss_acc, owner, GU, g_ablate, st);
+                     loss_acc, owner, GU, hot, g_ablate, st);
     const int64_t tpw = 64 / (d / 4);
     const unsigned g2 = (unsigned)grid_1d((batch + tpw - 1) / tpw * 64);
     switch (d) {
@@ -454,6 +597,24 @@ RSX_API int rsx_pair_score(const float *P, const float *Q, const int32_t *u_dev,
     return RSX_OK;
 }
 
+RSX_API int rsx_fold_hot_grad(float *G, float *G_hot, const int32_t *hot_items_dev, int n_hot,
+                              int hot_replicas, int d, rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(G && G_hot && hot_items_dev, "null pointer");
+    RSX_CHECK_ARG(rsx_dim_ok(d) && n_hot >= 0 && hot_replicas >= 1, "bad shape");
+    if (n_hot == 0) return RSX_OK;
+    const int threads = n_hot * (d / 4);
+    const unsigned g = (unsigned)((threads + kBlock - 1) / kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    switch (d) {
+    case 32: hipLaunchKernelGGL(fold_hot_kernel<32>, dim3(g), dim3(kBlock), 0, st, G, G_hot, hot_items_dev, n_hot, hot_replicas); break;
+    case 64: hipLaunchKernelGGL(fold_hot_kernel<64>, dim3(g), dim3(kBlock), 0, st, G, G_hot, hot_items_dev, n_hot, hot_replicas); break;
+    default: hipLaunchKernelGGL(fold_hot_kernel<128>, dim3(g), dim3(kBlock), 0, st, G, G_hot, hot_items_dev, n_hot, hot_replicas); break;
+    }
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+}
+
 RSX_API int rsx_apply_item_grad(float *Q, float *G, int64_t num_items, int d, float lr,
                                 rsx_stream_t stream)
 {
@@ -462,26 +623,6 @@ RSX_API int rsx_apply_item_grad(float *Q, float *G, int64_t num_items, int d, fl
     const int64_t n4 = num_items * d / 4;
     hipLaunchKernelGGL(apply_item_grad_kernel, dim3((unsigned)grid_1d(n4)), dim3(kBlock), 0,
                        (hipStream_t)stream, (float4 *)Q, (float4 *)G, n4, lr);
-    RSX_CHECK_LAUNCH();
-    return RSX_OK;
-}
-
-RSX_API int rsx_bpr_sample(const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users,
-                           int64_t num_items, int64_t batch, uint64_t seed, uint64_t step,
-                           int64_t epoch_pos, int32_t *u_out, int32_t *i_out, int32_t *j_out,
-                           rsx_stream_t stream)
-{
-    RSX_CHECK_ARG(indptr_dev && indices_dev && u_out && i_out && j_out, "null pointer");
-    RSX_CHECK_ARG(num_users > 0 && num_users < (1ll << 31) && num_items > 0 && num_items < (1ll << 31),
-                  "table sizes must fit int32");
-    RSX_CHECK_ARG(batch >= 0 && epoch_pos >= 0, "negative size");
-    if (batch == 0) return RSX_OK;
-    int bits = 1;
-    while ((1ll << bits) < num_users) ++bits;
-    const int hb = (bits + 1) / 2;
-    hipLaunchKernelGGL(bpr_sample_kernel, dim3((unsigned)grid_1d(batch)), dim3(kBlock), 0,
-                       (hipStream_t)stream, indptr_dev, indices_dev, num_users, num_items, batch, seed,
-                       step, epoch_pos, hb, u_out, i_out, j_out);
     RSX_CHECK_LAUNCH();
     return RSX_OK;
 }

@@ -38,3 +38,52 @@ __device__ __forceinline__ void rsx_atomic_add(float *p, float v)
 {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// ---- shared by the sampler (rsx_sample.hip) and the step kernels (rsx_bpr.hip) --------------
+constexpr int kMaxNegBlock = 16;
+
+__host__ __device__ __forceinline__ int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ uint32_t xorshift32(uint32_t &s)
+{
+    s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+    return s;
+}
+
+__host__ __device__ __forceinline__ int half_bits_for(int64_t n)
+{
+    int bits = 1;
+    while ((1ll << bits) < n) ++bits;
+    return (bits + 1) / 2;
+}
+
+// keyed bijection of [0,n): 4-round Feistel over 2*hb bits with cycle walking
+__host__ __device__ __forceinline__ uint32_t feistel_perm(uint32_t x, uint32_t n, int hb, uint64_t key)
+{
+    const uint32_t mask = (1u << hb) - 1u;
+    do {
+        uint32_t l = x >> hb, r = x & mask;
+        for (int round = 0; round < 4; ++round) {
+            const uint32_t f = (uint32_t)splitmix64(key ^ ((uint64_t)r << 8) ^ (uint64_t)round) & mask;
+            const uint32_t t = l ^ f;
+            l = r; r = t;
+        }
+        x = (l << hb) | r;
+    } while (x >= n);
+    return x;
+}
+
+// item block whose negatives batch-position block `w` draws from: identity, or a per-step
+// keyed permutation of the blocks (needed when the batch is ordered by positive item)
+__host__ __device__ __forceinline__ int64_t neg_block_of(int64_t w, int64_t nblocks, uint64_t neg_key)
+{
+    return neg_key == 0 ? w : (int64_t)feistel_perm((uint32_t)w, (uint32_t)nblocks, half_bits_for(nblocks), neg_key);
+}

@@ -15,6 +15,7 @@ _lib = None
 
 RSX_USERS_UNIQUE = 1
 RSX_NO_UPDATE = 2
+RSX_SAMPLE_SORT_POS = 1
 RSX_LOSS_SLOTS = 64
 SUPPORTED_DIMS = (32, 64, 128)
 
@@ -25,11 +26,15 @@ SIGNATURES = {
     "rsx_last_error": (C.c_char_p, []),
     "rsx_device_info_get": (C.c_int, [C.c_int, _P]),
     "rsx_bpr_step_workspace": (_I64, [_I64, _I64, _I32]),
-    "rsx_bpr_step": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _I64, _I32, _F, _F, _P, _U, _P, _I64, _P]),
+    "rsx_bpr_step": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _I64, _I32, _F, _F, _P, _U, _P, _I64,
+                               _P, _P, _I32, _I32, _U64, _P]),
+    "rsx_fold_hot_grad": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P]),
     "rsx_apply_item_grad": (C.c_int, [_P, _P, _I64, _I32, _F, _P]),
     "rsx_pair_score": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P]),
     "rsx_eval_holdout": (C.c_int, [_I64, _P, _I32, _P, _I32, _P, _P, _P]),
-    "rsx_bpr_sample": (C.c_int, [_P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _P, _P, _P, _P]),
+    "rsx_bpr_sample_workspace": (_I64, [_I64, _I64]),
+    "rsx_bpr_sample": (C.c_int, [_P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _I32, _U64, _U, _P, _I64,
+                                 _P, _P, _P, _P]),
     "rsx_score": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P, _P, _P, _P]),
     "rsx_topk": (C.c_int, [_P, _I64, _I64, _I32, _P, _P, _P]),
     "rsx_score_topk_workspace": (_I64, [_I64, _I64]),
@@ -96,8 +101,28 @@ def bpr_step_workspace(num_users, max_batch, d):
     return n
 
 
+class HotItems:
+    """Replicated gradient rows for the most popular items (include/rsx.h: hot_slot_dev)."""
+
+    def __init__(self, item_counts, num_hot, replicas, d, device):
+        counts = torch.as_tensor(item_counts).to(device)
+        num_hot = int(min(num_hot, counts.numel()))
+        self.items = torch.topk(counts, num_hot).indices.to(torch.int32).contiguous()
+        self.slot = torch.full((counts.numel(),), -1, dtype=torch.int32, device=device)
+        self.slot[self.items.long()] = torch.arange(num_hot, dtype=torch.int32, device=device)
+        self.replicas = int(replicas)
+        self.ghot = torch.zeros(num_hot * self.replicas * d, dtype=torch.float32, device=device)
+        self.n = num_hot
+
+
+def fold_hot_grad(G, hot):
+    _check(lib().rsx_fold_hot_grad(_dev(G, torch.float32, "G"), _dev(hot.ghot, torch.float32, "ghot"),
+                                   _dev(hot.items, torch.int32, "hot items"), hot.n, hot.replicas,
+                                   G.shape[1], _stream()), "rsx_fold_hot_grad")
+
+
 def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False, ws=None,
-             no_update=False):
+             no_update=False, hot=None, neg_block=0, neg_key=0):
     """One batch of include/rsx.h:rsx_bpr_step.  u, i, j: int32 device tensors."""
     d = P.shape[1]
     _check(lib().rsx_bpr_step(
@@ -108,7 +133,11 @@ def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False,
         _dev(loss_acc, torch.float32, "loss_acc") if loss_acc is not None else None,
         (RSX_USERS_UNIQUE if users_unique else 0) | (RSX_NO_UPDATE if no_update else 0),
         C.c_void_p(ws.data_ptr()) if ws is not None else None,
-        ws.numel() * ws.element_size() if ws is not None else 0, _stream()), "rsx_bpr_step")
+        ws.numel() * ws.element_size() if ws is not None else 0,
+        _dev(hot.slot, torch.int32, "hot slot") if hot is not None else None,
+        _dev(hot.ghot, torch.float32, "ghot") if hot is not None else None,
+        hot.replicas if hot is not None else 0, int(neg_block), int(neg_key) & (2**64 - 1), _stream()),
+        "rsx_bpr_step")
 
 
 def apply_item_grad(Q, G, lr):
@@ -141,10 +170,21 @@ def eval_holdout(rankings, ks, truth_indptr, truth_indices):
     return res
 
 
-def bpr_sample(indptr, indices, num_items, batch, seed, step, epoch_pos, u_out, i_out, j_out):
+def bpr_sample_workspace(batch, num_items):
+    n = lib().rsx_bpr_sample_workspace(batch, num_items)
+    if n < 0:
+        raise RsxError("rsx_bpr_sample_workspace: invalid shape")
+    return n
+
+
+def bpr_sample(indptr, indices, num_items, batch, seed, step, epoch_pos, u_out, i_out, j_out, neg_block=0,
+               neg_key=0, sort_pos=False, ws=None):
     _check(lib().rsx_bpr_sample(
         _dev(indptr, torch.int64, "indptr"), _dev(indices, torch.int32, "indices"),
-        indptr.numel() - 1, num_items, batch, seed & (2**64 - 1), step, epoch_pos,
+        indptr.numel() - 1, num_items, batch, seed & (2**64 - 1), step, epoch_pos, int(neg_block),
+        int(neg_key) & (2**64 - 1), RSX_SAMPLE_SORT_POS if sort_pos else 0,
+        C.c_void_p(ws.data_ptr()) if ws is not None else None,
+        ws.numel() * ws.element_size() if ws is not None else 0,
         _dev(u_out, torch.int32, "u_out"), _dev(i_out, torch.int32, "i_out"),
         _dev(j_out, torch.int32, "j_out"), _stream()), "rsx_bpr_sample")
 

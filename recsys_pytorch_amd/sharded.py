@@ -51,6 +51,31 @@ class BPREngine:
         self._loss = torch.zeros(self.k.RSX_LOSS_SLOTS, dtype=torch.float32, device=Q.device)
         self._trip = None
         self._count = torch.zeros(1, dtype=torch.int64, device=Q.device) if self.sharded else None
+        self.hot = None
+        self.neg_block = 0          # > 0: negatives stratified by item block, batch sorted by positive item
+        self._sample_ws = None
+        self._bufs = None           # double-buffered triplets for the overlapped sampler
+        self._side = None
+
+    def set_neg_block(self, batch, max_block=8):
+        """enable the on-chip gradient summation (blocked negatives + batch sorted by positive
+        item, include/rsx.h: neg_block / RSX_SAMPLE_SORT_POS) when every item row gets >= 2
+        updates per step; below that there is nothing to combine."""
+        self.neg_block = int(max_block) if batch >= 2 * self.Q.shape[0] else 0
+        return self.neg_block
+
+    def _neg_key(self, step):
+        """per-step key of the negative-block permutation (nonzero); 0 = identity when not sorting"""
+        if not self.neg_block:
+            return 0
+        z = (self.seed * 0x9E3779B97F4A7C15 + (step + 1) * 0xD1B54A32D192ED03) & (2**64 - 1)
+        z ^= z >> 31
+        return z | 1
+
+    def set_hot_items(self, item_counts, num_hot=256, replicas=16):
+        """spread the gradients of the `num_hot` most popular items over `replicas` private rows
+        (contention relief at the atomic unit, include/rsx.h:rsx_bpr_step hot_slot_dev)"""
+        self.hot = self.k.HotItems(item_counts, num_hot, replicas, self.Q.shape[1], self.Q.device) if num_hot > 0 else None
 
     # -- helpers ---------------------------------------------------------------
     def _workspace(self, batch):
@@ -69,7 +94,8 @@ class BPREngine:
         return int(self._count.item())
 
     # -- one step on explicit triplets (local user ids) ---------------------------
-    def step(self, u_local, i, j, global_batch=None, users_unique=False, want_loss=True):
+    def step(self, u_local, i, j, global_batch=None, users_unique=False, want_loss=True, neg_block=0,
+             neg_key=0):
         """returns the device tensor of loss slots (sum_b softplus(-x_b) striped) or None"""
         B = int(u_local.numel())
         gb = self._global_batch(B, global_batch)
@@ -78,8 +104,14 @@ class BPREngine:
             loss = self._loss
             loss.zero_()
         if B > 0:
+            kw = {"hot": self.hot} if self.hot is not None else {}
+            if neg_block:
+                kw["neg_block"], kw["neg_key"] = neg_block, neg_key
+                kw.pop("hot", None)            # runs of equal positives replace the replicas
             self.k.bpr_step(self.P, self.Q, self.G, u_local, i, j, self.lr, 1.0 / gb, loss_acc=loss,
-                            users_unique=users_unique, ws=None if users_unique else self._workspace(B))
+                            users_unique=users_unique, ws=None if users_unique else self._workspace(B), **kw)
+            if "hot" in kw:
+                self.k.fold_hot_grad(self.G, self.hot)
         if self.sharded:
             # the one exchange of the step: item gradients, summed over ranks (RCCL over xGMI)
             dist.all_reduce(self.G, op=dist.ReduceOp.SUM, group=self.group)
@@ -90,26 +122,77 @@ class BPREngine:
         return loss
 
     # -- one step on triplets sampled on the device from this rank's CSR rows -----------
-    def sample(self, indptr, indices, batch):
-        """device sampler (include/rsx.h:rsx_bpr_sample); users unique inside the batch.
-        A batch never straddles two passes over the user permutation: when fewer than
-        `batch` users remain in the pass, the pass restarts (tail dropped)."""
+    def _launch_sample(self, indptr, indices, batch, out, step):
+        """device sampler (include/rsx.h:rsx_bpr_sample) on the CURRENT stream; users unique
+        inside the batch.  A batch never straddles two passes over the user permutation: when
+        fewer than `batch` users remain in the pass, the pass restarts (tail dropped)."""
         U = indptr.numel() - 1
-        batch = min(int(batch), U)
-        if self._trip is None or self._trip[0].numel() != batch:
-            mk = lambda: torch.empty(batch, dtype=torch.int32, device=self.Q.device)
-            self._trip = (mk(), mk(), mk())
         if (self.epoch_pos % U) + batch > U:
             self.epoch_pos = (self.epoch_pos // U + 1) * U
-        u, i, j = self._trip
+        u, i, j = out
+        kw = {}
+        key = self._neg_key(step)
+        if self.neg_block:
+            need = self.k.bpr_sample_workspace(batch, self.Q.shape[0])
+            if self._sample_ws is None or self._sample_ws.numel() < need:
+                self._sample_ws = torch.empty(need, dtype=torch.uint8, device=self.Q.device)
+            kw = {"neg_block": self.neg_block, "neg_key": key, "sort_pos": True, "ws": self._sample_ws}
         self.k.bpr_sample(indptr, indices, self.Q.shape[0], batch, self.seed + 7919 * self.user_begin,
-                          self.step_count, self.epoch_pos, u, i, j)
+                          step, self.epoch_pos, u, i, j, **kw)
         self.epoch_pos += batch
-        return u, i, j
+        return key
+
+    def _triplet_buffers(self, batch):
+        mk = lambda: torch.empty(batch, dtype=torch.int32, device=self.Q.device)
+        return (mk(), mk(), mk())
+
+    def sample(self, indptr, indices, batch):
+        batch = min(int(batch), indptr.numel() - 1)
+        if self._trip is None or self._trip[0].numel() != batch:
+            self._trip = self._triplet_buffers(batch)
+        self.last_neg_key = self._launch_sample(indptr, indices, batch, self._trip, self.step_count)
+        return self._trip
 
     def sampled_step(self, indptr, indices, batch, global_batch=None, want_loss=True):
         u, i, j = self.sample(indptr, indices, batch)
-        return self.step(u, i, j, global_batch=global_batch, users_unique=True, want_loss=want_loss)
+        return self.step(u, i, j, global_batch=global_batch, users_unique=True, want_loss=want_loss,
+                         neg_block=self.neg_block, neg_key=self.last_neg_key)
+
+    def sampled_step_overlapped(self, indptr, indices, batch, global_batch=None, want_loss=True):
+        """same result as sampled_step, but the sampler of step t+1 runs on a second HIP stream
+        while step t's kernels run (it reads only the CSR, never the tables)."""
+        batch = min(int(batch), indptr.numel() - 1)
+        main = torch.cuda.current_stream()
+        if self._bufs is None or self._bufs[0]["t"][0].numel() != batch:
+            self._side = torch.cuda.Stream(device=self.Q.device)
+            self._bufs = [{"t": self._triplet_buffers(batch), "ready": None, "free": None, "key": 0} for _ in range(2)]
+            self._cur = 0
+            self._sampled_upto = self.step_count          # next step index to sample for
+
+        def prefetch(slot):
+            buf = self._bufs[slot]
+            if buf["free"] is not None:
+                self._side.wait_event(buf["free"])        # the step that read this buffer is done
+            with torch.cuda.stream(self._side):
+                buf["key"] = self._launch_sample(indptr, indices, batch, buf["t"], self._sampled_upto)
+                buf["ready"] = torch.cuda.Event()
+                buf["ready"].record(self._side)
+            self._sampled_upto += 1
+
+        cur = self._cur
+        if self._sampled_upto == self.step_count:
+            self._side.wait_stream(main)
+            prefetch(cur)
+        buf = self._bufs[cur]
+        main.wait_event(buf["ready"])
+        prefetch(cur ^ 1)                                  # sampler of the next step, concurrently
+        u, i, j = buf["t"]
+        loss = self.step(u, i, j, global_batch=global_batch, users_unique=True, want_loss=want_loss,
+                         neg_block=self.neg_block, neg_key=buf["key"])
+        buf["free"] = torch.cuda.Event()
+        buf["free"].record(main)
+        self._cur = cur ^ 1
+        return loss
 
     # -- replay of GLOBAL-id triplets: each rank keeps the triplets of its own users -----
     def route(self, u_global, i, j):

@@ -16,7 +16,8 @@ def bpr_step_workspace(num_users, max_batch, d):
     return 16
 
 
-def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False, ws=None, no_update=False):
+def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False, ws=None, no_update=False,
+             hot=None, neg_block=0, neg_key=0):
     """same contract as include/rsx.h:rsx_bpr_step, on host tensors: G += dQ (scaled by
     inv_batch), P -= lr*dP, loss slots += sum softplus(-x)."""
     Pn, Qn = P.numpy(), Q.numpy()
@@ -41,7 +42,8 @@ def apply_item_grad(Q, G, lr):
     G.zero_()
 
 
-def bpr_sample(indptr, indices, num_items, batch, seed, step, epoch_pos, u_out, i_out, j_out):
+def bpr_sample(indptr, indices, num_items, batch, seed, step, epoch_pos, u_out, i_out, j_out, neg_block=0,
+               neg_key=0, sort_pos=False, ws=None):
     """simple host sampler with the same guarantees (unique users, true pos, true neg)"""
     U = indptr.numel() - 1
     rng = np.random.default_rng(seed + 1000003 * step)

@@ -150,6 +150,118 @@ def test_sampled_triplets_replay_through_oracle(oracle_mod):
     assert rel_err(P.cpu().numpy(), orc.P) < 1e-5 and rel_err(Q.cpu().numpy(), orc.Q) < 1e-5
 
 
+@pytest.mark.parametrize("replicas", [1, 4, 16])
+def test_hot_item_replicas_do_not_change_the_sums(oracle_mod, replicas):
+    """popular items' gradients spread over private replicas and folded back: same result"""
+    from recsys_pytorch_amd.sharded import BPREngine
+    rng = np.random.default_rng(11)
+    U, I, d, B = 6000, 400, 128, 5000
+    P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+    w = 1.0 / np.arange(1, I + 1); w /= w.sum()
+    orc = oracle_mod.MFOracle(P0, Q0, "sgd", 0.05)
+    P, Q = torch.from_numpy(P0).cuda(), torch.from_numpy(Q0).cuda()
+    eng = BPREngine(P, Q, 0.05)
+    eng.set_hot_items(torch.from_numpy(w), num_hot=37, replicas=replicas)
+    for unique in (True, False):
+        for _ in range(3):
+            u = rng.permutation(U)[:B] if unique else rng.integers(0, U, B)
+            i, j = rng.choice(I, B, p=w), rng.integers(0, I, B)      # Zipf positives: heavy hot-row traffic
+            lo = orc.step(u, i, j)
+            acc = eng.step(*(torch.from_numpy(a).int().cuda() for a in (u, i, j)), users_unique=unique)
+            assert abs(float(acc.sum()) / B - lo) < 1e-5
+    assert float(eng.hot.ghot.abs().max()) == 0.0                    # folded and re-zeroed
+    assert rel_err(P.cpu().numpy(), orc.P) < 1e-5 and rel_err(Q.cpu().numpy(), orc.Q) < 1e-5
+
+
+@pytest.mark.parametrize("d,B,I,c", [(128, 40_000, 5_000, 8), (64, 30_001, 2_999, 16), (32, 9_000, 4_000, 3)])
+def test_sorted_blocked_sampled_path_replays_through_oracle(oracle_mod, d, B, I, c):
+    """batch sorted by positive item + negatives stratified by item block + on-chip summation:
+    dump the sampled triplets, replay them on the CPU oracle, and check the sampler's guarantees"""
+    from recsys_pytorch_amd.data import synthetic_csr
+    from recsys_pytorch_amd.sharded import BPREngine
+    U = 50_000
+    ip, ix = synthetic_csr(U, I, 12, "cuda", seed=4)
+    torch.manual_seed(8)
+    P = torch.randn(U, d, device="cuda") * 0.1
+    Q = torch.randn(I, d, device="cuda") * 0.1
+    orc = oracle_mod.MFOracle(P.cpu().numpy(), Q.cpu().numpy(), "sgd", 0.05)
+    eng = BPREngine(P, Q, 0.05)
+    eng.neg_block = c
+    hist = np.zeros(I)
+    ipn, ixn = ip.cpu().numpy(), ix.cpu().numpy()
+    keys = set()
+    for s in range(3):
+        u, i, j = eng.sample(ip, ix, B)
+        keys.add(eng.last_neg_key)
+        un, inn, jn = u.cpu().numpy(), i.cpu().numpy(), j.cpu().numpy()
+        assert len(np.unique(un)) == B                                   # users unique in the batch
+        assert np.all(np.diff(inn) >= 0)                                 # sorted by positive item
+        nominal = (np.arange(B, dtype=np.int64) * I // B) // c           # batch-position block
+        bad = 0
+        for w in np.unique(nominal)[:: max(1, len(np.unique(nominal)) // 200)]:
+            blocks = jn[nominal == w] // c                               # all its negatives: ONE item block
+            vals, cnt = np.unique(blocks, return_counts=True)
+            bad += cnt.sum() - cnt.max()
+        assert bad <= 0.01 * B
+        for a, b_, c_ in list(zip(un, inn, jn))[:: max(1, B // 500)]:
+            row = ixn[ipn[a]:ipn[a + 1]]
+            assert b_ in row and c_ not in row                           # true positive, true negative
+        hist += np.bincount(jn, minlength=I)
+        lo = orc.step(un, inn, jn)
+        acc = eng.step(u, i, j, users_unique=True, neg_block=c, neg_key=eng.last_neg_key)
+        assert abs(float(acc.sum()) / B - lo) < 1e-5
+    assert len(keys) == 3 and 0 not in keys                              # fresh block permutation per step
+    assert rel_err(P.cpu().numpy(), orc.P) < 1e-5 and rel_err(Q.cpu().numpy(), orc.Q) < 1e-5
+    exp = 3 * B / I
+    assert abs(hist.mean() - exp) < 1e-9 and hist.std() < 1.5 * np.sqrt(exp) + 1   # ~Poisson spread
+    assert hist.min() > 0 or exp < 8
+
+
+def test_overlapped_sampler_equals_inline_sampler():
+    """sampling one step ahead on a second stream must not change a single bit"""
+    from recsys_pytorch_amd.data import synthetic_csr
+    from recsys_pytorch_amd.sharded import BPREngine
+    U, I, d, B = 60_000, 3_000, 128, 20_000
+    ip, ix = synthetic_csr(U, I, 10, "cuda", seed=5)
+    out = []
+    for mode in ("inline", "overlapped"):
+        torch.manual_seed(9)
+        P = torch.randn(U, d, device="cuda") * 0.1
+        Q = torch.randn(I, d, device="cuda") * 0.1
+        eng = BPREngine(P, Q, 0.05)
+        eng.set_neg_block(B, 8)
+        assert eng.neg_block == 8
+        losses = []
+        for _ in range(7):   # crosses a pass boundary of the user permutation (3 batches per pass)
+            fn = eng.sampled_step if mode == "inline" else eng.sampled_step_overlapped
+            losses.append(float(fn(ip, ix, B).sum()))
+        torch.cuda.synchronize()
+        out.append((P.clone(), Q.clone(), losses))
+    assert out[0][2] == out[1][2]
+    # fp32 atomics reorder sums between runs: compare to rounding, not bitwise
+    assert torch.allclose(out[0][0], out[1][0], rtol=0, atol=1e-6) and torch.allclose(out[0][1], out[1][1], rtol=0, atol=1e-6)
+
+
+def test_blocked_kernel_is_exact_on_foreign_triplets(oracle_mod):
+    """neg_block set but the triplets do NOT follow the sampler contract: still exact"""
+    from recsys_pytorch_amd import rsx
+    rng = np.random.default_rng(21)
+    U, I, d, B = 9000, 777, 128, 6000
+    P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+    orc = oracle_mod.MFOracle(P0, Q0, "sgd", 0.05)
+    P, Q = torch.from_numpy(P0).cuda(), torch.from_numpy(Q0).cuda()
+    G = torch.zeros_like(Q)
+    for _ in range(3):
+        u, i, j = rng.permutation(U)[:B], rng.integers(0, I, B), rng.integers(0, I, B)
+        orc.step(u, i, j)
+        rsx.bpr_step(P, Q, G, *(torch.from_numpy(a).int().cuda() for a in (u, i, j)), 0.05, 1.0 / B,
+                     users_unique=True, neg_block=8)
+        rsx.apply_item_grad(Q, G, 0.05)
+    assert rel_err(P.cpu().numpy(), orc.P) < 1e-5 and rel_err(Q.cpu().numpy(), orc.Q) < 1e-5
+
+
 def test_synthetic_csr_shape_and_popularity():
     from recsys_pytorch_amd.data import synthetic_csr
     ip, ix = synthetic_csr(50_000, 10_000, 20, "cuda", seed=2020)

@@ -13,8 +13,13 @@ __global__ __launch_bounds__(256) void k(float* G, const int* rows, int64_t n)
     const int lane = threadIdx.x & 63, sub = lane >> 5, kk = lane & 31;
     int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * 4;
+    unsigned xcc = 0;
+    if (MODE >= 8) { asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); xcc &= 7; }
     for (int64_t b = w * 2 + sub; b < n; b += nw * 2) {
-        float* row = G + (size_t)rows[b] * 128;
+        int r = rows[b];
+        if (MODE == 8 || MODE == 10) r = (r & ~7) | (int)xcc;           // row affine to this XCD
+        if (MODE == 9) r = (r & ~7) | (int)((xcc + 1) & 7);           // row affine to ANOTHER XCD
+        float* row = G + (size_t)r * 128;
         if (MODE == 0) {          // 4 x f32 atomics, 128 B contiguous per row per instr
             for (int c = 0; c < 4; ++c) __hip_atomic_fetch_add(row + kk + 32 * c, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (MODE == 1) {   // 2 x u64 atomics, 256 B contiguous per row per instr
@@ -32,6 +37,10 @@ __global__ __launch_bounds__(256) void k(float* G, const int* rows, int64_t n)
             for (int c = 0; c < 4; ++c) __hip_atomic_fetch_add(row + kk + 32 * c, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else if (MODE == 6) {   // plain stores only
             for (int c = 0; c < 4; ++c) row[kk + 32 * c] = 1.0f;
+        } else if (MODE == 8 || MODE == 9) {
+            for (int c = 0; c < 4; ++c) __hip_atomic_fetch_add(row + kk + 32 * c, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (MODE == 10) {
+            for (int c = 0; c < 4; ++c) row[kk + 32 * c] += 1.0f;
         } else if (MODE == 7) {   // packed bf16 atomics: 2 x (2 bf16 per dword)... use pk_add_f16 via builtin if available
             for (int c = 0; c < 2; ++c) {
                 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -51,10 +60,10 @@ int main()
     for (auto& x : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; x = (int)(s % I); }
     CK(hipMalloc(&rows, n * 4)); CK(hipMemcpy(rows, h.data(), n * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const char* names[] = {"f32 atomic x4 (512B/row)", "u64 atomic x2 (512B/row)", "u32 atomic x4", "f64 atomic x2", "plain RMW x4", "f32 atomic wg-scope x4", "plain store x4", "pk f16 atomic x2 (256B/row)"};
+    const char* names[] = {"f32 atomic x4 (512B/row)", "u64 atomic x2 (512B/row)", "u32 atomic x4", "f64 atomic x2", "plain RMW x4", "f32 atomic wg-scope x4", "plain store x4", "pk f16 atomic x2 (256B/row)", "f32 atomic, row%8 == own XCD", "f32 atomic, row%8 == other XCD", "plain RMW, row%8 == own XCD"};
 #define RUN(M) { for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(k<M>, dim3(2048), dim3(256), 0, 0, G, rows, n); \
     hipEventRecord(e0); for (int it = 0; it < 10; ++it) hipLaunchKernelGGL(k<M>, dim3(2048), dim3(256), 0, 0, G, rows, n); hipEventRecord(e1); hipEventSynchronize(e1); \
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10; printf("%-32s %8.1f us  %7.1f M rows/s\n", names[M], ms * 1e3, n / ms / 1e3); }
-    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7)
+    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10)
     return 0;
 }
