@@ -238,7 +238,7 @@ def test_overlapped_sampler_equals_inline_sampler():
             losses.append(float(fn(ip, ix, B).sum()))
         torch.cuda.synchronize()
         out.append((P.clone(), Q.clone(), losses))
-    assert out[0][2] == out[1][2]
+    assert np.allclose(out[0][2], out[1][2], rtol=1e-6)              # same triplets; atomics reorder fp32 sums
     # fp32 atomics reorder sums between runs: compare to rounding, not bitwise
     assert torch.allclose(out[0][0], out[1][0], rtol=0, atol=1e-6) and torch.allclose(out[0][1], out[1][1], rtol=0, atol=1e-6)
 
