@@ -122,6 +122,20 @@ int rsx_fold_hot_grad(float *G, float *G_hot, const int32_t *hot_items_dev, int 
 int rsx_apply_item_grad(float *Q, float *G, int64_t num_items, int d, float lr,
                         rsx_stream_t stream);
 
+/* ---- reference-exact optimizer ----------------------------
+ * The reference ships dense Adam (models/MF.py:30).  rsx_bpr_grad leaves the tables
+ * untouched and sums the DENSE gradients of the batch (loss.backward(), MF.py:67; duplicates
+ * summed, any triplets): GP [num_users x d] += dP, GQ [num_items x d] += dQ, both zero
+ * between steps.  rsx_adam_apply then is torch.optim.Adam's single-tensor update over ALL n
+ * elements of one table (rows with a zero gradient move too once their moments are non-zero):
+ *   m += (1-b1)(g-m);  v = b2 v + (1-b2) g^2;  w -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * and zeroes G.  t = 1 for the first step.  Call it once per table per step.             */
+int rsx_bpr_grad(const float *P, const float *Q, float *GP, float *GQ, int64_t num_users,
+                 int64_t num_items, const int32_t *u_dev, const int32_t *i_dev, const int32_t *j_dev,
+                 int64_t batch, int d, float inv_batch, float *loss_acc, rsx_stream_t stream);
+int rsx_adam_apply(float *W, float *M, float *V, float *G, int64_t n, float lr, float beta1,
+                   float beta2, float eps, int64_t t, rsx_stream_t stream);
+
 /* rsx_pair_score: r[b] = <P[u[b]], Q[i[b]]>   (models/MF.py:38-42, MF.forward)            */
 int rsx_pair_score(const float *P, const float *Q, const int32_t *u_dev, const int32_t *i_dev,
                    int64_t n, int d, float *r_out, rsx_stream_t stream);

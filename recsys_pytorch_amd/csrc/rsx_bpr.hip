@@ -15,6 +15,8 @@
 // 64/LPR triplets at once (2 at d=128, 4 at d=64, 8 at d=32), the dot product
 // is a butterfly inside the lane group, and every load/store/atomic of a row is
 // coalesced over that lane group (see ROW LAYOUT below).
+#include <math.h>
+
 #include "rsx_common.h"
 
 namespace {
@@ -112,6 +114,8 @@ struct HotMap {
 
 // MODE 0: users unique in the batch -> P[u] updated in place by its owner group.
 // MODE 1: users may repeat          -> user deltas summed into GU[owner slot].
+// MODE 2: gradients only            -> dP summed into the dense buffer GU[u] (P untouched);
+//                                      the optimizer sweep (adam_apply_kernel) consumes it.
 template <int D, bool VEC, int MODE>
 __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
     float *__restrict__ P, const float *__restrict__ Q, float *__restrict__ G,
@@ -180,8 +184,12 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
                 Row<D, VEC> dq;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) dq.v[c] = qi.v[c] - qj.v[c];
-                const int32_t slot = owner[u] - 1;
-                dq.atomic_axpy(GU + (size_t)slot * D, k, s);
+                if constexpr (MODE == 1) {
+                    const int32_t slot = owner[u] - 1;
+                    dq.atomic_axpy(GU + (size_t)slot * D, k, s);
+                } else {
+                    dq.atomic_axpy(GU + (size_t)u * D, k, g);
+                }
             }
         }
         b = bn; u = un; i = in; j = jn;
@@ -390,6 +398,27 @@ __global__ __launch_bounds__(kBlock) void bpr_release_kernel(const int32_t *__re
     }
 }
 
+// dense Adam sweep as torch's single-tensor Adam does it (models/MF.py:30: lr 1e-3, betas
+// (0.9, 0.999), eps 1e-8, no weight decay), then G = 0.  Every element moves, also where g == 0.
+__global__ __launch_bounds__(kBlock) void adam_apply_kernel(float4 *__restrict__ W, float4 *__restrict__ M,
+                                                            float4 *__restrict__ V, float4 *__restrict__ G,
+                                                            int64_t n4, float beta1, float beta2, float eps,
+                                                            float step_size, float bc2_sqrt)
+{
+    for (int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x; n < n4; n += (int64_t)gridDim.x * kBlock) {
+        const float4 g = G[n];
+        float4 m = M[n], v = V[n], w = W[n];
+#define RSX_ADAM1(c)                                             \
+        m.c = m.c + (1.0f - beta1) * (g.c - m.c);                \
+        v.c = beta2 * v.c + (1.0f - beta2) * g.c * g.c;          \
+        w.c = w.c - step_size * (m.c / (sqrtf(v.c) / bc2_sqrt + eps));
+        RSX_ADAM1(x) RSX_ADAM1(y) RSX_ADAM1(z) RSX_ADAM1(w)
+#undef RSX_ADAM1
+        M[n] = m; V[n] = v; W[n] = w;
+        if (g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f) G[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 // r[b] = <P[u_b], Q[i_b]>  (MF.forward); one lane group per pair
 template <int D>
 __global__ __launch_bounds__(kBlock) void pair_score_kernel(const float *__restrict__ P,
@@ -574,6 +603,37 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
     default: hipLaunchKernelGGL(bpr_apply_user_kernel<128>, dim3(g2), dim3(kBlock), 0, st, P, u_dev, i_dev, batch, owner, GU); break;
     }
     hipLaunchKernelGGL(bpr_release_kernel, dim3(g1), dim3(kBlock), 0, st, u_dev, i_dev, batch, owner);
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+}
+
+RSX_API int rsx_bpr_grad(const float *P, const float *Q, float *GP, float *GQ, int64_t num_users,
+                         int64_t num_items, const int32_t *u_dev, const int32_t *i_dev,
+                         const int32_t *j_dev, int64_t batch, int d, float inv_batch, float *loss_acc,
+                         rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(P && Q && GP && GQ, "null table pointer");
+    RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64 or 128");
+    RSX_CHECK_ARG(batch >= 0 && num_users > 0 && num_items > 0, "negative size");
+    if (batch == 0) return RSX_OK;
+    RSX_CHECK_ARG(u_dev && i_dev && j_dev, "null index pointer");
+    dispatch_step<2>(d, false, const_cast<float *>(P), Q, GQ, u_dev, i_dev, j_dev, batch, 0.0f, inv_batch,
+                     loss_acc, nullptr, GP, HotMap{nullptr, nullptr, 1}, 0, (hipStream_t)stream);
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+}
+
+RSX_API int rsx_adam_apply(float *W, float *M, float *V, float *G, int64_t n, float lr, float beta1,
+                           float beta2, float eps, int64_t t, rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(W && M && V && G, "null pointer");
+    RSX_CHECK_ARG(n >= 0 && n % 4 == 0 && t >= 1, "n must be a multiple of 4 and t >= 1");
+    if (n == 0) return RSX_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)t);
+    const double bc2 = 1.0 - pow((double)beta2, (double)t);
+    hipLaunchKernelGGL(adam_apply_kernel, dim3((unsigned)grid_1d(n / 4)), dim3(kBlock), 0, (hipStream_t)stream,
+                       (float4 *)W, (float4 *)M, (float4 *)V, (float4 *)G, n / 4, beta1, beta2, eps,
+                       (float)((double)lr / bc1), (float)sqrt(bc2));
     RSX_CHECK_LAUNCH();
     return RSX_OK;
 }

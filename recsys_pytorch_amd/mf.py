@@ -11,8 +11,8 @@ torch: every step/score goes through librsx.so (include/rsx.h).  torch tensors a
 storage.  There is no CPU fallback.
 
 Divergences from the reference, all documented in DESIGN.md:
-  * optimizer: SGD (north star) instead of dense Adam lr=1e-3 (MF.py:30);
-    hparams['lr'] (default 0.05), hparams['optimizer'] must be 'sgd'.
+  * optimizer: hparams['optimizer'] = 'sgd' (default, north star; lr default 0.05) or 'adam'
+    (the reference's dense Adam, MF.py:30, reference-exact; lr default 1e-3).
   * triplets: sampled on the device every step (include/rsx.h:rsx_bpr_sample), true
     BPR sampling, instead of PairwiseGenerator's once-per-fit host sampling with its
     quirks (data/generators.py:165,182-185).  `train_step` replays explicit triplets.
@@ -65,10 +65,10 @@ class MF(BaseModel):
         if self.pointwise:
             raise NotImplementedError("pointwise MF (models/MF.py:48-51) is outside the BPR hot path")
         opt = _get(hparams, "optimizer", "sgd")
-        if opt != "sgd":
-            raise NotImplementedError("only SGD runs on the HIP path; the reference's dense Adam "
-                                      "(models/MF.py:30) is the 'next' row f3 of SURVEY section 8")
-        self.lr = float(_get(hparams, "lr", 0.05))
+        if opt not in ("sgd", "adam"):
+            raise ValueError("optimizer must be 'sgd' (north star) or 'adam' (as shipped, models/MF.py:30)")
+        self.optimizer_name = opt
+        self.lr = float(_get(hparams, "lr", 0.05 if opt == "sgd" else 1e-3))
         self.seed = int(_get(hparams, "seed", 2020))
         self.device = torch.device(device)
         self._dpad = _pad_dim(self.hidden_dim)
@@ -85,7 +85,7 @@ class MF(BaseModel):
         self.user_embedding.weight.requires_grad_(False)
         self.item_embedding.weight.requires_grad_(False)
         self._kernels = kernels
-        self._engine = BPREngine(self._P, self._Q, self.lr, kernels=kernels, seed=self.seed)
+        self._engine = BPREngine(self._P, self._Q, self.lr, kernels=kernels, seed=self.seed, optimizer=opt)
         self._k = self._engine.k
 
     # -- tables ---------------------------------------------------------------------
@@ -132,6 +132,8 @@ class MF(BaseModel):
         # (data/generators.py:182-195); the last batch of an epoch is short, not dropped (:213)
         n_data = self.num_users
         num_batches = int(np.ceil(n_data / batch_size))
+        if self.optimizer_name == "sgd":
+            self._engine.set_neg_block(batch_size)   # on-chip gradient summation when batch >= 2 * items
         scores = None
         for epoch in range(1, num_epochs + 1):
             self.train()

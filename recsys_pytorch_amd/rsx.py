@@ -30,6 +30,8 @@ SIGNATURES = {
                                _P, _P, _I32, _I32, _U64, _P]),
     "rsx_fold_hot_grad": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P]),
     "rsx_apply_item_grad": (C.c_int, [_P, _P, _I64, _I32, _F, _P]),
+    "rsx_bpr_grad": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _I64, _I32, _F, _P, _P]),
+    "rsx_adam_apply": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I64, _P]),
     "rsx_pair_score": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P]),
     "rsx_eval_holdout": (C.c_int, [_I64, _P, _I32, _P, _I32, _P, _P, _P]),
     "rsx_bpr_sample_workspace": (_I64, [_I64, _I64]),
@@ -143,6 +145,23 @@ def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False,
 def apply_item_grad(Q, G, lr):
     _check(lib().rsx_apply_item_grad(_dev(Q, torch.float32, "Q"), _dev(G, torch.float32, "G"),
                                      Q.shape[0], Q.shape[1], float(lr), _stream()), "rsx_apply_item_grad")
+
+
+def bpr_grad(P, Q, GP, GQ, u, i, j, inv_batch, loss_acc=None):
+    """dense gradients of one batch (loss.backward(), models/MF.py:67); tables untouched"""
+    _check(lib().rsx_bpr_grad(
+        _dev(P, torch.float32, "P"), _dev(Q, torch.float32, "Q"), _dev(GP, torch.float32, "GP"),
+        _dev(GQ, torch.float32, "GQ"), P.shape[0], Q.shape[0], _dev(u, torch.int32, "u"),
+        _dev(i, torch.int32, "i"), _dev(j, torch.int32, "j"), u.numel(), P.shape[1], float(inv_batch),
+        _dev(loss_acc, torch.float32, "loss_acc") if loss_acc is not None else None, _stream()), "rsx_bpr_grad")
+
+
+def adam_apply(W, M, V, G, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):
+    """torch.optim.Adam single-tensor update over a whole table (models/MF.py:30), then G = 0"""
+    _check(lib().rsx_adam_apply(_dev(W, torch.float32, "W"), _dev(M, torch.float32, "M"),
+                                _dev(V, torch.float32, "V"), _dev(G, torch.float32, "G"), W.numel(),
+                                float(lr), float(beta1), float(beta2), float(eps), int(t), _stream()),
+           "rsx_adam_apply")
 
 
 def pair_score(P, Q, u, i):

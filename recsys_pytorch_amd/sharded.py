@@ -33,7 +33,7 @@ class BPREngine:
     Q       : [I x d] fp32, replicated
     """
 
-    def __init__(self, P_local, Q, lr, kernels=None, group=None, user_begin=0, seed=2020):
+    def __init__(self, P_local, Q, lr, kernels=None, group=None, user_begin=0, seed=2020, optimizer="sgd"):
         if kernels is None:
             from . import rsx as kernels   # the HIP path; raises if librsx.so is missing
         self.k = kernels
@@ -51,6 +51,13 @@ class BPREngine:
         self._loss = torch.zeros(self.k.RSX_LOSS_SLOTS, dtype=torch.float32, device=Q.device)
         self._trip = None
         self._count = torch.zeros(1, dtype=torch.int64, device=Q.device) if self.sharded else None
+        self.optimizer = optimizer
+        if optimizer == "adam":      # the reference's shipped optimizer (models/MF.py:30): dense moments
+            self.GP = torch.zeros_like(P_local)
+            self.mP, self.vP = torch.zeros_like(P_local), torch.zeros_like(P_local)
+            self.mQ, self.vQ = torch.zeros_like(Q), torch.zeros_like(Q)
+        elif optimizer != "sgd":
+            raise ValueError(optimizer)
         self.hot = None
         self.neg_block = 0          # > 0: negatives stratified by item block, batch sorted by positive item
         self._sample_ws = None
@@ -103,6 +110,17 @@ class BPREngine:
         if want_loss:
             loss = self._loss
             loss.zero_()
+        if self.optimizer == "adam":
+            if B > 0:
+                self.k.bpr_grad(self.P, self.Q, self.GP, self.G, u_local, i, j, 1.0 / gb, loss_acc=loss)
+            if self.sharded:
+                dist.all_reduce(self.G, op=dist.ReduceOp.SUM, group=self.group)
+                if want_loss:
+                    dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.group)
+            self.step_count += 1
+            self.k.adam_apply(self.Q, self.mQ, self.vQ, self.G, self.lr, self.step_count)
+            self.k.adam_apply(self.P, self.mP, self.vP, self.GP, self.lr, self.step_count)
+            return loss
         if B > 0:
             kw = {"hot": self.hot} if self.hot is not None else {}
             if neg_block:

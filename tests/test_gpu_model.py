@@ -39,6 +39,19 @@ def test_model_replay_matches_reference_golden(ml100k):
     assert rel_err(m.user_embedding.weight.cpu().numpy(), g["P0"]) == 0.0   # nothing was updated
 
 
+def test_model_adam_as_shipped_matches_reference_golden(ml100k):
+    """hparams optimizer='adam': models/MF.py:30 semantics through the model class"""
+    import recsys_pytorch_amd as pkg
+    g = golden("g1b_adam_ml100k_d32_b256")
+    m = pkg.MF(ml100k, dict(HP, optimizer="adam"), "cuda")
+    assert m.lr == 1e-3
+    m.load_tables(g["P0"], g["Q0"])
+    for t, (u, i, j) in enumerate(split_batches(g)):
+        assert abs(float(m.train_step(u, i, j)) - g["loss"][t]) < 1e-5
+    assert rel_err(m.user_embedding.weight.cpu().numpy(), g["PT"]) < 1e-5
+    assert rel_err(m.item_embedding.weight.cpu().numpy(), g["QT"]) < 1e-5
+
+
 def test_hidden_dim_padding_d50(oracle_mod):
     """conf/MF.yaml ships hidden_dim 50: stored as 64 columns, the pad stays zero"""
     import recsys_pytorch_amd as pkg

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import G1_SGD, G23, golden, rel_err, split_batches
+from conftest import G1_ADAM, G1_SGD, G23, golden, rel_err, split_batches
 
 pytestmark = pytest.mark.gpu
 REL_TOL = 1e-5
@@ -59,6 +59,29 @@ def test_bpr_step_matches_reference_golden(rsx, name, layout):
     assert rel_err(P, g["PT"]) < REL_TOL
     assert rel_err(Q, g["QT"]) < REL_TOL
     assert np.allclose(losses, g["loss"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", G1_ADAM)
+def test_adam_as_shipped_matches_reference_golden(rsx, name):
+    """the reference's own optimizer (dense Adam lr 1e-3, models/MF.py:30), 12-20 steps"""
+    g = golden(name)
+    P, Q = dev(g["P0"]), dev(g["Q0"])
+    GP, GQ = torch.zeros_like(P), torch.zeros_like(Q)
+    mP, vP, mQ, vQ = (torch.zeros_like(t) for t in (P, P, Q, Q))
+    lr = float(g["lr"])
+    for t, (u, i, j) in enumerate(split_batches(g)):
+        acc = torch.zeros(rsx.RSX_LOSS_SLOTS, dtype=torch.float32, device="cuda")
+        rsx.bpr_grad(P, Q, GP, GQ, dev(u, torch.int32), dev(i, torch.int32), dev(j, torch.int32),
+                     1.0 / len(u), loss_acc=acc)
+        if t == 0:
+            assert rel_err(GP.cpu().numpy(), g["gP1"]) < REL_TOL      # dense grads of step 1 (MF.py:67)
+            assert rel_err(GQ.cpu().numpy(), g["gQ1"]) < REL_TOL
+        rsx.adam_apply(Q, mQ, vQ, GQ, lr, t + 1)
+        rsx.adam_apply(P, mP, vP, GP, lr, t + 1)
+        assert abs(float(acc.sum()) / len(u) - g["loss"][t]) < 1e-5
+    assert float(GP.abs().max()) == 0.0 and float(GQ.abs().max()) == 0.0
+    assert rel_err(P.cpu().numpy(), g["PT"]) < REL_TOL
+    assert rel_err(Q.cpu().numpy(), g["QT"]) < REL_TOL
 
 
 def test_first_step_gradients(rsx):
