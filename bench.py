@@ -13,7 +13,7 @@ tables N(0, 0.1^2) resident in HBM before the timed region.  Weak scaling: every
 rank owns its own 1M-user block (user rows sharded, items replicated).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel
-(bpr_step_kernel): algorithmic bytes 24*d per triplet over the
+(bpr_step_blocked_kernel, or bpr_step_kernel when the batch is < 2x the catalog): algorithmic bytes 24*d per triplet over the
 kernel's average launch duration measured with HIP events on the launch stream.
 `cpu_baseline` is the torch-CPU port of the reference path (oracle/torch_port.py)
 timed on this host on a bounded sample; it is test infrastructure and is used here
@@ -44,7 +44,9 @@ def parse():
     ap.add_argument("--users", type=int, default=1_000_000, help="users PER GPU")
     ap.add_argument("--items", type=int, default=100_000)
     ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--batch", type=int, default=262_144, help="triplets per step PER GPU")
+    ap.add_argument("--batch", type=int, default=1_000_000,
+                    help="triplets per step PER GPU (default: one triplet per user per step, the reference's epoch, "
+                         "data/generators.py:182-195)")
     ap.add_argument("--degree", type=int, default=20)
     ap.add_argument("--popularity", default="zipf", choices=["zipf", "uniform"])
     ap.add_argument("--lr", type=float, default=0.05)
@@ -214,7 +216,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 t = json.load(open(tpath))
-                key = f"U{U}_I{I}_d{d}_B{B}_{args.popularity}"
+                key = f"U{U}_I{I}_d{d}_B{B}_{args.popularity}_nb{neg_block}"
                 traffic = t.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -231,7 +233,7 @@ def main():
                        "sampler": "on device, overlapped on a second HIP stream",
                        "hot_items": args.hot, "hot_replicas": args.hot_replicas if args.hot > 0 else 0,
                        "parallelism": f"user-sharded x{world}, items replicated, 1 all-reduce(G)/step" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "bpr_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "bpr_step_blocked_kernel" if neg_block else "bpr_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},
         }

@@ -80,11 +80,32 @@ struct Row {
     }
 };
 
+// sum over the LPR lanes of a lane group, result in every lane of the group.  Pure cross-lane
+// VALU (DPP inside a 16-lane row, v_permlane16/32_swap across rows): no LDS round trips
+// (__shfl_xor lowers to ds_bpermute_b32, 10 of them per triplet on the dependent path).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+
 template <int LPR>
 __device__ __forceinline__ float group_sum(float x)
 {
-#pragma unroll
-    for (int m = LPR / 2; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+    x += dpp_mov<0xB1>(x);                       // quad_perm [1,0,3,2]  : lane ^ 1
+    x += dpp_mov<0x4E>(x);                       // quad_perm [2,3,0,1]  : lane ^ 2
+    if constexpr (LPR >= 8) x += dpp_mov<0x141>(x);    // row_half_mirror: the other quad of the 8
+    if constexpr (LPR >= 16) x += dpp_mov<0x140>(x);   // row_mirror     : the other half of the 16
+    if constexpr (LPR >= 32) {                         // rows 0<->1, 2<->3
+        const unsigned b = __builtin_bit_cast(unsigned, x);
+        const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+        x = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
+    if constexpr (LPR >= 64) {                         // halves
+        const unsigned b = __builtin_bit_cast(unsigned, x);
+        const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+        x = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
     return x;
 }
 
@@ -216,7 +237,7 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
 // Neither is a correctness contract: a negative outside the wave's block and an unsorted batch
 // take the global-atomic path / runs of length one, and the sums are the same.
 template <int D>
-__global__ __launch_bounds__(kBlock) void bpr_step_blocked_kernel(
+__global__ __launch_bounds__(kBlock, 5) void bpr_step_blocked_kernel(
     float *__restrict__ P, const float *__restrict__ Q, float *__restrict__ G,
     const int32_t *__restrict__ U_idx, const int32_t *__restrict__ I_idx,
     const int32_t *__restrict__ J_idx, int64_t B, int64_t num_items, int c, uint64_t neg_key, float lr,
@@ -248,24 +269,33 @@ __global__ __launch_bounds__(kBlock) void bpr_step_blocked_kernel(
     const int64_t g_hi = (g_lo + len < b1) ? g_lo + len : b1;
 
     float loss_local = 0.0f;
-    int32_t run_item = -1;                       // positive item of the current run
-    float run[4] = {0.f, 0.f, 0.f, 0.f};         // sum of g*P[u] over the run
-    int32_t u = -1, i = -1, j = -1;
-    if (g_lo < g_hi) { u = U_idx[g_lo]; i = I_idx[g_lo]; j = J_idx[g_lo]; }
-    for (int64_t t = 0; t < len; ++t) {          // wave-uniform trip count
-        const int64_t b = g_lo + t;
-        const int64_t bn = b + 1;
-        int32_t un = -1, in = -1, jn = -1;
-        if (bn < g_hi) { un = U_idx[bn]; in = I_idx[bn]; jn = J_idx[bn]; }
+    // running sums of g*P[u] for the current positive item(s).  Two accumulators, chosen by item
+    // parity: the 16-bit-key sort orders the batch by item >> 1, so within one key the two items
+    // interleave; each keeps its own run.
+    int32_t run_item0 = -1, run_item1 = -1;
+    float r0x = 0.f, r0y = 0.f, r0z = 0.f, r0w = 0.f, r1x = 0.f, r1y = 0.f, r1z = 0.f, r1w = 0.f;
+    // (scalars, not arrays: arrays selected through a reference end up in scratch memory)
+#define RSX_RUN_FLUSH(RI, RX, RY, RZ, RW)                                         \
+    if (RI >= 0 && !(ablate & 1)) {                                               \
+        float *grow = G + (size_t)RI * D;                                         \
+        rsx_atomic_add(grow + k, RX); rsx_atomic_add(grow + k + LPR, RY);         \
+        rsx_atomic_add(grow + k + 2 * LPR, RZ); rsx_atomic_add(grow + k + 3 * LPR, RW); \
+    }
+#define RSX_RUN_ADD(RI, RX, RY, RZ, RW)                                           \
+    if (i != RI) {                                                                \
+        RSX_RUN_FLUSH(RI, RX, RY, RZ, RW)                                         \
+        RI = i; RX = 0.f; RY = 0.f; RZ = 0.f; RW = 0.f;                           \
+    }                                                                             \
+    RX = fmaf(g, p.v[0], RX); RY = fmaf(g, p.v[1], RY);                           \
+    RZ = fmaf(g, p.v[2], RZ); RW = fmaf(g, p.v[3], RW);
+
+    // one triplet whose three rows are already in registers
+    auto process = [&](bool live, int32_t u, int32_t i, int32_t j, Row<D, false> &p,
+                       const Row<D, false> &qi, const Row<D, false> &qj) __attribute__((always_inline)) {
         bool neg_local = false;
         float neg_g = 0.0f;
         float pv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (b < g_hi && i >= 0) {
-            float *prow = P + (size_t)u * D;
-            Row<D, false> p, qi, qj;
-            p.load(prow, k);
-            qi.load(Q + (size_t)i * D, k);
-            qj.load(Q + (size_t)j * D, k);
+        if (live) {
             float dpos = 0.0f, dneg = 0.0f;
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
@@ -278,19 +308,18 @@ __global__ __launch_bounds__(kBlock) void bpr_step_blocked_kernel(
             const float sneg = 1.0f / (1.0f + __expf(x));
             const float g = -sneg * inv_batch;
             if (k == 0) loss_local += softplus_neg(x);
-            // positive item: extend the run, or flush it and start a new one
-            if (i != run_item) {
-                if (run_item >= 0 && !(ablate & 1)) {
-                    float *grow = G + (size_t)run_item * D;
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) rsx_atomic_add(grow + k + cc * LPR, run[cc]);
-                }
-                run_item = i;
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) run[cc] = 0.0f;
+            // positive item: extend its run, or flush the run and start a new one
+            // (select in / select out: a branch per parity makes the compiler fold the two
+            //  accumulators into a dynamically indexed scratch array)
+            {
+                const bool odd = (i & 1) != 0;
+                int32_t ri = odd ? run_item1 : run_item0;
+                float tx = odd ? r1x : r0x, ty = odd ? r1y : r0y, tz = odd ? r1z : r0z, tw = odd ? r1w : r0w;
+                RSX_RUN_ADD(ri, tx, ty, tz, tw)
+                run_item0 = odd ? run_item0 : ri; run_item1 = odd ? ri : run_item1;
+                r0x = odd ? r0x : tx; r0y = odd ? r0y : ty; r0z = odd ? r0z : tz; r0w = odd ? r0w : tw;
+                r1x = odd ? tx : r1x; r1y = odd ? ty : r1y; r1z = odd ? tz : r1z; r1w = odd ? tw : r1w;
             }
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) run[cc] = fmaf(g, p.v[cc], run[cc]);
             // negative item: the wave's own block goes to LDS, anything else to G
             neg_local = ((int64_t)j >= item_lo && (int64_t)j < item_hi);
             if (!neg_local && !(ablate & 2)) p.atomic_axpy(G + (size_t)j * D, k, -g);
@@ -300,7 +329,7 @@ __global__ __launch_bounds__(kBlock) void bpr_step_blocked_kernel(
             const float s = -lr * g;
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) p.v[cc] = fmaf(s, qi.v[cc] - qj.v[cc], p.v[cc]);
-            if (!(ablate & 4)) p.store(prow, k);
+            if (!(ablate & 4)) p.store(P + (size_t)u * D, k);
         }
         // wave-private LDS tile, plain read-modify-write (ds_add_f32 measured ~120 clk per
         // wave instruction).  The lane groups of one wavefront may hit the same row, so they
@@ -317,13 +346,31 @@ __global__ __launch_bounds__(kBlock) void bpr_step_blocked_kernel(
                 }
             }
         }
-        u = un; i = in; j = jn;
+    };
+
+    // two positions per lane group per trip: all six row gathers are in flight together
+    // (the gather is latency-bound: ~2 us per dependent trip under load)
+    int32_t ua = -1, ia = -1, ja = -1, ub = -1, ib = -1, jb = -1;
+    if (g_lo < g_hi) { ua = U_idx[g_lo]; ia = I_idx[g_lo]; ja = J_idx[g_lo]; }
+    if (g_lo + 1 < g_hi) { ub = U_idx[g_lo + 1]; ib = I_idx[g_lo + 1]; jb = J_idx[g_lo + 1]; }
+    for (int64_t t = 0; t < len; t += 2) {       // wave-uniform trip count
+        const int64_t b = g_lo + t;
+        int32_t una = -1, ina = -1, jna = -1, unb = -1, inb = -1, jnb = -1;
+        if (b + 2 < g_hi) { una = U_idx[b + 2]; ina = I_idx[b + 2]; jna = J_idx[b + 2]; }
+        if (b + 3 < g_hi) { unb = U_idx[b + 3]; inb = I_idx[b + 3]; jnb = J_idx[b + 3]; }
+        const bool live_a = (b < g_hi) && (ia >= 0);
+        const bool live_b = (b + 1 < g_hi) && (ib >= 0);
+        Row<D, false> pa, qia, qja, pb, qib, qjb;
+        if (live_a) { pa.load(P + (size_t)ua * D, k); qia.load(Q + (size_t)ia * D, k); qja.load(Q + (size_t)ja * D, k); }
+        if (live_b) { pb.load(P + (size_t)ub * D, k); qib.load(Q + (size_t)ib * D, k); qjb.load(Q + (size_t)jb * D, k); }
+        process(live_a, ua, ia, ja, pa, qia, qja);
+        process(live_b, ub, ib, jb, pb, qib, qjb);
+        ua = una; ia = ina; ja = jna; ub = unb; ib = inb; jb = jnb;
     }
-    if (run_item >= 0 && !(ablate & 1)) {        // last run of this lane group
-        float *grow = G + (size_t)run_item * D;
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) rsx_atomic_add(grow + k + cc * LPR, run[cc]);
-    }
+    RSX_RUN_FLUSH(run_item0, r0x, r0y, r0z, r0w)     // last runs of this lane group
+    RSX_RUN_FLUSH(run_item1, r1x, r1y, r1z, r1w)
+#undef RSX_RUN_ADD
+#undef RSX_RUN_FLUSH
     // flush the block's rows: one global atomic row per touched item
     const int rows = (int)(item_hi - item_lo);
     for (int m = sub; m - sub < rows; m += TPW) {
