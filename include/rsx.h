@@ -185,7 +185,14 @@ int rsx_bpr_sample(const int64_t *indptr_dev, const int32_t *indices_dev, int64_
  *              (CSR is indexed by USER ID, as MF.py:128-130 does).
  * rsx_topk   : per row of `scores` the K largest, descending; ties by lower index.
  *              topk_val_out nullable.  K <= 1024 and K <= num_items.
- * rsx_score_topk : both, tile by tile through `ws` without exposing the scores.
+ * rsx_score_topk : both, tile by tile through `ws`, without exposing the scores.  For catalogs
+ *              of >= 32768 items the dense [rows x items] matrix is never formed: a strided
+ *              sample of the catalog gives each row a lower bound tau of its K-th score, the
+ *              full product is then computed with an epilogue that keeps only scores >= tau,
+ *              and the survivors are masked, sorted and cut to K.  Same result as
+ *              rsx_score + rsx_topk.  This entry point waits for the stream once before it
+ *              returns (it reads a counter of rows that must be re-done densely: massive
+ *              exact ties).
  */
 int rsx_score(const float *P, const int32_t *user_ids_dev, int64_t num_rows, const float *Q,
               int64_t num_items, int d, const int64_t *mask_indptr_dev,

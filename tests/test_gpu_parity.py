@@ -231,6 +231,47 @@ def test_topk_ties_and_masked_rows(rsx, oracle_mod):
         assert np.array_equal(got, want), K
 
 
+@pytest.mark.parametrize("d,I,rows,K", [(64, 40_001, 300, 50), (128, 65_537, 1500, 10), (32, 33_000, 77, 200)])
+def test_fused_score_topk_equals_dense_path(rsx, oracle_mod, d, I, rows, K):
+    """catalogs >= 32768 items take the fused path (sample threshold -> filtered MFMA epilogue ->
+    merge); it must give exactly what dense scoring + row top-k gives, mask included"""
+    torch.manual_seed(d + K)
+    U = 5000
+    P = torch.randn(U, d, device="cuda") * 0.1
+    Q = torch.randn(I, d, device="cuda") * 0.1
+    users = torch.randperm(U, device="cuda")[:rows].to(torch.int32)
+    from recsys_pytorch_amd.data import synthetic_csr
+    mask = synthetic_csr(U, I, 30, "cuda", seed=3)
+    idx, val = rsx.score_topk(P, Q, users, K, mask=mask, want_values=True)
+    S = rsx.score(P, Q, users, mask=mask)
+    ref_i, ref_v = rsx.topk(S, K, want_values=True)
+    assert torch.equal(val, ref_v) and torch.equal(idx, ref_i)
+    Sn = S.cpu().numpy()
+    want = oracle_mod.topk(Sn, K)                                  # and the CPU oracle agrees
+    assert np.array_equal(idx.cpu().numpy(), want)
+    assert not torch.isinf(val).any()
+
+
+def test_fused_score_topk_degenerate_ties_take_the_dense_redo(rsx, oracle_mod):
+    """all-zero user rows: every score ties at 0 -> candidate lists overflow -> dense re-do;
+    mixed with ordinary rows in the same call"""
+    torch.manual_seed(4)
+    U, I, d, K = 400, 50_000, 64, 20
+    P = torch.randn(U, d, device="cuda") * 0.1
+    P[::3] = 0.0
+    Q = torch.randn(I, d, device="cuda") * 0.1
+    users = torch.arange(U, device="cuda", dtype=torch.int32)
+    from recsys_pytorch_amd.data import synthetic_csr
+    mask = synthetic_csr(U, I, 10, "cuda", seed=9)
+    idx = rsx.score_topk(P, Q, users, K, mask=mask).cpu().numpy()
+    S = rsx.score(P, Q, users, mask=mask).cpu().numpy()
+    assert np.array_equal(idx, oracle_mod.topk(S, K))
+    ip, ix = mask[0].cpu().numpy(), mask[1].cpu().numpy()
+    r = 0                                                           # a tied row: lowest unseen indices
+    seen = set(ix[ip[0]:ip[1]])
+    assert list(idx[r]) == [x for x in range(K + len(seen)) if x not in seen][:K]
+
+
 def test_score_large_tile_vs_torch_fp64(rsx):
     """ragged tile edges (rows, items not multiples of 128) against an fp64 product"""
     torch.manual_seed(1)
