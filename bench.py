@@ -96,11 +96,16 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)      # "nccl" IS RCCL on ROCm
+        backend = os.environ.get("RSX_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; gloo only to
+        if backend == "nccl":                                   # smoke-test the N>1 code path on one GPU
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from recsys_pytorch_amd import rsx
     from recsys_pytorch_amd.data import synthetic_csr

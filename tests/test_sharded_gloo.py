@@ -59,3 +59,49 @@ def test_two_ranks_equal_one_process(oracle_mod):
     assert out[0][5] == out[1][5]
     err = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
     assert err(P, single.P) < 1e-5 and err(out[0][3], single.Q) < 1e-5
+
+
+def _gpu_worker(rank, world, port, P0, Q0, batches, lr, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from recsys_pytorch_amd.sharded import BPREngine, user_block
+    dev = torch.device("cuda", 0)                      # both ranks share the one GPU of the test box
+    lo, hi = user_block(P0.shape[0], rank, world)
+    P = torch.from_numpy(P0[lo:hi].copy()).to(dev)
+    Q = torch.from_numpy(Q0.copy()).to(dev)
+    eng = BPREngine(P, Q, lr, user_begin=lo)            # default kernels: the HIP library
+    losses = []
+    for (u, i, j) in batches:
+        ul, il, jl = eng.route(torch.from_numpy(u).to(dev), torch.from_numpy(i).to(dev), torch.from_numpy(j).to(dev))
+        acc = eng.step(ul, il, jl)
+        losses.append(float(acc.sum()) / len(u))
+    torch.cuda.synchronize()
+    out[rank] = (lo, hi, P.cpu().numpy(), Q.cpu().numpy(), losses)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_two_ranks_on_hip_kernels_equal_one_process(oracle_mod):
+    """same check with the real HIP kernels: two processes (sharing the box's GPU, gloo for the
+    all-reduce) on their own triplets == one process on the concatenated batch"""
+    rng = np.random.default_rng(19)
+    U, I, d, B, T, lr = 4001, 1500, 128, 3000, 4, 0.05
+    P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+    batches = [(rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)) for _ in range(T)]
+    single = oracle_mod.MFOracle(P0, Q0, "sgd", lr)
+    ref_losses = [single.step(*b) for b in batches]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29500 + (os.getpid() + 7) % 2000
+    mp.spawn(_gpu_worker, args=(2, port, P0, Q0, batches, lr, out), nprocs=2, join=True)
+    P = np.zeros_like(P0)
+    for r in range(2):
+        lo, hi, Pr, Qr, losses = out[r]
+        P[lo:hi] = Pr
+        assert np.allclose(losses, ref_losses, rtol=1e-5, atol=1e-6)
+    err = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
+    assert np.array_equal(out[0][3], out[1][3]), "item replicas diverged"
+    assert err(P, single.P) < 1e-5 and err(out[0][3], single.Q) < 1e-5
