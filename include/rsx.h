@@ -208,6 +208,25 @@ int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t num_rows
                    const int32_t *mask_indices_dev, int K, int32_t *topk_idx_out,
                    float *topk_val_out, void *ws, int64_t ws_bytes, rsx_stream_t stream);
 
+/* ---- LightGCN propagation (BASELINE config 5) ------------------
+ * Replaces models/LightGCN.py:188-197: all_emb = torch.sparse.mm(A_hat, all_emb), L times,
+ * mean over the L+1 layers (:198-200).  A_hat = D^-1/2 [[0,R],[R^T,0]] D^-1/2 is built on the
+ * host as the reference builds it (:228-258) and passed as CSR (indptr int64 [N+1], indices
+ * int32, vals fp32, N = users + items).  A_hat is symmetric: the backward of the propagation
+ * is the same product applied to the gradient.
+ * rsx_spmm_plan (HOST): cuts rows into segments of <= max_seg non-zeros (item rows of a
+ *   popularity-skewed graph have 10^5+ neighbours); call with NULL outputs for the count.
+ * rsx_spmm_csr: Y = A X   (Y is overwritten; X [N x d] must not alias Y or S_acc);
+ *   if S_acc != NULL also S_acc += A X (the running layer sum).
+ * rsx_scale: X *= alpha (the 1/(L+1) of the layer mean).                                   */
+int64_t rsx_spmm_plan(const int64_t *indptr_host, int64_t num_rows, int max_seg, int32_t *seg_row_out,
+                      int64_t *seg_begin_out, int32_t *seg_len_out);
+int rsx_spmm_csr(const int32_t *seg_row_dev, const int64_t *seg_begin_dev, const int32_t *seg_len_dev,
+                 int64_t num_segs, const int64_t *indptr_dev, const int32_t *indices_dev,
+                 const float *vals_dev, const float *X, float *Y, float *S_acc, int64_t num_rows, int d,
+                 rsx_stream_t stream);
+int rsx_scale(float *X, int64_t n, float alpha, rsx_stream_t stream);
+
 /* ---- holdout metrics (HOST function, host pointers) --------------------------------
  * Replaces evaluation/backend/cython/include/holdout.h:20-103 (evaluate_holdout) and its
  * wrapper holdout_func.pyx: Prec@K = hits/K, Recall@K = hits/truth_len,

@@ -61,6 +61,16 @@ def lib():
         L.orc_topk.argtypes = [_f32p, C.c_int64, C.c_int64, C.c_int, _i32p]
         L.orc_holdout.restype = None
         L.orc_holdout.argtypes = [C.c_int64, _i32p, C.c_int, _i32p, C.c_int, _i64p, _i32p, _f32p]
+        L.orc_spmm_csr.restype = None
+        L.orc_spmm_csr.argtypes = [_i64p, _i32p, _f32p, _f32p, _f32p, C.c_int64, C.c_int]
+        L.orc_lightgcn_propagate.restype = None
+        L.orc_lightgcn_propagate.argtypes = [_i64p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_int64,
+                                             C.c_int, C.c_int]
+        L.orc_lightgcn_step_adam.restype = None
+        L.orc_lightgcn_step_adam.argtypes = [_f32p, _f32p, _f32p, C.c_int64, C.c_int64, _i64p, _i32p, _f32p,
+                                             C.c_int, _i64p, _i64p, _i64p, C.c_int64, C.c_int, C.c_float,
+                                             C.c_float, C.c_float, C.c_float, C.c_int64, _f32p, _f32p, _f32p,
+                                             _f32p, _f32p, C.POINTER(C.c_double)]
         _LIB = L
     return _LIB
 
@@ -169,3 +179,58 @@ def holdout(rankings, Ks, t_indptr, t_indices, use_ref=False):
     else:
         lib().orc_holdout(n, rankings, rankings.shape[1], Ks, len(Ks), tp, ti, res)
     return res
+
+
+def normalized_adjacency(train_csr):
+    """A_hat = D^-1/2 [[0,R],[R^T,0]] D^-1/2 as CSR float32 (models/LightGCN.py:228-258), built the
+    direct way with scipy (the reference goes through lil/dok matrices; same matrix)."""
+    import scipy.sparse as sp
+    R = sp.csr_matrix(train_csr, dtype=np.float32)
+    U, I = R.shape
+    A = sp.bmat([[None, R], [R.T, None]], format="csr", dtype=np.float32)
+    deg = np.asarray(A.sum(axis=1)).ravel()
+    with np.errstate(divide="ignore"):
+        dinv = np.power(deg, -0.5)
+    dinv[np.isinf(dinv)] = 0.0
+    D = sp.diags(dinv.astype(np.float32))
+    A = (D @ A @ D).tocsr().astype(np.float32)
+    A.sort_indices()
+    return A
+
+
+class LightGCNOracle:
+    """CPU LightGCN: base table E0 = [P;Q], Adam as shipped (models/LightGCN.py:46)."""
+
+    def __init__(self, P0, Q0, A_hat, num_layers, lr=1e-3):
+        self.U, self.d = P0.shape
+        self.I = Q0.shape[0]
+        self.N = self.U + self.I
+        self.E0 = np.ascontiguousarray(np.concatenate([P0, Q0]), np.float32)
+        self.m, self.v = np.zeros_like(self.E0), np.zeros_like(self.E0)
+        self.indptr = _i64(A_hat.indptr)
+        self.indices = np.ascontiguousarray(A_hat.indices, np.int32)
+        self.vals = np.ascontiguousarray(A_hat.data, np.float32)
+        self.L, self.lr, self.t = int(num_layers), float(lr), 0
+        self._s = [np.zeros_like(self.E0) for _ in range(5)]
+
+    def propagate(self):
+        out = np.empty_like(self.E0)
+        lib().orc_lightgcn_propagate(self.indptr, self.indices, self.vals, self.E0, out, self._s[0], self._s[1],
+                                     self.N, self.d, self.L)
+        return out[:self.U], out[self.U:]
+
+    def step(self, u, i, j):
+        self.t += 1
+        loss = C.c_double(0)
+        lib().orc_lightgcn_step_adam(self.E0, self.m, self.v, self.U, self.I, self.indptr, self.indices,
+                                     self.vals, self.L, _i64(u), _i64(i), _i64(j), len(u), self.d, self.lr,
+                                     0.9, 0.999, 1e-8, self.t, *self._s, C.byref(loss))
+        return loss.value
+
+    @property
+    def P(self):
+        return self.E0[:self.U]
+
+    @property
+    def Q(self):
+        return self.E0[self.U:]

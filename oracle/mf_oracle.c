@@ -248,3 +248,71 @@ ORC_EXPORT void orc_holdout(int64_t users_num, const int32_t *rankings, int max_
         }
     }
 }
+
+/* ==== LightGCN (BASELINE config 5) ==================================
+ * models/LightGCN.py:174-202 (_lightgcn_embedding): all_emb = cat(user_w, item_w);
+ * L times all_emb = A_hat @ all_emb (torch.sparse.mm, :196); output = mean over the L+1 layers
+ * (:198-200).  A_hat = D^-1/2 [[0,R],[R^T,0]] D^-1/2 is built on the host by the reference
+ * (:228-258) and handed over here as CSR.                                                    */
+ORC_EXPORT void orc_spmm_csr(const int64_t *indptr, const int32_t *indices, const float *vals,
+                             const float *X, float *Y, int64_t N, int d)
+{
+    for (int64_t r = 0; r < N; ++r) {
+        float *y = Y + r * d;
+        for (int k = 0; k < d; ++k) y[k] = 0.0f;
+        for (int64_t p = indptr[r]; p < indptr[r + 1]; ++p) {
+            const float a = vals[p];
+            const float *x = X + (int64_t)indices[p] * d;
+            for (int k = 0; k < d; ++k) y[k] += a * x[k];
+        }
+    }
+}
+
+/* out = mean_{k=0..L} A_hat^k E0 ; tmpA/tmpB scratch [N*d] */
+ORC_EXPORT void orc_lightgcn_propagate(const int64_t *indptr, const int32_t *indices, const float *vals,
+                                       const float *E0, float *out, float *tmpA, float *tmpB,
+                                       int64_t N, int d, int L)
+{
+    const float *cur = E0;
+    float *nxt = tmpA;
+    for (int64_t n = 0; n < N * d; ++n) out[n] = E0[n];
+    for (int l = 0; l < L; ++l) {
+        orc_spmm_csr(indptr, indices, vals, cur, nxt, N, d);
+        for (int64_t n = 0; n < N * d; ++n) out[n] += nxt[n];
+        cur = nxt;
+        nxt = (nxt == tmpA) ? tmpB : tmpA;
+    }
+    const float inv = 1.0f / (float)(L + 1);      /* torch.mean over the stacked layers */
+    for (int64_t n = 0; n < N * d; ++n) out[n] *= inv;
+}
+
+/* One training step, models/LightGCN.py:83-87,117-123 with the optimizer as shipped (:46, Adam
+ * lr 1e-3): propagate, BPR loss on the propagated tables, backward through the L sparse products
+ * (A_hat is symmetric: dE0 = mean_k A_hat^k dOut), dense Adam on E0 = [P;Q].
+ * scratch: out, dout, tA, tB, g: [N*d] each.                                                  */
+ORC_EXPORT void orc_lightgcn_step_adam(float *E0, float *mE, float *vE, int64_t U, int64_t I,
+                                       const int64_t *indptr, const int32_t *indices, const float *vals,
+                                       int L, const int64_t *u, const int64_t *i, const int64_t *j,
+                                       int64_t B, int d, float lr, float b1, float b2, float eps, int64_t t,
+                                       float *out, float *dout, float *tA, float *tB, float *g,
+                                       double *loss_out)
+{
+    const int64_t N = U + I;
+    orc_lightgcn_propagate(indptr, indices, vals, E0, out, tA, tB, N, d, L);
+    memset(dout, 0, sizeof(float) * (size_t)N * d);
+    /* dense gradients w.r.t. the PROPAGATED tables: same closed form as MF (orc_bpr_grad) */
+    orc_bpr_grad(out, out + U * d, u, i, j, B, d, dout, dout + U * d, loss_out);
+    /* back through the propagation */
+    const float *cur = dout;
+    float *nxt = tA;
+    for (int64_t n = 0; n < N * d; ++n) g[n] = dout[n];
+    for (int l = 0; l < L; ++l) {
+        orc_spmm_csr(indptr, indices, vals, cur, nxt, N, d);
+        for (int64_t n = 0; n < N * d; ++n) g[n] += nxt[n];
+        cur = nxt;
+        nxt = (nxt == tA) ? tB : tA;
+    }
+    const float inv = 1.0f / (float)(L + 1);
+    for (int64_t n = 0; n < N * d; ++n) g[n] *= inv;
+    orc_adam_apply(E0, mE, vE, g, N * d, lr, b1, b2, eps, t);
+}

@@ -5,5 +5,6 @@ this package is the host-side mirror of the reference interface."""
 __version__ = "0.1.0"
 
 from .mf import BaseModel, MF            # noqa: E402,F401  (registry: getattr(recsys_pytorch_amd, 'MF'))
+from .lightgcn import LightGCN           # noqa: E402,F401
 from .evaluator import Evaluator         # noqa: E402,F401
 from .data import InteractionData        # noqa: E402,F401

@@ -1,0 +1,148 @@
+// rsx_graph.hip -- LightGCN embedding propagation for gfx950 (SURVEY section 8f row f1,
+// BASELINE config 5): Y = A_hat X as a row gather, the same access pattern as bpr_step's gather.
+//
+// Restates models/LightGCN.py:188-197: `all_emb = torch.sparse.mm(graph, all_emb)` with
+// A_hat = D^-1/2 [[0,R],[R^T,0]] D^-1/2 (built on the host exactly as the reference does,
+// LightGCN.py:228-258, and handed over as CSR).  A_hat is symmetric, so the backward pass of
+// the propagation is the same product applied to the gradient.
+//
+// HBM-bound: nnz * (4 d + 8) bytes gathered per product.  Item rows of a popularity-skewed
+// graph are enormous (hundreds of thousands of neighbours), user rows tiny: the rows are cut
+// into segments of at most `seg` non-zeros by a host-side plan (the graph is static), one lane
+// group per segment; a row with a single segment is stored, a split row is combined with fp32
+// atomics into a pre-zeroed Y.
+#include <vector>
+
+#include "rsx_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void spmm_csr_kernel(
+    const int32_t *__restrict__ seg_row, const int64_t *__restrict__ seg_begin,
+    const int32_t *__restrict__ seg_len, int64_t num_segs, const int64_t *__restrict__ indptr,
+    const int32_t *__restrict__ indices, const float *__restrict__ vals, const float *__restrict__ X,
+    float *__restrict__ Y, float *__restrict__ S)
+{
+    constexpr int LPR = D / 4;
+    constexpr int GPW = 64 / LPR;                 // lane groups (segments) per wavefront
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR;
+    const int k = lane % LPR;
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+    for (int64_t s = wave * GPW + sub; s < num_segs; s += nwaves * GPW) {
+        const int32_t row = seg_row[s];
+        const int64_t pb = seg_begin[s];
+        const int len = seg_len[s];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int p = 0;
+        for (; p + 4 <= len; p += 4) {            // four neighbour rows in flight
+            const float a0 = vals[pb + p], a1 = vals[pb + p + 1], a2 = vals[pb + p + 2], a3 = vals[pb + p + 3];
+            const float4 x0 = reinterpret_cast<const float4 *>(X + (size_t)indices[pb + p] * D)[k];
+            const float4 x1 = reinterpret_cast<const float4 *>(X + (size_t)indices[pb + p + 1] * D)[k];
+            const float4 x2 = reinterpret_cast<const float4 *>(X + (size_t)indices[pb + p + 2] * D)[k];
+            const float4 x3 = reinterpret_cast<const float4 *>(X + (size_t)indices[pb + p + 3] * D)[k];
+            acc.x = fmaf(a0, x0.x, acc.x); acc.y = fmaf(a0, x0.y, acc.y); acc.z = fmaf(a0, x0.z, acc.z); acc.w = fmaf(a0, x0.w, acc.w);
+            acc.x = fmaf(a1, x1.x, acc.x); acc.y = fmaf(a1, x1.y, acc.y); acc.z = fmaf(a1, x1.z, acc.z); acc.w = fmaf(a1, x1.w, acc.w);
+            acc.x = fmaf(a2, x2.x, acc.x); acc.y = fmaf(a2, x2.y, acc.y); acc.z = fmaf(a2, x2.z, acc.z); acc.w = fmaf(a2, x2.w, acc.w);
+            acc.x = fmaf(a3, x3.x, acc.x); acc.y = fmaf(a3, x3.y, acc.y); acc.z = fmaf(a3, x3.z, acc.z); acc.w = fmaf(a3, x3.w, acc.w);
+        }
+        for (; p < len; ++p) {
+            const float a = vals[pb + p];
+            const float4 x = reinterpret_cast<const float4 *>(X + (size_t)indices[pb + p] * D)[k];
+            acc.x = fmaf(a, x.x, acc.x); acc.y = fmaf(a, x.y, acc.y); acc.z = fmaf(a, x.z, acc.z); acc.w = fmaf(a, x.w, acc.w);
+        }
+        const bool whole = (int64_t)len == indptr[row + 1] - indptr[row];
+        float *y = Y + (size_t)row * D + 4 * k;
+        if (whole) {
+            *reinterpret_cast<float4 *>(y) = acc;
+            if (S != nullptr) {
+                float4 *sp = reinterpret_cast<float4 *>(S + (size_t)row * D) + k;
+                float4 t = *sp;
+                t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w;
+                *sp = t;
+            }
+        } else {
+            rsx_atomic_add(y, acc.x); rsx_atomic_add(y + 1, acc.y); rsx_atomic_add(y + 2, acc.z); rsx_atomic_add(y + 3, acc.w);
+            if (S != nullptr) {
+                float *sp = S + (size_t)row * D + 4 * k;
+                rsx_atomic_add(sp, acc.x); rsx_atomic_add(sp + 1, acc.y); rsx_atomic_add(sp + 2, acc.z); rsx_atomic_add(sp + 3, acc.w);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void scale_kernel(float4 *__restrict__ X, int64_t n4, float alpha)
+{
+    for (int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x; n < n4; n += (int64_t)gridDim.x * kBlock) {
+        float4 v = X[n];
+        v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+        X[n] = v;
+    }
+}
+
+unsigned grid_for(int64_t threads)
+{
+    int64_t blocks = (threads + kBlock - 1) / kBlock;
+    const int64_t cap = (int64_t)rsx_num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    return (unsigned)(blocks < 1 ? 1 : blocks);
+}
+
+}  // namespace
+
+// HOST: cut CSR rows into segments of at most max_seg non-zeros (empty rows get one empty
+// segment so that Y[row] is written).  Call with out arrays NULL to get the count.
+RSX_API int64_t rsx_spmm_plan(const int64_t *indptr_host, int64_t num_rows, int max_seg,
+                              int32_t *seg_row_out, int64_t *seg_begin_out, int32_t *seg_len_out)
+{
+    if (indptr_host == nullptr || num_rows < 0 || max_seg < 1) return RSX_E_INVALID;
+    int64_t n = 0;
+    for (int64_t r = 0; r < num_rows; ++r) {
+        const int64_t lo = indptr_host[r], hi = indptr_host[r + 1];
+        int64_t p = lo;
+        do {
+            const int64_t len = (hi - p < max_seg) ? hi - p : max_seg;
+            if (seg_row_out) { seg_row_out[n] = (int32_t)r; seg_begin_out[n] = p; seg_len_out[n] = (int32_t)len; }
+            ++n;
+            p += len;
+        } while (p < hi);
+    }
+    return n;
+}
+
+RSX_API int rsx_spmm_csr(const int32_t *seg_row_dev, const int64_t *seg_begin_dev, const int32_t *seg_len_dev,
+                         int64_t num_segs, const int64_t *indptr_dev, const int32_t *indices_dev,
+                         const float *vals_dev, const float *X, float *Y, float *S_acc, int64_t num_rows,
+                         int d, rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(seg_row_dev && seg_begin_dev && seg_len_dev && indptr_dev && indices_dev && vals_dev && X && Y,
+                  "null pointer");
+    RSX_CHECK_ARG(rsx_dim_ok(d) && num_rows >= 0 && num_segs >= 0, "bad shape");
+    RSX_CHECK_ARG(X != Y && X != S_acc, "X must not alias an output");
+    if (num_rows == 0) return RSX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(Y, 0, (size_t)num_rows * d * sizeof(float), st);   // split rows add into zeros
+    if (e != hipSuccess) { rsx_set_error("rsx_spmm_csr: %s", hipGetErrorString(e)); return RSX_E_HIP; }
+    const int gpw = 64 / (d / 4);
+    const unsigned g = grid_for((num_segs + gpw - 1) / gpw * 64);
+    switch (d) {
+    case 32: hipLaunchKernelGGL(spmm_csr_kernel<32>, dim3(g), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, indices_dev, vals_dev, X, Y, S_acc); break;
+    case 64: hipLaunchKernelGGL(spmm_csr_kernel<64>, dim3(g), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, indices_dev, vals_dev, X, Y, S_acc); break;
+    default: hipLaunchKernelGGL(spmm_csr_kernel<128>, dim3(g), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, indices_dev, vals_dev, X, Y, S_acc); break;
+    }
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+}
+
+RSX_API int rsx_scale(float *X, int64_t n, float alpha, rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(X != nullptr && n >= 0 && n % 4 == 0, "n must be a multiple of 4");
+    if (n == 0) return RSX_OK;
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n / 4)), dim3(kBlock), 0, (hipStream_t)stream, (float4 *)X, n / 4, alpha);
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+}

@@ -1,0 +1,214 @@
+"""Host-side mirror of models/LightGCN.py for the accelerated path.
+
+    LightGCN(dataset, hparams, device); fit(dataset, exp_config, evaluator, early_stop, loggers);
+    predict(eval_users, eval_pos, test_batch_size); registry name `LightGCN` (models/__init__.py:15)
+
+What the reference does per batch (models/LightGCN.py:83-87,117-123): propagate the WHOLE graph
+(L sparse products, :188-197), mean over the L+1 layers, BPR loss on the propagated tables,
+autograd back through the L products, Adam(lr 1e-3) on the base tables (:46).  Here:
+  propagate  rsx_spmm_csr x L (+ running layer sum) + rsx_scale          csrc/rsx_graph.hip
+  loss/grad  rsx_bpr_grad on the propagated tables (dense dOut)          csrc/rsx_bpr.hip
+  backward   A_hat is symmetric: dE0 = mean_k A_hat^k dOut  ->  rsx_spmm_csr x L again
+  optimizer  rsx_adam_apply on E0 = [P; Q]                               (reference-exact Adam)
+hparams keys as conf/LightGCN.yaml: emb_dim, num_layers, node_dropout (must be 0: the reference's
+dropout path crashes), split (ignored: one CSR), reg (read but unused by the reference,
+:33).  The normalised adjacency is built on the host with scipy like the reference (:228-258).
+Triplets come from the device sampler (see mf.py); `train_step` replays explicit triplets.
+"""
+import numpy as np
+import scipy.sparse as sp
+import torch
+import torch.nn as nn
+
+from .data import csr_to_device
+from .mf import BaseModel, _get, _pad_dim
+
+
+def normalized_adjacency(train_csr):
+    """A_hat = D^-1/2 [[0,R],[R^T,0]] D^-1/2 (models/LightGCN.py:241-252), CSR float32"""
+    R = sp.csr_matrix(train_csr, dtype=np.float32)
+    A = sp.bmat([[None, R], [R.T, None]], format="csr", dtype=np.float32)
+    deg = np.asarray(A.sum(axis=1)).ravel()
+    with np.errstate(divide="ignore"):
+        dinv = np.power(deg, -0.5)
+    dinv[np.isinf(dinv)] = 0.0
+    D = sp.diags(dinv.astype(np.float32))
+    A = (D @ A @ D).tocsr().astype(np.float32)
+    A.sort_indices()
+    return A
+
+
+class LightGCN(BaseModel):
+    def __init__(self, dataset, hparams, device):
+        super().__init__()
+        from . import rsx
+        self._k = rsx
+        self.num_users, self.num_items = dataset.num_users, dataset.num_items
+        self.emb_dim = int(hparams["emb_dim"])
+        self.num_layers = int(hparams["num_layers"])
+        if float(_get(hparams, "node_dropout", 0.0)) > 0:
+            raise NotImplementedError("node_dropout > 0 crashes in the reference too (LightGCN.py:165,182)")
+        self.lr = float(_get(hparams, "lr", 1e-3))                      # LightGCN.py:46
+        self.seed = int(_get(hparams, "seed", 2020))
+        self.device = torch.device(device)
+        d, dp = self.emb_dim, _pad_dim(self.emb_dim)
+        self._dpad = dp
+        N = self.num_users + self.num_items
+        E0 = torch.zeros(N, dp, dtype=torch.float32)
+        E0[:, :d].normal_(0, 0.01)                                      # LightGCN.py:50-51
+        self._E0 = E0.to(self.device).contiguous()
+        self._m, self._v = torch.zeros_like(self._E0), torch.zeros_like(self._E0)
+        self._out = torch.zeros_like(self._E0)                          # propagated tables (mean of layers)
+        self._dout = torch.zeros_like(self._E0)                         # dL/dOut, dense
+        self._g = torch.zeros_like(self._E0)
+        self._ta, self._tb = torch.zeros_like(self._E0), torch.zeros_like(self._E0)
+        U = self.num_users
+        self.user_embedding = nn.Embedding(U, d, _weight=self._E0[:U, :d])
+        self.item_embedding = nn.Embedding(self.num_items, d, _weight=self._E0[U:, :d])
+        self.user_embedding.weight.requires_grad_(False)
+        self.item_embedding.weight.requires_grad_(False)
+        self.Graph = None
+        self._t = 0
+        self._fresh = False            # is self._out the propagation of the current E0?
+
+    # -- tables / graph ------------------------------------------------------------------------
+    def load_tables(self, P, Q):
+        d, U = self.emb_dim, self.num_users
+        self._E0.zero_()
+        self._E0[:U, :d] = torch.as_tensor(np.asarray(P), dtype=torch.float32).to(self.device)
+        self._E0[U:, :d] = torch.as_tensor(np.asarray(Q), dtype=torch.float32).to(self.device)
+        self._fresh = False
+
+    def getSparseGraph(self, rating_matrix, adjacency=None):
+        """models/LightGCN.py:228-266; `adjacency` lets a caller hand in a prebuilt A_hat"""
+        A = normalized_adjacency(rating_matrix) if adjacency is None else adjacency
+        self.Graph = self._k.SpmmGraph(A, self.device)
+        return self.Graph
+
+    def _idx(self, t):
+        return torch.as_tensor(t).to(device=self.device, dtype=torch.int32).contiguous()
+
+    # -- models/LightGCN.py:174-202 ----------------------------------------------------------------
+    def _propagate(self, src, acc):
+        """acc = mean_{k=0..L} A_hat^k src   (src untouched)"""
+        k = self._k
+        if self.Graph is None:
+            raise RuntimeError("no graph yet: call fit() or getSparseGraph(train_matrix) first "
+                               "(the reference builds it in fit, models/LightGCN.py:70)")
+        acc.copy_(src)
+        cur, nxt = src, self._ta
+        for _ in range(self.num_layers):
+            k.spmm(self.Graph, cur, nxt, S_acc=acc)
+            cur, nxt = nxt, (self._tb if nxt is self._ta else self._ta)
+        k.scale(acc, 1.0 / (self.num_layers + 1))
+
+    def update_lightgcn_embedding(self):
+        self._propagate(self._E0, self._out)
+        U = self.num_users
+        self.user_embeddings, self.item_embeddings = self._out[:U], self._out[U:]
+        self._fresh = True
+
+    def forward(self, user_ids, item_ids):
+        if not self._fresh:
+            self.update_lightgcn_embedding()
+        return self._k.pair_score(self._out[:self.num_users], self._out[self.num_users:], self._idx(user_ids),
+                                  self._idx(item_ids))
+
+    # -- one training step: LightGCN.py:83-87 (zero_grad, process_one_batch, backward, Adam step) --
+    def train_step(self, users, pos, neg):
+        k, U = self._k, self.num_users
+        u, i, j = self._idx(users), self._idx(pos), self._idx(neg)
+        self.update_lightgcn_embedding()
+        acc = torch.zeros(k.RSX_LOSS_SLOTS, dtype=torch.float32, device=self.device)
+        k.bpr_grad(self._out[:U], self._out[U:], self._dout[:U], self._dout[U:], u, i, j, 1.0 / max(1, u.numel()),
+                   loss_acc=acc)
+        self._propagate(self._dout, self._g)                           # back through the L products
+        self._dout.zero_()
+        self._t += 1
+        k.adam_apply(self._E0, self._m, self._v, self._g, self.lr, self._t)
+        self._fresh = False
+        return acc.sum() / max(1, u.numel())
+
+    def process_one_batch(self, users, pos_items, neg_items):
+        """loss only (LightGCN.py:117-123)"""
+        k, U = self._k, self.num_users
+        self.update_lightgcn_embedding()
+        acc = torch.zeros(k.RSX_LOSS_SLOTS, dtype=torch.float32, device=self.device)
+        u = self._idx(users)
+        k.bpr_step(self._out[:U], self._out[U:], None, u, self._idx(pos_items), self._idx(neg_items), 0.0, 1.0,
+                   loss_acc=acc, no_update=True)
+        return acc.sum() / max(1, u.numel())
+
+    # -- models/LightGCN.py:68-115 ---------------------------------------------------------------------
+    def fit(self, dataset, exp_config, evaluator=None, early_stop=None, loggers=None):
+        from .sharded import BPREngine
+        train_matrix = dataset.train_data
+        self.getSparseGraph(train_matrix)
+        indptr, indices = csr_to_device(train_matrix, self.device)
+        batch_size = int(_get(exp_config, "batch_size"))
+        num_epochs = int(_get(exp_config, "num_epochs"))
+        verbose = _get(exp_config, "verbose", 0)
+        test_from, test_step = int(_get(exp_config, "test_from", 1)), int(_get(exp_config, "test_step", 1))
+        sampler = BPREngine(self._E0[:self.num_users], self._E0[self.num_users:], self.lr, seed=self.seed)
+        n_data = self.num_users
+        num_batches = int(np.ceil(n_data / batch_size))
+        scores = None
+        for epoch in range(1, num_epochs + 1):
+            self.train()
+            epoch_loss = 0.0
+            sampler.epoch_pos = (epoch - 1) * n_data
+            for b in range(num_batches):
+                bsz = min(batch_size, n_data - b * batch_size)
+                u, i, j = sampler.sample(indptr, indices, bsz)
+                sampler.step_count += 1
+                batch_loss = float(self.train_step(u, i, j))
+                epoch_loss += batch_loss
+                if verbose and b % 50 == 0:
+                    print('(%3d / %3d) loss = %.4f' % (b, num_batches, batch_loss))
+            epoch_summary = {'loss': epoch_loss}
+            if evaluator is not None and epoch >= test_from and epoch % test_step == 0:
+                scores = evaluator.evaluate(self)
+                epoch_summary.update(scores)
+                if loggers is not None:
+                    for logger in loggers:
+                        logger.log_metrics(epoch_summary, epoch=epoch)
+                if early_stop is not None:
+                    is_update, should_stop = early_stop.step(scores, epoch)
+                    if should_stop:
+                        break
+            else:
+                if loggers is not None:
+                    for logger in loggers:
+                        logger.log_metrics(epoch_summary, epoch=epoch)
+        best_score = early_stop.best_score if early_stop is not None else scores
+        return {'scores': best_score}
+
+    # -- models/LightGCN.py:125-150 -------------------------------------------------------------------------
+    def predict_batch_users(self, user_ids):
+        if not self._fresh:
+            self.update_lightgcn_embedding()
+        return self._k.score(self._out[:self.num_users], self._out[self.num_users:], self._idx(user_ids))
+
+    def predict(self, eval_users, eval_pos, test_batch_size):
+        self.update_lightgcn_embedding()                                # LightGCN.py:131
+        eval_users = np.asarray(eval_users)
+        pred_matrix = np.zeros(eval_pos.shape)
+        mask = csr_to_device(eval_pos, self.device)
+        U = self.num_users
+        for s in range(0, len(eval_users), test_batch_size):
+            batch_users = eval_users[s:s + test_batch_size]
+            S = self._k.score(self._out[:U], self._out[U:], self._idx(batch_users), mask=mask)
+            pred_matrix[batch_users] = S.cpu().numpy()
+        return pred_matrix
+
+    def predict_topk(self, eval_users, eval_pos, K, test_batch_size=1024, want_values=False):
+        self.update_lightgcn_embedding()
+        eval_users = np.asarray(eval_users)
+        mask = csr_to_device(eval_pos, self.device) if eval_pos is not None else None
+        U = self.num_users
+        out = []
+        for s in range(0, len(eval_users), test_batch_size):
+            r = self._k.score_topk(self._out[:U], self._out[U:], self._idx(eval_users[s:s + test_batch_size]), K,
+                                   mask=mask, want_values=False)
+            out.append(r.cpu().numpy())
+        return np.concatenate(out) if out else np.zeros((0, K), np.int32)

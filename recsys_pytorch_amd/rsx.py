@@ -32,6 +32,9 @@ SIGNATURES = {
     "rsx_apply_item_grad": (C.c_int, [_P, _P, _I64, _I32, _F, _P]),
     "rsx_bpr_grad": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _I64, _I32, _F, _P, _P]),
     "rsx_adam_apply": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I64, _P]),
+    "rsx_spmm_plan": (_I64, [_P, _I64, _I32, _P, _P, _P]),
+    "rsx_spmm_csr": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
+    "rsx_scale": (C.c_int, [_P, _I64, _F, _P]),
     "rsx_pair_score": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P]),
     "rsx_eval_holdout": (C.c_int, [_I64, _P, _I32, _P, _I32, _P, _P, _P]),
     "rsx_bpr_sample_workspace": (_I64, [_I64, _I64]),
@@ -162,6 +165,43 @@ def adam_apply(W, M, V, G, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):
                                 _dev(V, torch.float32, "V"), _dev(G, torch.float32, "G"), W.numel(),
                                 float(lr), float(beta1), float(beta2), float(eps), int(t), _stream()),
            "rsx_adam_apply")
+
+
+class SpmmGraph:
+    """device CSR of a (square) sparse matrix + its segment plan (include/rsx.h:rsx_spmm_plan)"""
+
+    def __init__(self, csr, device, max_seg=128):
+        import numpy as np
+        csr = csr.tocsr()
+        csr.sort_indices()
+        indptr = np.ascontiguousarray(csr.indptr, dtype=np.int64)
+        n = csr.shape[0]
+        cnt = lib().rsx_spmm_plan(indptr.ctypes.data, n, max_seg, None, None, None)
+        if cnt < 0:
+            raise RsxError("rsx_spmm_plan failed")
+        row, beg, ln = np.empty(cnt, np.int32), np.empty(cnt, np.int64), np.empty(cnt, np.int32)
+        lib().rsx_spmm_plan(indptr.ctypes.data, n, max_seg, row.ctypes.data, beg.ctypes.data, ln.ctypes.data)
+        to = lambda a: torch.from_numpy(a).to(device).contiguous()
+        self.n, self.num_segs = n, int(cnt)
+        self.seg_row, self.seg_begin, self.seg_len = to(row), to(beg), to(ln)
+        self.indptr = to(indptr)
+        self.indices = to(np.ascontiguousarray(csr.indices, dtype=np.int32))
+        self.vals = to(np.ascontiguousarray(csr.data, dtype=np.float32))
+
+
+def spmm(graph, X, Y, S_acc=None):
+    """Y = A X (and S_acc += A X) -- include/rsx.h:rsx_spmm_csr"""
+    _check(lib().rsx_spmm_csr(
+        _dev(graph.seg_row, torch.int32, "seg_row"), _dev(graph.seg_begin, torch.int64, "seg_begin"),
+        _dev(graph.seg_len, torch.int32, "seg_len"), graph.num_segs, _dev(graph.indptr, torch.int64, "indptr"),
+        _dev(graph.indices, torch.int32, "indices"), _dev(graph.vals, torch.float32, "vals"),
+        _dev(X, torch.float32, "X"), _dev(Y, torch.float32, "Y"),
+        _dev(S_acc, torch.float32, "S_acc") if S_acc is not None else None, graph.n, X.shape[1], _stream()),
+        "rsx_spmm_csr")
+
+
+def scale(X, alpha):
+    _check(lib().rsx_scale(_dev(X, torch.float32, "X"), X.numel(), float(alpha), _stream()), "rsx_scale")
 
 
 def pair_score(P, Q, u, i):
