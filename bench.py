@@ -126,7 +126,7 @@ def main():
 
     # the sampler of step t+1 runs on a second HIP stream while step t computes (it reads only
     # the CSR); both are inside the timed region
-    side = torch.cuda.Stream(device=dev)
+    side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("RSX_SIDE_PRIORITY", "0")))
     bufs = [{"t": eng._triplet_buffers(B), "ready": None, "free": None, "key": 0} for _ in range(2)]
     state = {"cur": 0, "next_step": 0}
 
