@@ -11,10 +11,10 @@
 //
 // Mapping to the machine: this is HBM/fabric-bound row traffic (24*d bytes per
 // triplet algorithmically), no reuse, so no LDS staging and no MFMA.  A row of
-// d fp32 is spread over LPR = d/4 lanes; a 64-lane wavefront therefore owns
-// 64/LPR triplets at once (2 at d=128, 4 at d=64, 8 at d=32), the dot product
-// is a butterfly inside the lane group, and every load/store/atomic of a row is
-// coalesced over that lane group (see ROW LAYOUT below).
+// d fp32 is spread over a lane group of 32 lanes (d/32 floats per lane); a 64-lane
+// wavefront owns two triplets at once, the dot product is a butterfly inside the
+// lane group, and every load/store/atomic instruction covers whole 128-byte lines
+// of a row (see ROW LAYOUT below).
 #include <math.h>
 
 #include "rsx_common.h"
@@ -24,71 +24,49 @@ namespace {
 constexpr int kBlock = 256;           // 4 wavefronts per workgroup
 constexpr int kWavesPerBlock = kBlock / 64;
 
-// ROW LAYOUT.  A row of D floats is spread over LPR = D/4 lanes, 4 floats per lane.
-//   VEC=true : lane k holds elements [4k, 4k+4)  (one dwordx4 per row; kept as an A/B knob)
-//   VEC=false: "line" layout -- every wave instruction covers whole 128-byte lines of a row:
-//              D=128: lane k holds k, k+32, k+64, k+96            (4 x dword,   128 B each)
-//              D=64 : lane k holds {2k,2k+1}, {32+2k,33+2k}        (2 x dwordx2, 128 B each)
-//              D=32 : lane k holds {4k..4k+3}                      (1 x dwordx4, 128 B)
-//              so one atomic / load / store instruction touches ONE line per row (measured
-//              3.7x faster than the dwordx4 layout at D=128, where it touched four).
-template <int D, bool VEC>
+// ROW LAYOUT.  A row of D floats is spread over the 32 lanes of a lane group; lane k holds
+// elements k, k+32, ... (EPL = D/32 of them).  Every wave instruction therefore covers ONE whole
+// 128-byte line per row, for loads, stores and atomics alike.  (The obvious alternative, one
+// dwordx4 per lane = lane k holds [4k,4k+4), makes each atomic instruction touch four lines per
+// row and measured 3.7x slower at d=128: 226 us vs 60.7 us for B=65536, tools/microbench.py.)
+constexpr int LPR = 32;   // lanes per row
+constexpr int TPW = 2;    // lane groups (triplets) per wavefront
+
+template <int D>
 struct Row {
-    static constexpr int LPR = D / 4;
-    static constexpr int VW = VEC ? 4 : (32 / LPR);     // floats per vector access
-    static constexpr int NV = 4 / VW;                   // vector accesses per row per lane
-    float v[4];
-    // element index of this lane's c-th float
-    static __device__ __forceinline__ int elem(int k, int c) { return (c / VW) * (LPR * VW) + k * VW + (c % VW); }
+    static constexpr int EPL = D / 32;
+    float v[EPL];
+    static __device__ __forceinline__ int elem(int k, int c) { return k + 32 * c; }
     __device__ __forceinline__ void load(const float *row, int k)
     {
-        if constexpr (VW == 4) {
-            const float4 t = *reinterpret_cast<const float4 *>(row + elem(k, 0));
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-        } else if constexpr (VW == 2) {
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const float2 t = *reinterpret_cast<const float2 *>(row + elem(k, 2 * n));
-                v[2 * n] = t.x; v[2 * n + 1] = t.y;
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = row[elem(k, c)];
-        }
+        for (int c = 0; c < EPL; ++c) v[c] = row[elem(k, c)];
     }
     // streaming (non-temporal) variants for rows nobody re-reads (measured: no effect)
     __device__ __forceinline__ void load_nt(const float *row, int k)
     {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = __builtin_nontemporal_load(row + elem(k, c));
+        for (int c = 0; c < EPL; ++c) v[c] = __builtin_nontemporal_load(row + elem(k, c));
     }
     __device__ __forceinline__ void store_nt(float *row, int k) const
     {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) __builtin_nontemporal_store(v[c], row + elem(k, c));
+        for (int c = 0; c < EPL; ++c) __builtin_nontemporal_store(v[c], row + elem(k, c));
     }
     __device__ __forceinline__ void store(float *row, int k) const
     {
-        if constexpr (VW == 4) {
-            *reinterpret_cast<float4 *>(row + elem(k, 0)) = make_float4(v[0], v[1], v[2], v[3]);
-        } else if constexpr (VW == 2) {
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
-                *reinterpret_cast<float2 *>(row + elem(k, 2 * n)) = make_float2(v[2 * n], v[2 * n + 1]);
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) row[elem(k, c)] = v[c];
-        }
+        for (int c = 0; c < EPL; ++c) row[elem(k, c)] = v[c];
     }
     // row[...] += s * v   (hardware fp32 atomics, no return)
     __device__ __forceinline__ void atomic_axpy(float *row, int k, float s) const
     {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) rsx_atomic_add(row + elem(k, c), s * v[c]);
+        for (int c = 0; c < EPL; ++c) rsx_atomic_add(row + elem(k, c), s * v[c]);
     }
 };
 
-// sum over the LPR lanes of a lane group, result in every lane of the group.  Pure cross-lane
+// sum over the 32 lanes of a lane group, result in every lane of the group.  Pure cross-lane
 // VALU (DPP inside a 16-lane row, v_permlane16/32_swap across rows): no LDS round trips
 // (__shfl_xor lowers to ds_bpermute_b32, 10 of them per triplet on the dependent path).
 template <int CTRL>
@@ -97,24 +75,15 @@ __device__ __forceinline__ float dpp_mov(float x)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
 }
 
-template <int LPR>
 __device__ __forceinline__ float group_sum(float x)
 {
     x += dpp_mov<0xB1>(x);                       // quad_perm [1,0,3,2]  : lane ^ 1
     x += dpp_mov<0x4E>(x);                       // quad_perm [2,3,0,1]  : lane ^ 2
-    if constexpr (LPR >= 8) x += dpp_mov<0x141>(x);    // row_half_mirror: the other quad of the 8
-    if constexpr (LPR >= 16) x += dpp_mov<0x140>(x);   // row_mirror     : the other half of the 16
-    if constexpr (LPR >= 32) {                         // rows 0<->1, 2<->3
-        const unsigned b = __builtin_bit_cast(unsigned, x);
-        const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
-        x = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-    }
-    if constexpr (LPR >= 64) {                         // halves
-        const unsigned b = __builtin_bit_cast(unsigned, x);
-        const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
-        x = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-    }
-    return x;
+    x += dpp_mov<0x141>(x);                      // row_half_mirror: the other quad of the 8
+    x += dpp_mov<0x140>(x);                      // row_mirror     : the other half of the 16
+    const unsigned b = __builtin_bit_cast(unsigned, x);      // rows 0<->1, 2<->3
+    const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
 }
 
 __device__ __forceinline__ float wave_sum(float x)
@@ -131,6 +100,22 @@ __device__ __forceinline__ float softplus_neg(float x)
     return fmaxf(-x, 0.0f) + log1pf(__expf(-fabsf(x)));
 }
 
+// EPL contiguous floats of a wave-private LDS tile (one ds_read/ds_write of 4, 8 or 16 bytes)
+template <int EPL>
+__device__ __forceinline__ void tile_load(const float *cell, float (&a)[EPL])
+{
+    if constexpr (EPL == 4) { const float4 t = *reinterpret_cast<const float4 *>(cell); a[0] = t.x; a[1] = t.y; a[2] = t.z; a[3] = t.w; }
+    else if constexpr (EPL == 2) { const float2 t = *reinterpret_cast<const float2 *>(cell); a[0] = t.x; a[1] = t.y; }
+    else { a[0] = *cell; }
+}
+template <int EPL>
+__device__ __forceinline__ void tile_store(float *cell, const float (&a)[EPL])
+{
+    if constexpr (EPL == 4) *reinterpret_cast<float4 *>(cell) = make_float4(a[0], a[1], a[2], a[3]);
+    else if constexpr (EPL == 2) *reinterpret_cast<float2 *>(cell) = make_float2(a[0], a[1]);
+    else *cell = a[0];
+}
+
 // Hot item rows (popular items hit by thousands of triplets per step) serialise at the
 // memory-side atomic unit (~40 same-line ops/us measured).  Their gradient is therefore
 // spread over `replicas` private copies, picked by wavefront id, and folded into G by
@@ -145,7 +130,7 @@ struct HotMap {
 // MODE 1: users may repeat          -> user deltas summed into GU[owner slot].
 // MODE 2: gradients only            -> dP summed into the dense buffer GU[u] (P untouched);
 //                                      the optimizer sweep (adam_apply_kernel) consumes it.
-template <int D, bool VEC, int MODE>
+template <int D, int MODE>
 __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
     float *__restrict__ P, const float *__restrict__ Q, float *__restrict__ G,
     const int32_t *__restrict__ U_idx, const int32_t *__restrict__ I_idx,
@@ -153,8 +138,7 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
     float *__restrict__ loss_acc, const int32_t *__restrict__ owner, float *__restrict__ GU,
     HotMap hot, int ablate)
 {
-    constexpr int LPR = D / 4;
-    constexpr int TPW = 64 / LPR;  // triplets per wavefront
+    constexpr int EPL = D / 32;
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR;
     const int k = lane % LPR;
@@ -176,20 +160,20 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
             float *prow = P + (size_t)u * D;
             const float *qi_row = Q + (size_t)i * D;
             const float *qj_row = Q + (size_t)j * D;
-            Row<D, VEC> p, qi, qj;
+            Row<D> p, qi, qj;
             if (ablate & 8) p.load_nt(prow, k); else p.load(prow, k);
             qi.load(qi_row, k);
             qj.load(qj_row, k);
             float dpos = 0.0f, dneg = 0.0f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < EPL; ++c) {
                 dpos = fmaf(p.v[c], qi.v[c], dpos);
                 dneg = fmaf(p.v[c], qj.v[c], dneg);
             }
-            // (inactive groups skip the butterfly; the group is LPR-aligned so the
-            //  xor partners are always inside the same live/dead group)
-            dpos = group_sum<LPR>(dpos);
-            dneg = group_sum<LPR>(dneg);
+            // (inactive groups skip the butterfly; the partners of every cross-lane step are
+            //  inside the same 32-lane group, which is live or dead as a whole)
+            dpos = group_sum(dpos);
+            dneg = group_sum(dneg);
             const float x = dpos - dneg;
             const float sneg = 1.0f / (1.0f + __expf(x));      // sigmoid(-x)
             const float g = -sneg * inv_batch;                 // dL/dx
@@ -207,12 +191,12 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
             const float s = -lr * g;
             if constexpr (MODE == 0) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) p.v[c] = fmaf(s, qi.v[c] - qj.v[c], p.v[c]);
+                for (int c = 0; c < EPL; ++c) p.v[c] = fmaf(s, qi.v[c] - qj.v[c], p.v[c]);
                 if (!(ablate & 4)) { if (ablate & 16) p.store_nt(prow, k); else p.store(prow, k); }
             } else {
-                Row<D, VEC> dq;
+                Row<D> dq;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) dq.v[c] = qi.v[c] - qj.v[c];
+                for (int c = 0; c < EPL; ++c) dq.v[c] = qi.v[c] - qj.v[c];
                 if constexpr (MODE == 1) {
                     const int32_t slot = owner[u] - 1;
                     dq.atomic_axpy(GU + (size_t)slot * D, k, s);
@@ -252,9 +236,8 @@ __global__ __launch_bounds__(kBlock, 5) void bpr_step_blocked_kernel(
     float inv_batch, float *__restrict__ loss_acc, HotMap hot, int ablate)
 {
     extern __shared__ __attribute__((aligned(16))) float neg_acc[];   // [4 waves][c][D]
-    using RowT = Row<D, false>;
-    constexpr int LPR = D / 4;
-    constexpr int TPW = 64 / LPR;
+    using RowT = Row<D>;
+    constexpr int EPL = D / 32;
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR;
     const int k = lane % LPR;
@@ -282,37 +265,34 @@ __global__ __launch_bounds__(kBlock, 5) void bpr_step_blocked_kernel(
     // parity: the 16-bit-key sort orders the batch by item >> 1, so within one key the two items
     // interleave; each keeps its own run.
     int32_t run_item0 = -1, run_item1 = -1;
-    float r0x = 0.f, r0y = 0.f, r0z = 0.f, r0w = 0.f, r1x = 0.f, r1y = 0.f, r1z = 0.f, r1w = 0.f;
-    // (scalars, not arrays: arrays selected through a reference end up in scratch memory)
-#define RSX_RUN_FLUSH(RI, RX, RY, RZ, RW)                                         \
+    float r0[EPL], r1[EPL];
+#pragma unroll
+    for (int cc = 0; cc < EPL; ++cc) { r0[cc] = 0.f; r1[cc] = 0.f; }
+    // (all indices below are compile-time constants after unrolling, so the arrays stay in
+    //  registers; choosing between r0 and r1 through a reference or a branch does not)
+#define RSX_RUN_FLUSH(RI, R)                                                      \
     if (RI >= 0 && !(ablate & 1)) {                                               \
         float *grow = G + (size_t)RI * D;                                         \
-        rsx_atomic_add(grow + RowT::elem(k, 0), RX); rsx_atomic_add(grow + RowT::elem(k, 1), RY); \
-        rsx_atomic_add(grow + RowT::elem(k, 2), RZ); rsx_atomic_add(grow + RowT::elem(k, 3), RW); \
+        _Pragma("unroll") for (int cc = 0; cc < EPL; ++cc) rsx_atomic_add(grow + RowT::elem(k, cc), R[cc]); \
     }
-#define RSX_RUN_ADD(RI, RX, RY, RZ, RW)                                           \
-    if (i != RI) {                                                                \
-        RSX_RUN_FLUSH(RI, RX, RY, RZ, RW)                                         \
-        RI = i; RX = 0.f; RY = 0.f; RZ = 0.f; RW = 0.f;                           \
-    }                                                                             \
-    RX = fmaf(g, p.v[0], RX); RY = fmaf(g, p.v[1], RY);                           \
-    RZ = fmaf(g, p.v[2], RZ); RW = fmaf(g, p.v[3], RW);
 
     // one triplet whose three rows are already in registers
-    auto process = [&](bool live, int32_t u, int32_t i, int32_t j, Row<D, false> &p,
-                       const Row<D, false> &qi, const Row<D, false> &qj) __attribute__((always_inline)) {
+    auto process = [&](bool live, int32_t u, int32_t i, int32_t j, Row<D> &p,
+                       const Row<D> &qi, const Row<D> &qj) __attribute__((always_inline)) {
         bool neg_local = false;
         float neg_g = 0.0f;
-        float pv[4] = {0.f, 0.f, 0.f, 0.f};
+        float pv[EPL];
+#pragma unroll
+        for (int cc = 0; cc < EPL; ++cc) pv[cc] = 0.f;
         if (live) {
             float dpos = 0.0f, dneg = 0.0f;
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
+            for (int cc = 0; cc < EPL; ++cc) {
                 dpos = fmaf(p.v[cc], qi.v[cc], dpos);
                 dneg = fmaf(p.v[cc], qj.v[cc], dneg);
             }
-            dpos = group_sum<LPR>(dpos);
-            dneg = group_sum<LPR>(dneg);
+            dpos = group_sum(dpos);
+            dneg = group_sum(dneg);
             const float x = dpos - dneg;
             const float sneg = 1.0f / (1.0f + __expf(x));
             const float g = -sneg * inv_batch;
@@ -323,21 +303,30 @@ __global__ __launch_bounds__(kBlock, 5) void bpr_step_blocked_kernel(
             {
                 const bool odd = (i & 1) != 0;
                 int32_t ri = odd ? run_item1 : run_item0;
-                float tx = odd ? r1x : r0x, ty = odd ? r1y : r0y, tz = odd ? r1z : r0z, tw = odd ? r1w : r0w;
-                RSX_RUN_ADD(ri, tx, ty, tz, tw)
+                float t[EPL];
+#pragma unroll
+                for (int cc = 0; cc < EPL; ++cc) t[cc] = odd ? r1[cc] : r0[cc];
+                if (i != ri) {
+                    RSX_RUN_FLUSH(ri, t)
+                    ri = i;
+#pragma unroll
+                    for (int cc = 0; cc < EPL; ++cc) t[cc] = 0.f;
+                }
+#pragma unroll
+                for (int cc = 0; cc < EPL; ++cc) t[cc] = fmaf(g, p.v[cc], t[cc]);
                 run_item0 = odd ? run_item0 : ri; run_item1 = odd ? ri : run_item1;
-                r0x = odd ? r0x : tx; r0y = odd ? r0y : ty; r0z = odd ? r0z : tz; r0w = odd ? r0w : tw;
-                r1x = odd ? tx : r1x; r1y = odd ? ty : r1y; r1z = odd ? tz : r1z; r1w = odd ? tw : r1w;
+#pragma unroll
+                for (int cc = 0; cc < EPL; ++cc) { r0[cc] = odd ? r0[cc] : t[cc]; r1[cc] = odd ? t[cc] : r1[cc]; }
             }
             // negative item: the wave's own block goes to LDS, anything else to G
             neg_local = ((int64_t)j >= item_lo && (int64_t)j < item_hi);
             if (!neg_local && !(ablate & 2)) p.atomic_axpy(G + (size_t)j * D, k, -g);
             neg_g = -g;
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) pv[cc] = p.v[cc];
+            for (int cc = 0; cc < EPL; ++cc) pv[cc] = p.v[cc];
             const float s = -lr * g;
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) p.v[cc] = fmaf(s, qi.v[cc] - qj.v[cc], p.v[cc]);
+            for (int cc = 0; cc < EPL; ++cc) p.v[cc] = fmaf(s, qi.v[cc] - qj.v[cc], p.v[cc]);
             if (!(ablate & 4)) p.store(P + (size_t)u * D, k);
         }
         // wave-private LDS tile, plain read-modify-write (ds_add_f32 measured ~120 clk per
@@ -347,11 +336,12 @@ __global__ __launch_bounds__(kBlock, 5) void bpr_step_blocked_kernel(
 #pragma unroll
             for (int tt = 0; tt < TPW; ++tt) {
                 if (sub == tt && neg_local) {
-                    float4 *cell = reinterpret_cast<float4 *>(acc) + (size_t)(j - item_lo) * LPR + k;
-                    float4 a = *cell;
-                    a.x = fmaf(neg_g, pv[0], a.x); a.y = fmaf(neg_g, pv[1], a.y);
-                    a.z = fmaf(neg_g, pv[2], a.z); a.w = fmaf(neg_g, pv[3], a.w);
-                    *cell = a;
+                    float *cell = acc + ((size_t)(j - item_lo) * LPR + k) * EPL;   // lane k's EPL floats
+                    float a[EPL];
+                    tile_load<EPL>(cell, a);
+#pragma unroll
+                    for (int cc = 0; cc < EPL; ++cc) a[cc] = fmaf(neg_g, pv[cc], a[cc]);
+                    tile_store<EPL>(cell, a);
                 }
             }
         }
@@ -369,33 +359,34 @@ __global__ __launch_bounds__(kBlock, 5) void bpr_step_blocked_kernel(
         if (b + 3 < g_hi) { unb = U_idx[b + 3]; inb = I_idx[b + 3]; jnb = J_idx[b + 3]; }
         const bool live_a = (b < g_hi) && (ia >= 0);
         const bool live_b = (b + 1 < g_hi) && (ib >= 0);
-        Row<D, false> pa, qia, qja, pb, qib, qjb;
+        Row<D> pa, qia, qja, pb, qib, qjb;
         if (live_a) { pa.load(P + (size_t)ua * D, k); qia.load(Q + (size_t)ia * D, k); qja.load(Q + (size_t)ja * D, k); }
         if (live_b) { pb.load(P + (size_t)ub * D, k); qib.load(Q + (size_t)ib * D, k); qjb.load(Q + (size_t)jb * D, k); }
         process(live_a, ua, ia, ja, pa, qia, qja);
         process(live_b, ub, ib, jb, pb, qib, qjb);
         ua = una; ia = ina; ja = jna; ub = unb; ib = inb; jb = jnb;
     }
-    RSX_RUN_FLUSH(run_item0, r0x, r0y, r0z, r0w)     // last runs of this lane group
-    RSX_RUN_FLUSH(run_item1, r1x, r1y, r1z, r1w)
-#undef RSX_RUN_ADD
+    RSX_RUN_FLUSH(run_item0, r0)     // last runs of this lane group
+    RSX_RUN_FLUSH(run_item1, r1)
 #undef RSX_RUN_FLUSH
     // flush the block's rows: one global atomic row per touched item
     const int rows = (int)(item_hi - item_lo);
     for (int m = sub; m - sub < rows; m += TPW) {
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        float v[EPL];
+#pragma unroll
+        for (int cc = 0; cc < EPL; ++cc) v[cc] = 0.f;
         bool nz = false;
         if (m < rows) {
-            const float4 a = reinterpret_cast<const float4 *>(acc)[(size_t)m * LPR + k];   // cell = lane k's 4 elements
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-            nz = (a.x != 0.0f) | (a.y != 0.0f) | (a.z != 0.0f) | (a.w != 0.0f);
+            tile_load<EPL>(acc + ((size_t)m * LPR + k) * EPL, v);
+#pragma unroll
+            for (int cc = 0; cc < EPL; ++cc) nz |= (v[cc] != 0.0f);
         }
         const unsigned long long bal = __ballot(nz);
-        const unsigned long long gmask = (LPR == 64) ? ~0ull : (((1ull << LPR) - 1ull) << (sub * LPR));
+        const unsigned long long gmask = 0xFFFFFFFFull << (sub * 32);
         if (m < rows && (bal & gmask) != 0ull) {
             float *grow = G + (size_t)(item_lo + m) * D;
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) rsx_atomic_add(grow + RowT::elem(k, cc), v[cc]);
+            for (int cc = 0; cc < EPL; ++cc) rsx_atomic_add(grow + RowT::elem(k, cc), v[cc]);
         }
     }
     if (loss_acc != nullptr) {
@@ -423,14 +414,14 @@ __global__ __launch_bounds__(kBlock) void bpr_apply_user_kernel(float *__restric
                                                                 int64_t B, int32_t *__restrict__ owner,
                                                                 float *__restrict__ GU)
 {
-    constexpr int LPR = D / 4;
-    constexpr int TPW = 64 / LPR;
+    constexpr int L4 = D / 4;          // lanes per row with one float4 each
+    constexpr int G4 = 64 / L4;
     const int lane = threadIdx.x & 63;
-    const int sub = lane / LPR;
-    const int k = lane % LPR;
+    const int sub = lane / L4;
+    const int k = lane % L4;
     const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock * TPW;
-    for (int64_t b = wave * TPW + sub; b < B; b += stride) {
+    const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock * G4;
+    for (int64_t b = wave * G4 + sub; b < B; b += stride) {
         if (I_idx[b] < 0) continue;
         const int32_t u = U_idx[b];
         if (owner[u] != (int32_t)(b + 1)) continue;   // only the owner triplet applies
@@ -483,8 +474,6 @@ __global__ __launch_bounds__(kBlock) void pair_score_kernel(const float *__restr
                                                             const int32_t *__restrict__ I_idx,
                                                             int64_t n, float *__restrict__ out)
 {
-    constexpr int LPR = D / 4;
-    constexpr int TPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR;
     const int k = lane % LPR;
@@ -493,13 +482,13 @@ __global__ __launch_bounds__(kBlock) void pair_score_kernel(const float *__restr
     for (int64_t b = wave * TPW + sub; b - sub < n; b += stride) {
         float acc = 0.0f;
         if (b < n) {
-            Row<D, false> p, q;
+            Row<D> p, q;
             p.load(P + (size_t)U_idx[b] * D, k);
             q.load(Q + (size_t)I_idx[b] * D, k);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc = fmaf(p.v[c], q.v[c], acc);
+            for (int c = 0; c < D / 32; ++c) acc = fmaf(p.v[c], q.v[c], acc);
         }
-        acc = group_sum<LPR>(acc);
+        acc = group_sum(acc);
         if (b < n && k == 0) out[b] = acc;
     }
 }
@@ -543,36 +532,32 @@ __global__ __launch_bounds__(kBlock) void fold_hot_kernel(float *__restrict__ G,
     *dst = g;
 }
 
-int g_layout_vec = 0;   // row layout used by bpr_step (0 = strided dwords, 1 = dwordx4); tuning knob
 int g_ablate = 0;       // development only: 1 = skip pos-item atomics, 2 = skip neg-item atomics, 4 = skip P store
 
-template <int D, bool VEC, int MODE>
+template <int D, int MODE>
 void launch_step(float *P, const float *Q, float *G, const int32_t *u, const int32_t *i,
                  const int32_t *j, int64_t B, float lr, float inv_batch, float *loss_acc,
                  const int32_t *owner, float *GU, HotMap hot, int ablate, hipStream_t st)
 {
-    constexpr int TPW = 64 / (D / 4);
     const int64_t waves = (B + TPW - 1) / TPW;
     int64_t blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
     const int64_t cap = (int64_t)rsx_num_cus() * 8;   // 8 blocks x 4 waves = 32 waves per CU
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((bpr_step_kernel<D, VEC, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, P, Q,
+    hipLaunchKernelGGL((bpr_step_kernel<D, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, P, Q,
                        G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot, ablate);
 }
 
 template <int MODE>
-void dispatch_step(int d, bool vec, float *P, const float *Q, float *G, const int32_t *u,
-                   const int32_t *i, const int32_t *j, int64_t B, float lr, float inv_batch,
-                   float *loss_acc, const int32_t *owner, float *GU, HotMap hot, int ablate, hipStream_t st)
+void dispatch_step(int d, float *P, const float *Q, float *G, const int32_t *u, const int32_t *i,
+                   const int32_t *j, int64_t B, float lr, float inv_batch, float *loss_acc,
+                   const int32_t *owner, float *GU, HotMap hot, int ablate, hipStream_t st)
 {
-#define RSX_CASE(DD)                                                                                   \
-    case DD:                                                                                           \
-        if (vec) launch_step<DD, true, MODE>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot, ablate, st); \
-        else launch_step<DD, false, MODE>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot, ablate, st);    \
-        break;
-    switch (d) { RSX_CASE(32) RSX_CASE(64) RSX_CASE(128) }
-#undef RSX_CASE
+    switch (d) {
+    case 32: launch_step<32, MODE>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot, ablate, st); break;
+    case 64: launch_step<64, MODE>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot, ablate, st); break;
+    default: launch_step<128, MODE>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot, ablate, st); break;
+    }
 }
 
 int64_t grid_1d(int64_t n)
@@ -586,7 +571,6 @@ int64_t grid_1d(int64_t n)
 }  // namespace
 
 // undocumented tuning hook (bench / tests): select the row layout of bpr_step
-RSX_API int rsx_debug_set_layout(int vec) { g_layout_vec = vec ? 1 : 0; return RSX_OK; }
 RSX_API int rsx_debug_set_ablation(int mask) { g_ablate = mask; return RSX_OK; }
 
 RSX_API int64_t rsx_bpr_step_workspace(int64_t num_users, int64_t max_batch, int d)
@@ -615,13 +599,13 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
         hot = HotMap{hot_slot_dev, G_hot, hot_replicas};
     }
     if (flags & RSX_NO_UPDATE) {   // loss only: the in-place kernel with every write suppressed
-        dispatch_step<0>(d, g_layout_vec != 0, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch,
+        dispatch_step<0>(d, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch,
                          loss_acc, nullptr, nullptr, HotMap{nullptr, nullptr, 1}, /*suppress every write*/ 7, st);
         RSX_CHECK_LAUNCH();
         return RSX_OK;
     }
     RSX_CHECK_ARG(neg_block >= 0 && neg_block <= kMaxNegBlock, "neg_block must be in [0, 16]");
-    if ((flags & RSX_USERS_UNIQUE) && neg_block > 0 && g_layout_vec == 0) {
+    if ((flags & RSX_USERS_UNIQUE) && neg_block > 0) {
         const int64_t waves = ceil_div64(num_items, neg_block);
         const unsigned blocks = (unsigned)ceil_div64(waves, kWavesPerBlock);
         const size_t lds = (size_t)kWavesPerBlock * neg_block * d * sizeof(float);
@@ -634,7 +618,7 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
         return RSX_OK;
     }
     if (flags & RSX_USERS_UNIQUE) {
-        dispatch_step<0>(d, g_layout_vec != 0, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch,
+        dispatch_step<0>(d, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch,
                          loss_acc, nullptr, nullptr, hot, g_ablate, st);
         RSX_CHECK_LAUNCH();
         return RSX_OK;
@@ -649,9 +633,9 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
     float *GU = (float *)((char *)ws + ((num_users * 4 + 255) / 256) * 256);
     const unsigned g1 = (unsigned)grid_1d(batch);
     hipLaunchKernelGGL(bpr_claim_kernel, dim3(g1), dim3(kBlock), 0, st, u_dev, i_dev, batch, owner);
-    dispatch_step<1>(d, g_layout_vec != 0, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch,
+    dispatch_step<1>(d, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch,
                      loss_acc, owner, GU, hot, g_ablate, st);
-    const int64_t tpw = 64 / (d / 4);
+    const int64_t tpw = 64 / (d / 4);     // bpr_apply_user_kernel: one float4 per lane
     const unsigned g2 = (unsigned)grid_1d((batch + tpw - 1) / tpw * 64);
     switch (d) {
     case 32: hipLaunchKernelGGL(bpr_apply_user_kernel<32>, dim3(g2), dim3(kBlock), 0, st, P, u_dev, i_dev, batch, owner, GU); break;
@@ -673,7 +657,7 @@ RSX_API int rsx_bpr_grad(const float *P, const float *Q, float *GP, float *GQ, i
     RSX_CHECK_ARG(batch >= 0 && num_users > 0 && num_items > 0, "negative size");
     if (batch == 0) return RSX_OK;
     RSX_CHECK_ARG(u_dev && i_dev && j_dev, "null index pointer");
-    dispatch_step<2>(d, false, const_cast<float *>(P), Q, GQ, u_dev, i_dev, j_dev, batch, 0.0f, inv_batch,
+    dispatch_step<2>(d, const_cast<float *>(P), Q, GQ, u_dev, i_dev, j_dev, batch, 0.0f, inv_batch,
                      loss_acc, nullptr, GP, HotMap{nullptr, nullptr, 1}, 0, (hipStream_t)stream);
     RSX_CHECK_LAUNCH();
     return RSX_OK;
@@ -701,8 +685,7 @@ RSX_API int rsx_pair_score(const float *P, const float *Q, const int32_t *u_dev,
     RSX_CHECK_ARG(rsx_dim_ok(d) && n >= 0, "bad shape");
     if (n == 0) return RSX_OK;
     RSX_CHECK_ARG(u_dev && i_dev, "null index pointer");
-    const int64_t tpw = 64 / (d / 4);
-    const unsigned g = (unsigned)grid_1d((n + tpw - 1) / tpw * 64);
+    const unsigned g = (unsigned)grid_1d((n + TPW - 1) / TPW * 64);
     hipStream_t st = (hipStream_t)stream;
     switch (d) {
     case 32: hipLaunchKernelGGL(pair_score_kernel<32>, dim3(g), dim3(kBlock), 0, st, P, Q, u_dev, i_dev, n, r_out); break;

@@ -28,8 +28,7 @@ def dev(a, dtype=None):
     return t.cuda().contiguous()
 
 
-def run_steps(rsx, P0, Q0, batches, lr, unique_flag, layout):
-    rsx.lib().rsx_debug_set_layout(layout)
+def run_steps(rsx, P0, Q0, batches, lr, unique_flag):
     P, Q = dev(P0), dev(Q0)
     G = torch.zeros_like(Q)
     U, d = P.shape
@@ -49,13 +48,12 @@ def run_steps(rsx, P0, Q0, batches, lr, unique_flag, layout):
     return P.cpu().numpy(), Q.cpu().numpy(), losses
 
 
-@pytest.mark.parametrize("layout", [0, 1])
 @pytest.mark.parametrize("name", G1_SGD)
-def test_bpr_step_matches_reference_golden(rsx, name, layout):
+def test_bpr_step_matches_reference_golden(rsx, name):
     """20 SGD steps on the reference's own triplets (duplicates inside batches)."""
     g = golden(name)
     batches = list(split_batches(g))
-    P, Q, losses = run_steps(rsx, g["P0"], g["Q0"], batches, float(g["lr"]), True, layout)
+    P, Q, losses = run_steps(rsx, g["P0"], g["Q0"], batches, float(g["lr"]), True)
     assert rel_err(P, g["PT"]) < REL_TOL
     assert rel_err(Q, g["QT"]) < REL_TOL
     assert np.allclose(losses, g["loss"], rtol=1e-5, atol=1e-6)
@@ -110,7 +108,7 @@ def test_bpr_step_random_vs_oracle(rsx, oracle_mod, d, B):
     batches = [(rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)) for _ in range(3)]
     orc = oracle_mod.MFOracle(P0, Q0, "sgd", 0.05)
     ol = [orc.step(*b) for b in batches]
-    P, Q, losses = run_steps(rsx, P0, Q0, batches, 0.05, False, 0)
+    P, Q, losses = run_steps(rsx, P0, Q0, batches, 0.05, False)
     assert rel_err(P, orc.P) < REL_TOL and rel_err(Q, orc.Q) < REL_TOL
     assert np.allclose(losses, ol, rtol=1e-5, atol=1e-6)
 
@@ -124,11 +122,10 @@ def test_bpr_step_unique_users_fast_path_equals_general_path(rsx, oracle_mod):
     orc = oracle_mod.MFOracle(P0, Q0, "sgd", 0.05)
     for b in batches:
         orc.step(*b)
-    for layout in (0, 1):
-        Pf, Qf, _ = run_steps(rsx, P0, Q0, batches, 0.05, True, layout)
-        Pg, Qg, _ = run_steps(rsx, P0, Q0, batches, 0.05, False, layout)
-        assert rel_err(Pf, orc.P) < REL_TOL and rel_err(Qf, orc.Q) < REL_TOL
-        assert rel_err(Pg, orc.P) < REL_TOL and rel_err(Qg, orc.Q) < REL_TOL
+    Pf, Qf, _ = run_steps(rsx, P0, Q0, batches, 0.05, True)
+    Pg, Qg, _ = run_steps(rsx, P0, Q0, batches, 0.05, False)
+    assert rel_err(Pf, orc.P) < REL_TOL and rel_err(Qf, orc.Q) < REL_TOL
+    assert rel_err(Pg, orc.P) < REL_TOL and rel_err(Qg, orc.Q) < REL_TOL
 
 
 def test_bpr_step_empty_and_skipped_triplets(rsx):

@@ -38,8 +38,7 @@ def main():
             ju = torch.randint(0, I, (B,), device="cuda", dtype=torch.int32, generator=gen)
             for items in ("uniform", "zipf"):
                 i = torch.randint(0, I, (B,), device="cuda", dtype=torch.int32, generator=gen) if items == "uniform" else zipf_items(B, I, gen)
-                for layout in (0, 1):
-                    rsx.lib().rsx_debug_set_layout(layout)
+                for layout in (0,):
                     t_step = timeit(lambda: rsx.bpr_step(P, Q, G, u, i, ju, 0.05, 1.0 / B, users_unique=True))
                     t_app = timeit(lambda: rsx.apply_item_grad(Q, G, 0.05))
                     def both():
