@@ -146,7 +146,9 @@ int rsx_pair_score(const float *P, const float *Q, const int32_t *u_dev, const i
  * reference's quirks (SURVEY appendix A, Q1-Q3 documented in DESIGN.md):
  *   user  : position (epoch_pos + b) of a keyed pseudo-random PERMUTATION of the
  *           local users -> no user repeats while batch <= num_users
- *           (the reference also visits each user once per epoch, generators.py:206-210)
+ *           (the reference also visits each user once per epoch, generators.py:206-210);
+ *           a batch of exactly num_users positions starting a pass holds every user once
+ *           and is walked in id order (a batch is a set; the reads become coalesced)
  *   pos i : uniform over the user's CSR row (indices[indptr[u]:indptr[u+1]])
  *   neg j : uniform over [0,num_items) rejected while j is in that row
  *           (generators.py:178-185: p = 0 on the user's positives)

@@ -34,10 +34,14 @@ __device__ __forceinline__ uint32_t rng_seed(uint64_t seed, uint64_t step, uint6
     return s | (s == 0);
 }
 
+// hb < 0: the batch holds every user exactly once (batch == num_users), so no permutation is
+// needed -- a batch is a set -- and walking the users in id order makes the indptr / row reads
+// of the sampling pass coalesced instead of one random sector per user.
 __device__ __forceinline__ uint32_t user_at(int64_t gpos, int64_t U, int hb, uint64_t seed)
 {
     const uint64_t epoch = (uint64_t)(gpos / U);
     const uint32_t pos = (uint32_t)(gpos % U);
+    if (hb < 0) return pos;
     return feistel_perm(pos, (uint32_t)U, hb, splitmix64(seed ^ (epoch * 0xD1B54A32D192ED03ull)));
 }
 
@@ -224,7 +228,7 @@ RSX_API int rsx_bpr_sample(const int64_t *indptr_dev, const int32_t *indices_dev
     RSX_CHECK_ARG(batch >= 0 && epoch_pos >= 0, "negative size");
     RSX_CHECK_ARG(neg_block >= 0 && neg_block <= kMaxNegBlock, "neg_block must be in [0, 16]");
     if (batch == 0) return RSX_OK;
-    const int hb = half_bits_for(num_users);
+    const int hb = (batch == num_users && epoch_pos % num_users == 0) ? -1 : half_bits_for(num_users);
     hipStream_t st = (hipStream_t)stream;
     if (!(flags & RSX_SAMPLE_SORT_POS)) {
         hipLaunchKernelGGL(bpr_sample_kernel, dim3(grid_1d(batch)), dim3(kBlock), 0, st, indptr_dev, indices_dev,

@@ -123,7 +123,7 @@ def test_device_sampler_properties(ml100k):
     u, i, j = mk(U), mk(U), mk(U)
     rsx.bpr_sample(ip, ix, I, U, 2020, 3, 0, u, i, j)
     un, inn, jn = u.cpu().numpy(), i.cpu().numpy(), j.cpu().numpy()
-    assert sorted(un) == list(range(U))                          # a permutation: every user exactly once
+    assert list(un) == list(range(U))                            # a full pass: every user once, in id order
     ipn, ixn = ip.cpu().numpy(), ix.cpu().numpy()
     for a, b, c in zip(un, inn, jn):
         row = ixn[ipn[a]:ipn[a + 1]]
@@ -132,8 +132,16 @@ def test_device_sampler_properties(ml100k):
     rsx.bpr_sample(ip, ix, I, U, 2020, 3, 0, u2, i2, j2)
     assert torch.equal(u, u2) and torch.equal(i, i2) and torch.equal(j, j2)   # deterministic
     rsx.bpr_sample(ip, ix, I, U, 2020, 4, U, u2, i2, j2)
-    assert not torch.equal(u, u2)                                # next epoch: another permutation
-    assert sorted(u2.cpu().numpy()) == list(range(U))
+    assert not torch.equal(i, i2)                                # another step: other positives
+    # partial batches walk a keyed PERMUTATION of the users: unique inside a pass, reshuffled per pass
+    h = U // 2
+    a1, a2, b1 = mk(h), mk(h), mk(h)
+    rsx.bpr_sample(ip, ix, I, h, 2020, 5, 0, a1, i2[:h], j2[:h])
+    rsx.bpr_sample(ip, ix, I, h, 2020, 6, h, a2, i2[:h], j2[:h])
+    rsx.bpr_sample(ip, ix, I, h, 2020, 7, U, b1, i2[:h], j2[:h])
+    both = torch.cat([a1, a2]).cpu().numpy()
+    assert len(np.unique(both)) == 2 * h and list(a1.cpu().numpy()) != sorted(a1.cpu().numpy())
+    assert not torch.equal(a1, b1)                               # next pass: another permutation
     # negatives are ~uniform over non-positives: chi-square-ish sanity on 8 item buckets
     big = 200_000
     ub, ib, jb = mk(big), mk(big), mk(big)
