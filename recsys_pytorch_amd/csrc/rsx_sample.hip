@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void sample_ui_kernel(
 __global__ __launch_bounds__(kBlock) void sample_ui16_kernel(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t U, int64_t I,
     int64_t B, uint64_t seed, uint64_t step, int64_t epoch_pos, int hb, int shift,
-    uint16_t *__restrict__ keys, uint64_t *__restrict__ vals)
+    uint16_t *__restrict__ keys, uint32_t *__restrict__ vals)
 {
     for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < B; b += (int64_t)gridDim.x * kBlock) {
         const uint32_t u = user_at(epoch_pos + b, U, hb, seed);
@@ -127,18 +127,20 @@ __global__ __launch_bounds__(kBlock) void sample_ui16_kernel(
         uint32_t item = (uint32_t)I;                       // "no positive": sorts last
         if (deg > 0 && (int64_t)deg < I) item = (uint32_t)indices[lo + (int64_t)(((uint64_t)xorshift32(s) * deg) >> 32)];
         keys[b] = (uint16_t)(item >> shift);
-        vals[b] = ((uint64_t)u << 32) | item;
+        vals[b] = (u << shift) | (item & ((1u << shift) - 1u));
     }
 }
 
 __global__ __launch_bounds__(kBlock) void sample_neg16_kernel(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t I, int64_t B,
-    uint64_t seed, uint64_t step, int neg_block, uint64_t neg_key, const uint64_t *__restrict__ vals_sorted,
+    uint64_t seed, uint64_t step, int neg_block, uint64_t neg_key, int shift,
+    const uint16_t *__restrict__ keys_sorted, const uint32_t *__restrict__ vals_sorted,
     int32_t *__restrict__ u_out, int32_t *__restrict__ i_out, int32_t *__restrict__ j_out)
 {
     for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < B; p += (int64_t)gridDim.x * kBlock) {
-        const uint64_t v = vals_sorted[p];
-        const uint32_t u = (uint32_t)(v >> 32), item = (uint32_t)v;
+        const uint32_t v = vals_sorted[p];
+        const uint32_t u = v >> shift;
+        const uint32_t item = ((uint32_t)keys_sorted[p] << shift) | (v & ((1u << shift) - 1u));
         int32_t pi = -1, nj = -1;
         if ((int64_t)item < I) {
             uint32_t s = rng_seed(seed, step, (uint64_t)p, 0x5bd1e995ull);
@@ -194,13 +196,13 @@ size_t sort_temp_bytes(int64_t batch, int bits)
 
 int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
 
-bool use_key16(int64_t num_items) { return num_items < (1ll << 17); }
+bool use_key16(int64_t num_items) { return num_items < (1ll << 17) - 1; }   // key 0xFFFF>>... reserved for "no positive"
 
 size_t sort16_temp_bytes(int64_t batch)
 {
     size_t n = 0;
     uint16_t *k = nullptr;
-    uint64_t *v = nullptr;
+    uint32_t *v = nullptr;
     (void)rocprim::radix_sort_pairs(nullptr, n, k, k, v, v, (size_t)batch, 0, 16u, (hipStream_t)0);
     return n;
 }
@@ -212,7 +214,7 @@ RSX_API int64_t rsx_bpr_sample_workspace(int64_t batch, int64_t num_items)
     if (batch < 0 || num_items <= 0 || num_items >= (1ll << 31)) return RSX_E_INVALID;
     if (batch == 0) return 0;
     if (use_key16(num_items))
-        return 2 * align256(batch * 2) + 2 * align256(batch * 8) + align256((int64_t)sort16_temp_bytes(batch));
+        return 2 * align256(batch * 2) + 2 * align256(batch * 4) + align256((int64_t)sort16_temp_bytes(batch));
     return 4 * align256(batch * 4) + align256((int64_t)sort_temp_bytes(batch, key_bits(num_items)));
 }
 
@@ -245,9 +247,9 @@ RSX_API int rsx_bpr_sample(const int64_t *indptr_dev, const int32_t *indices_dev
     }
     if (use_key16(num_items)) {
         const int shift = num_items < (1ll << 16) ? 0 : 1;
-        const int64_t ka = align256(batch * 2), va = align256(batch * 8);
+        const int64_t ka = align256(batch * 2), va = align256(batch * 4);
         uint16_t *k_in = (uint16_t *)ws, *k_out = (uint16_t *)((char *)ws + ka);
-        uint64_t *v_in = (uint64_t *)((char *)ws + 2 * ka), *v_out = (uint64_t *)((char *)ws + 2 * ka + va);
+        uint32_t *v_in = (uint32_t *)((char *)ws + 2 * ka), *v_out = (uint32_t *)((char *)ws + 2 * ka + va);
         void *tmp = (char *)ws + 2 * ka + 2 * va;
         size_t tmp_bytes = sort16_temp_bytes(batch);
         hipLaunchKernelGGL(sample_ui16_kernel, dim3(grid_1d(batch)), dim3(kBlock), 0, st, indptr_dev, indices_dev,
@@ -258,7 +260,7 @@ RSX_API int rsx_bpr_sample(const int64_t *indptr_dev, const int32_t *indices_dev
             return RSX_E_HIP;
         }
         hipLaunchKernelGGL(sample_neg16_kernel, dim3(grid_1d(batch)), dim3(kBlock), 0, st, indptr_dev, indices_dev,
-                           num_items, batch, seed, step, neg_block, neg_key, v_out, u_out, i_out, j_out);
+                           num_items, batch, seed, step, neg_block, neg_key, shift, k_out, v_out, u_out, i_out, j_out);
         RSX_CHECK_LAUNCH();
         return RSX_OK;
     }
