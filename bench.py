@@ -193,8 +193,8 @@ def main():
     scoring = None
     if args.score_tiles > 0 and rank == 0:
         tiles, K = args.score_tiles, args.topk
-        ws = torch.empty(1024 * I, dtype=torch.float32, device=dev)
         users = torch.arange(1024 * tiles, device=dev, dtype=torch.int32) % U
+        ws = torch.empty(rsx.lib().rsx_score_topk_workspace(users.numel(), I) // 4 + 64, dtype=torch.float32, device=dev)
         mask = (indptr, indices)
         rsx.score_topk(P, Q, users[:1024], K, mask=mask, ws=ws)
         torch.cuda.synchronize()

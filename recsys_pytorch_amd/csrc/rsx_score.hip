@@ -22,7 +22,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int kSlots = 4;     // private candidate slots per (item tile, row) of the filtered product
+constexpr int kSlots = 2;     // private candidate slots per (64-item strip, row) of the filtered product
 constexpr int LDT = BM + 1;   // K-major tile leading dimension (odd -> conflict-free transpose)
 
 // ---------------------------------------------------------------- scoring -------
@@ -40,15 +40,12 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict
                                                          float *__restrict__ cand_val,
                                                          int32_t *__restrict__ cand_idx,
                                                          int32_t *__restrict__ cand_cnt, int cand_cap,
-                                                         float *__restrict__ slot_val,
-                                                         int32_t *__restrict__ slot_idx,
+                                                         uint2 *__restrict__ slots,
                                                          uint8_t *__restrict__ slot_cnt, int ablate)
 {
     __shared__ float As[BK * LDT];
     __shared__ float Bs[BK * LDT];
     __shared__ float tau_s[BM];
-    __shared__ int s_hits;
-    __shared__ int row_hits[BM];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -128,74 +125,55 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict
         __syncthreads();
     }
 
-    // FILTER: survivors are first compacted in LDS (the staging tiles are free now), then the block
-    // reserves their slots with ONE round of global atomics; a returning global atomic per hit
-    // inside the accumulator walk serialises ~40 round trips per wavefront (measured 2.4x slower).
-    constexpr int HCAP = 2048;
-    float *hit_val = As;                                   // [HCAP]
-    int *hit_col = reinterpret_cast<int *>(As) + HCAP;     // [HCAP]   (As + Bs hold 2*32*129 floats)
-    int *hit_row = reinterpret_cast<int *>(Bs);            // [HCAP]
-    if constexpr (FILTER) {
-        if (tid == 0) s_hits = 0;
-        if (tid < BM) row_hits[tid] = 0;
-        __syncthreads();
-    }
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     if constexpr (FILTER) {
-        // pass 1 (VALU only): how many of this lane's 64 scores survive
-        int mine = 0;
+        // No barrier, no LDS, no global atomic on the common path.  For one accumulator register
+        // (m, r) the 32 lanes of a half-wave hold 2 x 32 consecutive columns of ONE row, so the
+        // survivors' ranks inside this wavefront's 64-column strip come from two ballots and a
+        // popcount.  Each (64-column strip, row) cell owns kSlots private slots; its count byte is
+        // written by the half-wave's first lane.  (History, all measured on a 1024 x 100K tile:
+        // a returning global atomic per hit 909 us; LDS compaction + per-row global counters
+        // 560 us -- 782 item tiles x 8 XCDs on 1024 counters cost ~0.5 us per atomic; LDS
+        // compaction + private cells 345 us; this form: see DESIGN.md.)
+        const int64_t tile_rows = (int64_t)gridDim.y * BM;                       // rows of the slot array
+        const size_t strip = (size_t)blockIdx.x * 2 + wc;                        // 64-column strip id
+        const unsigned long long half = hi ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
+        const unsigned long long below = half & ((1ull << lane) - 1ull);
+        const int64_t col0 = item0 + wc * 64 + l31, col1 = col0 + 32;
+        // (recording the survivors in registers and storing them after the walk was tried: the
+        //  fully unrolled walk then needs 126 VGPRs and the whole kernel slows down by 15 %)
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int lrow = wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 const float t = tau_s[lrow];           // +inf for rows past the edge
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    const int64_t col = item0 + wc * 64 + n * 32 + l31;
-                    mine += (col < num_items && acc[m][n][r] >= t) ? 1 : 0;
-                    if (ablate & 4) mine = 0;
-                }
-            }
-        // one LDS reservation per wavefront: inclusive scan of the counts, lane 63 holds the total
-        int incl = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int up = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += up;
-        }
-        const int total = __shfl(incl, 63, 64);
-        int base = 0;
-        if (lane == 0 && total > 0) base = atomicAdd(&s_hits, total);      // LDS, once per wavefront
-        base = __shfl(base, 0, 64);
-        int pos = base + incl - mine;
-        // pass 2: emit (plain LDS stores; a full block list spills straight to the global lists)
-        if (mine > 0 && !(ablate & 2)) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int lrow = wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const float t = tau_s[lrow];
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        const int64_t col = item0 + wc * 64 + n * 32 + l31;
-                        const float v = acc[m][n][r];
-                        if (col < num_items && v >= t) {
-                            if (pos < HCAP) {
-                                hit_val[pos] = v; hit_col[pos] = (int)(col - item0); hit_row[pos] = lrow;
-                            } else {
-                                const int64_t row = row0 + lrow;
-                                const int slot = atomicAdd(cand_cnt + row, 1);
-                                if (slot < cand_cap) {
-                                    cand_val[(size_t)row * cand_cap + slot] = v;
-                                    cand_idx[(size_t)row * cand_cap + slot] = (int32_t)col;
-                                }
-                            }
-                            ++pos;
+                const float v0 = acc[m][0][r], v1 = acc[m][1][r];
+                const bool h0 = (col0 < num_items) && (v0 >= t) && !(ablate & 4);
+                const bool h1 = (col1 < num_items) && (v1 >= t) && !(ablate & 4);
+                const unsigned long long b0 = __ballot(h0), b1 = __ballot(h1);
+                if ((b0 | b1) == 0ull) continue;                                  // wave-uniform
+                const int cnt0 = __popcll(b0 & half);
+                const int total = cnt0 + __popcll(b1 & half);
+                const int64_t row = row0 + lrow;
+                const size_t cell = strip * (size_t)tile_rows + (size_t)row;
+                auto emit = [&](int rank, float v, int64_t col) {
+                    if (rank < kSlots) {
+                        slots[cell * kSlots + rank] = make_uint2(__float_as_uint(v), (unsigned)col);
+                    } else {                            // rare: more than kSlots survivors in one cell
+                        const int slot = atomicAdd(cand_cnt + row, 1);
+                        if (slot < cand_cap) {
+                            cand_val[(size_t)row * cand_cap + slot] = v;
+                            cand_idx[(size_t)row * cand_cap + slot] = (int32_t)col;
                         }
                     }
+                };
+                if (!(ablate & 2)) {
+                    if (h0) emit(__popcll(b0 & below), v0, col0);
+                    if (h1) emit(cnt0 + __popcll(b1 & below), v1, col1);
                 }
+                if (l31 == 0 && total > 0) slot_cnt[cell] = (uint8_t)(total < kSlots ? total : kSlots);
+            }
         }
     } else {
 #pragma unroll
@@ -212,36 +190,6 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict
                     if (col < num_items) orow[col] = acc[m][n][r];
                 }
             }
-        }
-    }
-    if constexpr (FILTER) {
-        // No global atomics on the common path: this (row tile, item tile) block owns kSlots private
-        // slots per row.  (A per-row global counter costs ~0.5 us per returning atomic once 782 item
-        // tiles hammer the same 1024 counters from all XCDs: measured +300 us per 1024-row tile.)
-        __syncthreads();
-        const int n = (ablate & 1) ? 0 : (s_hits < HCAP ? s_hits : HCAP);
-        const int64_t tile_rows = (int64_t)gridDim.y * BM;            // rows of the slot arrays
-        const size_t cell0 = (size_t)blockIdx.x * tile_rows;          // [item tile][row]
-        for (int e = tid; e < n; e += 256) {
-            const int lrow = hit_row[e];
-            const int rank = atomicAdd(&row_hits[lrow], 1);           // LDS
-            const int64_t row = row0 + lrow;
-            if (rank < kSlots) {
-                const size_t c = (cell0 + (size_t)row) * kSlots + rank;
-                slot_val[c] = hit_val[e];
-                slot_idx[c] = (int32_t)(item0 + hit_col[e]);
-            } else {                                                   // rare: more than kSlots in one cell
-                const int slot = atomicAdd(cand_cnt + row, 1);
-                if (slot < cand_cap) {
-                    cand_val[(size_t)row * cand_cap + slot] = hit_val[e];
-                    cand_idx[(size_t)row * cand_cap + slot] = (int32_t)(item0 + hit_col[e]);
-                }
-            }
-        }
-        __syncthreads();
-        if (tid < BM) {
-            const int c = row_hits[tid];
-            slot_cnt[cell0 + (size_t)(row0 + tid)] = (uint8_t)(c < kSlots ? c : kSlots);
         }
     }
 }
@@ -467,8 +415,7 @@ constexpr int MG_THREADS = 256;
 constexpr int MG_CAP = 4096;    // candidate list capacity per row
 
 __global__ __launch_bounds__(MG_THREADS) void merge_candidates_kernel(
-    const float *__restrict__ slot_val, const int32_t *__restrict__ slot_idx,
-    const uint8_t *__restrict__ slot_cnt, int64_t n_item_tiles, int64_t tile_rows,
+    const uint2 *__restrict__ slots, const uint8_t *__restrict__ slot_cnt, int64_t n_strips, int64_t tile_rows,
     const float *__restrict__ cand_val, const int32_t *__restrict__ cand_idx,
     const int32_t *__restrict__ cand_cnt, int cand_cap, const int32_t *__restrict__ user_ids,
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices, int K,
@@ -483,7 +430,7 @@ __global__ __launch_bounds__(MG_THREADS) void merge_candidates_kernel(
     __syncthreads();
     // how many candidates does this row have in all item tiles + the spill list?
     uint32_t mine = 0;
-    for (int64_t cb = tid; cb < n_item_tiles; cb += MG_THREADS) mine += slot_cnt[(size_t)cb * tile_rows + row];
+    for (int64_t cb = tid; cb < n_strips; cb += MG_THREADS) mine += slot_cnt[(size_t)cb * tile_rows + row];
     atomicAdd(&s_total, mine);
     __syncthreads();
     const int spill = cand_cnt[row];
@@ -499,10 +446,13 @@ __global__ __launch_bounds__(MG_THREADS) void merge_candidates_kernel(
         if (a < hi && indices[a] == it) return;
         cand[atomicAdd(&s_n, 1u)] = ((unsigned long long)f2key(v) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)it);
     };
-    for (int64_t cb = tid; cb < n_item_tiles; cb += MG_THREADS) {
+    for (int64_t cb = tid; cb < n_strips; cb += MG_THREADS) {
         const size_t cell = (size_t)cb * tile_rows + row;
         const int c = slot_cnt[cell];
-        for (int q = 0; q < c; ++q) push(slot_val[cell * kSlots + q], slot_idx[cell * kSlots + q]);
+        for (int q = 0; q < c; ++q) {
+            const uint2 e = slots[cell * kSlots + q];
+            push(__uint_as_float(e.x), (int32_t)e.y);
+        }
     }
     for (int t = tid; t < spill; t += MG_THREADS)
         push(cand_val[(size_t)row * cand_cap + t], cand_idx[(size_t)row * cand_cap + t]);
@@ -536,14 +486,14 @@ int g_score_ablate = 0;   // development only
 template <bool FILTER>
 int launch_score(const float *P, const int32_t *users, int64_t rows, const float *Q, int64_t cols,
                  int64_t item_stride, int d, float *out, const float *tau, float *cand_val,
-                 int32_t *cand_idx, int32_t *cand_cnt, int cand_cap, float *slot_val, int32_t *slot_idx,
-                 uint8_t *slot_cnt, hipStream_t st)
+                 int32_t *cand_idx, int32_t *cand_cnt, int cand_cap, uint2 *slots, uint8_t *slot_cnt,
+                 hipStream_t st)
 {
     dim3 grid((unsigned)((cols + BN - 1) / BN), (unsigned)((rows + BM - 1) / BM));
     switch (d) {
-    case 32: hipLaunchKernelGGL((score_tile_kernel<32, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slot_val, slot_idx, slot_cnt, g_score_ablate); break;
-    case 64: hipLaunchKernelGGL((score_tile_kernel<64, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slot_val, slot_idx, slot_cnt, g_score_ablate); break;
-    default: hipLaunchKernelGGL((score_tile_kernel<128, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slot_val, slot_idx, slot_cnt, g_score_ablate); break;
+    case 32: hipLaunchKernelGGL((score_tile_kernel<32, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, slot_cnt, g_score_ablate); break;
+    case 64: hipLaunchKernelGGL((score_tile_kernel<64, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, slot_cnt, g_score_ablate); break;
+    default: hipLaunchKernelGGL((score_tile_kernel<128, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, slot_cnt, g_score_ablate); break;
     }
     return 0;
 }
@@ -567,7 +517,7 @@ RSX_API int rsx_score(const float *P, const int32_t *user_ids_dev, int64_t num_r
     for (int64_t r0 = 0; r0 < num_rows; r0 += 65535 * (int64_t)BM) {   // gridDim.y limit
         const int64_t nr = (num_rows - r0 < 65535 * (int64_t)BM) ? num_rows - r0 : 65535 * (int64_t)BM;
         launch_score<false>(P, user_ids_dev + r0, nr, Q, num_items, 1, d, scores_out + (size_t)r0 * num_items,
-                            nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, st);
+                            nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, st);
     }
     if (mask_indptr_dev) {
         for (int64_t r0 = 0; r0 < num_rows; r0 += (1ll << 30)) {
@@ -597,6 +547,9 @@ RSX_API int rsx_topk(const float *scores_dev, int64_t num_rows, int64_t num_item
 namespace {
 
 constexpr int64_t kSampleCols = 8192;      // sample size of the fused path
+constexpr int64_t kFusedRows = 8192;       // rows per pass of the fused path: one launch of ~50K workgroups
+                                           // (a 1024-row pass is 8.15 rounds of 768 resident workgroups:
+                                           //  11 % of the time is the ragged last round, plus 7 launches)
 constexpr int64_t kFusedMinItems = 4 * kSampleCols;
 constexpr int64_t kFallbackRows = 64;      // dense re-do granularity for overflowed rows
 constexpr int kSpillCap = 1024;            // per-row spill list of the filtered product
@@ -613,9 +566,8 @@ struct FusedWs {
     float *cval;        // [rows x kSpillCap]   spill lists (cells with more than kSlots survivors)
     int32_t *cidx;      // [rows x kSpillCap]
     int32_t *ccnt;      // [rows]
-    float *sval;        // [item tiles x rows x kSlots]
-    int32_t *sidx;      // [item tiles x rows x kSlots]
-    uint8_t *scnt;      // [item tiles x rows]
+    uint2 *slots;       // [64-item strips x rows x kSlots] {score bits, item}
+    uint8_t *scnt;      // [64-item strips x rows] survivors per cell, zeroed per pass
     int32_t *ovf_rows;  // [rows]
     int32_t *ovf_cnt;   // [1]
     int32_t *fb_users;  // [kFallbackRows]
@@ -635,9 +587,8 @@ FusedWs carve(void *ws, int64_t tile_rows, int64_t all_rows, int64_t num_items, 
     w.cval = (float *)take(tile_rows * kSpillCap * 4);
     w.cidx = (int32_t *)take(tile_rows * kSpillCap * 4);
     w.ccnt = (int32_t *)take(tile_rows * 4);
-    const int64_t n_it = (num_items + BN - 1) / BN, rows_pad = (tile_rows + BM - 1) / BM * BM;
-    w.sval = (float *)take(n_it * rows_pad * kSlots * 4);
-    w.sidx = (int32_t *)take(n_it * rows_pad * kSlots * 4);
+    const int64_t n_it = 2 * ((num_items + BN - 1) / BN), rows_pad = (tile_rows + BM - 1) / BM * BM;
+    w.slots = (uint2 *)take(n_it * rows_pad * kSlots * 8);
     w.scnt = (uint8_t *)take(n_it * rows_pad);
     w.ovf_rows = (int32_t *)take(all_rows * 4);
     w.ovf_cnt = (int32_t *)take(4);
@@ -655,7 +606,8 @@ RSX_API int64_t rsx_score_topk_workspace(int64_t num_rows, int64_t num_items)
     const int64_t rows = num_rows < kRowTile ? num_rows : kRowTile;
     const int64_t dense = rows * num_items * 4;
     if (num_items < kFusedMinItems) return dense;
-    const int64_t fused = carve(nullptr, rows, num_rows, num_items, 512).bytes;
+    const int64_t frows = num_rows < kFusedRows ? num_rows : kFusedRows;
+    const int64_t fused = carve(nullptr, frows, num_rows, num_items, 512).bytes;
     return fused > dense ? fused : dense;   // (K > 512 still takes the dense path)
 }
 
@@ -692,16 +644,16 @@ RSX_API int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t 
     RSX_CHECK_ARG(K >= 1 && K <= num_items, "K must be in [1, num_items]");
     RSX_CHECK_ARG((mask_indptr_dev == nullptr) == (mask_indices_dev == nullptr), "mask needs both CSR arrays");
     const int64_t stride = num_items / kSampleCols;          // sample = items 0, stride, 2 stride, ...
-    const int64_t tile_rows = num_rows < kRowTile ? num_rows : kRowTile;
+    const int64_t tile_rows = num_rows < kFusedRows ? num_rows : kFusedRows;
     FusedWs w = carve(ws, tile_rows, num_rows, num_items, K);
-    const int64_t n_tiles = (num_rows + kRowTile - 1) / kRowTile;
+    const int64_t n_tiles = (num_rows + kFusedRows - 1) / kFusedRows;
     (void)hipMemsetAsync(w.ovf_cnt, 0, 4, st);
     for (int64_t ti = 0; ti < n_tiles; ++ti) {
-        const int64_t r0 = ti * kRowTile;
-        const int64_t nr = (num_rows - r0 < kRowTile) ? num_rows - r0 : kRowTile;
+        const int64_t r0 = ti * kFusedRows;
+        const int64_t nr = (num_rows - r0 < kFusedRows) ? num_rows - r0 : kFusedRows;
         const int32_t *users = user_ids_dev + r0;
         launch_score<false>(P, users, nr, Q, kSampleCols, stride, d, w.sample, nullptr, nullptr, nullptr, nullptr, 0,
-                            nullptr, nullptr, nullptr, st);
+                            nullptr, nullptr, st);
         if (mask_indptr_dev)
             hipLaunchKernelGGL(mask_seen_strided_kernel, dim3((unsigned)nr), dim3(256), 0, st, w.sample, users, nr,
                                kSampleCols, stride, mask_indptr_dev, mask_indices_dev);
@@ -709,10 +661,11 @@ RSX_API int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t 
                            w.topi, w.topv);
         hipLaunchKernelGGL(take_tau_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, w.topv, nr, K,
                            w.tau, w.ccnt);
+        const int64_t n_it = 2 * ((num_items + BN - 1) / BN), rows_pad = (nr + BM - 1) / BM * BM;
+        (void)hipMemsetAsync(w.scnt, 0, (size_t)(n_it * rows_pad), st);
         launch_score<true>(P, users, nr, Q, num_items, 1, d, nullptr, w.tau, w.cval, w.cidx, w.ccnt, kSpillCap,
-                           w.sval, w.sidx, w.scnt, st);
-        const int64_t n_it = (num_items + BN - 1) / BN, rows_pad = (nr + BM - 1) / BM * BM;
-        hipLaunchKernelGGL(merge_candidates_kernel, dim3((unsigned)nr), dim3(MG_THREADS), 0, st, w.sval, w.sidx,
+                           w.slots, w.scnt, st);
+        hipLaunchKernelGGL(merge_candidates_kernel, dim3((unsigned)nr), dim3(MG_THREADS), 0, st, w.slots,
                            w.scnt, n_it, rows_pad, w.cval, w.cidx, w.ccnt, kSpillCap, users, mask_indptr_dev,
                            mask_indices_dev, K,
                            topk_idx_out + (size_t)r0 * K, topk_val_out ? topk_val_out + (size_t)r0 * K : nullptr,
