@@ -135,7 +135,9 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict
         // a returning global atomic per hit 909 us; LDS compaction + per-row global counters
         // 560 us -- 782 item tiles x 8 XCDs on 1024 counters cost ~0.5 us per atomic; LDS
         // compaction + private cells 345 us; this form: see DESIGN.md.)
-        const int64_t tile_rows = (int64_t)gridDim.y * BM;                       // rows of the slot array
+        // slot / count arrays are ROW-major [row][strip]: the merge kernel then reads one contiguous
+        // run per row (strip-major made every count byte a separate cache line: 33 -> ~10 us)
+        const size_t n_strips = (size_t)gridDim.x * 2;
         const size_t strip = (size_t)blockIdx.x * 2 + wc;                        // 64-column strip id
         const unsigned long long half = hi ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
         const unsigned long long below = half & ((1ull << lane) - 1ull);
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict
                 const int cnt0 = __popcll(b0 & half);
                 const int total = cnt0 + __popcll(b1 & half);
                 const int64_t row = row0 + lrow;
-                const size_t cell = strip * (size_t)tile_rows + (size_t)row;
+                const size_t cell = (size_t)row * n_strips + strip;
                 auto emit = [&](int rank, float v, int64_t col) {
                     if (rank < kSlots) {
                         slots[cell * kSlots + rank] = make_uint2(__float_as_uint(v), (unsigned)col);
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(MG_THREADS) void merge_candidates_kernel(
     __syncthreads();
     // how many candidates does this row have in all item tiles + the spill list?
     uint32_t mine = 0;
-    for (int64_t cb = tid; cb < n_strips; cb += MG_THREADS) mine += slot_cnt[(size_t)cb * tile_rows + row];
+    for (int64_t cb = tid; cb < n_strips; cb += MG_THREADS) mine += slot_cnt[(size_t)row * n_strips + cb];
     atomicAdd(&s_total, mine);
     __syncthreads();
     const int spill = cand_cnt[row];
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(MG_THREADS) void merge_candidates_kernel(
         cand[atomicAdd(&s_n, 1u)] = ((unsigned long long)f2key(v) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)it);
     };
     for (int64_t cb = tid; cb < n_strips; cb += MG_THREADS) {
-        const size_t cell = (size_t)cb * tile_rows + row;
+        const size_t cell = (size_t)row * n_strips + cb;
         const int c = slot_cnt[cell];
         for (int q = 0; q < c; ++q) {
             const uint2 e = slots[cell * kSlots + q];
