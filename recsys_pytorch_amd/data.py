@@ -82,3 +82,71 @@ def synthetic_csr(num_users, num_items, degree, device, seed=2020, popularity="z
         raise RuntimeError("could not de-duplicate synthetic rows (degree too close to num_items?)")
     indptr = torch.arange(num_users + 1, device=device, dtype=torch.int64) * degree
     return indptr.contiguous(), items.reshape(-1).to(torch.int32).contiguous()
+
+
+def load_uirt(path, separator="\t", min_item_per_user=0, min_user_per_item=0, valid_ratio=0.1,
+              test_ratio=0.2, split_random=True, seed=None):
+    """Read a `user item rating timestamp` text file and split it like the reference's
+    UIRTDataset(protocol='holdout', generalization='weak') does:
+
+      data/dataset.py:124-167  filter users with < min_item_per_user items, then items with
+                               < min_user_per_item users; new ids in ascending raw-id order
+      data/preprocess.py:12-19 weak split: FIRST a "test" part of `valid_ratio` (sic: the two
+                               ratios are crossed in the reference, quirk Q8), THEN a "valid"
+                               part of `test_ratio` of what is left
+      data/preprocess.py:52-90 per user (ascending id): sort by timestamp, hold out
+                               ceil(ratio * n) interactions chosen with np.random.choice
+                               (split_random) or the last ones
+    Ratings are binarised to 1 (implicit=True, data/dataset.py:46-51).  With `seed` the numpy
+    global RNG is seeded first (main.py:30).  On ml-100k this reproduces the reference's
+    per-user train/valid/test SIZES exactly (tests/test_loader.py against the fixture the
+    reference's own loader produced); which interactions are drawn is not bit-identical (pandas'
+    sort of tied timestamps), and SURVEY row f4 does not ask for that.  No on-disk cache is
+    written.  Returns an InteractionData.
+    """
+    raw = np.loadtxt(path, delimiter=separator, dtype=np.float64, ndmin=2)
+    users, items, ts = raw[:, 0].astype(np.int64), raw[:, 1].astype(np.int64), raw[:, 3]
+    # filter users, then items (dataset.py:131-146)
+    uid, ucnt = np.unique(users, return_counts=True)
+    keep = np.isin(users, uid[ucnt >= min_item_per_user])
+    users, items, ts = users[keep], items[keep], ts[keep]
+    iid, icnt = np.unique(items, return_counts=True)
+    keep = np.isin(items, iid[icnt >= min_user_per_item])
+    users, items, ts = users[keep], items[keep], ts[keep]
+    uid = np.unique(users)                       # ascending raw ids -> 0..U-1 (dataset.py:153-167)
+    iid = np.unique(items)
+    users = np.searchsorted(uid, users)
+    items = np.searchsorted(iid, items)
+    U, I = len(uid), len(iid)
+    if seed is not None:
+        np.random.seed(seed)
+
+    def split(us, its, tss, ratio):
+        """data/preprocess.py:52-90 on arrays; returns (kept, held-out) index arrays"""
+        order = np.argsort(us, kind="stable")
+        bounds = np.flatnonzero(np.diff(us[order])) + 1
+        keep_idx, out_idx = [], []
+        for grp in np.split(order, bounds):
+            grp = grp[np.argsort(tss[grp], kind="stable")]          # sort_values(by='timestamp')
+            n = len(grp)
+            n_out = int(np.ceil(ratio * n)) if isinstance(ratio, float) else int(ratio)
+            mask = np.ones(n, dtype=bool)
+            if split_random:
+                mask[np.random.choice(n, n_out, replace=False)] = False
+            else:
+                mask[n - n_out:] = False
+            keep_idx.append(grp[mask]); out_idx.append(grp[~mask])
+        return np.concatenate(keep_idx), np.concatenate(out_idx)
+
+    all_idx = np.arange(len(users))
+    k1, test = split(users, items, ts, valid_ratio)                 # sic (quirk Q8)
+    k2, valid = split(users[k1], items[k1], ts[k1], test_ratio)
+    train, valid = k1[k2], k1[valid]
+
+    def csr(idx):
+        m = sp.csr_matrix((np.ones(len(idx)), (users[idx], items[idx])), shape=(U, I))
+        m.sum_duplicates()
+        m.data[:] = 1.0
+        return m
+    del all_idx
+    return InteractionData(csr(train), csr(valid), csr(test))
