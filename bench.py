@@ -148,7 +148,8 @@ def main():
         cur = state["cur"]
         buf = bufs[cur]
         main.wait_event(buf["ready"])
-        prefetch(cur ^ 1)
+        if world == 1:
+            prefetch(cur ^ 1)           # sampler of step t+1 runs beside step t's kernel
         u, i, j = buf["t"]
         use_hot = eng.hot is not None and not neg_block
         if ev is not None:
@@ -159,6 +160,11 @@ def main():
             ev[1].record()
         buf["free"] = torch.cuda.Event()
         buf["free"].record(main)
+        if world > 1:
+            # with an exchange in the step, the sampler of step t+1 is better placed beside the
+            # all-reduce (the CUs idle while xGMI moves G) than beside the kernel
+            side.wait_event(buf["free"])
+            prefetch(cur ^ 1)
         if use_hot:
             rsx.fold_hot_grad(eng.G, eng.hot)
         if world > 1:
