@@ -93,3 +93,14 @@ def test_g5_reference_sampler_quirks():
     ip, ix = c["train_indptr"], c["train_indices"]
     for u, j in zip(g["users"], g["neg"]):
         assert j not in ix[ip[u]:ip[u + 1]]
+
+
+def test_oracle_is_clean_under_address_and_ub_sanitizers():
+    """every oracle entry point once under -fsanitize=address,undefined (CPU build only)"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-s", "-C", os.path.join(root, "oracle"), "asan"], capture_output=True, text=True)
+    if r.returncode != 0 and "cannot find" in (r.stderr + r.stdout):
+        pytest.skip("sanitizer runtime not installed")
+    assert r.returncode == 0 and "asan_check ok" in r.stdout, r.stdout + r.stderr
