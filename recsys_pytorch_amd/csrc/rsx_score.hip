@@ -40,8 +40,7 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict
                                                          float *__restrict__ cand_val,
                                                          int32_t *__restrict__ cand_idx,
                                                          int32_t *__restrict__ cand_cnt, int cand_cap,
-                                                         uint2 *__restrict__ slots,
-                                                         uint8_t *__restrict__ slot_cnt, int ablate)
+                                                         uint2 *__restrict__ slots, int ablate)
 {
     __shared__ float As[BK * LDT];
     __shared__ float Bs[BK * LDT];
@@ -135,34 +134,36 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict
         // a returning global atomic per hit 909 us; LDS compaction + per-row global counters
         // 560 us -- 782 item tiles x 8 XCDs on 1024 counters cost ~0.5 us per atomic; LDS
         // compaction + private cells 345 us; this form: see DESIGN.md.)
-        // slot / count arrays are ROW-major [row][strip]: the merge kernel then reads one contiguous
-        // run per row (strip-major made every count byte a separate cache line: 33 -> ~10 us)
-        const size_t n_strips = (size_t)gridDim.x * 2;
-        const size_t strip = (size_t)blockIdx.x * 2 + wc;                        // 64-column strip id
+        // the slot array is ROW-major [row][strip][kSlots] (the merge kernel reads one contiguous
+        // run per row) and 0xFF-filled before the launch: an unused slot keeps item index -1, so
+        // no per-cell count has to be written.  32-bit cell arithmetic, one base per wavefront.
+        const int n_strips = (int)gridDim.x * 2;
+        const int strip = (int)blockIdx.x * 2 + wc;                              // 64-column strip id
         const unsigned long long half = hi ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
         const unsigned long long below = half & ((1ull << lane) - 1ull);
         const int64_t col0 = item0 + wc * 64 + l31, col1 = col0 + 32;
+        const int wave_row = (int)row0 + wr * 64 + 4 * hi;                       // + per-site constant
+        uint2 *wbase = slots + ((size_t)wave_row * n_strips + strip) * kSlots;
         // (recording the survivors in registers and storing them after the walk was tried: the
         //  fully unrolled walk then needs 126 VGPRs and the whole kernel slows down by 15 %)
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int lrow = wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float t = tau_s[lrow];           // +inf for rows past the edge
+                const int site = m * 32 + (r & 3) + 8 * (r >> 2);                // compile-time constant
+                const float t = tau_s[wr * 64 + 4 * hi + site];                  // +inf for rows past the edge
                 const float v0 = acc[m][0][r], v1 = acc[m][1][r];
                 const bool h0 = (col0 < num_items) && (v0 >= t) && !(ablate & 4);
                 const bool h1 = (col1 < num_items) && (v1 >= t) && !(ablate & 4);
                 const unsigned long long b0 = __ballot(h0), b1 = __ballot(h1);
                 if ((b0 | b1) == 0ull) continue;                                  // wave-uniform
                 const int cnt0 = __popcll(b0 & half);
-                const int total = cnt0 + __popcll(b1 & half);
-                const int64_t row = row0 + lrow;
-                const size_t cell = (size_t)row * n_strips + strip;
+                uint2 *cellp = wbase + (size_t)(site * n_strips) * kSlots;
                 auto emit = [&](int rank, float v, int64_t col) {
                     if (rank < kSlots) {
-                        slots[cell * kSlots + rank] = make_uint2(__float_as_uint(v), (unsigned)col);
+                        cellp[rank] = make_uint2(__float_as_uint(v), (unsigned)col);
                     } else {                            // rare: more than kSlots survivors in one cell
+                        const int64_t row = wave_row + site;
                         const int slot = atomicAdd(cand_cnt + row, 1);
                         if (slot < cand_cap) {
                             cand_val[(size_t)row * cand_cap + slot] = v;
@@ -174,7 +175,6 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict
                     if (h0) emit(__popcll(b0 & below), v0, col0);
                     if (h1) emit(cnt0 + __popcll(b1 & below), v1, col1);
                 }
-                if (l31 == 0 && total > 0) slot_cnt[cell] = (uint8_t)(total < kSlots ? total : kSlots);
             }
         }
     } else {
@@ -417,7 +417,7 @@ constexpr int MG_THREADS = 256;
 constexpr int MG_CAP = 4096;    // candidate list capacity per row
 
 __global__ __launch_bounds__(MG_THREADS) void merge_candidates_kernel(
-    const uint2 *__restrict__ slots, const uint8_t *__restrict__ slot_cnt, int64_t n_strips, int64_t tile_rows,
+    const uint2 *__restrict__ slots, int64_t n_strips, int64_t tile_rows,
     const float *__restrict__ cand_val, const int32_t *__restrict__ cand_idx,
     const int32_t *__restrict__ cand_cnt, int cand_cap, const int32_t *__restrict__ user_ids,
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices, int K,
@@ -431,8 +431,10 @@ __global__ __launch_bounds__(MG_THREADS) void merge_candidates_kernel(
     if (tid == 0) { s_n = 0; s_total = 0; }
     __syncthreads();
     // how many candidates does this row have in all item tiles + the spill list?
-    uint32_t mine = 0;
-    for (int64_t cb = tid; cb < n_strips; cb += MG_THREADS) mine += slot_cnt[(size_t)row * n_strips + cb];
+    const uint2 *rslots = slots + (size_t)row * n_strips * kSlots;     // this row's cells, contiguous
+    const int64_t n_slots = n_strips * kSlots;
+    uint32_t mine = 0;                          // an unused slot still holds the 0xFF fill: item < 0
+    for (int64_t q = tid; q < n_slots; q += MG_THREADS) mine += ((int32_t)rslots[q].y >= 0) ? 1u : 0u;
     atomicAdd(&s_total, mine);
     __syncthreads();
     const int spill = cand_cnt[row];
@@ -448,13 +450,9 @@ __global__ __launch_bounds__(MG_THREADS) void merge_candidates_kernel(
         if (a < hi && indices[a] == it) return;
         cand[atomicAdd(&s_n, 1u)] = ((unsigned long long)f2key(v) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)it);
     };
-    for (int64_t cb = tid; cb < n_strips; cb += MG_THREADS) {
-        const size_t cell = (size_t)row * n_strips + cb;
-        const int c = slot_cnt[cell];
-        for (int q = 0; q < c; ++q) {
-            const uint2 e = slots[cell * kSlots + q];
-            push(__uint_as_float(e.x), (int32_t)e.y);
-        }
+    for (int64_t q = tid; q < n_slots; q += MG_THREADS) {
+        const uint2 e = rslots[q];
+        if ((int32_t)e.y >= 0) push(__uint_as_float(e.x), (int32_t)e.y);
     }
     for (int t = tid; t < spill; t += MG_THREADS)
         push(cand_val[(size_t)row * cand_cap + t], cand_idx[(size_t)row * cand_cap + t]);
@@ -488,14 +486,13 @@ int g_score_ablate = 0;   // development only
 template <bool FILTER>
 int launch_score(const float *P, const int32_t *users, int64_t rows, const float *Q, int64_t cols,
                  int64_t item_stride, int d, float *out, const float *tau, float *cand_val,
-                 int32_t *cand_idx, int32_t *cand_cnt, int cand_cap, uint2 *slots, uint8_t *slot_cnt,
-                 hipStream_t st)
+                 int32_t *cand_idx, int32_t *cand_cnt, int cand_cap, uint2 *slots, hipStream_t st)
 {
     dim3 grid((unsigned)((cols + BN - 1) / BN), (unsigned)((rows + BM - 1) / BM));
     switch (d) {
-    case 32: hipLaunchKernelGGL((score_tile_kernel<32, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, slot_cnt, g_score_ablate); break;
-    case 64: hipLaunchKernelGGL((score_tile_kernel<64, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, slot_cnt, g_score_ablate); break;
-    default: hipLaunchKernelGGL((score_tile_kernel<128, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, slot_cnt, g_score_ablate); break;
+    case 32: hipLaunchKernelGGL((score_tile_kernel<32, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, g_score_ablate); break;
+    case 64: hipLaunchKernelGGL((score_tile_kernel<64, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, g_score_ablate); break;
+    default: hipLaunchKernelGGL((score_tile_kernel<128, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, g_score_ablate); break;
     }
     return 0;
 }
@@ -519,7 +516,7 @@ RSX_API int rsx_score(const float *P, const int32_t *user_ids_dev, int64_t num_r
     for (int64_t r0 = 0; r0 < num_rows; r0 += 65535 * (int64_t)BM) {   // gridDim.y limit
         const int64_t nr = (num_rows - r0 < 65535 * (int64_t)BM) ? num_rows - r0 : 65535 * (int64_t)BM;
         launch_score<false>(P, user_ids_dev + r0, nr, Q, num_items, 1, d, scores_out + (size_t)r0 * num_items,
-                            nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, st);
+                            nullptr, nullptr, nullptr, nullptr, 0, nullptr, st);
     }
     if (mask_indptr_dev) {
         for (int64_t r0 = 0; r0 < num_rows; r0 += (1ll << 30)) {
@@ -568,8 +565,7 @@ struct FusedWs {
     float *cval;        // [rows x kSpillCap]   spill lists (cells with more than kSlots survivors)
     int32_t *cidx;      // [rows x kSpillCap]
     int32_t *ccnt;      // [rows]
-    uint2 *slots;       // [64-item strips x rows x kSlots] {score bits, item}
-    uint8_t *scnt;      // [64-item strips x rows] survivors per cell, zeroed per pass
+    uint2 *slots;       // [rows x 64-item strips x kSlots] {score bits, item}; 0xFF-filled per pass
     int32_t *ovf_rows;  // [rows]
     int32_t *ovf_cnt;   // [1]
     int32_t *fb_users;  // [kFallbackRows]
@@ -591,7 +587,6 @@ FusedWs carve(void *ws, int64_t tile_rows, int64_t all_rows, int64_t num_items, 
     w.ccnt = (int32_t *)take(tile_rows * 4);
     const int64_t n_it = 2 * ((num_items + BN - 1) / BN), rows_pad = (tile_rows + BM - 1) / BM * BM;
     w.slots = (uint2 *)take(n_it * rows_pad * kSlots * 8);
-    w.scnt = (uint8_t *)take(n_it * rows_pad);
     w.ovf_rows = (int32_t *)take(all_rows * 4);
     w.ovf_cnt = (int32_t *)take(4);
     w.fb_users = (int32_t *)take(kFallbackRows * 4);
@@ -655,7 +650,7 @@ RSX_API int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t 
         const int64_t nr = (num_rows - r0 < kFusedRows) ? num_rows - r0 : kFusedRows;
         const int32_t *users = user_ids_dev + r0;
         launch_score<false>(P, users, nr, Q, kSampleCols, stride, d, w.sample, nullptr, nullptr, nullptr, nullptr, 0,
-                            nullptr, nullptr, st);
+                            nullptr, st);
         if (mask_indptr_dev)
             hipLaunchKernelGGL(mask_seen_strided_kernel, dim3((unsigned)nr), dim3(256), 0, st, w.sample, users, nr,
                                kSampleCols, stride, mask_indptr_dev, mask_indices_dev);
@@ -664,11 +659,11 @@ RSX_API int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t 
         hipLaunchKernelGGL(take_tau_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, w.topv, nr, K,
                            w.tau, w.ccnt);
         const int64_t n_it = 2 * ((num_items + BN - 1) / BN), rows_pad = (nr + BM - 1) / BM * BM;
-        (void)hipMemsetAsync(w.scnt, 0, (size_t)(n_it * rows_pad), st);
+        (void)hipMemsetAsync(w.slots, 0xFF, (size_t)(n_it * rows_pad) * kSlots * 8, st);
         launch_score<true>(P, users, nr, Q, num_items, 1, d, nullptr, w.tau, w.cval, w.cidx, w.ccnt, kSpillCap,
-                           w.slots, w.scnt, st);
+                           w.slots, st);
         hipLaunchKernelGGL(merge_candidates_kernel, dim3((unsigned)nr), dim3(MG_THREADS), 0, st, w.slots,
-                           w.scnt, n_it, rows_pad, w.cval, w.cidx, w.ccnt, kSpillCap, users, mask_indptr_dev,
+                           n_it, rows_pad, w.cval, w.cidx, w.ccnt, kSpillCap, users, mask_indptr_dev,
                            mask_indices_dev, K,
                            topk_idx_out + (size_t)r0 * K, topk_val_out ? topk_val_out + (size_t)r0 * K : nullptr,
                            r0, w.ovf_rows, w.ovf_cnt);
