@@ -415,6 +415,8 @@ __global__ __launch_bounds__(256) void take_tau_kernel(const float *__restrict__
 
 constexpr int MG_THREADS = 256;
 constexpr int MG_CAP = 4096;    // candidate list capacity per row
+constexpr int MG_BIN_BITS = 10;
+constexpr int MG_BINS = 1 << MG_BIN_BITS;
 
 __global__ __launch_bounds__(MG_THREADS) void merge_candidates_kernel(
     const uint2 *__restrict__ slots, int64_t n_strips, int64_t tile_rows,
@@ -457,7 +459,65 @@ __global__ __launch_bounds__(MG_THREADS) void merge_candidates_kernel(
     for (int t = tid; t < spill; t += MG_THREADS)
         push(cand_val[(size_t)row * cand_cap + t], cand_idx[(size_t)row * cand_cap + t]);
     __syncthreads();
-    const uint32_t ncand = s_n;
+    uint32_t ncand = s_n;
+    // Only K of the (typically ~K I / 8192 + K) survivors are wanted: one histogram of the keys,
+    // linear between the smallest and largest key, finds the bin of the K-th; everything in or
+    // above that bin is compacted to the front (a handful more than K) and only that is sorted.
+    if (ncand > 2u * (uint32_t)K && ncand > 128u) {
+        __shared__ uint32_t hist[MG_BINS];
+        __shared__ uint32_t s_lo, s_hi, s_bin, s_m, s_wv[MG_THREADS / 64];
+        if (tid == 0) { s_lo = 0xFFFFFFFFu; s_hi = 0u; s_m = 0u; }
+        for (int b_ = tid; b_ < MG_BINS; b_ += MG_THREADS) hist[b_] = 0u;
+        __syncthreads();
+        uint32_t lo = 0xFFFFFFFFu, hi_ = 0u;
+        for (uint32_t t = tid; t < ncand; t += MG_THREADS) {
+            const uint32_t k32 = (uint32_t)(cand[t] >> 32);
+            lo = k32 < lo ? k32 : lo; hi_ = k32 > hi_ ? k32 : hi_;
+        }
+        atomicMin(&s_lo, lo); atomicMax(&s_hi, hi_);
+        __syncthreads();
+        const uint32_t klo = s_lo;
+        const uint32_t width = s_hi - klo;                         // largest offset, >= 0
+        const uint32_t shift = width >= (uint32_t)MG_BINS ? (32u - (uint32_t)__clz(width)) - MG_BIN_BITS : 0u;
+        for (uint32_t t = tid; t < ncand; t += MG_THREADS)
+            atomicAdd(&hist[((uint32_t)(cand[t] >> 32) - klo) >> shift], 1u);
+        __syncthreads();
+        // bin of the K-th largest: suffix counts from the top bin (thread t owns MG_BINS/threads bins)
+        constexpr int per = MG_BINS / MG_THREADS;
+        uint32_t mine_b = 0;
+        for (int q = 0; q < per; ++q) mine_b += hist[tid * per + q];
+        uint32_t suf = mine_b;
+        {
+            const int ln = tid & 63;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_down(suf, o, 64); if (ln + o < 64) suf += x; }
+            if (ln == 0) s_wv[tid >> 6] = suf;
+            __syncthreads();
+            for (int w_ = (tid >> 6) + 1; w_ < MG_THREADS / 64; ++w_) suf += s_wv[w_];
+        }
+        const uint32_t above = suf - mine_b;
+        if (above < (uint32_t)K && suf >= (uint32_t)K) {
+            uint32_t run = above;
+            for (int q = per - 1; q >= 0; --q) {
+                run += hist[tid * per + q];
+                if (run >= (uint32_t)K) { s_bin = (uint32_t)(tid * per + q); break; }
+            }
+        }
+        __syncthreads();
+        const uint32_t kbin = s_bin;
+        // compact in place, a round of MG_THREADS elements at a time: everything a round reads is
+        // in registers before anything is written, and writes only land below the read frontier
+        for (uint32_t r0 = 0; r0 < ncand; r0 += MG_THREADS) {
+            const uint32_t t = r0 + tid;
+            unsigned long long e = 0ull;
+            bool live = false;
+            if (t < ncand) { e = cand[t]; live = (((uint32_t)(e >> 32) - klo) >> shift) >= kbin; }
+            __syncthreads();
+            if (live) cand[atomicAdd(&s_m, 1u)] = e;
+        }
+        __syncthreads();
+        ncand = s_m;
+    }
     uint32_t n2 = 1;
     while (n2 < ncand) n2 <<= 1;
     for (uint32_t t = ncand + tid; t < n2; t += MG_THREADS) cand[t] = 0ull;
