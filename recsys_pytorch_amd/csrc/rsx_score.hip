@@ -664,7 +664,8 @@ RSX_API int64_t rsx_score_topk_workspace(int64_t num_rows, int64_t num_items)
     const int64_t dense = rows * num_items * 4;
     if (num_items < kFusedMinItems) return dense;
     const int64_t frows = num_rows < kFusedRows ? num_rows : kFusedRows;
-    const int64_t fused = carve(nullptr, frows, num_rows, num_items, 512).bytes;
+    const int64_t lanes = num_rows > kFusedRows ? 2 : 1;      // two passes in flight (two streams)
+    const int64_t fused = lanes * carve(nullptr, frows, num_rows, num_items, 512).bytes;
     return fused > dense ? fused : dense;   // (K > 512 still takes the dense path)
 }
 
@@ -702,32 +703,62 @@ RSX_API int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t 
     RSX_CHECK_ARG((mask_indptr_dev == nullptr) == (mask_indices_dev == nullptr), "mask needs both CSR arrays");
     const int64_t stride = num_items / kSampleCols;          // sample = items 0, stride, 2 stride, ...
     const int64_t tile_rows = num_rows < kFusedRows ? num_rows : kFusedRows;
-    FusedWs w = carve(ws, tile_rows, num_rows, num_items, K);
     const int64_t n_tiles = (num_rows + kFusedRows - 1) / kFusedRows;
+    // Two passes in flight on two streams: the selection kernels of one pass (sample top-K, merge;
+    // memory / LDS bound) overlap the matrix-core product of the other.
+    const int n_lanes = n_tiles > 1 ? 2 : 1;
+    FusedWs lane_ws[2];
+    lane_ws[0] = carve(ws, tile_rows, num_rows, num_items, K);
+    lane_ws[1] = n_lanes > 1 ? carve((char *)ws + lane_ws[0].bytes, tile_rows, num_rows, num_items, K) : lane_ws[0];
+    FusedWs &w = lane_ws[0];                   // overflow list and dense re-do buffers are lane 0's
+    static hipStream_t side_stream = nullptr;
+    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t lane_st[2] = {st, st};
+    if (n_lanes > 1) {
+        if (side_stream == nullptr) {
+            if (hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
+                rsx_set_error("rsx_score_topk: could not create the second stream");
+                return RSX_E_HIP;
+            }
+        }
+        lane_st[1] = side_stream;
+    }
     (void)hipMemsetAsync(w.ovf_cnt, 0, 4, st);
+    if (n_lanes > 1) {
+        (void)hipEventRecord(ev_fork, st);
+        (void)hipStreamWaitEvent(side_stream, ev_fork, 0);
+    }
     for (int64_t ti = 0; ti < n_tiles; ++ti) {
         const int64_t r0 = ti * kFusedRows;
         const int64_t nr = (num_rows - r0 < kFusedRows) ? num_rows - r0 : kFusedRows;
         const int32_t *users = user_ids_dev + r0;
-        launch_score<false>(P, users, nr, Q, kSampleCols, stride, d, w.sample, nullptr, nullptr, nullptr, nullptr, 0,
-                            nullptr, st);
+        FusedWs &lw = lane_ws[ti % n_lanes];
+        hipStream_t ls = lane_st[ti % n_lanes];
+        launch_score<false>(P, users, nr, Q, kSampleCols, stride, d, lw.sample, nullptr, nullptr, nullptr, nullptr, 0,
+                            nullptr, ls);
         if (mask_indptr_dev)
-            hipLaunchKernelGGL(mask_seen_strided_kernel, dim3((unsigned)nr), dim3(256), 0, st, w.sample, users, nr,
+            hipLaunchKernelGGL(mask_seen_strided_kernel, dim3((unsigned)nr), dim3(256), 0, ls, lw.sample, users, nr,
                                kSampleCols, stride, mask_indptr_dev, mask_indices_dev);
-        hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)nr), dim3(TK_THREADS), 0, st, w.sample, kSampleCols, K,
-                           w.topi, w.topv);
-        hipLaunchKernelGGL(take_tau_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, w.topv, nr, K,
-                           w.tau, w.ccnt);
+        hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)nr), dim3(TK_THREADS), 0, ls, lw.sample, kSampleCols, K,
+                           lw.topi, lw.topv);
+        hipLaunchKernelGGL(take_tau_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, ls, lw.topv, nr, K,
+                           lw.tau, lw.ccnt);
         const int64_t n_it = 2 * ((num_items + BN - 1) / BN), rows_pad = (nr + BM - 1) / BM * BM;
-        (void)hipMemsetAsync(w.slots, 0xFF, (size_t)(n_it * rows_pad) * kSlots * 8, st);
-        launch_score<true>(P, users, nr, Q, num_items, 1, d, nullptr, w.tau, w.cval, w.cidx, w.ccnt, kSpillCap,
-                           w.slots, st);
-        hipLaunchKernelGGL(merge_candidates_kernel, dim3((unsigned)nr), dim3(MG_THREADS), 0, st, w.slots,
-                           n_it, rows_pad, w.cval, w.cidx, w.ccnt, kSpillCap, users, mask_indptr_dev,
+        (void)hipMemsetAsync(lw.slots, 0xFF, (size_t)(n_it * rows_pad) * kSlots * 8, ls);
+        launch_score<true>(P, users, nr, Q, num_items, 1, d, nullptr, lw.tau, lw.cval, lw.cidx, lw.ccnt, kSpillCap,
+                           lw.slots, ls);
+        hipLaunchKernelGGL(merge_candidates_kernel, dim3((unsigned)nr), dim3(MG_THREADS), 0, ls, lw.slots,
+                           n_it, rows_pad, lw.cval, lw.cidx, lw.ccnt, kSpillCap, users, mask_indptr_dev,
                            mask_indices_dev, K,
                            topk_idx_out + (size_t)r0 * K, topk_val_out ? topk_val_out + (size_t)r0 * K : nullptr,
                            r0, w.ovf_rows, w.ovf_cnt);
         RSX_CHECK_LAUNCH();
+    }
+    if (n_lanes > 1) {
+        (void)hipEventRecord(ev_join, side_stream);
+        (void)hipStreamWaitEvent(st, ev_join, 0);
     }
     // rows whose candidate list overflowed (massive exact ties, or fewer than K unmasked sample
     // items) are re-done through the dense path.  This is the one place the call waits for the

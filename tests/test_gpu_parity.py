@@ -228,7 +228,8 @@ def test_topk_ties_and_masked_rows(rsx, oracle_mod):
         assert np.array_equal(got, want), K
 
 
-@pytest.mark.parametrize("d,I,rows,K", [(64, 40_001, 300, 50), (128, 65_537, 1500, 10), (32, 33_000, 77, 200)])
+@pytest.mark.parametrize("d,I,rows,K", [(64, 40_001, 300, 50), (128, 65_537, 1500, 10), (32, 33_000, 77, 200),
+                                        (32, 33_000, 17_000, 20)])   # > 8192 rows: passes on two streams
 def test_fused_score_topk_equals_dense_path(rsx, oracle_mod, d, I, rows, K):
     """catalogs >= 32768 items take the fused path (sample threshold -> filtered MFMA epilogue ->
     merge); it must give exactly what dense scoring + row top-k gives, mask included"""
@@ -236,7 +237,8 @@ def test_fused_score_topk_equals_dense_path(rsx, oracle_mod, d, I, rows, K):
     U = 5000
     P = torch.randn(U, d, device="cuda") * 0.1
     Q = torch.randn(I, d, device="cuda") * 0.1
-    users = torch.randperm(U, device="cuda")[:rows].to(torch.int32)
+    users = (torch.randperm(U, device="cuda")[:rows] if rows <= U else
+             torch.randint(0, U, (rows,), device="cuda")).to(torch.int32)
     from recsys_pytorch_amd.data import synthetic_csr
     mask = synthetic_csr(U, I, 30, "cuda", seed=3)
     idx, val = rsx.score_topk(P, Q, users, K, mask=mask, want_values=True)
