@@ -152,7 +152,7 @@ def main():
         if world == 1:
             prefetch(cur ^ 1)           # sampler of step t+1 runs beside step t's kernel
         u, i, j = buf["t"]
-        use_hot = eng.hot is not None and not neg_block
+        use_hot = eng.hot is not None
         if ev is not None:
             ev[0].record()
         rsx.bpr_step(eng.P, eng.Q, eng.G, u, i, j, eng.lr, 1.0 / gb, users_unique=True,

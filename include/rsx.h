@@ -101,7 +101,7 @@ int rsx_device_info_get(int device, rsx_device_info *out);
  *     permutation key (0 = identity).  Consecutive triplets with the same positive item
  *     (RSX_SAMPLE_SORT_POS) are summed in registers and reach G once per run.  Triplets
  *     that do not honour either contract are still summed correctly (atomic path).
- *     hot_slot_dev is ignored in this mode (runs replace the replicas).
+ *     With hot_slot_dev the runs of popular items are flushed into the replicas.
  */
 int64_t rsx_bpr_step_workspace(int64_t num_users, int64_t max_batch, int d);
 

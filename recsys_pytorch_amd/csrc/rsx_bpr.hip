@@ -270,9 +270,15 @@ __global__ __launch_bounds__(kBlock, 5) void bpr_step_blocked_kernel(
     for (int cc = 0; cc < EPL; ++cc) { r0[cc] = 0.f; r1[cc] = 0.f; }
     // (all indices below are compile-time constants after unrolling, so the arrays stay in
     //  registers; choosing between r0 and r1 through a reference or a branch does not)
+    // a popular item's run spans hundreds of wavefronts, which all flush into the same row at
+    // about the same time (same-line atomics serialise): such rows go to the replicas (HotMap)
 #define RSX_RUN_FLUSH(RI, R)                                                      \
     if (RI >= 0 && !(ablate & 1)) {                                               \
         float *grow = G + (size_t)RI * D;                                         \
+        if (hot.slot != nullptr) {                                                \
+            const int32_t hs = hot.slot[RI];                                      \
+            if (hs >= 0) grow = hot.ghot + ((size_t)hs * hot.replicas + (size_t)(wave & (hot.replicas - 1))) * D; \
+        }                                                                         \
         _Pragma("unroll") for (int cc = 0; cc < EPL; ++cc) rsx_atomic_add(grow + RowT::elem(k, cc), R[cc]); \
     }
 
@@ -360,8 +366,8 @@ __global__ __launch_bounds__(kBlock, 5) void bpr_step_blocked_kernel(
         const bool live_a = (b < g_hi) && (ia >= 0);
         const bool live_b = (b + 1 < g_hi) && (ib >= 0);
         Row<D> pa, qia, qja, pb, qib, qjb;
-        if (live_a) { pa.load(P + (size_t)ua * D, k); qia.load(Q + (size_t)ia * D, k); qja.load(Q + (size_t)ja * D, k); }
-        if (live_b) { pb.load(P + (size_t)ub * D, k); qib.load(Q + (size_t)ib * D, k); qjb.load(Q + (size_t)jb * D, k); }
+        if (live_a) { pa.load(P + (size_t)ua * D, k); qia.load(Q + (size_t)((ablate & 32) ? 0 : ia) * D, k); qja.load(Q + (size_t)((ablate & 64) ? 1 : ja) * D, k); }
+        if (live_b) { pb.load(P + (size_t)ub * D, k); qib.load(Q + (size_t)((ablate & 32) ? 0 : ib) * D, k); qjb.load(Q + (size_t)((ablate & 64) ? 1 : jb) * D, k); }
         process(live_a, ua, ia, ja, pa, qia, qja);
         process(live_b, ub, ib, jb, pb, qib, qjb);
         ua = una; ia = ina; ja = jna; ub = unb; ib = inb; jb = jnb;

@@ -125,7 +125,6 @@ class BPREngine:
             kw = {"hot": self.hot} if self.hot is not None else {}
             if neg_block:
                 kw["neg_block"], kw["neg_key"] = neg_block, neg_key
-                kw.pop("hot", None)            # runs of equal positives replace the replicas
             self.k.bpr_step(self.P, self.Q, self.G, u_local, i, j, self.lr, 1.0 / gb, loss_acc=loss,
                             users_unique=users_unique, ws=None if users_unique else self._workspace(B), **kw)
             if "hot" in kw:
