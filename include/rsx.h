@@ -171,8 +171,16 @@ int64_t rsx_bpr_sample_workspace(int64_t batch, int64_t num_items);
 int rsx_bpr_sample(const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users,
                    int64_t num_items, int64_t batch, uint64_t seed, uint64_t step,
                    int64_t epoch_pos, int neg_block, uint64_t neg_key, unsigned flags,
-                   void *ws, int64_t ws_bytes, int32_t *u_out, int32_t *i_out, int32_t *j_out,
-                   rsx_stream_t stream);
+                   void *ws, int64_t ws_bytes, const uint64_t *user_sig_dev, int32_t *u_out,
+                   int32_t *i_out, int32_t *j_out, rsx_stream_t stream);
+
+/* Optional accelerator of the rejection test of the sorted layout: user_sig_dev[u] (uint64,
+ * static per CSR and neg_block, built by rsx_bpr_build_signature) has one hashed bit per item
+ * block that holds a positive of u; a clear bit proves every item of the drawn block negative
+ * for u, so indptr and the row are not read at all for that draw.  NULL = always check the row.
+ * Same distribution either way.                                                             */
+int rsx_bpr_build_signature(const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users,
+                            int neg_block, uint64_t *sig_out, rsx_stream_t stream);
 
 /* ---- full-catalog scoring + Top-K ----------------------------------------------
  * Replaces

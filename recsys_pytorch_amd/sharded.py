@@ -153,7 +153,12 @@ class BPREngine:
             need = self.k.bpr_sample_workspace(batch, self.Q.shape[0])
             if self._sample_ws is None or self._sample_ws.numel() < need:
                 self._sample_ws = torch.empty(need, dtype=torch.uint8, device=self.Q.device)
+            if getattr(self, "_sig_for", None) != (indptr.data_ptr(), self.neg_block) and hasattr(self.k, "build_signature"):
+                self._sig = self.k.build_signature(indptr, indices, self.neg_block)   # static per CSR
+                self._sig_for = (indptr.data_ptr(), self.neg_block)
             kw = {"neg_block": self.neg_block, "neg_key": key, "sort_pos": True, "ws": self._sample_ws}
+            if getattr(self, "_sig", None) is not None:
+                kw["user_sig"] = self._sig
         self.k.bpr_sample(indptr, indices, self.Q.shape[0], batch, self.seed + 7919 * self.user_begin,
                           step, self.epoch_pos, u, i, j, **kw)
         self.epoch_pos += batch
