@@ -166,11 +166,11 @@ def main():
             # all-reduce (the CUs idle while xGMI moves G) than beside the kernel
             side.wait_event(buf["free"])
             prefetch(cur ^ 1)
-        if use_hot:
-            rsx.fold_hot_grad(eng.G, eng.hot)
+        if use_hot and world > 1:
+            rsx.fold_hot_grad(eng.G, eng.hot)          # the all-reduce needs the folded G
         if world > 1:
             dist.all_reduce(eng.G, op=dist.ReduceOp.SUM)
-        rsx.apply_item_grad(eng.Q, eng.G, eng.lr)
+        rsx.apply_item_grad(eng.Q, eng.G, eng.lr, hot=eng.hot if (use_hot and world == 1) else None)
         eng.step_count += 1
         state["cur"] = cur ^ 1
 

@@ -118,8 +118,12 @@ int rsx_fold_hot_grad(float *G, float *G_hot, const int32_t *hot_items_dev, int 
 /* rsx_apply_item_grad  (phase 2 of a step; after the all-reduce of G when sharded)
  *   Q -= lr * G ;  G = 0        for every row of the [num_items x d] tables.
  *   Replaces the item-table half of optimizer.step() (models/MF.py:68) for SGD.
- *   Rows whose gradient is entirely zero are not written.                       */
+ *   Rows whose gradient is entirely zero are not written.
+ *   hot_slot_dev / G_hot / hot_replicas (nullable): fold the popular rows' replicas in
+ *   here instead of calling rsx_fold_hot_grad (only when no all-reduce of G sits between
+ *   rsx_bpr_step and this call: the all-reduce needs the folded G).                 */
 int rsx_apply_item_grad(float *Q, float *G, int64_t num_items, int d, float lr,
+                        const int32_t *hot_slot_dev, float *G_hot, int hot_replicas,
                         rsx_stream_t stream);
 
 /* ---- reference-exact optimizer ----------------------------

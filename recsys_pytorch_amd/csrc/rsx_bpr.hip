@@ -499,13 +499,27 @@ __global__ __launch_bounds__(kBlock) void pair_score_kernel(const float *__restr
     }
 }
 
-// Q -= lr*G ; G = 0   (streaming; rows with an all-zero gradient quad are not written)
+// Q -= lr*G ; G = 0   (streaming; rows with an all-zero gradient quad are not written).
+// With a HotMap the replicas of a popular row are summed in here (and zeroed), which saves the
+// separate fold launch when no all-reduce sits between the step and the apply.
 __global__ __launch_bounds__(kBlock) void apply_item_grad_kernel(float4 *__restrict__ Q,
                                                                  float4 *__restrict__ G, int64_t n4,
-                                                                 float lr)
+                                                                 float lr, HotMap hot, int d4)
 {
     for (int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x; n < n4; n += (int64_t)gridDim.x * kBlock) {
-        const float4 g = G[n];
+        float4 g = G[n];
+        if (hot.slot != nullptr) {
+            const int64_t row = n / d4;
+            const int32_t hs = hot.slot[row];
+            if (hs >= 0) {
+                float4 *src = reinterpret_cast<float4 *>(hot.ghot) + ((size_t)hs * hot.replicas) * d4 + (n - row * d4);
+                for (int r = 0; r < hot.replicas; ++r) {
+                    const float4 v = src[(size_t)r * d4];
+                    g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+                    src[(size_t)r * d4] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
         if (g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f) {
             float4 q = Q[n];
             q.x = fmaf(-lr, g.x, q.x); q.y = fmaf(-lr, g.y, q.y);
@@ -721,13 +735,19 @@ RSX_API int rsx_fold_hot_grad(float *G, float *G_hot, const int32_t *hot_items_d
 }
 
 RSX_API int rsx_apply_item_grad(float *Q, float *G, int64_t num_items, int d, float lr,
+                                const int32_t *hot_slot_dev, float *G_hot, int hot_replicas,
                                 rsx_stream_t stream)
 {
     RSX_CHECK_ARG(Q && G, "null table pointer");
     RSX_CHECK_ARG(rsx_dim_ok(d) && num_items > 0, "bad shape");
+    HotMap hot{nullptr, nullptr, 1};
+    if (hot_slot_dev != nullptr) {
+        RSX_CHECK_ARG(G_hot != nullptr && hot_replicas >= 1, "hot_slot_dev given without G_hot");
+        hot = HotMap{hot_slot_dev, G_hot, hot_replicas};
+    }
     const int64_t n4 = num_items * d / 4;
     hipLaunchKernelGGL(apply_item_grad_kernel, dim3((unsigned)grid_1d(n4)), dim3(kBlock), 0,
-                       (hipStream_t)stream, (float4 *)Q, (float4 *)G, n4, lr);
+                       (hipStream_t)stream, (float4 *)Q, (float4 *)G, n4, lr, hot, d / 4);
     RSX_CHECK_LAUNCH();
     return RSX_OK;
 }

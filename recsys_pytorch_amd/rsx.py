@@ -29,7 +29,7 @@ SIGNATURES = {
     "rsx_bpr_step": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _I64, _I32, _F, _F, _P, _U, _P, _I64,
                                _P, _P, _I32, _I32, _U64, _P]),
     "rsx_fold_hot_grad": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P]),
-    "rsx_apply_item_grad": (C.c_int, [_P, _P, _I64, _I32, _F, _P]),
+    "rsx_apply_item_grad": (C.c_int, [_P, _P, _I64, _I32, _F, _P, _P, _I32, _P]),
     "rsx_bpr_grad": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _I64, _I32, _F, _P, _P]),
     "rsx_adam_apply": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I64, _P]),
     "rsx_spmm_plan": (_I64, [_P, _I64, _I32, _P, _P, _P]),
@@ -146,9 +146,13 @@ def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False,
         "rsx_bpr_step")
 
 
-def apply_item_grad(Q, G, lr):
+def apply_item_grad(Q, G, lr, hot=None):
+    """Q -= lr*G; G = 0.  With `hot` the replicas of the popular rows are folded in here."""
     _check(lib().rsx_apply_item_grad(_dev(Q, torch.float32, "Q"), _dev(G, torch.float32, "G"),
-                                     Q.shape[0], Q.shape[1], float(lr), _stream()), "rsx_apply_item_grad")
+                                     Q.shape[0], Q.shape[1], float(lr),
+                                     _dev(hot.slot, torch.int32, "hot slot") if hot is not None else None,
+                                     _dev(hot.ghot, torch.float32, "ghot") if hot is not None else None,
+                                     hot.replicas if hot is not None else 0, _stream()), "rsx_apply_item_grad")
 
 
 def bpr_grad(P, Q, GP, GQ, u, i, j, inv_batch, loss_acc=None):

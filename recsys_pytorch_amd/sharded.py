@@ -127,14 +127,17 @@ class BPREngine:
                 kw["neg_block"], kw["neg_key"] = neg_block, neg_key
             self.k.bpr_step(self.P, self.Q, self.G, u_local, i, j, self.lr, 1.0 / gb, loss_acc=loss,
                             users_unique=users_unique, ws=None if users_unique else self._workspace(B), **kw)
-            if "hot" in kw:
-                self.k.fold_hot_grad(self.G, self.hot)
+            if "hot" in kw and self.sharded:
+                self.k.fold_hot_grad(self.G, self.hot)      # the all-reduce needs the folded G
         if self.sharded:
             # the one exchange of the step: item gradients, summed over ranks (RCCL over xGMI)
             dist.all_reduce(self.G, op=dist.ReduceOp.SUM, group=self.group)
             if want_loss:
                 dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.group)
-        self.k.apply_item_grad(self.Q, self.G, self.lr)
+        if self.hot is not None and not self.sharded:
+            self.k.apply_item_grad(self.Q, self.G, self.lr, hot=self.hot)   # replicas folded in the sweep
+        else:
+            self.k.apply_item_grad(self.Q, self.G, self.lr)
         self.step_count += 1
         return loss
 

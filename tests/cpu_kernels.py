@@ -37,7 +37,7 @@ def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False,
     P -= torch.from_numpy(gP * np.float32(scale * lr))
 
 
-def apply_item_grad(Q, G, lr):
+def apply_item_grad(Q, G, lr, hot=None):
     Q -= lr * G
     G.zero_()
 

@@ -55,5 +55,5 @@ def test_argument_errors_use_the_error_channel(libpath):
     from recsys_pytorch_amd import rsx
     L = rsx.lib()
     assert L.rsx_bpr_step_workspace(10, 10, 48) < 0          # unsupported d
-    rc = L.rsx_apply_item_grad(None, None, 10, 32, 0.1, None)
+    rc = L.rsx_apply_item_grad(None, None, 10, 32, 0.1, None, None, 0, None)
     assert rc == -1 and b"null" in L.rsx_last_error()
