@@ -121,6 +121,8 @@ def main():
     indptr, indices = synthetic_csr(U, I, args.degree, dev, seed=2020 + rank, popularity=args.popularity)
     eng = BPREngine(P, Q, args.lr, user_begin=rank * U, seed=2020)
     gb = B * world
+    eng.use_item_cdf = os.environ.get("RSX_NO_CDF", "0") != "1"         # development knobs
+    inline_sampler = os.environ.get("RSX_INLINE_SAMPLER", "0") == "1"
     neg_block = eng.set_neg_block(B, args.neg_block) if args.neg_block > 0 else 0
     if args.hot > 0:
         eng.set_hot_items(torch.bincount(indices.long(), minlength=I), args.hot, args.hot_replicas)
@@ -128,6 +130,8 @@ def main():
     # the sampler of step t+1 runs on a second HIP stream while step t computes (it reads only
     # the CSR); both are inside the timed region
     side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("RSX_SIDE_PRIORITY", "0")))
+    if inline_sampler:
+        side = torch.cuda.current_stream()
     bufs = [{"t": eng._triplet_buffers(B), "ready": None, "free": None, "key": 0} for _ in range(2)]
     state = {"cur": 0, "next_step": 0}
 
@@ -182,18 +186,22 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events around the step kernel of every 5th timed step (an event pair costs ~9 us of
+    # launch gap on this queue, so bracketing every step would slow the thing being measured)
+    ev_every = 1 if args.steps < 10 else 5
+    events = {s: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for s in range(0, args.steps, ev_every)}
     fence()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        one_step(events[s])
+        one_step(events.get(s))
     fence()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))   # bpr_step_kernel, HIP events
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events.values()]))   # bpr_step_kernel, HIP events
     assert torch.isfinite(P).all() and torch.isfinite(Q).all()
 
     # ---- scoring leg (reported beside the headline; its own timed region) ---------------

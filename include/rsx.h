@@ -175,16 +175,33 @@ int64_t rsx_bpr_sample_workspace(int64_t batch, int64_t num_items);
 int rsx_bpr_sample(const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users,
                    int64_t num_items, int64_t batch, uint64_t seed, uint64_t step,
                    int64_t epoch_pos, int neg_block, uint64_t neg_key, unsigned flags,
-                   void *ws, int64_t ws_bytes, const uint64_t *user_sig_dev, int32_t *u_out,
-                   int32_t *i_out, int32_t *j_out, rsx_stream_t stream);
+                   void *ws, int64_t ws_bytes, const uint64_t *user_sig_dev,
+                   const uint32_t *item_cdf_dev, int32_t *u_out, int32_t *i_out, int32_t *j_out,
+                   rsx_stream_t stream);
 
-/* Optional accelerator of the rejection test of the sorted layout: user_sig_dev[u] (uint64,
- * static per CSR and neg_block, built by rsx_bpr_build_signature) has one hashed bit per item
- * block that holds a positive of u; a clear bit proves every item of the drawn block negative
- * for u, so indptr and the row are not read at all for that draw.  NULL = always check the row.
- * Same distribution either way.                                                             */
+/* Optional accelerator of the rejection test of the sorted layout: user_sig_dev holds one
+ * 16-byte record per user (two uint64, 16-byte aligned; static per CSR and neg_block, built by
+ * rsx_bpr_build_signature; sig_out = 16 * num_users bytes).  Word 0 has one hashed bit per item
+ * block that holds a positive of u: a clear bit proves every item of the drawn block negative
+ * for u, so indptr and the row are not read at all for that draw.  Word 1 is the row's start in
+ * `indices` (low 40 bits) and its length (high 24 bits), which saves the indptr look-up when the
+ * row does have to be read.  NULL = always check the row through indptr.  Same draws either way. */
 int rsx_bpr_build_signature(const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users,
                             int neg_block, uint64_t *sig_out, rsx_stream_t stream);
+
+/* Optional accelerator of RSX_SAMPLE_SORT_POS: item_cdf_dev (uint32 [num_items + 1], static per
+ * CSR) is the CDF of the positive-item distribution (item i with weight sum over its users of
+ * 1/deg(u)) in 2^-32 units.  With it the batch is ordered by positive item without a device-wide
+ * sort: the pairs are cut into item-range buckets of equal expected size from the CDF (a popular
+ * item spreads over several buckets by a hash of the user) and every bucket is sorted by
+ * (item, user) inside one workgroup; batches above 2^21 positions are ordered piece by piece.
+ * NULL = device radix sort by item.  Same triplet distribution either way; the order inside the
+ * batch differs, and is in both cases a pure function of (seed, step, CSR).
+ * ws for the build: rsx_bpr_item_cdf_workspace(num_items) bytes.                                 */
+int64_t rsx_bpr_item_cdf_workspace(int64_t num_items);
+int rsx_bpr_build_item_cdf(const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users,
+                           int64_t num_items, uint32_t *cdf_out, void *ws, int64_t ws_bytes,
+                           rsx_stream_t stream);
 
 /* ---- full-catalog scoring + Top-K ----------------------------------------------
  * Replaces

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
 // Neither is a correctness contract: a negative outside the wave's block and an unsorted batch
 // take the global-atomic path / runs of length one, and the sums are the same.
 template <int D>
-__global__ __launch_bounds__(kBlock, 5) void bpr_step_blocked_kernel(
+__global__ __launch_bounds__(kBlock, 6) void bpr_step_blocked_kernel(
     float *__restrict__ P, const float *__restrict__ Q, float *__restrict__ G,
     const int32_t *__restrict__ U_idx, const int32_t *__restrict__ I_idx,
     const int32_t *__restrict__ J_idx, int64_t B, int64_t num_items, int c, uint64_t neg_key, float lr,
@@ -261,15 +261,11 @@ __global__ __launch_bounds__(kBlock, 5) void bpr_step_blocked_kernel(
     const int64_t g_hi = (g_lo + len < b1) ? g_lo + len : b1;
 
     float loss_local = 0.0f;
-    // running sums of g*P[u] for the current positive item(s).  Two accumulators, chosen by item
-    // parity: the 16-bit-key sort orders the batch by item >> 1, so within one key the two items
-    // interleave; each keeps its own run.
-    int32_t run_item0 = -1, run_item1 = -1;
-    float r0[EPL], r1[EPL];
+    // running sum of g*P[u] for the current positive item (the sampler orders the batch by it)
+    int32_t run_item = -1;
+    float run[EPL];
 #pragma unroll
-    for (int cc = 0; cc < EPL; ++cc) { r0[cc] = 0.f; r1[cc] = 0.f; }
-    // (all indices below are compile-time constants after unrolling, so the arrays stay in
-    //  registers; choosing between r0 and r1 through a reference or a branch does not)
+    for (int cc = 0; cc < EPL; ++cc) run[cc] = 0.f;
     // a popular item's run spans hundreds of wavefronts, which all flush into the same row at
     // about the same time (same-line atomics serialise): such rows go to the replicas (HotMap)
 #define RSX_RUN_FLUSH(RI, R)                                                      \
@@ -304,26 +300,14 @@ __global__ __launch_bounds__(kBlock, 5) void bpr_step_blocked_kernel(
             const float g = -sneg * inv_batch;
             if (k == 0) loss_local += softplus_neg(x);
             // positive item: extend its run, or flush the run and start a new one
-            // (select in / select out: a branch per parity makes the compiler fold the two
-            //  accumulators into a dynamically indexed scratch array)
-            {
-                const bool odd = (i & 1) != 0;
-                int32_t ri = odd ? run_item1 : run_item0;
-                float t[EPL];
+            if (i != run_item) {
+                RSX_RUN_FLUSH(run_item, run)
+                run_item = i;
 #pragma unroll
-                for (int cc = 0; cc < EPL; ++cc) t[cc] = odd ? r1[cc] : r0[cc];
-                if (i != ri) {
-                    RSX_RUN_FLUSH(ri, t)
-                    ri = i;
-#pragma unroll
-                    for (int cc = 0; cc < EPL; ++cc) t[cc] = 0.f;
-                }
-#pragma unroll
-                for (int cc = 0; cc < EPL; ++cc) t[cc] = fmaf(g, p.v[cc], t[cc]);
-                run_item0 = odd ? run_item0 : ri; run_item1 = odd ? ri : run_item1;
-#pragma unroll
-                for (int cc = 0; cc < EPL; ++cc) { r0[cc] = odd ? r0[cc] : t[cc]; r1[cc] = odd ? t[cc] : r1[cc]; }
+                for (int cc = 0; cc < EPL; ++cc) run[cc] = 0.f;
             }
+#pragma unroll
+            for (int cc = 0; cc < EPL; ++cc) run[cc] = fmaf(g, p.v[cc], run[cc]);
             // negative item: the wave's own block goes to LDS, anything else to G
             neg_local = ((int64_t)j >= item_lo && (int64_t)j < item_hi);
             if (!neg_local && !(ablate & 2)) p.atomic_axpy(G + (size_t)j * D, k, -g);
@@ -372,8 +356,7 @@ __global__ __launch_bounds__(kBlock, 5) void bpr_step_blocked_kernel(
         process(live_b, ub, ib, jb, pb, qib, qjb);
         ua = una; ia = ina; ja = jna; ub = unb; ib = inb; jb = jnb;
     }
-    RSX_RUN_FLUSH(run_item0, r0)     // last runs of this lane group
-    RSX_RUN_FLUSH(run_item1, r1)
+    RSX_RUN_FLUSH(run_item, run)     // last run of this lane group
 #undef RSX_RUN_FLUSH
     // flush the block's rows: one global atomic row per touched item
     const int rows = (int)(item_hi - item_lo);

@@ -23,6 +23,7 @@
 namespace {
 
 constexpr int kBlock = 256;
+constexpr uint64_t kSigStartMask = (1ull << 40) - 1, kSigLenClip = (1ull << 24) - 1;
 
 // rocPRIM's default policy (merge sort up to 1M pairs, ~195 us for 1M on MI355X) measured
 // faster here than forcing Onesweep (MergeSortLimit = 0: ~415 us for 1M 17-bit keys)
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void sample_neg16_kernel(
                 // negative for this user (73 % of the draws at 20 positives per user)
                 int64_t neg_lo, neg_n;
                 neg_range(I, p, B, neg_block, neg_key, neg_lo, neg_n);
-                if (((user_sig[u] >> sig_bit(neg_lo / neg_block)) & 1ull) == 0ull) {
+                if (((user_sig[2 * (size_t)u] >> sig_bit(neg_lo / neg_block)) & 1ull) == 0ull) {
                     nj = (int32_t)(neg_lo + (int64_t)(((uint64_t)xorshift32(s) * (uint64_t)neg_n) >> 32));
                     done = true;
                 }
@@ -173,15 +174,19 @@ __global__ __launch_bounds__(kBlock) void sample_neg16_kernel(
     }
 }
 
-// user_sig[u] = OR over the user's positives of (1 << sig_bit(item / neg_block)); static per CSR
+// user_sig[2u] = OR over the user's positives of (1 << sig_bit(item / neg_block)); user_sig[2u+1] =
+// row start | row length << 40 (length clipped to 2^24-1: "look it up in indptr"); static per CSR
 __global__ __launch_bounds__(kBlock) void build_signature_kernel(const int64_t *__restrict__ indptr,
                                                                  const int32_t *__restrict__ indices, int64_t U,
                                                                  int neg_block, uint64_t *__restrict__ sig)
 {
     for (int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x; u < U; u += (int64_t)gridDim.x * kBlock) {
         uint64_t m = 0ull;
-        for (int64_t q = indptr[u]; q < indptr[u + 1]; ++q) m |= 1ull << sig_bit(indices[q] / neg_block);
-        sig[u] = m;
+        const int64_t lo = indptr[u], hi = indptr[u + 1];
+        for (int64_t q = lo; q < hi; ++q) m |= 1ull << sig_bit(indices[q] / neg_block);
+        const uint64_t len = (uint64_t)(hi - lo) < kSigLenClip ? (uint64_t)(hi - lo) : kSigLenClip;
+        sig[2 * u] = m;
+        sig[2 * u + 1] = ((uint64_t)lo & kSigStartMask) | (len << 40);
     }
 }
 
@@ -203,6 +208,497 @@ __global__ __launch_bounds__(kBlock) void sample_neg_kernel(
         }
         u_out[p] = (int32_t)u; i_out[p] = pi; j_out[p] = nj;
     }
+}
+
+
+// ---- sorted layout without a device-wide sort (item_cdf given) --------------------------------
+// A device radix sort is a chain of small dependent kernels with decoupled look-back; run beside
+// the step kernel (which fills every wave slot) it stretched from 79 us to ~400 us and became the
+// critical path of the training step.  The sampling distribution over positive items is static per
+// CSR, so the batch is cut into BALANCED item-range buckets from that distribution's CDF instead:
+//   bucket_chunk_kernel   one workgroup per 4096 positions: sample (u, i), bucket = floor(NB * t),
+//                         t a point of item i's CDF interval chosen by a hash of u (a popular item
+//                         spreads over several buckets in proportion), LDS counting sort of the
+//                         chunk by bucket, chunk + its per-bucket (offset, count) row written out
+//   bucket_sort_kernel    one workgroup per bucket (~832 pairs): gather the bucket's slices of all
+//                         chunks into LDS, bitonic sort by (item, user), draw the negatives per
+//                         final position, write u/i/j
+// Buckets are monotone in the item, so the concatenation is ordered by positive item; the order
+// is a pure function of the sampled set (no atomics decide a position).
+constexpr int kChunk = 4096;              // positions per bucket_chunk workgroup (16 per thread)
+constexpr int kChunkThreads = 1024;
+constexpr int kPerThread = kChunk / kChunkThreads;
+constexpr int kBucketMean = 832;          // expected pairs per bucket: 1024 - 6.6 sigma
+constexpr int kSortCap = 2048;            // pairs a bucket may hold and still be sorted in LDS
+constexpr int64_t kPiece = 1ll << 21;     // positions bucketed per pass (bounds LDS bins and workspace)
+constexpr int kMaxBuckets = (int)(kPiece / kBucketMean) + 3;
+constexpr int kMaxChunks = (int)(kPiece / kChunk);        // 512
+constexpr int kTotalStride = 32;          // bucket totals sit one per 128-B line (same-line atomics serialise)
+constexpr int kRangeCap = 256;            // negative-block ranges a bucket's positions may span and still use the LDS table
+static_assert((kMaxBuckets + 4) * 4 + kChunk * 8 <= 64 * 1024, "bucket_chunk_kernel's LDS");
+
+int g_sort_cap = kSortCap;                // test hook: lower it to exercise the out-of-LDS path
+
+// adjacent table entries fetched with one load (dword / qword alignment is enough for global loads)
+struct __attribute__((packed, aligned(4))) U32Pair { uint32_t a, b; };
+struct __attribute__((packed, aligned(8))) I64Pair { int64_t a, b; };
+
+__device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+
+__device__ __forceinline__ int bucket_of(const uint32_t *__restrict__ cdf, uint32_t item, uint32_t u, int64_t I, int nbm)
+{
+    if ((int64_t)item >= I) return nbm;                               // "no positive": own last bucket
+    const uint32_t lo = cdf[item], hi = cdf[item + 1];
+    const uint32_t t = lo + mulhi32((uint32_t)splitmix64(0xC2B2AE3D27D4EB4Full ^ u), hi - lo);
+    return (int)mulhi32(t, (uint32_t)nbm);
+}
+
+__global__ __launch_bounds__(kChunkThreads) void bucket_chunk_kernel(
+    const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices, const uint32_t *__restrict__ cdf,
+    int64_t U, int64_t I, int64_t piece_lo, int64_t n, uint64_t seed, uint64_t step, int64_t epoch_pos, int hb,
+    int nbm, int nblk, uint2 *__restrict__ pairs, uint32_t *__restrict__ table, uint32_t *__restrict__ totals)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int NB = nbm + 1;
+    uint32_t *hist = smem;                                    // [NB] counts, then exclusive offsets
+    uint2 *stage = (uint2 *)(smem + ((NB + 3) & ~3));         // [kChunk]
+    __shared__ uint32_t wave_sum[kChunkThreads / 64];
+    const int tid = threadIdx.x;
+    const int blk = blockIdx.x;
+    for (int q = tid; q < NB; q += kChunkThreads) hist[q] = 0u;
+    __syncthreads();
+    // the kPerThread positions of a thread advance in lockstep, one dependent load level at a
+    // time, so that their global loads are in flight together (the pass is latency-bound)
+    uint32_t eu[kPerThread], ei[kPerThread], eb[kPerThread];  // user, item, bucket << 13 | rank in bucket
+    int64_t rlo[kPerThread], rhi[kPerThread];
+    bool ok[kPerThread];
+#pragma unroll
+    for (int e = 0; e < kPerThread; ++e) {
+        const int64_t loc = (int64_t)blk * kChunk + e * kChunkThreads + tid;
+        ok[e] = loc < n;
+        eu[e] = ok[e] ? user_at(epoch_pos + piece_lo + loc, U, hb, seed) : 0u;
+        const I64Pair rb = *reinterpret_cast<const I64Pair *>(indptr + eu[e]);
+        rlo[e] = rb.a; rhi[e] = rb.b;
+    }
+#pragma unroll
+    for (int e = 0; e < kPerThread; ++e) {
+        const int64_t b = piece_lo + (int64_t)blk * kChunk + e * kChunkThreads + tid;
+        uint32_t s = rng_seed(seed, step, (uint64_t)b, 0);
+        const uint32_t deg = (uint32_t)(rhi[e] - rlo[e]);
+        const bool has = ok[e] && deg > 0 && (int64_t)deg < I;
+        ei[e] = (uint32_t)I;
+        if (has) ei[e] = (uint32_t)indices[rlo[e] + (int64_t)(((uint64_t)xorshift32(s) * deg) >> 32)];
+    }
+    uint32_t c0[kPerThread], c1[kPerThread];
+#pragma unroll
+    for (int e = 0; e < kPerThread; ++e) {
+        const uint32_t it = (int64_t)ei[e] < I ? ei[e] : 0u;
+        const U32Pair cc = *reinterpret_cast<const U32Pair *>(cdf + it);
+        c0[e] = cc.a; c1[e] = cc.b;
+    }
+#pragma unroll
+    for (int e = 0; e < kPerThread; ++e) {
+        eb[e] = 0xFFFFFFFFu;
+        if (ok[e]) {
+            int bk = nbm;                                              // "no positive": own last bucket
+            if ((int64_t)ei[e] < I)
+                bk = (int)mulhi32(c0[e] + mulhi32((uint32_t)splitmix64(0xC2B2AE3D27D4EB4Full ^ eu[e]), c1[e] - c0[e]),
+                                  (uint32_t)nbm);
+            eb[e] = ((uint32_t)bk << 13) | atomicAdd(&hist[bk], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the NB counts: a contiguous slice per thread, then a block scan of the slice sums
+    const int per = (NB + kChunkThreads - 1) / kChunkThreads;
+    const int q0 = tid * per < NB ? tid * per : NB, q1 = (q0 + per < NB) ? q0 + per : NB;
+    uint32_t mine = 0;
+    for (int q = q0; q < q1; ++q) mine += hist[q];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off);
+        if ((tid & 63) >= off) incl += v;
+    }
+    if ((tid & 63) == 63) wave_sum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t base = incl - mine;
+    for (int w = 0; w < (tid >> 6); ++w) base += wave_sum[w];
+    for (int q = q0; q < q1; ++q) {
+        const uint32_t cnt = hist[q];
+        hist[q] = base;
+        table[(size_t)blk * NB + q] = (base << 16) | cnt;     // cnt <= 4096, base < 4096 (row of this chunk: contiguous)
+        if (cnt) atomicAdd(&totals[(size_t)q * kTotalStride], cnt);   // integer: order-independent; one counter per 128-B line
+        base += cnt;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < kPerThread; ++e)
+        if (eb[e] != 0xFFFFFFFFu) stage[hist[eb[e] >> 13] + (eb[e] & 0x1FFFu)] = make_uint2(eu[e], ei[e]);
+    __syncthreads();
+    const int64_t chunk_n = (n - (int64_t)blk * kChunk < kChunk) ? n - (int64_t)blk * kChunk : kChunk;
+    for (int q = tid; q < chunk_n; q += kChunkThreads) pairs[(size_t)blk * kChunk + q] = stage[q];
+}
+
+// ascending-only bitonic network (each merge starts with a mirror stage), so positions >= n act
+// as +infinity without being stored: a pair whose upper index is >= n is skipped
+template <class Acc>
+__device__ __forceinline__ void bitonic_sort(Acc a, int n, int tid)
+{
+    int n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (n2 >> 1); t += kBlock) {
+                int lo, hi;
+                if (j == (k >> 1)) { const int w = t & (j - 1); lo = ((t - w) << 1) + w; hi = lo + ((j - w) << 1) - 1; }
+                else               { const int w = t & (j - 1); lo = ((t - w) << 1) + w; hi = lo + j; }
+                if (hi < n) {
+                    const uint64_t x = a.get(lo), y = a.get(hi);
+                    if (x > y) { a.set(lo, y); a.set(hi, x); }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ void sort2(uint64_t &x, uint64_t &y)
+{
+    const bool sw = y < x;
+    const uint64_t lo = sw ? y : x, hi = sw ? x : y;
+    x = lo; y = hi;
+}
+
+// the same network on LDS keys, two stages per pass: a thread owns the four keys that the stages
+// j and j/2 (or the mirror stage and j = k/4) permute among themselves, so the LDS traffic, the
+// index arithmetic and the barriers are halved (30 passes instead of 55 stages for 1024 keys).
+// keys[n .. n2) are padded with +infinity (no (item, user) key is all ones).
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t *keys, int n, int tid)
+{
+    int n2 = 4;
+    while (n2 < n) n2 <<= 1;
+    for (int q = n + tid; q < n2; q += kBlock) keys[q] = ~0ull;
+    __syncthreads();
+    const int groups = n2 >> 2;
+    for (int g = tid; g < groups; g += kBlock) {          // k = 2 and k = 4 inside four consecutive keys
+        uint64_t *c = keys + 4 * g;
+        uint64_t v0 = c[0], v1 = c[1], v2 = c[2], v3 = c[3];
+        sort2(v0, v1); sort2(v2, v3);
+        sort2(v0, v3); sort2(v1, v2);
+        sort2(v0, v1); sort2(v2, v3);
+        c[0] = v0; c[1] = v1; c[2] = v2; c[3] = v3;
+    }
+    __syncthreads();
+    for (int k = 8; k <= n2; k <<= 1) {
+        const int q = k >> 2;                             // mirror stage of this merge + stage j = k/4
+        for (int g = tid; g < groups; g += kBlock) {
+            const int low = g & (q - 1), base = (g - low) << 2;
+            const int e0 = base + low, e1 = e0 + q, e3 = base + k - 1 - low, e2 = e3 - q;
+            uint64_t v0 = keys[e0], v1 = keys[e1], v2 = keys[e2], v3 = keys[e3];
+            sort2(v0, v3); sort2(v1, v2);
+            sort2(v0, v1); sort2(v2, v3);
+            keys[e0] = v0; keys[e1] = v1; keys[e2] = v2; keys[e3] = v3;
+        }
+        __syncthreads();
+        int j = k >> 3;
+        for (; j >= 4; j >>= 2) {                         // stages j and j/2
+            const int h = j >> 1;
+            for (int g = tid; g < groups; g += kBlock) {
+                const int low = g & (h - 1), a = ((g - low) << 2) | low;
+                uint64_t v0 = keys[a], v1 = keys[a + h], v2 = keys[a + 2 * h], v3 = keys[a + 3 * h];
+                sort2(v0, v2); sort2(v1, v3);
+                sort2(v0, v1); sort2(v2, v3);
+                keys[a] = v0; keys[a + h] = v1; keys[a + 2 * h] = v2; keys[a + 3 * h] = v3;
+            }
+            __syncthreads();
+        }
+        if (j >= 1) {                                     // stages 2 and 1, or 1 alone: four consecutive keys
+            for (int g = tid; g < groups; g += kBlock) {
+                uint64_t *c = keys + 4 * g;
+                uint64_t v0 = c[0], v1 = c[1], v2 = c[2], v3 = c[3];
+                if (j == 2) { sort2(v0, v2); sort2(v1, v3); }
+                sort2(v0, v1); sort2(v2, v3);
+                c[0] = v0; c[1] = v1; c[2] = v2; c[3] = v3;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// a bucket too large for LDS is sorted in place in its own slice of u_out / i_out (one workgroup,
+// device-scope relaxed accesses so nothing is cached in registers across the barriers)
+struct GlobalKeys {
+    int32_t *u, *i;
+    __device__ __forceinline__ uint64_t get(int q) const
+    {
+        const uint32_t uu = (uint32_t)__hip_atomic_load(u + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t ii = (uint32_t)__hip_atomic_load(i + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return ((uint64_t)ii << 32) | uu;
+    }
+    __device__ __forceinline__ void set(int q, uint64_t v) const
+    {
+        __hip_atomic_store(u + q, (int32_t)(uint32_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(i + q, (int32_t)(uint32_t)(v >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+
+// negatives of kNegGroup batch positions per thread, advanced in lockstep (one dependent load
+// level at a time: signature, row bounds, each binary-search probe), same draws as draw_negative()
+constexpr int kNegGroup = 4;
+
+__device__ __forceinline__ void negatives_lockstep(
+    const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices, const uint64_t *__restrict__ user_sig,
+    int64_t I, int64_t B, uint64_t seed, uint64_t step, int neg_block, uint64_t neg_key, const int64_t *wstart,
+    const int32_t *wlo, int m, const bool (&live)[kNegGroup], const int64_t (&p)[kNegGroup],
+    const uint32_t (&u)[kNegGroup], int32_t (&nj)[kNegGroup])
+{
+    int64_t nlo[kNegGroup], nn[kNegGroup], rlo[kNegGroup], rhi[kNegGroup];
+    uint32_t s[kNegGroup];
+    ulonglong2 rec[kNegGroup];
+    bool need[kNegGroup];
+    const bool use_sig = user_sig != nullptr && neg_block > 0;
+#pragma unroll
+    for (int g = 0; g < kNegGroup; ++g) {
+        rec[g] = make_ulonglong2(~0ull, 0ull);
+        if (live[g] && use_sig) rec[g] = reinterpret_cast<const ulonglong2 *>(user_sig)[u[g]];
+    }
+    bool any = false;
+#pragma unroll
+    for (int g = 0; g < kNegGroup; ++g) {
+        nj[g] = -1; need[g] = false; nlo[g] = 0; nn[g] = I; s[g] = 1u; rlo[g] = 0; rhi[g] = 0;
+        if (live[g]) {
+            s[g] = rng_seed(seed, step, (uint64_t)p[g], 0x5bd1e995ull);
+            if (m > 0) {           // the bucket's table of (first position, item block) per negative range
+                int lo = 0, hi = m;
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wstart[mid] <= p[g]) lo = mid; else hi = mid; }
+                nlo[g] = wlo[lo];
+                nn[g] = (nlo[g] + neg_block <= I) ? neg_block : I - nlo[g];
+            } else {
+                neg_range(I, p[g], B, neg_block, neg_key, nlo[g], nn[g]);
+            }
+            // a clear signature bit proves the whole item block negative for this user
+            // (73 % of the draws at 20 positives per user): no row read at all
+            need[g] = !use_sig || ((rec[g].x >> sig_bit(nlo[g] / neg_block)) & 1ull) != 0ull;
+            if (!need[g]) nj[g] = (int32_t)(nlo[g] + (int64_t)(((uint64_t)xorshift32(s[g]) * (uint64_t)nn[g]) >> 32));
+            any |= need[g];
+        }
+    }
+    if (!any) return;
+    // the exact test.  The signature record also carries the row's start and length, so a short
+    // row is fetched whole with independent loads (one latency instead of indptr + a chain of
+    // binary-search probes) and every redraw is then tested in registers.
+    constexpr int kRowRegs = 24;
+    any = false;
+#pragma unroll
+    for (int g = 0; g < kNegGroup; ++g) {
+        if (!need[g]) continue;
+        const uint64_t len = rec[g].y >> 40;
+        if (use_sig && len < kSigLenClip) { rlo[g] = (int64_t)(rec[g].y & kSigStartMask); rhi[g] = rlo[g] + (int64_t)len; }
+        else { rlo[g] = indptr[u[g]]; rhi[g] = indptr[u[g] + 1]; }
+        if (rhi[g] - rlo[g] <= kRowRegs) {
+            const int32_t *row = indices + rlo[g];
+            const int deg = (int)(rhi[g] - rlo[g]);
+            int32_t v[kRowRegs];
+#pragma unroll
+            for (int q = 0; q < kRowRegs; ++q) v[q] = q < deg ? row[q] : -1;
+            for (int tries = 0;; ++tries) {
+                if (tries == 64) { nlo[g] = 0; nn[g] = I; }     // the user owns (nearly) the whole block
+                const int32_t cand = (int32_t)(nlo[g] + (int64_t)(((uint64_t)xorshift32(s[g]) * (uint64_t)nn[g]) >> 32));
+                bool in = false;
+#pragma unroll
+                for (int q = 0; q < kRowRegs; ++q) in |= v[q] == cand;
+                if (!in) { nj[g] = cand; break; }
+            }
+            need[g] = false;
+        }
+        any |= need[g];
+    }
+    for (int tries = 0; any; ++tries) {                          // long rows: binary search, in lockstep
+        int64_t a[kNegGroup], z[kNegGroup];
+        int32_t cand[kNegGroup];
+#pragma unroll
+        for (int g = 0; g < kNegGroup; ++g) {
+            a[g] = 0; z[g] = 0; cand[g] = 0;
+            if (need[g]) {
+                if (tries == 64) { nlo[g] = 0; nn[g] = I; }
+                cand[g] = (int32_t)(nlo[g] + (int64_t)(((uint64_t)xorshift32(s[g]) * (uint64_t)nn[g]) >> 32));
+                a[g] = rlo[g]; z[g] = rhi[g];
+            }
+        }
+        for (;;) {                                               // lower_bound of cand in the sorted row
+            bool more = false;
+            int32_t v[kNegGroup];
+            int64_t mid[kNegGroup];
+#pragma unroll
+            for (int g = 0; g < kNegGroup; ++g) {
+                mid[g] = (a[g] + z[g]) >> 1; v[g] = 0;
+                if (a[g] < z[g]) { v[g] = indices[mid[g]]; more = true; }
+            }
+            if (!more) break;
+#pragma unroll
+            for (int g = 0; g < kNegGroup; ++g)
+                if (a[g] < z[g]) { if (v[g] < cand[g]) a[g] = mid[g] + 1; else z[g] = mid[g]; }
+        }
+        int32_t at[kNegGroup];
+#pragma unroll
+        for (int g = 0; g < kNegGroup; ++g) at[g] = (need[g] && a[g] < rhi[g]) ? indices[a[g]] : -1;
+        any = false;
+#pragma unroll
+        for (int g = 0; g < kNegGroup; ++g)
+            if (need[g]) {
+                if (at[g] != cand[g]) { nj[g] = cand[g]; need[g] = false; }
+                any |= need[g];
+            }
+    }
+}
+
+__global__ __launch_bounds__(kBlock, 5) void bucket_sort_kernel(
+    const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices, const uint64_t *__restrict__ user_sig,
+    int64_t I, int64_t B, int64_t piece_lo, uint64_t seed, uint64_t step, int neg_block, uint64_t neg_key, int nbm,
+    int nblk, int sort_cap, const uint2 *__restrict__ pairs, const uint32_t *__restrict__ table,
+    const uint32_t *__restrict__ totals, int32_t *u_out, int32_t *i_out, int32_t *__restrict__ j_out)
+{
+    __shared__ uint64_t keys[kSortCap];
+    __shared__ uint32_t cstart[kMaxChunks + 1];    // first bucket-local rank of each chunk's slice
+    __shared__ uint16_t csrc[kMaxChunks];          // where that slice starts inside the chunk
+    __shared__ uint32_t red[kBlock / 64];
+    __shared__ uint32_t wsum[kBlock / 64];
+    __shared__ int64_t wstart[kRangeCap];          // first batch position of each negative range met here
+    __shared__ int32_t wlo[kRangeCap];             // and the item block it draws from
+    const int tid = threadIdx.x;
+    const int bk = blockIdx.x;
+    const int n = (int)totals[(size_t)bk * kTotalStride];
+    if (n == 0) return;
+    // first output position of this bucket = pairs in the buckets before it
+    uint32_t before = 0;
+    for (int q = tid; q < bk; q += kBlock) before += totals[(size_t)q * kTotalStride];
+    // this bucket's slice of every chunk: (offset in chunk, count) -> exclusive scan of the counts
+    constexpr int kEnt = kMaxChunks / kBlock;      // 2 table entries per thread
+    uint32_t ent[kEnt], mine = 0;
+#pragma unroll
+    for (int e = 0; e < kEnt; ++e) {
+        const int blk = tid * kEnt + e;
+        ent[e] = blk < nblk ? table[(size_t)blk * (nbm + 1) + bk] : 0u;
+        mine += ent[e] & 0xFFFFu;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off);
+        if ((tid & 63) >= off) incl += v;
+    }
+    if ((tid & 63) == 0) red[tid >> 6] = before;
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t base = incl - mine;
+    for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+#pragma unroll
+    for (int e = 0; e < kEnt; ++e) {
+        const int blk = tid * kEnt + e;
+        cstart[blk] = base; csrc[blk] = (uint16_t)(ent[e] >> 16);
+        base += ent[e] & 0xFFFFu;
+    }
+    if (tid == kBlock - 1) cstart[kMaxChunks] = base;
+    const int64_t p0 = piece_lo + red[0] + red[1] + red[2] + red[3];
+    const bool in_lds = n <= sort_cap;
+    int32_t *ug = u_out + p0, *ig = i_out + p0;
+    // negative ranges (rsx.h: neg_block) the positions [p0, p0 + n) fall in: range w starts at
+    // position ceil(w*c*B/I) and draws from item block pi(w); 64-bit divisions and the block
+    // permutation are paid once per range here instead of once per position
+    int m = 0;
+    if (neg_block > 0) {
+        const int64_t w_first = ((p0 * I) / B) / neg_block, w_last = (((p0 + n - 1) * I) / B) / neg_block;
+        if (w_last - w_first < kRangeCap) {
+            m = (int)(w_last - w_first) + 1;
+            const int64_t nblocks = ceil_div64(I, neg_block);
+            for (int q = tid; q < m; q += kBlock) {
+                wstart[q] = ceil_div64((w_first + q) * neg_block * B, I);
+                wlo[q] = (int32_t)(neg_block_of(w_first + q, nblocks, neg_key) * neg_block);
+            }
+        }
+    }
+    __syncthreads();
+    // gather: rank r of the bucket lives in the chunk whose slice covers r
+    for (int r = tid; r < n; r += kBlock) {
+        int lo = 0, hi = kMaxChunks;                               // last chunk with cstart <= r
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cstart[mid] <= (uint32_t)r) lo = mid; else hi = mid; }
+        const uint2 pr = pairs[(size_t)lo * kChunk + csrc[lo] + ((uint32_t)r - cstart[lo])];
+        const uint64_t kv = ((uint64_t)pr.y << 32) | pr.x;
+        if (in_lds) keys[r] = kv; else GlobalKeys{ug, ig}.set(r, kv);
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (in_lds) {
+        bitonic_sort_lds(keys, n, tid);
+    } else if (bk != nbm) {        // (the "no positive" bucket holds one key; its order is irrelevant)
+        bitonic_sort(GlobalKeys{ug, ig}, n, tid);
+    }
+    for (int r0 = 0; r0 < n; r0 += kBlock * kNegGroup) {
+        bool live[kNegGroup];
+        int64_t p[kNegGroup];
+        uint32_t u[kNegGroup], item[kNegGroup];
+        int32_t nj[kNegGroup];
+#pragma unroll
+        for (int g = 0; g < kNegGroup; ++g) {
+            const int r = r0 + g * kBlock + tid;
+            uint64_t kv = ~0ull;
+            if (r < n) kv = in_lds ? keys[r] : GlobalKeys{ug, ig}.get(r);
+            u[g] = (uint32_t)kv; item[g] = (uint32_t)(kv >> 32);
+            p[g] = p0 + r;
+            live[g] = r < n && (int64_t)item[g] < I;
+        }
+        negatives_lockstep(indptr, indices, user_sig, I, B, seed, step, neg_block, neg_key, wstart, wlo, m, live, p, u, nj);
+#pragma unroll
+        for (int g = 0; g < kNegGroup; ++g) {
+            const int r = r0 + g * kBlock + tid;
+            if (r < n) { u_out[p[g]] = (int32_t)u[g]; i_out[p[g]] = live[g] ? (int32_t)item[g] : -1; j_out[p[g]] = nj[g]; }
+        }
+    }
+}
+
+// ---- item CDF of the positive-sampling distribution (static per CSR) -------------------------
+// mass[i] = sum over users holding i of floor(2^32 / deg(u)) (64-bit integer atomics: exact and
+// order-independent), cdf[i] = floor(2^32 * prefix(mass)[i] / total), cdf[I] = 2^32 - 1
+__global__ __launch_bounds__(kBlock) void item_mass_kernel(const int64_t *__restrict__ indptr,
+                                                           const int32_t *__restrict__ indices, int64_t U, int64_t I,
+                                                           unsigned long long *__restrict__ mass)
+{
+    for (int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x; u < U; u += (int64_t)gridDim.x * kBlock) {
+        const int64_t lo = indptr[u], hi = indptr[u + 1];
+        if (hi <= lo || hi - lo >= I) continue;                // never sampled (see bucket_chunk_kernel)
+        const unsigned long long w = 0x100000000ull / (unsigned long long)(hi - lo);
+        for (int64_t q = lo; q < hi; ++q) atomicAdd(&mass[indices[q]], w);
+    }
+}
+
+constexpr int kScanBlock = 1024;
+__global__ __launch_bounds__(kScanBlock) void item_cdf_kernel(const unsigned long long *__restrict__ mass, int64_t I,
+                                                              uint32_t *__restrict__ cdf)
+{
+    __shared__ unsigned long long part[kScanBlock];
+    const int tid = threadIdx.x;
+    const int64_t per = (I + kScanBlock - 1) / kScanBlock;
+    const int64_t q0 = tid * per, q1 = (q0 + per < I) ? q0 + per : I;
+    unsigned long long mine = 0;
+    for (int64_t q = q0; q < q1; ++q) mine += mass[q];
+    part[tid] = mine;
+    __syncthreads();
+    for (int off = 1; off < kScanBlock; off <<= 1) {          // Hillis-Steele inclusive scan
+        const unsigned long long v = (tid >= off) ? part[tid - off] : 0ull;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const double total = (double)part[kScanBlock - 1];
+    unsigned long long run = part[tid] - mine;
+    for (int64_t q = q0; q < q1; ++q) {
+        double f = total > 0.0 ? floor((double)run * 4294967296.0 / total) : 0.0;
+        cdf[q] = f >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)f;
+        run += mass[q];
+    }
+    if (tid == 0) cdf[I] = 0xFFFFFFFFu;
 }
 
 unsigned grid_1d(int64_t n)
@@ -254,20 +750,76 @@ RSX_API int rsx_bpr_build_signature(const int64_t *indptr_dev, const int32_t *in
     return RSX_OK;
 }
 
+// bucketed path: one piece of at most kPiece positions at a time
+struct BucketWs { uint2 *pairs; uint32_t *table; uint32_t *totals; };
+int buckets_for(int64_t n) { return (int)((n + kBucketMean - 1) / kBucketMean); }   // without the "no positive" bucket
+int64_t bucket_ws_bytes(int64_t batch)
+{
+    const int64_t n = batch < kPiece ? batch : kPiece;
+    const int64_t NB = buckets_for(n) + 1, nblk = (n + kChunk - 1) / kChunk;
+    return align256(n * 8) + align256(NB * nblk * 4) + align256(NB * 4 * kTotalStride);
+}
+BucketWs bucket_carve(void *ws, int64_t n)
+{
+    const int64_t NB = buckets_for(n) + 1, nblk = (n + kChunk - 1) / kChunk;
+    BucketWs w;
+    char *p = (char *)ws;
+    w.pairs = (uint2 *)p;      p += align256(n * 8);
+    w.table = (uint32_t *)p;   p += align256(NB * nblk * 4);
+    w.totals = (uint32_t *)p;
+    return w;
+}
+
 RSX_API int64_t rsx_bpr_sample_workspace(int64_t batch, int64_t num_items)
 {
     if (batch < 0 || num_items <= 0 || num_items >= (1ll << 31)) return RSX_E_INVALID;
     if (batch == 0) return 0;
+    int64_t sort_bytes;
     if (use_key16(num_items))
-        return 2 * align256(batch * 2) + 2 * align256(batch * 4) + align256((int64_t)sort16_temp_bytes(batch));
-    return 4 * align256(batch * 4) + align256((int64_t)sort_temp_bytes(batch, key_bits(num_items)));
+        sort_bytes = 2 * align256(batch * 2) + 2 * align256(batch * 4) + align256((int64_t)sort16_temp_bytes(batch));
+    else
+        sort_bytes = 4 * align256(batch * 4) + align256((int64_t)sort_temp_bytes(batch, key_bits(num_items)));
+    const int64_t bucket_bytes = bucket_ws_bytes(batch);
+    return sort_bytes > bucket_bytes ? sort_bytes : bucket_bytes;
+}
+
+RSX_API int64_t rsx_bpr_item_cdf_workspace(int64_t num_items)
+{
+    return num_items > 0 ? align256(num_items * 8) : RSX_E_INVALID;
+}
+
+RSX_API int rsx_bpr_build_item_cdf(const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users,
+                                   int64_t num_items, uint32_t *cdf_out, void *ws, int64_t ws_bytes,
+                                   rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(indptr_dev && indices_dev && cdf_out && ws, "null pointer");
+    RSX_CHECK_ARG(num_users > 0 && num_items > 0 && num_items < (1ll << 31), "bad shape");
+    RSX_CHECK_ARG(ws_bytes >= rsx_bpr_item_cdf_workspace(num_items), "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *mass = (unsigned long long *)ws;
+    if (hipMemsetAsync(mass, 0, (size_t)num_items * 8, st) != hipSuccess) {
+        rsx_set_error("rsx_bpr_build_item_cdf: memset failed");
+        return RSX_E_HIP;
+    }
+    hipLaunchKernelGGL(item_mass_kernel, dim3(grid_1d(num_users)), dim3(kBlock), 0, st, indptr_dev, indices_dev,
+                       num_users, num_items, mass);
+    hipLaunchKernelGGL(item_cdf_kernel, dim3(1), dim3(kScanBlock), 0, st, mass, num_items, cdf_out);
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+}
+
+RSX_API int rsx_debug_set_sample_sort_cap(int cap)
+{
+    g_sort_cap = (cap >= 1 && cap <= kSortCap) ? cap : kSortCap;
+    return RSX_OK;
 }
 
 RSX_API int rsx_bpr_sample(const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users,
                            int64_t num_items, int64_t batch, uint64_t seed, uint64_t step,
                            int64_t epoch_pos, int neg_block, uint64_t neg_key, unsigned flags,
-                           void *ws, int64_t ws_bytes, const uint64_t *user_sig_dev, int32_t *u_out,
-                           int32_t *i_out, int32_t *j_out, rsx_stream_t stream)
+                           void *ws, int64_t ws_bytes, const uint64_t *user_sig_dev,
+                           const uint32_t *item_cdf_dev, int32_t *u_out, int32_t *i_out, int32_t *j_out,
+                           rsx_stream_t stream)
 {
     RSX_CHECK_ARG(indptr_dev && indices_dev && u_out && i_out && j_out, "null pointer");
     RSX_CHECK_ARG(num_users > 0 && num_users < (1ll << 31) && num_items > 0 && num_items < (1ll << 31),
@@ -289,6 +841,27 @@ RSX_API int rsx_bpr_sample(const int64_t *indptr_dev, const int32_t *indices_dev
         rsx_set_error("rsx_bpr_sample: RSX_SAMPLE_SORT_POS needs a workspace of %lld bytes, got %lld",
                       (long long)need, (long long)ws_bytes);
         return RSX_E_WORKSPACE;
+    }
+    if (item_cdf_dev != nullptr) {
+        for (int64_t piece_lo = 0; piece_lo < batch; piece_lo += kPiece) {
+            const int64_t n = (batch - piece_lo < kPiece) ? batch - piece_lo : kPiece;
+            const int nbm = buckets_for(n), NB = nbm + 1;
+            const int nblk = (int)((n + kChunk - 1) / kChunk);
+            const BucketWs w = bucket_carve(ws, n);
+            if (hipMemsetAsync(w.totals, 0, (size_t)NB * 4 * kTotalStride, st) != hipSuccess) {
+                rsx_set_error("rsx_bpr_sample: memset failed");
+                return RSX_E_HIP;
+            }
+            const size_t lds = ((size_t)((NB + 3) & ~3)) * 4 + (size_t)kChunk * sizeof(uint2);
+            hipLaunchKernelGGL(bucket_chunk_kernel, dim3(nblk), dim3(kChunkThreads), lds, st, indptr_dev, indices_dev,
+                               item_cdf_dev, num_users, num_items, piece_lo, n, seed, step, epoch_pos, hb, nbm, nblk,
+                               w.pairs, w.table, w.totals);
+            hipLaunchKernelGGL(bucket_sort_kernel, dim3(NB), dim3(kBlock), 0, st, indptr_dev, indices_dev,
+                               user_sig_dev, num_items, batch, piece_lo, seed, step, neg_block, neg_key, nbm, nblk,
+                               g_sort_cap, w.pairs, w.table, w.totals, u_out, i_out, j_out);
+        }
+        RSX_CHECK_LAUNCH();
+        return RSX_OK;
     }
     if (use_key16(num_items)) {
         const int shift = num_items < (1ll << 16) ? 0 : 1;

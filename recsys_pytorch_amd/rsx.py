@@ -39,8 +39,10 @@ SIGNATURES = {
     "rsx_eval_holdout": (C.c_int, [_I64, _P, _I32, _P, _I32, _P, _P, _P]),
     "rsx_bpr_sample_workspace": (_I64, [_I64, _I64]),
     "rsx_bpr_sample": (C.c_int, [_P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _I32, _U64, _U, _P, _I64,
-                                 _P, _P, _P, _P, _P]),
+                                 _P, _P, _P, _P, _P, _P]),
     "rsx_bpr_build_signature": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "rsx_bpr_item_cdf_workspace": (_I64, [_I64]),
+    "rsx_bpr_build_item_cdf": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _I64, _P]),
     "rsx_score": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P, _P, _P, _P]),
     "rsx_topk": (C.c_int, [_P, _I64, _I64, _I32, _P, _P, _P]),
     "rsx_score_topk_workspace": (_I64, [_I64, _I64]),
@@ -236,11 +238,21 @@ def eval_holdout(rankings, ks, truth_indptr, truth_indices):
 
 def build_signature(indptr, indices, neg_block):
     """per-user block signature for the sampler's rejection test (include/rsx.h)"""
-    sig = torch.empty(indptr.numel() - 1, dtype=torch.int64, device=indptr.device)
+    sig = torch.empty((indptr.numel() - 1, 2), dtype=torch.int64, device=indptr.device)   # (bits, row start | length << 40)
     _check(lib().rsx_bpr_build_signature(_dev(indptr, torch.int64, "indptr"), _dev(indices, torch.int32, "indices"),
                                          indptr.numel() - 1, int(neg_block), _dev(sig, torch.int64, "sig"),
                                          _stream()), "rsx_bpr_build_signature")
     return sig
+
+
+def build_item_cdf(indptr, indices, num_items):
+    """CDF of the positive-item distribution, lets the sampler order a batch without a device sort"""
+    cdf = torch.empty(num_items + 1, dtype=torch.int32, device=indptr.device)
+    ws = torch.empty(lib().rsx_bpr_item_cdf_workspace(num_items), dtype=torch.uint8, device=indptr.device)
+    _check(lib().rsx_bpr_build_item_cdf(_dev(indptr, torch.int64, "indptr"), _dev(indices, torch.int32, "indices"),
+                                        indptr.numel() - 1, num_items, _dev(cdf, torch.int32, "cdf"),
+                                        C.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "rsx_bpr_build_item_cdf")
+    return cdf
 
 
 def bpr_sample_workspace(batch, num_items):
@@ -251,7 +263,7 @@ def bpr_sample_workspace(batch, num_items):
 
 
 def bpr_sample(indptr, indices, num_items, batch, seed, step, epoch_pos, u_out, i_out, j_out, neg_block=0,
-               neg_key=0, sort_pos=False, ws=None, user_sig=None):
+               neg_key=0, sort_pos=False, ws=None, user_sig=None, item_cdf=None):
     _check(lib().rsx_bpr_sample(
         _dev(indptr, torch.int64, "indptr"), _dev(indices, torch.int32, "indices"),
         indptr.numel() - 1, num_items, batch, seed & (2**64 - 1), step, epoch_pos, int(neg_block),
@@ -259,6 +271,7 @@ def bpr_sample(indptr, indices, num_items, batch, seed, step, epoch_pos, u_out, 
         C.c_void_p(ws.data_ptr()) if ws is not None else None,
         ws.numel() * ws.element_size() if ws is not None else 0,
         _dev(user_sig, torch.int64, "user_sig") if user_sig is not None else None,
+        _dev(item_cdf, torch.int32, "item_cdf") if item_cdf is not None else None,
         _dev(u_out, torch.int32, "u_out"), _dev(i_out, torch.int32, "i_out"),
         _dev(j_out, torch.int32, "j_out"), _stream()), "rsx_bpr_sample")
 

@@ -60,6 +60,7 @@ class BPREngine:
             raise ValueError(optimizer)
         self.hot = None
         self.neg_block = 0          # > 0: negatives stratified by item block, batch sorted by positive item
+        self.use_item_cdf = True    # order the batch through the item-CDF buckets (False: device radix sort)
         self._sample_ws = None
         self._bufs = None           # double-buffered triplets for the overlapped sampler
         self._side = None
@@ -159,9 +160,14 @@ class BPREngine:
             if getattr(self, "_sig_for", None) != (indptr.data_ptr(), self.neg_block) and hasattr(self.k, "build_signature"):
                 self._sig = self.k.build_signature(indptr, indices, self.neg_block)   # static per CSR
                 self._sig_for = (indptr.data_ptr(), self.neg_block)
+            if getattr(self, "_cdf_for", None) != indptr.data_ptr() and hasattr(self.k, "build_item_cdf"):
+                self._cdf = self.k.build_item_cdf(indptr, indices, self.Q.shape[0])   # static per CSR
+                self._cdf_for = indptr.data_ptr()
             kw = {"neg_block": self.neg_block, "neg_key": key, "sort_pos": True, "ws": self._sample_ws}
             if getattr(self, "_sig", None) is not None:
                 kw["user_sig"] = self._sig
+            if getattr(self, "_cdf", None) is not None and self.use_item_cdf:
+                kw["item_cdf"] = self._cdf
         self.k.bpr_sample(indptr, indices, self.Q.shape[0], batch, self.seed + 7919 * self.user_begin,
                           step, self.epoch_pos, u, i, j, **kw)
         self.epoch_pos += batch

@@ -43,7 +43,7 @@ def apply_item_grad(Q, G, lr, hot=None):
 
 
 def bpr_sample(indptr, indices, num_items, batch, seed, step, epoch_pos, u_out, i_out, j_out, neg_block=0,
-               neg_key=0, sort_pos=False, ws=None, user_sig=None):
+               neg_key=0, sort_pos=False, ws=None, user_sig=None, item_cdf=None):
     """simple host sampler with the same guarantees (unique users, true pos, true neg)"""
     U = indptr.numel() - 1
     rng = np.random.default_rng(seed + 1000003 * step)

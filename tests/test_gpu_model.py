@@ -195,9 +195,10 @@ def test_hot_item_replicas_do_not_change_the_sums(oracle_mod, replicas):
     assert rel_err(P.cpu().numpy(), orc.P) < 1e-5 and rel_err(Q.cpu().numpy(), orc.Q) < 1e-5
 
 
+@pytest.mark.parametrize("cdf", [True, False])
 @pytest.mark.parametrize("d,B,I,c", [(128, 40_000, 5_000, 8), (64, 30_001, 2_999, 16), (32, 9_000, 4_000, 3),
                                      (128, 50_000, 70_001, 8), (32, 20_000, 140_000, 8)])
-def test_sorted_blocked_sampled_path_replays_through_oracle(oracle_mod, d, B, I, c):
+def test_sorted_blocked_sampled_path_replays_through_oracle(oracle_mod, d, B, I, c, cdf):
     """batch sorted by positive item + negatives stratified by item block + on-chip summation:
     dump the sampled triplets, replay them on the CPU oracle, and check the sampler's guarantees"""
     from recsys_pytorch_amd.data import synthetic_csr
@@ -210,6 +211,7 @@ def test_sorted_blocked_sampled_path_replays_through_oracle(oracle_mod, d, B, I,
     orc = oracle_mod.MFOracle(P.cpu().numpy(), Q.cpu().numpy(), "sgd", 0.05)
     eng = BPREngine(P, Q, 0.05)
     eng.neg_block = c
+    eng.use_item_cdf = cdf          # item-CDF buckets, or the device radix sort
     hist = np.zeros(I)
     ipn, ixn = ip.cpu().numpy(), ix.cpu().numpy()
     keys = set()
@@ -218,7 +220,7 @@ def test_sorted_blocked_sampled_path_replays_through_oracle(oracle_mod, d, B, I,
         keys.add(eng.last_neg_key)
         un, inn, jn = u.cpu().numpy(), i.cpu().numpy(), j.cpu().numpy()
         assert len(np.unique(un)) == B                                   # users unique in the batch
-        shift = 0 if I < 65536 else (1 if I < 131072 else 0)            # 16-bit sort keys drop the item's low bit
+        shift = 0 if (cdf or I < 65536) else (1 if I < 131072 else 0)   # 16-bit sort keys drop the item's low bit
         assert np.all(np.diff(inn >> shift) >= 0)                        # sorted by positive item (>> shift)
         nominal = (np.arange(B, dtype=np.int64) * I // B) // c           # batch-position block
         bad = 0
@@ -239,6 +241,98 @@ def test_sorted_blocked_sampled_path_replays_through_oracle(oracle_mod, d, B, I,
     exp = 3 * B / I
     assert abs(hist.mean() - exp) < 1e-9 and hist.std() < 1.5 * np.sqrt(exp) + 1   # ~Poisson spread
     assert hist.min() > 0 or exp < 8
+
+
+def _sample_sorted(ip, ix, I, B, step, cdf, sig=None, c=8, key=77, epoch_pos=0):
+    from recsys_pytorch_amd import rsx
+    u, i, j = (torch.full((B,), -7, dtype=torch.int32, device="cuda") for _ in range(3))
+    ws = torch.empty(rsx.bpr_sample_workspace(B, I), dtype=torch.uint8, device="cuda")
+    rsx.bpr_sample(ip, ix, I, B, 11, step, epoch_pos, u, i, j, neg_block=c, neg_key=key, sort_pos=True, ws=ws,
+                   user_sig=sig, item_cdf=cdf)
+    torch.cuda.synchronize()
+    return u.cpu().numpy(), i.cpu().numpy(), j.cpu().numpy()
+
+
+@pytest.mark.parametrize("U,I,deg,B,pop", [(30_000, 5_000, 12, 30_000, "zipf"), (30_000, 5_000, 12, 7_001, "zipf"),
+                                           (20_000, 200_000, 6, 20_000, "uniform"), (5_000, 300, 40, 5_000, "zipf"),
+                                           (1_000, 50, 3, 37, "zipf")])
+def test_item_cdf_buckets_order_the_same_pairs_as_the_device_sort(U, I, deg, B, pop):
+    """same (seed, step) -> the bucketed layout holds exactly the (user, positive) pairs of the
+    radix-sorted layout, ordered by item; twice the same call gives the same bits"""
+    from recsys_pytorch_amd import rsx
+    from recsys_pytorch_amd.data import synthetic_csr
+    ip, ix = synthetic_csr(U, I, deg, "cuda", seed=3, popularity=pop)
+    cdf = rsx.build_item_cdf(ip, ix, I)
+    cn = cdf.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    assert cn[0] == 0 and cn[-1] == 0xFFFFFFFF and np.all(np.diff(cn) >= 0)
+    # CDF against numpy: item mass = sum over its users of 1/deg(u)
+    ipn, ixn = ip.cpu().numpy(), ix.cpu().numpy()
+    mass = np.bincount(ixn, weights=np.repeat(1.0 / np.diff(ipn), np.diff(ipn)), minlength=I)
+    want = np.concatenate([[0.0], np.cumsum(mass)]) / mass.sum()
+    assert np.abs(cn / 2.0**32 - want).max() < 1e-6
+    sig = rsx.build_signature(ip, ix, 8)
+    for step in (1, 2):
+        ua, ia, ja = _sample_sorted(ip, ix, I, B, step, cdf, sig)
+        ub, ib, jb = _sample_sorted(ip, ix, I, B, step, None, sig)
+        key_a = ia.astype(np.int64) << 32 | ua
+        # ordered by item; by user inside an item's bucket (a popular item owns several buckets)
+        assert np.all(np.diff(ia) >= 0) and len(np.unique(key_a)) == B
+        assert np.array_equal(np.sort(key_a), np.sort(ib.astype(np.int64) << 32 | ub))
+        for u_, i_, j_ in list(zip(ua, ia, ja))[:: max(1, B // 400)]:
+            row = ixn[ipn[u_]:ipn[u_ + 1]]
+            assert i_ in row and j_ not in row and 0 <= j_ < I
+        u2, i2, j2 = _sample_sorted(ip, ix, I, B, step, cdf, sig)
+        assert np.array_equal(ua, u2) and np.array_equal(ia, i2) and np.array_equal(ja, j2)
+        u3, i3, j3 = _sample_sorted(ip, ix, I, B, step, cdf, None)       # signatures only skip row reads
+        assert np.array_equal(ja, j3)
+
+
+def test_item_cdf_buckets_outside_lds_and_rows_without_a_positive():
+    """buckets larger than the LDS sort capacity take the in-place path; users with an empty row
+    (or owning the whole catalog) come last with i = j = -1"""
+    import scipy.sparse as sp
+    from recsys_pytorch_amd import rsx
+    from recsys_pytorch_amd.data import csr_to_device
+    rng = np.random.default_rng(5)
+    U, I = 12_000, 40
+    dense = rng.random((U, I)) < 0.2
+    dense[::7] = False                   # empty rows
+    dense[3::1001] = True                # rows owning every item: no negative exists
+    ip, ix = csr_to_device(sp.csr_matrix(dense.astype(np.float32)), "cuda")
+    cdf = rsx.build_item_cdf(ip, ix, I)
+    n_dead = int((dense.sum(1) == 0).sum() + (dense.sum(1) == I).sum())
+    try:
+        for cap in (2048, 64):
+            rsx.lib().rsx_debug_set_sample_sort_cap(cap)
+            u, i, j = _sample_sorted(ip, ix, I, U, 4, cdf, None, c=4)
+            live = i >= 0
+            assert (~live).sum() == n_dead and np.all(live[:U - n_dead]) and np.all(j[~live] == -1)
+            assert len(np.unique(u)) == U
+            assert np.all(np.diff(i[live]) >= 0)
+            assert dense[u[live], i[live]].all() and not dense[u[live], j[live]].any()
+            if cap == 2048:
+                first = (u.copy(), i.copy(), j.copy())
+            else:                                                        # same order from both paths
+                assert np.array_equal(first[1], i) and np.array_equal(first[0][live], u[live]) and np.array_equal(first[2], j)
+    finally:
+        rsx.lib().rsx_debug_set_sample_sort_cap(0)
+
+
+def test_item_cdf_buckets_piecewise_above_two_million_positions():
+    from recsys_pytorch_amd import rsx
+    from recsys_pytorch_amd.data import synthetic_csr
+    U, I, B = 2_300_000, 20_000, 2_300_000
+    ip, ix = synthetic_csr(U, I, 4, "cuda", seed=6)
+    cdf = rsx.build_item_cdf(ip, ix, I)
+    u, i, j = _sample_sorted(ip, ix, I, B, 1, cdf, None)
+    assert len(np.unique(u)) == B and i.min() >= 0 and j.min() >= 0
+    piece = 1 << 21
+    for lo in (0, piece):
+        assert np.all(np.diff(i[lo:lo + piece]) >= 0)                    # each piece ordered on its own
+    ipn, ixn = ip.cpu().numpy(), ix.cpu().numpy()
+    for q in range(0, B, 9973):
+        row = ixn[ipn[u[q]]:ipn[u[q] + 1]]
+        assert i[q] in row and j[q] not in row
 
 
 def test_overlapped_sampler_equals_inline_sampler():
