@@ -489,26 +489,45 @@ __global__ __launch_bounds__(kBlock) void apply_item_grad_kernel(float4 *__restr
                                                                  float4 *__restrict__ G, int64_t n4,
                                                                  float lr, HotMap hot, int d4)
 {
-    for (int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x; n < n4; n += (int64_t)gridDim.x * kBlock) {
-        float4 g = G[n];
+    // four quads per thread per trip, G and Q loads of all four issued before anything is used
+    // (the sweep is latency-bound otherwise: 3.6 TB/s with one dependent G -> Q pair in flight)
+    constexpr int kQuads = 4;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t n0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; n0 < n4; n0 += stride * kQuads) {
+        float4 g[kQuads], q[kQuads];
+#pragma unroll
+        for (int c = 0; c < kQuads; ++c) {
+            const int64_t n = n0 + c * stride;
+            g[c] = make_float4(0.f, 0.f, 0.f, 0.f); q[c] = g[c];
+            if (n < n4) { g[c] = G[n]; q[c] = Q[n]; }
+        }
         if (hot.slot != nullptr) {
-            const int64_t row = n / d4;
-            const int32_t hs = hot.slot[row];
-            if (hs >= 0) {
-                float4 *src = reinterpret_cast<float4 *>(hot.ghot) + ((size_t)hs * hot.replicas) * d4 + (n - row * d4);
-                for (int r = 0; r < hot.replicas; ++r) {
-                    const float4 v = src[(size_t)r * d4];
-                    g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
-                    src[(size_t)r * d4] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int c = 0; c < kQuads; ++c) {
+                const int64_t n = n0 + c * stride;
+                if (n >= n4) continue;
+                const int64_t row = n / d4;
+                const int32_t hs = hot.slot[row];
+                if (hs >= 0) {
+                    float4 *src = reinterpret_cast<float4 *>(hot.ghot) + ((size_t)hs * hot.replicas) * d4 + (n - row * d4);
+                    for (int r = 0; r < hot.replicas; ++r) {
+                        const float4 v = src[(size_t)r * d4];
+                        g[c].x += v.x; g[c].y += v.y; g[c].z += v.z; g[c].w += v.w;
+                        src[(size_t)r * d4] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
                 }
             }
         }
-        if (g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f) {
-            float4 q = Q[n];
-            q.x = fmaf(-lr, g.x, q.x); q.y = fmaf(-lr, g.y, q.y);
-            q.z = fmaf(-lr, g.z, q.z); q.w = fmaf(-lr, g.w, q.w);
-            Q[n] = q;
-            G[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < kQuads; ++c) {
+            const int64_t n = n0 + c * stride;
+            if (n < n4 && (g[c].x != 0.f || g[c].y != 0.f || g[c].z != 0.f || g[c].w != 0.f)) {
+                float4 w = q[c];
+                w.x = fmaf(-lr, g[c].x, w.x); w.y = fmaf(-lr, g[c].y, w.y);
+                w.z = fmaf(-lr, g[c].z, w.z); w.w = fmaf(-lr, g[c].w, w.w);
+                Q[n] = w;
+                G[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     }
 }

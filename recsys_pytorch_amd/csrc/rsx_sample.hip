@@ -8,12 +8,13 @@
 //   neg j  uniform over candidate items, rejected while j is in that row
 // The batch is a SET (the step is batch-synchronous), so its order is free.  Two layouts:
 //   plain   one kernel, triplet b sits at batch position b
-//   sorted  (RSX_SAMPLE_SORT_POS) the (i, u) pairs are radix-sorted by positive item,
-//           then negatives are drawn per sorted position from a keyed item block.
+//   sorted  (RSX_SAMPLE_SORT_POS) the (i, u) pairs are ordered by positive item, then
+//           negatives are drawn per ordered position from a keyed item block.
 //           Equal positives become contiguous, so the step kernel sums their gradient
 //           in registers, and all negatives of an item block belong to one wavefront.
-// The sort is rocPRIM's device radix sort (a plain library primitive, like a library
-// GEMM); everything arithmetic stays in this repository's kernels.
+//           With the item CDF (rsx_bpr_build_item_cdf) the order comes from this file's
+//           bucket kernels; without it from rocPRIM's device radix sort (a plain library
+//           primitive, like a library GEMM).
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -121,59 +122,6 @@ __global__ __launch_bounds__(kBlock) void sample_ui_kernel(
     }
 }
 
-// 16-bit-key variant (catalogs below 2^17 items): rocPRIM sorts 2-byte keys with Onesweep,
-// measured ~2.5x faster than the 4-byte merge-sort path.  key = item >> shift (shift <= 1), the
-// value carries (user, item); the step kernel keeps one run accumulator per item parity.
-__global__ __launch_bounds__(kBlock) void sample_ui16_kernel(
-    const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t U, int64_t I,
-    int64_t B, uint64_t seed, uint64_t step, int64_t epoch_pos, int hb, int shift,
-    uint16_t *__restrict__ keys, uint32_t *__restrict__ vals)
-{
-    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < B; b += (int64_t)gridDim.x * kBlock) {
-        const uint32_t u = user_at(epoch_pos + b, U, hb, seed);
-        uint32_t s = rng_seed(seed, step, (uint64_t)b, 0);
-        const int64_t lo = indptr[u], hi = indptr[u + 1];
-        const uint32_t deg = (uint32_t)(hi - lo);
-        uint32_t item = (uint32_t)I;                       // "no positive": sorts last
-        if (deg > 0 && (int64_t)deg < I) item = (uint32_t)indices[lo + (int64_t)(((uint64_t)xorshift32(s) * deg) >> 32)];
-        keys[b] = (uint16_t)(item >> shift);
-        vals[b] = (u << shift) | (item & ((1u << shift) - 1u));
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void sample_neg16_kernel(
-    const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t I, int64_t B,
-    uint64_t seed, uint64_t step, int neg_block, uint64_t neg_key, int shift,
-    const uint16_t *__restrict__ keys_sorted, const uint32_t *__restrict__ vals_sorted,
-    const uint64_t *__restrict__ user_sig,
-    int32_t *__restrict__ u_out, int32_t *__restrict__ i_out, int32_t *__restrict__ j_out)
-{
-    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < B; p += (int64_t)gridDim.x * kBlock) {
-        const uint32_t v = vals_sorted[p];
-        const uint32_t u = v >> shift;
-        const uint32_t item = ((uint32_t)keys_sorted[p] << shift) | (v & ((1u << shift) - 1u));
-        int32_t pi = -1, nj = -1;
-        if ((int64_t)item < I) {
-            uint32_t s = rng_seed(seed, step, (uint64_t)p, 0x5bd1e995ull);
-            pi = (int32_t)item;
-            bool done = false;
-            if (user_sig != nullptr && neg_block > 0) {
-                // one 8-byte read instead of indptr + the row: the user's signature has a bit for
-                // every item block holding one of its positives; a clear bit proves the whole block
-                // negative for this user (73 % of the draws at 20 positives per user)
-                int64_t neg_lo, neg_n;
-                neg_range(I, p, B, neg_block, neg_key, neg_lo, neg_n);
-                if (((user_sig[2 * (size_t)u] >> sig_bit(neg_lo / neg_block)) & 1ull) == 0ull) {
-                    nj = (int32_t)(neg_lo + (int64_t)(((uint64_t)xorshift32(s) * (uint64_t)neg_n) >> 32));
-                    done = true;
-                }
-            }
-            if (!done) nj = draw_negative(indices, indptr[u], indptr[u + 1], I, p, B, neg_block, neg_key, s);
-        }
-        u_out[p] = (int32_t)u; i_out[p] = pi; j_out[p] = nj;
-    }
-}
-
 // user_sig[2u] = OR over the user's positives of (1 << sig_bit(item / neg_block)); user_sig[2u+1] =
 // row start | row length << 40 (length clipped to 2^24-1: "look it up in indptr"); static per CSR
 __global__ __launch_bounds__(kBlock) void build_signature_kernel(const int64_t *__restrict__ indptr,
@@ -195,6 +143,7 @@ __global__ __launch_bounds__(kBlock) void sample_neg_kernel(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t I, int64_t B,
     uint64_t seed, uint64_t step, int neg_block, uint64_t neg_key,
     const uint32_t *__restrict__ keys_sorted, const uint32_t *__restrict__ vals_sorted,
+    const uint64_t *__restrict__ user_sig,
     int32_t *__restrict__ u_out, int32_t *__restrict__ i_out, int32_t *__restrict__ j_out)
 {
     for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < B; p += (int64_t)gridDim.x * kBlock) {
@@ -204,7 +153,16 @@ __global__ __launch_bounds__(kBlock) void sample_neg_kernel(
         if ((int64_t)key < I) {
             uint32_t s = rng_seed(seed, step, (uint64_t)p, 0x5bd1e995ull);
             pi = (int32_t)key;
-            nj = draw_negative(indices, indptr[u], indptr[u + 1], I, p, B, neg_block, neg_key, s);
+            bool done = false;
+            if (user_sig != nullptr && neg_block > 0) {      // clear signature bit: the whole block is negative
+                int64_t neg_lo, neg_n;
+                neg_range(I, p, B, neg_block, neg_key, neg_lo, neg_n);
+                if (((user_sig[2 * (size_t)u] >> sig_bit(neg_lo / neg_block)) & 1ull) == 0ull) {
+                    nj = (int32_t)(neg_lo + (int64_t)(((uint64_t)xorshift32(s) * (uint64_t)neg_n) >> 32));
+                    done = true;
+                }
+            }
+            if (!done) nj = draw_negative(indices, indptr[u], indptr[u + 1], I, p, B, neg_block, neg_key, s);
         }
         u_out[p] = (int32_t)u; i_out[p] = pi; j_out[p] = nj;
     }
@@ -726,17 +684,6 @@ size_t sort_temp_bytes(int64_t batch, int bits)
 
 int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
 
-bool use_key16(int64_t num_items) { return num_items < (1ll << 17) - 1; }   // key 0xFFFF>>... reserved for "no positive"
-
-size_t sort16_temp_bytes(int64_t batch)
-{
-    size_t n = 0;
-    uint16_t *k = nullptr;
-    uint32_t *v = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, n, k, k, v, v, (size_t)batch, 0, 16u, (hipStream_t)0);
-    return n;
-}
-
 }  // namespace
 
 RSX_API int rsx_bpr_build_signature(const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users,
@@ -774,11 +721,7 @@ RSX_API int64_t rsx_bpr_sample_workspace(int64_t batch, int64_t num_items)
 {
     if (batch < 0 || num_items <= 0 || num_items >= (1ll << 31)) return RSX_E_INVALID;
     if (batch == 0) return 0;
-    int64_t sort_bytes;
-    if (use_key16(num_items))
-        sort_bytes = 2 * align256(batch * 2) + 2 * align256(batch * 4) + align256((int64_t)sort16_temp_bytes(batch));
-    else
-        sort_bytes = 4 * align256(batch * 4) + align256((int64_t)sort_temp_bytes(batch, key_bits(num_items)));
+    const int64_t sort_bytes = 4 * align256(batch * 4) + align256((int64_t)sort_temp_bytes(batch, key_bits(num_items)));
     const int64_t bucket_bytes = bucket_ws_bytes(batch);
     return sort_bytes > bucket_bytes ? sort_bytes : bucket_bytes;
 }
@@ -863,26 +806,6 @@ RSX_API int rsx_bpr_sample(const int64_t *indptr_dev, const int32_t *indices_dev
         RSX_CHECK_LAUNCH();
         return RSX_OK;
     }
-    if (use_key16(num_items)) {
-        const int shift = num_items < (1ll << 16) ? 0 : 1;
-        const int64_t ka = align256(batch * 2), va = align256(batch * 4);
-        uint16_t *k_in = (uint16_t *)ws, *k_out = (uint16_t *)((char *)ws + ka);
-        uint32_t *v_in = (uint32_t *)((char *)ws + 2 * ka), *v_out = (uint32_t *)((char *)ws + 2 * ka + va);
-        void *tmp = (char *)ws + 2 * ka + 2 * va;
-        size_t tmp_bytes = sort16_temp_bytes(batch);
-        hipLaunchKernelGGL(sample_ui16_kernel, dim3(grid_1d(batch)), dim3(kBlock), 0, st, indptr_dev, indices_dev,
-                           num_users, num_items, batch, seed, step, epoch_pos, hb, shift, k_in, v_in);
-        hipError_t e16 = rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)batch, 0, 16u, st);
-        if (e16 != hipSuccess) {
-            rsx_set_error("rsx_bpr_sample: radix sort failed: %s", hipGetErrorString(e16));
-            return RSX_E_HIP;
-        }
-        hipLaunchKernelGGL(sample_neg16_kernel, dim3(grid_1d(batch)), dim3(kBlock), 0, st, indptr_dev, indices_dev,
-                           num_items, batch, seed, step, neg_block, neg_key, shift, k_out, v_out, user_sig_dev,
-                           u_out, i_out, j_out);
-        RSX_CHECK_LAUNCH();
-        return RSX_OK;
-    }
     const int64_t arr = align256(batch * 4);
     uint32_t *keys_in = (uint32_t *)ws;
     uint32_t *vals_in = (uint32_t *)((char *)ws + arr);
@@ -900,7 +823,7 @@ RSX_API int rsx_bpr_sample(const int64_t *indptr_dev, const int32_t *indices_dev
         return RSX_E_HIP;
     }
     hipLaunchKernelGGL(sample_neg_kernel, dim3(grid_1d(batch)), dim3(kBlock), 0, st, indptr_dev, indices_dev,
-                       num_items, batch, seed, step, neg_block, neg_key, keys_out, vals_out, u_out, i_out, j_out);
+                       num_items, batch, seed, step, neg_block, neg_key, keys_out, vals_out, user_sig_dev, u_out, i_out, j_out);
     RSX_CHECK_LAUNCH();
     return RSX_OK;
 }

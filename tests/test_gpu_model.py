@@ -220,8 +220,7 @@ def test_sorted_blocked_sampled_path_replays_through_oracle(oracle_mod, d, B, I,
         keys.add(eng.last_neg_key)
         un, inn, jn = u.cpu().numpy(), i.cpu().numpy(), j.cpu().numpy()
         assert len(np.unique(un)) == B                                   # users unique in the batch
-        shift = 0 if (cdf or I < 65536) else (1 if I < 131072 else 0)   # 16-bit sort keys drop the item's low bit
-        assert np.all(np.diff(inn >> shift) >= 0)                        # sorted by positive item (>> shift)
+        assert np.all(np.diff(inn) >= 0)                                 # ordered by positive item
         nominal = (np.arange(B, dtype=np.int64) * I // B) // c           # batch-position block
         bad = 0
         for w in np.unique(nominal)[:: max(1, len(np.unique(nominal)) // 200)]:
