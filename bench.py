@@ -163,8 +163,12 @@ def main():
                      hot=eng.hot if use_hot else None, neg_block=neg_block, neg_key=buf["key"])
         if ev is not None:
             ev[1].record()
-        buf["free"] = torch.cuda.Event()
-        buf["free"].record(main)
+        # an event record between two kernels of this queue costs ~10 us of launch gap: with one
+        # GPU the buffer is released after the apply sweep instead of between kernel and sweep
+        late_free = world == 1
+        if not late_free:
+            buf["free"] = torch.cuda.Event()
+            buf["free"].record(main)
         if world > 1:
             # with an exchange in the step, the sampler of step t+1 is better placed beside the
             # all-reduce (the CUs idle while xGMI moves G) than beside the kernel
@@ -175,6 +179,9 @@ def main():
         if world > 1:
             dist.all_reduce(eng.G, op=dist.ReduceOp.SUM)
         rsx.apply_item_grad(eng.Q, eng.G, eng.lr, hot=eng.hot if (use_hot and world == 1) else None)
+        if late_free:
+            buf["free"] = torch.cuda.Event()
+            buf["free"].record(main)
         eng.step_count += 1
         state["cur"] = cur ^ 1
 
