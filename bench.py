@@ -147,6 +147,7 @@ def main():
 
     side.wait_stream(torch.cuda.current_stream())
     prefetch(0)
+    two_pass = world > 1 and os.environ.get("RSX_TWO_PASS", "1") == "1"
 
     def one_step(ev=None):
         main = torch.cuda.current_stream()
@@ -157,14 +158,33 @@ def main():
             prefetch(cur ^ 1)           # sampler of step t+1 runs beside step t's kernel
         u, i, j = buf["t"]
         use_hot = eng.hot is not None
+        hot = eng.hot if use_hot else None
+        kw = dict(users_unique=True, hot=hot, neg_block=neg_block, neg_key=buf["key"])
         if ev is not None:
             ev[0].record()
-        rsx.bpr_step(eng.P, eng.Q, eng.G, u, i, j, eng.lr, 1.0 / gb, users_unique=True,
-                     hot=eng.hot if use_hot else None, neg_block=neg_block, neg_key=buf["key"])
-        if ev is not None:
-            ev[1].record()
-        # an event record between two kernels of this queue costs ~10 us of launch gap: with one
-        # GPU the buffer is released after the apply sweep instead of between kernel and sweep
+        if world == 1:
+            rsx.bpr_step(eng.P, eng.Q, eng.G, u, i, j, eng.lr, 1.0 / gb, **kw)
+            if ev is not None:
+                ev[1].record()
+            rsx.apply_item_grad(eng.Q, eng.G, eng.lr, hot=hot)      # replicas folded inside the sweep
+        else:
+            # two passes over the same triplets (include/rsx.h RSX_ITEMS_ONLY / RSX_USERS_ONLY): the item
+            # pass completes G, and the one exchange of the step -- all_reduce(G) over RCCL/xGMI -- then
+            # travels under the user pass and the next step's sampler instead of behind the whole kernel
+            rsx.bpr_step(eng.P, eng.Q, eng.G, u, i, j, eng.lr, 1.0 / gb, only="items" if two_pass else None, **kw)
+            if ev is not None:
+                ev[1].record()
+            if use_hot:
+                rsx.fold_hot_grad(eng.G, eng.hot)              # the all-reduce needs the folded G
+            work = dist.all_reduce(eng.G, op=dist.ReduceOp.SUM, async_op=True)
+            if two_pass:
+                rsx.bpr_step(eng.P, eng.Q, eng.G, u, i, j, eng.lr, 1.0 / gb, only="users", **kw)
+            buf["free"] = torch.cuda.Event()
+            buf["free"].record(main)
+            side.wait_event(buf["free"])
+            prefetch(cur ^ 1)                                  # sampler of step t+1 beside the exchange
+            work.wait()
+            rsx.apply_item_grad(eng.Q, eng.G, eng.lr)
         late_free = world == 1
         if not late_free:
             buf["free"] = torch.cuda.Event()
@@ -236,7 +256,7 @@ def main():
 
     if rank == 0:
         value = gb * args.steps / elapsed
-        alg_bytes = 24 * d * B                                     # per launch
+        alg_bytes = (20 if two_pass else 24) * d * B               # per launch; item pass: no P write
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-measured HBM bytes per launch, if profiled
@@ -259,7 +279,8 @@ def main():
                        "negatives": f"stratified by item block of {neg_block}, batch sorted by positive item" if neg_block else "independent uniform",
                        "sampler": "on device, overlapped on a second HIP stream",
                        "hot_items": args.hot, "hot_replicas": args.hot_replicas if args.hot > 0 else 0,
-                       "parallelism": f"user-sharded x{world}, items replicated, 1 all-reduce(G)/step" if world > 1 else "single GPU"},
+                       "parallelism": (f"user-sharded x{world}, items replicated, 1 all-reduce(G)/step"
+                                       + (" under the user pass of a two-pass step" if two_pass else "")) if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "bpr_step_blocked_kernel" if neg_block else "bpr_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},

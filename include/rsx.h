@@ -40,6 +40,13 @@ extern "C" {
 
 #define RSX_NO_UPDATE 2u    /* evaluate the loss only: P and G are not written             */
                             /* (models/MF.py:99-107 process_one_batch without backward)    */
+/* One step in two passes over the same triplets (both need RSX_USERS_UNIQUE).  The item pass   */
+/* fills G and the loss and leaves P alone; the user pass updates P and touches neither G nor    */
+/* the loss.  Neither pass changes what the other reads (P, Q pre-step), so items-then-users    */
+/* equals the single call bit for bit on the user side.  Purpose: when the step is sharded,      */
+/* the all-reduce of G is launched after the item pass and travels under the user pass.          */
+#define RSX_ITEMS_ONLY 4u
+#define RSX_USERS_ONLY 8u
 
 /* flags for rsx_bpr_sample */
 #define RSX_SAMPLE_SORT_POS 1u /* order the batch by positive item (needs a workspace)       */

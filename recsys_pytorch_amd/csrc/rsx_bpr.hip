@@ -627,21 +627,29 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
         return RSX_OK;
     }
     RSX_CHECK_ARG(neg_block >= 0 && neg_block <= kMaxNegBlock, "neg_block must be in [0, 16]");
+    // two-pass step: the kernels' write switches (1 positive-item sums, 2 negative-item sums, 4 P store)
+    int ablate = g_ablate;
+    if (flags & (RSX_ITEMS_ONLY | RSX_USERS_ONLY)) {
+        RSX_CHECK_ARG(flags & RSX_USERS_UNIQUE, "RSX_ITEMS_ONLY / RSX_USERS_ONLY need RSX_USERS_UNIQUE");
+        RSX_CHECK_ARG((flags & (RSX_ITEMS_ONLY | RSX_USERS_ONLY)) != (RSX_ITEMS_ONLY | RSX_USERS_ONLY), "pick one pass");
+        if (flags & RSX_ITEMS_ONLY) ablate |= 4;
+        if (flags & RSX_USERS_ONLY) { ablate |= 3; loss_acc = nullptr; }
+    }
     if ((flags & RSX_USERS_UNIQUE) && neg_block > 0) {
         const int64_t waves = ceil_div64(num_items, neg_block);
         const unsigned blocks = (unsigned)ceil_div64(waves, kWavesPerBlock);
         const size_t lds = (size_t)kWavesPerBlock * neg_block * d * sizeof(float);
         switch (d) {
-        case 32: hipLaunchKernelGGL(bpr_step_blocked_kernel<32>, dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u_dev, i_dev, j_dev, batch, num_items, neg_block, neg_key, lr, inv_batch, loss_acc, hot, g_ablate); break;
-        case 64: hipLaunchKernelGGL(bpr_step_blocked_kernel<64>, dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u_dev, i_dev, j_dev, batch, num_items, neg_block, neg_key, lr, inv_batch, loss_acc, hot, g_ablate); break;
-        default: hipLaunchKernelGGL(bpr_step_blocked_kernel<128>, dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u_dev, i_dev, j_dev, batch, num_items, neg_block, neg_key, lr, inv_batch, loss_acc, hot, g_ablate); break;
+        case 32: hipLaunchKernelGGL(bpr_step_blocked_kernel<32>, dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u_dev, i_dev, j_dev, batch, num_items, neg_block, neg_key, lr, inv_batch, loss_acc, hot, ablate); break;
+        case 64: hipLaunchKernelGGL(bpr_step_blocked_kernel<64>, dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u_dev, i_dev, j_dev, batch, num_items, neg_block, neg_key, lr, inv_batch, loss_acc, hot, ablate); break;
+        default: hipLaunchKernelGGL(bpr_step_blocked_kernel<128>, dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u_dev, i_dev, j_dev, batch, num_items, neg_block, neg_key, lr, inv_batch, loss_acc, hot, ablate); break;
         }
         RSX_CHECK_LAUNCH();
         return RSX_OK;
     }
     if (flags & RSX_USERS_UNIQUE) {
         dispatch_step<0>(d, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch,
-                         loss_acc, nullptr, nullptr, hot, g_ablate, st);
+                         loss_acc, nullptr, nullptr, hot, ablate, st);
         RSX_CHECK_LAUNCH();
         return RSX_OK;
     }

@@ -15,6 +15,8 @@ _lib = None
 
 RSX_USERS_UNIQUE = 1
 RSX_NO_UPDATE = 2
+RSX_ITEMS_ONLY = 4
+RSX_USERS_ONLY = 8
 RSX_SAMPLE_SORT_POS = 1
 RSX_LOSS_SLOTS = 64
 SUPPORTED_DIMS = (32, 64, 128)
@@ -130,8 +132,9 @@ def fold_hot_grad(G, hot):
 
 
 def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False, ws=None,
-             no_update=False, hot=None, neg_block=0, neg_key=0):
-    """One batch of include/rsx.h:rsx_bpr_step.  u, i, j: int32 device tensors."""
+             no_update=False, hot=None, neg_block=0, neg_key=0, only=None):
+    """One batch of include/rsx.h:rsx_bpr_step.  u, i, j: int32 device tensors.
+    only = "items" | "users": one pass of the two-pass step (RSX_ITEMS_ONLY / RSX_USERS_ONLY)."""
     d = P.shape[1]
     _check(lib().rsx_bpr_step(
         _dev(P, torch.float32, "P"), _dev(Q, torch.float32, "Q"),
@@ -139,7 +142,8 @@ def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False,
         P.shape[0], Q.shape[0], _dev(u, torch.int32, "u"), _dev(i, torch.int32, "i"),
         _dev(j, torch.int32, "j"), u.numel(), d, float(lr), float(inv_batch),
         _dev(loss_acc, torch.float32, "loss_acc") if loss_acc is not None else None,
-        (RSX_USERS_UNIQUE if users_unique else 0) | (RSX_NO_UPDATE if no_update else 0),
+        (RSX_USERS_UNIQUE if users_unique else 0) | (RSX_NO_UPDATE if no_update else 0)
+        | {None: 0, "items": RSX_ITEMS_ONLY, "users": RSX_USERS_ONLY}[only],
         C.c_void_p(ws.data_ptr()) if ws is not None else None,
         ws.numel() * ws.element_size() if ws is not None else 0,
         _dev(hot.slot, torch.int32, "hot slot") if hot is not None else None,

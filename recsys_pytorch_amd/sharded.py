@@ -39,6 +39,7 @@ class BPREngine:
         self.k = kernels
         self.P, self.Q = P_local, Q
         self.G = torch.zeros_like(Q)
+        self.overlap_exchange = True   # sharded + unique users: all-reduce(G) travels under the user pass
         self.lr = float(lr)
         self.group = group
         self.world = dist.get_world_size(group) if (group is not None or dist.is_initialized()) else 1
@@ -122,10 +123,29 @@ class BPREngine:
             self.k.adam_apply(self.Q, self.mQ, self.vQ, self.G, self.lr, self.step_count)
             self.k.adam_apply(self.P, self.mP, self.vP, self.GP, self.lr, self.step_count)
             return loss
+        kw = {"hot": self.hot} if self.hot is not None else {}
+        if neg_block:
+            kw["neg_block"], kw["neg_key"] = neg_block, neg_key
+        if self.sharded and users_unique and self.overlap_exchange:
+            # two passes over the same triplets (include/rsx.h: RSX_ITEMS_ONLY / RSX_USERS_ONLY): the
+            # item pass completes G, whose all-reduce then runs while the user pass updates P --
+            # neither pass changes what the other reads, so the step is the same as in one launch
+            if B > 0:
+                self.k.bpr_step(self.P, self.Q, self.G, u_local, i, j, self.lr, 1.0 / gb, loss_acc=loss,
+                                users_unique=True, only="items", **kw)
+                if "hot" in kw:
+                    self.k.fold_hot_grad(self.G, self.hot)
+            work = dist.all_reduce(self.G, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if B > 0:
+                self.k.bpr_step(self.P, self.Q, self.G, u_local, i, j, self.lr, 1.0 / gb,
+                                users_unique=True, only="users", **kw)
+            work.wait()
+            if want_loss:
+                dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.group)
+            self.k.apply_item_grad(self.Q, self.G, self.lr)
+            self.step_count += 1
+            return loss
         if B > 0:
-            kw = {"hot": self.hot} if self.hot is not None else {}
-            if neg_block:
-                kw["neg_block"], kw["neg_key"] = neg_block, neg_key
             self.k.bpr_step(self.P, self.Q, self.G, u_local, i, j, self.lr, 1.0 / gb, loss_acc=loss,
                             users_unique=users_unique, ws=None if users_unique else self._workspace(B), **kw)
             if "hot" in kw and self.sharded:

@@ -17,7 +17,7 @@ def bpr_step_workspace(num_users, max_batch, d):
 
 
 def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False, ws=None, no_update=False,
-             hot=None, neg_block=0, neg_key=0):
+             hot=None, neg_block=0, neg_key=0, only=None):
     """same contract as include/rsx.h:rsx_bpr_step, on host tensors: G += dQ (scaled by
     inv_batch), P -= lr*dP, loss slots += sum softplus(-x)."""
     Pn, Qn = P.numpy(), Q.numpy()
@@ -29,12 +29,14 @@ def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False,
     if len(uu):
         oracle.lib().orc_bpr_grad(Pn, Qn, uu, ii, jj, len(uu), Pn.shape[1], gP, gQ, C.byref(loss))
     scale = float(inv_batch) * len(uu)      # orc_bpr_grad uses 1/len(batch); rescale to inv_batch
-    if loss_acc is not None:
+    if loss_acc is not None and only != "users":
         loss_acc[0] += float(loss.value) * len(uu)
     if no_update:
         return
-    G += torch.from_numpy(gQ * np.float32(scale))
-    P -= torch.from_numpy(gP * np.float32(scale * lr))
+    if only != "users":
+        G += torch.from_numpy(gQ * np.float32(scale))
+    if only != "items":
+        P -= torch.from_numpy(gP * np.float32(scale * lr))
 
 
 def apply_item_grad(Q, G, lr, hot=None):

@@ -128,6 +128,39 @@ def test_bpr_step_unique_users_fast_path_equals_general_path(rsx, oracle_mod):
     assert rel_err(Pg, orc.P) < REL_TOL and rel_err(Qg, orc.Q) < REL_TOL
 
 
+@pytest.mark.parametrize("neg_block", [0, 8])
+def test_bpr_step_in_two_passes_equals_one_launch(rsx, oracle_mod, neg_block):
+    """include/rsx.h RSX_ITEMS_ONLY then RSX_USERS_ONLY == one launch (user side bit for bit)"""
+    rng = np.random.default_rng(31)
+    U, I, d, B, lr = 5000, 777, 64, 4000, 0.05
+    P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+    u, i, j = rng.permutation(U)[:B], rng.integers(0, I, B), rng.integers(0, I, B)
+    orc = oracle_mod.MFOracle(P0, Q0, "sgd", lr)
+    want_loss = orc.step(u, i, j)
+    ut, it, jt = (torch.from_numpy(x.astype(np.int32)).cuda() for x in (u, i, j))
+    kw = dict(users_unique=True, neg_block=neg_block, neg_key=9 if neg_block else 0)
+    P1, Q1 = torch.from_numpy(P0).cuda(), torch.from_numpy(Q0).cuda()
+    G1 = torch.zeros_like(Q1)
+    rsx.bpr_step(P1, Q1, G1, ut, it, jt, lr, 1.0 / B, **kw)                      # one launch
+    P, Q = torch.from_numpy(P0).cuda(), torch.from_numpy(Q0).cuda()
+    G = torch.zeros_like(Q)
+    loss = torch.zeros(rsx.RSX_LOSS_SLOTS, device="cuda")
+    rsx.bpr_step(P, Q, G, ut, it, jt, lr, 1.0 / B, loss_acc=loss, only="items", **kw)
+    assert torch.equal(P, torch.from_numpy(P0).cuda())                           # item pass leaves P alone
+    g_items = G.clone()
+    rsx.bpr_step(P, Q, G, ut, it, jt, lr, 1.0 / B, loss_acc=loss, only="users", **kw)
+    assert torch.equal(G, g_items)                                               # user pass leaves G (and the loss) alone
+    assert torch.equal(P, P1)
+    assert torch.allclose(G, G1, rtol=0, atol=1e-7)
+    rsx.apply_item_grad(Q, G, lr)
+    assert abs(float(loss.sum()) / B - want_loss) < 1e-5
+    assert rel_err(P.cpu().numpy(), orc.P) < REL_TOL and rel_err(Q.cpu().numpy(), orc.Q) < REL_TOL
+    with pytest.raises(rsx.RsxError):      # a batch whose users may repeat cannot be run in two passes
+        rsx.bpr_step(P, Q, G, ut, it, jt, lr, 1.0 / B, users_unique=False, only="items",
+                     ws=torch.zeros(rsx.bpr_step_workspace(U, B, d), dtype=torch.uint8, device="cuda"))
+
+
 def test_bpr_step_empty_and_skipped_triplets(rsx):
     P = torch.randn(10, 32, device="cuda")
     Q = torch.randn(7, 32, device="cuda")

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def _worker(rank, world, port, P0, Q0, batches, lr, out):
+def _worker(rank, world, port, P0, Q0, batches, lr, out, unique=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import cpu_kernels
@@ -27,7 +27,7 @@ def _worker(rank, world, port, P0, Q0, batches, lr, out):
     losses, sums = [], []
     for (u, i, j) in batches:
         ul, il, jl = eng.route(torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(j))
-        acc = eng.step(ul, il, jl)                      # global batch size found by all-reduce
+        acc = eng.step(ul, il, jl, users_unique=unique)  # global batch size found by all-reduce
         losses.append(float(acc.sum()) / len(u))
         sums.append(eng.item_checksum())
     out[rank] = (lo, hi, P.numpy().copy(), Q.numpy().copy(), losses, sums)
@@ -61,7 +61,33 @@ def test_two_ranks_equal_one_process(oracle_mod):
     assert err(P, single.P) < 1e-5 and err(out[0][3], single.Q) < 1e-5
 
 
-def _gpu_worker(rank, world, port, P0, Q0, batches, lr, out):
+@pytest.mark.timeout(300)
+def test_two_ranks_with_the_exchange_under_the_user_pass_equal_one_process(oracle_mod):
+    """batches with unique users take the two-pass step (item pass -> async all-reduce of G ->
+    user pass, BPREngine.overlap_exchange): same step as one launch"""
+    rng = np.random.default_rng(10)
+    U, I, d, B, T, lr = 301, 97, 64, 200, 4, 0.05
+    P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+    batches = [(rng.permutation(U)[:B], rng.integers(0, I, B), rng.integers(0, I, B)) for _ in range(T)]
+    batches.append((rng.permutation(150)[:64], rng.integers(0, I, 64), rng.integers(0, I, 64)))   # rank 1 idle
+    single = oracle_mod.MFOracle(P0, Q0, "sgd", lr)
+    ref_losses = [single.step(*b) for b in batches]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29500 + (os.getpid() + 3) % 2000
+    mp.spawn(_worker, args=(2, port, P0, Q0, batches, lr, out, True), nprocs=2, join=True)
+    P = np.zeros_like(P0)
+    for r in range(2):
+        lo, hi, Pr, Qr, losses, sums = out[r]
+        P[lo:hi] = Pr
+        assert np.allclose(losses, ref_losses, rtol=1e-5, atol=1e-6)
+    assert np.array_equal(out[0][3], out[1][3]), "item replicas diverged"
+    err = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
+    assert err(P, single.P) < 1e-5 and err(out[0][3], single.Q) < 1e-5
+
+
+def _gpu_worker(rank, world, port, P0, Q0, batches, lr, out, unique=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from recsys_pytorch_amd.sharded import BPREngine, user_block
@@ -70,10 +96,15 @@ def _gpu_worker(rank, world, port, P0, Q0, batches, lr, out):
     P = torch.from_numpy(P0[lo:hi].copy()).to(dev)
     Q = torch.from_numpy(Q0.copy()).to(dev)
     eng = BPREngine(P, Q, lr, user_begin=lo)            # default kernels: the HIP library
+    if unique:
+        eng.set_hot_items(torch.bincount(torch.from_numpy(np.concatenate([b[1] for b in batches])), minlength=Q0.shape[0]), 16, 4)
     losses = []
-    for (u, i, j) in batches:
+    for s, (u, i, j) in enumerate(batches):
         ul, il, jl = eng.route(torch.from_numpy(u).to(dev), torch.from_numpy(i).to(dev), torch.from_numpy(j).to(dev))
-        acc = eng.step(ul, il, jl)
+        if unique:     # two-pass step; odd steps through the blocked kernel, even ones through the plain one
+            acc = eng.step(ul, il, jl, users_unique=True, neg_block=8 * (s % 2), neg_key=77 * (s % 2))
+        else:
+            acc = eng.step(ul, il, jl)
         losses.append(float(acc.sum()) / len(u))
     torch.cuda.synchronize()
     out[rank] = (lo, hi, P.cpu().numpy(), Q.cpu().numpy(), losses)
@@ -97,6 +128,30 @@ def test_two_ranks_on_hip_kernels_equal_one_process(oracle_mod):
     out = mgr.dict()
     port = 29500 + (os.getpid() + 7) % 2000
     mp.spawn(_gpu_worker, args=(2, port, P0, Q0, batches, lr, out), nprocs=2, join=True)
+    P = np.zeros_like(P0)
+    for r in range(2):
+        lo, hi, Pr, Qr, losses = out[r]
+        P[lo:hi] = Pr
+        assert np.allclose(losses, ref_losses, rtol=1e-5, atol=1e-6)
+    err = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
+    assert np.array_equal(out[0][3], out[1][3]), "item replicas diverged"
+    assert err(P, single.P) < 1e-5 and err(out[0][3], single.Q) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_two_ranks_on_hip_kernels_with_the_exchange_under_the_user_pass(oracle_mod):
+    rng = np.random.default_rng(29)
+    U, I, d, B, T, lr = 4001, 1500, 128, 3000, 4, 0.05
+    P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+    batches = [(rng.permutation(U)[:B], (rng.integers(0, I, B) ** 2) // I, rng.integers(0, I, B)) for _ in range(T)]
+    single = oracle_mod.MFOracle(P0, Q0, "sgd", lr)
+    ref_losses = [single.step(*b) for b in batches]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29500 + (os.getpid() + 11) % 2000
+    mp.spawn(_gpu_worker, args=(2, port, P0, Q0, batches, lr, out, True), nprocs=2, join=True)
     P = np.zeros_like(P0)
     for r in range(2):
         lo, hi, Pr, Qr, losses = out[r]
