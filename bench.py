@@ -177,12 +177,14 @@ def main():
             if use_hot:
                 rsx.fold_hot_grad(eng.G, eng.hot)              # the all-reduce needs the folded G
             work = dist.all_reduce(eng.G, op=dist.ReduceOp.SUM, async_op=True)
+            after_items = torch.cuda.Event()
+            after_items.record(main)
+            side.wait_event(after_items)
+            prefetch(cur ^ 1)                                  # sampler of step t+1 beside the exchange
             if two_pass:
                 rsx.bpr_step(eng.P, eng.Q, eng.G, u, i, j, eng.lr, 1.0 / gb, only="users", **kw)
             buf["free"] = torch.cuda.Event()
             buf["free"].record(main)
-            side.wait_event(buf["free"])
-            prefetch(cur ^ 1)                                  # sampler of step t+1 beside the exchange
             work.wait()
             rsx.apply_item_grad(eng.Q, eng.G, eng.lr)
         late_free = world == 1
