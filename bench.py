@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--hot", type=int, default=256, help="popular items whose gradient rows are replicated (0 = off)")
     ap.add_argument("--hot-replicas", type=int, default=16)
     ap.add_argument("--neg-block", type=int, default=8, help="item block of the stratified negatives (0 = independent uniform negatives)")
+    ap.add_argument("--small-batch", type=int, default=65_536, help="extra leg at this batch size (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=65_536)
     return ap.parse_args()
@@ -77,7 +78,7 @@ def cpu_baseline(args):
     for _ in range(2):
         m.step(*mk())
     times, t_all = [], time.time()
-    while len(times) < 10 and time.time() - t_all < 25.0:
+    while len(times) < 30 and time.time() - t_all < 15.0:    # ~15 s of CPU work, at least a few steps
         b = mk()
         t0 = time.time()
         m.step(*b)
@@ -233,6 +234,28 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events.values()]))   # bpr_step_kernel, HIP events
     assert torch.isfinite(P).all() and torch.isfinite(Q).all()
 
+    # ---- small-batch leg: SURVEY section 8d's base batch (65 536 triplets/step), reported beside
+    # the headline.  Below 2 triplets per item there is nothing to sum on chip: atomic path.
+    small = None
+    if world == 1 and args.small_batch > 0 and args.small_batch < B:
+        eng_s = BPREngine(P, Q, args.lr, seed=2021)
+        if args.hot > 0:
+            eng_s.set_hot_items(torch.bincount(indices.long(), minlength=I), args.hot, args.hot_replicas)
+        n_small = 200
+        for _ in range(10):
+            eng_s.sampled_step_overlapped(indptr, indices, args.small_batch, want_loss=False)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(n_small):
+            eng_s.sampled_step_overlapped(indptr, indices, args.small_batch, want_loss=False)
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - ts
+        small = {"batch": args.small_batch, "value": args.small_batch * n_small / dts, "unit": "triplets/s",
+                 "ms_per_step": dts / n_small * 1e3, "steps": n_small,
+                 "path": "bpr_step_kernel (one atomic row update per item row touched, hot-item replicas)",
+                 "frac_of_hbm_roofline": args.small_batch * n_small / dts * 24 * d / (HBM_PEAK_GBS * 1e9)}
+        assert torch.isfinite(P).all() and torch.isfinite(Q).all()
+
     # ---- scoring leg (reported beside the headline; its own timed region) ---------------
     scoring = None
     if args.score_tiles > 0 and rank == 0:
@@ -287,6 +310,8 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},
         }
+        if small is not None:
+            out["small_batch"] = small
         if scoring is not None:
             out["scoring"] = scoring
         if world == 1 and not args.no_cpu_baseline:

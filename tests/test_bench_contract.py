@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.timeout(600)
 def test_bench_json_contract_small_shape():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--users", "60000",
-           "--items", "40000", "--batch", "60000", "--score-tiles", "1", "--cpu-batch", "4096"]
+           "--items", "40000", "--batch", "60000", "--score-tiles", "1", "--cpu-batch", "4096", "--small-batch", "8192"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=500, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -31,5 +31,6 @@ def test_bench_json_contract_small_shape():
     assert abs(d["value"] - d["config"]["global_batch"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert d["small_batch"]["batch"] == 8192 and d["small_batch"]["value"] > 0
     s = d["scoring"]["roofline"]
     assert s["bound"] == "mfma" and s["peak"] == 157.3
