@@ -489,8 +489,8 @@ __global__ __launch_bounds__(kBlock) void apply_item_grad_kernel(float4 *__restr
                                                                  float4 *__restrict__ G, int64_t n4,
                                                                  float lr, HotMap hot, int d4)
 {
-    // four quads per thread per trip, G and Q loads of all four issued before anything is used
-    // (the sweep is latency-bound otherwise: 3.6 TB/s with one dependent G -> Q pair in flight)
+    // four quads per thread per trip: the four G loads are in flight together, then the Q loads of
+    // the quads that have a gradient (at small batches most rows have none and are never read)
     constexpr int kQuads = 4;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t n0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; n0 < n4; n0 += stride * kQuads) {
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(kBlock) void apply_item_grad_kernel(float4 *__restr
         for (int c = 0; c < kQuads; ++c) {
             const int64_t n = n0 + c * stride;
             g[c] = make_float4(0.f, 0.f, 0.f, 0.f); q[c] = g[c];
-            if (n < n4) { g[c] = G[n]; q[c] = Q[n]; }
+            if (n < n4) g[c] = G[n];
         }
         if (hot.slot != nullptr) {
 #pragma unroll
@@ -518,10 +518,17 @@ __global__ __launch_bounds__(kBlock) void apply_item_grad_kernel(float4 *__restr
                 }
             }
         }
+        bool nz[kQuads];
 #pragma unroll
         for (int c = 0; c < kQuads; ++c) {
             const int64_t n = n0 + c * stride;
-            if (n < n4 && (g[c].x != 0.f || g[c].y != 0.f || g[c].z != 0.f || g[c].w != 0.f)) {
+            nz[c] = n < n4 && (g[c].x != 0.f || g[c].y != 0.f || g[c].z != 0.f || g[c].w != 0.f);
+            if (nz[c]) q[c] = Q[n];
+        }
+#pragma unroll
+        for (int c = 0; c < kQuads; ++c) {
+            const int64_t n = n0 + c * stride;
+            if (nz[c]) {
                 float4 w = q[c];
                 w.x = fmaf(-lr, g[c].x, w.x); w.y = fmaf(-lr, g[c].y, w.y);
                 w.z = fmaf(-lr, g[c].z, w.z); w.w = fmaf(-lr, g[c].w, w.w);

@@ -334,6 +334,53 @@ def test_item_cdf_buckets_piecewise_above_two_million_positions():
         assert i[q] in row and j[q] not in row
 
 
+def test_full_size_sampled_step_invariants():
+    """the bench shape end to end (bucket sampler, blocked kernel, hot-item replicas) through
+    properties that hold at any size: every user exactly once, batch ordered by positive item,
+    true positives / negatives on a sample, negatives spread evenly over the catalog, column sums
+    of G zero (each triplet adds +g p to i and -g p to j), loss = mean softplus(-x) of the
+    sampled triplets on the pre-step tables, every user row moved, P finite"""
+    from recsys_pytorch_amd import rsx
+    from recsys_pytorch_amd.data import synthetic_csr
+    from recsys_pytorch_amd.sharded import BPREngine
+    U, I, d, B = 1_000_000, 100_000, 128, 1_000_000
+    ip, ix = synthetic_csr(U, I, 20, "cuda", seed=2020)
+    torch.manual_seed(1)
+    P = torch.randn(U, d, device="cuda") * 0.1
+    Q = torch.randn(I, d, device="cuda") * 0.1
+    P0 = P.clone()
+    eng = BPREngine(P, Q, 0.05)
+    assert eng.set_neg_block(B, 8) == 8
+    eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 256, 16)
+    u, i, j = eng.sample(ip, ix, B)
+    ul, il, jl = u.long(), i.long(), j.long()
+    assert int(torch.bincount(ul, minlength=U).max()) == 1 and int(ul.min()) == 0
+    assert bool((il[1:] >= il[:-1]).all()) and int(il.min()) >= 0 and int(jl.min()) >= 0 and int(jl.max()) < I
+    pick = torch.arange(0, B, 997, device="cuda")
+    ipn, ixn = ip.cpu().numpy(), ix.cpu().numpy()
+    for uu, ii, jj in zip(ul[pick].tolist(), il[pick].tolist(), jl[pick].tolist()):
+        row = ixn[ipn[uu]:ipn[uu + 1]]
+        assert ii in row and jj not in row
+    neg_hist = torch.bincount(jl, minlength=I).double()
+    assert abs(float(neg_hist.mean()) - B / I) < 1e-9 and float(neg_hist.std()) < 1.5 * (B / I) ** 0.5 + 1
+    x = (P[ul] * (Q[il] - Q[jl])).sum(1)
+    want_loss = float(torch.nn.functional.softplus(-x.double()).mean())
+    loss = torch.zeros(rsx.RSX_LOSS_SLOTS, device="cuda")
+    rsx.bpr_step(P, Q, eng.G, u, i, j, 0.05, 1.0 / B, loss_acc=loss, users_unique=True, hot=eng.hot,
+                 neg_block=8, neg_key=eng.last_neg_key)
+    rsx.fold_hot_grad(eng.G, eng.hot)
+    torch.cuda.synchronize()
+    assert abs(float(loss.double().sum()) / B - want_loss) < 1e-5
+    col = eng.G.double().sum(0)
+    assert float(col.abs().max()) < 1e-6 * float(eng.G.double().abs().sum(0).max()) + 1e-9
+    # G against a dense index_add in fp64 on the same triplets
+    g = (-torch.sigmoid(-x.double()) / B).unsqueeze(1) * P0[ul].double()
+    want = torch.zeros(I, d, dtype=torch.float64, device="cuda")
+    want.index_add_(0, il, g); want.index_add_(0, jl, -g)
+    assert float((eng.G.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
+    assert bool(torch.isfinite(P).all()) and int((P != P0).any(1).sum()) == B
+
+
 def test_overlapped_sampler_equals_inline_sampler():
     """sampling one step ahead on a second stream must not change a single bit"""
     from recsys_pytorch_amd.data import synthetic_csr
