@@ -188,21 +188,9 @@ def main():
             buf["free"].record(main)
             work.wait()
             rsx.apply_item_grad(eng.Q, eng.G, eng.lr)
-        late_free = world == 1
-        if not late_free:
-            buf["free"] = torch.cuda.Event()
-            buf["free"].record(main)
-        if world > 1:
-            # with an exchange in the step, the sampler of step t+1 is better placed beside the
-            # all-reduce (the CUs idle while xGMI moves G) than beside the kernel
-            side.wait_event(buf["free"])
-            prefetch(cur ^ 1)
-        if use_hot and world > 1:
-            rsx.fold_hot_grad(eng.G, eng.hot)          # the all-reduce needs the folded G
-        if world > 1:
-            dist.all_reduce(eng.G, op=dist.ReduceOp.SUM)
-        rsx.apply_item_grad(eng.Q, eng.G, eng.lr, hot=eng.hot if (use_hot and world == 1) else None)
-        if late_free:
+        if world == 1:
+            # (an event record between two kernels of this queue costs ~10 us of launch gap: with one
+            #  GPU the triplet buffer is released after the apply sweep, not between kernel and sweep)
             buf["free"] = torch.cuda.Event()
             buf["free"].record(main)
         eng.step_count += 1
