@@ -148,7 +148,13 @@ def main():
 
     side.wait_stream(torch.cuda.current_stream())
     prefetch(0)
-    two_pass = world > 1 and os.environ.get("RSX_TWO_PASS", "1") == "1"
+    # N > 1.  Two-pass step: the all-reduce runs under the user pass.  It pays
+    # when the exchange takes longer than the user pass plus the sampler (~375 us): expected with
+    # the 1 or 3 xGMI links of 2 or 4 GPUs, not with the 7 links of 8 (estimate; RSX_TWO_PASS overrides)
+    two_pass = world > 1 and os.environ.get("RSX_TWO_PASS", "1" if world <= 4 else "0") == "1"
+    n_chunks = max(1, int(os.environ.get("RSX_EXCHANGE_CHUNKS", "4"))) if world > 1 else 1
+    g_chunks = list(torch.chunk(eng.G, n_chunks, dim=0))
+    q_chunks = list(torch.chunk(eng.Q, n_chunks, dim=0))
 
     def one_step(ev=None):
         main = torch.cuda.current_stream()
@@ -177,7 +183,9 @@ def main():
                 ev[1].record()
             if use_hot:
                 rsx.fold_hot_grad(eng.G, eng.hot)              # the all-reduce needs the folded G
-            work = dist.all_reduce(eng.G, op=dist.ReduceOp.SUM, async_op=True)
+            # the exchange goes in item-range chunks so that the apply sweep of chunk k runs while the
+            # later chunks are still travelling (only the last chunk's sweep stays exposed)
+            works = [dist.all_reduce(c, op=dist.ReduceOp.SUM, async_op=True) for c in g_chunks]
             after_items = torch.cuda.Event()
             after_items.record(main)
             side.wait_event(after_items)
@@ -186,8 +194,9 @@ def main():
                 rsx.bpr_step(eng.P, eng.Q, eng.G, u, i, j, eng.lr, 1.0 / gb, only="users", **kw)
             buf["free"] = torch.cuda.Event()
             buf["free"].record(main)
-            work.wait()
-            rsx.apply_item_grad(eng.Q, eng.G, eng.lr)
+            for w, qc, gc in zip(works, q_chunks, g_chunks):
+                w.wait()
+                rsx.apply_item_grad(qc, gc, eng.lr)
         if world == 1:
             # (an event record between two kernels of this queue costs ~10 us of launch gap: with one
             #  GPU the triplet buffer is released after the apply sweep, not between kernel and sweep)
@@ -221,6 +230,12 @@ def main():
     elapsed = float(el.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events.values()]))   # bpr_step_kernel, HIP events
     assert torch.isfinite(P).all() and torch.isfinite(Q).all()
+    replicas_equal = None
+    if world > 1:      # every rank applied the same reduced gradient: the item replicas must be identical
+        cs = torch.stack([Q.double().sum(), -Q.double().sum()])
+        dist.all_reduce(cs, op=dist.ReduceOp.MAX)
+        replicas_equal = bool(float(cs[0] + cs[1]) == 0.0)    # max(sum) == min(sum)
+        assert replicas_equal, "item replicas diverged"
 
     # ---- small-batch leg: SURVEY section 8d's base batch (65 536 triplets/step), reported beside
     # the headline.  Below 2 triplets per item there is nothing to sum on chip: atomic path.
@@ -248,6 +263,8 @@ def main():
     scoring = None
     if args.score_tiles > 0 and rank == 0:
         tiles, K = args.score_tiles, args.topk
+        if os.environ.get("RSX_SCORE_LANES"):
+            rsx.lib().rsx_debug_set_score_lanes(int(os.environ["RSX_SCORE_LANES"]))
         users = torch.arange(1024 * tiles, device=dev, dtype=torch.int32) % U
         ws = torch.empty(rsx.lib().rsx_score_topk_workspace(users.numel(), I) // 4 + 64, dtype=torch.float32, device=dev)
         mask = (indptr, indices)
@@ -291,9 +308,11 @@ def main():
                        "positives_per_user": args.degree, "item_popularity": args.popularity, "lr": args.lr,
                        "negatives": f"stratified by item block of {neg_block}, batch sorted by positive item" if neg_block else "independent uniform",
                        "sampler": "on device, overlapped on a second HIP stream",
+                       **({"item_replicas_identical": replicas_equal} if world > 1 else {}),
                        "hot_items": args.hot, "hot_replicas": args.hot_replicas if args.hot > 0 else 0,
                        "parallelism": (f"user-sharded x{world}, items replicated, 1 all-reduce(G)/step"
-                                       + (" under the user pass of a two-pass step" if two_pass else "")) if world > 1 else "single GPU"},
+                                       + f" in {n_chunks} chunks pipelined with the apply sweep"
+                                       + (", under the user pass of a two-pass step" if two_pass else "")) if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "bpr_step_blocked_kernel" if neg_block else "bpr_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},

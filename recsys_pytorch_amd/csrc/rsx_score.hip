@@ -542,6 +542,8 @@ __global__ __launch_bounds__(MG_THREADS) void merge_candidates_kernel(
 }
 
 int g_score_ablate = 0;   // development only
+constexpr int kMaxLanes = 4;
+int g_score_lanes = 2;    // passes of the fused path in flight (one HIP stream each)
 
 template <bool FILTER>
 int launch_score(const float *P, const int32_t *users, int64_t rows, const float *Q, int64_t cols,
@@ -562,6 +564,7 @@ constexpr int64_t kRowTile = 1024;   // rows scored per pass of rsx_score_topk (
 }  // namespace
 
 RSX_API int rsx_debug_set_score_ablation(int mask) { g_score_ablate = mask; return RSX_OK; }
+RSX_API int rsx_debug_set_score_lanes(int n) { g_score_lanes = n < 1 ? 1 : (n > kMaxLanes ? kMaxLanes : n); return RSX_OK; }
 
 RSX_API int rsx_score(const float *P, const int32_t *user_ids_dev, int64_t num_rows, const float *Q,
                       int64_t num_items, int d, const int64_t *mask_indptr_dev,
@@ -664,7 +667,8 @@ RSX_API int64_t rsx_score_topk_workspace(int64_t num_rows, int64_t num_items)
     const int64_t dense = rows * num_items * 4;
     if (num_items < kFusedMinItems) return dense;
     const int64_t frows = num_rows < kFusedRows ? num_rows : kFusedRows;
-    const int64_t lanes = num_rows > kFusedRows ? 2 : 1;      // two passes in flight (two streams)
+    const int64_t passes = (num_rows + kFusedRows - 1) / kFusedRows;
+    const int64_t lanes = passes < kMaxLanes ? passes : kMaxLanes;   // passes in flight (one stream each)
     const int64_t fused = lanes * carve(nullptr, frows, num_rows, num_items, 512).bytes;
     return fused > dense ? fused : dense;   // (K > 512 still takes the dense path)
 }
@@ -704,31 +708,31 @@ RSX_API int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t 
     const int64_t stride = num_items / kSampleCols;          // sample = items 0, stride, 2 stride, ...
     const int64_t tile_rows = num_rows < kFusedRows ? num_rows : kFusedRows;
     const int64_t n_tiles = (num_rows + kFusedRows - 1) / kFusedRows;
-    // Two passes in flight on two streams: the selection kernels of one pass (sample top-K, merge;
-    // memory / LDS bound) overlap the matrix-core product of the other.
-    const int n_lanes = n_tiles > 1 ? 2 : 1;
-    FusedWs lane_ws[2];
-    lane_ws[0] = carve(ws, tile_rows, num_rows, num_items, K);
-    lane_ws[1] = n_lanes > 1 ? carve((char *)ws + lane_ws[0].bytes, tile_rows, num_rows, num_items, K) : lane_ws[0];
+    // Several passes in flight, one HIP stream each: the selection kernels of one pass (sample
+    // top-K, merge; memory / LDS bound) overlap the matrix-core product of the others.
+    const int n_lanes = (int)(n_tiles < g_score_lanes ? n_tiles : g_score_lanes);
+    FusedWs lane_ws[kMaxLanes];
+    for (int l = 0; l < n_lanes; ++l)
+        lane_ws[l] = carve((char *)ws + (l ? (size_t)l * lane_ws[0].bytes : 0), tile_rows, num_rows, num_items, K);
     FusedWs &w = lane_ws[0];                   // overflow list and dense re-do buffers are lane 0's
-    static hipStream_t side_stream = nullptr;
-    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipStream_t lane_st[2] = {st, st};
-    if (n_lanes > 1) {
-        if (side_stream == nullptr) {
-            if (hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
-                rsx_set_error("rsx_score_topk: could not create the second stream");
+    static hipStream_t side_stream[kMaxLanes - 1] = {nullptr, nullptr, nullptr};
+    static hipEvent_t ev_fork = nullptr, ev_join[kMaxLanes - 1] = {nullptr, nullptr, nullptr};
+    hipStream_t lane_st[kMaxLanes] = {st, st, st, st};
+    for (int l = 1; l < n_lanes; ++l) {
+        if (side_stream[l - 1] == nullptr) {
+            if (hipStreamCreateWithFlags(&side_stream[l - 1], hipStreamNonBlocking) != hipSuccess ||
+                (ev_fork == nullptr && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) ||
+                hipEventCreateWithFlags(&ev_join[l - 1], hipEventDisableTiming) != hipSuccess) {
+                rsx_set_error("rsx_score_topk: could not create a side stream");
                 return RSX_E_HIP;
             }
         }
-        lane_st[1] = side_stream;
+        lane_st[l] = side_stream[l - 1];
     }
     (void)hipMemsetAsync(w.ovf_cnt, 0, 4, st);
     if (n_lanes > 1) {
         (void)hipEventRecord(ev_fork, st);
-        (void)hipStreamWaitEvent(side_stream, ev_fork, 0);
+        for (int l = 1; l < n_lanes; ++l) (void)hipStreamWaitEvent(lane_st[l], ev_fork, 0);
     }
     for (int64_t ti = 0; ti < n_tiles; ++ti) {
         const int64_t r0 = ti * kFusedRows;
@@ -756,9 +760,9 @@ RSX_API int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t 
                            r0, w.ovf_rows, w.ovf_cnt);
         RSX_CHECK_LAUNCH();
     }
-    if (n_lanes > 1) {
-        (void)hipEventRecord(ev_join, side_stream);
-        (void)hipStreamWaitEvent(st, ev_join, 0);
+    for (int l = 1; l < n_lanes; ++l) {
+        (void)hipEventRecord(ev_join[l - 1], lane_st[l]);
+        (void)hipStreamWaitEvent(st, ev_join[l - 1], 0);
     }
     // rows whose candidate list overflowed (massive exact ties, or fewer than K unmasked sample
     // items) are re-done through the dense path.  This is the one place the call waits for the

@@ -39,11 +39,13 @@ class BPREngine:
         self.k = kernels
         self.P, self.Q = P_local, Q
         self.G = torch.zeros_like(Q)
-        self.overlap_exchange = True   # sharded + unique users: all-reduce(G) travels under the user pass
         self.lr = float(lr)
         self.group = group
         self.world = dist.get_world_size(group) if (group is not None or dist.is_initialized()) else 1
         self.sharded = self.world > 1
+        # sharded + unique users: all-reduce(G) travels under the user pass of a two-pass step.  It pays
+        # when the exchange is slower than that pass (few xGMI links: 2 or 4 GPUs)
+        self.overlap_exchange = self.sharded and self.world <= 4
         self.user_begin = int(user_begin)
         self.seed = int(seed)
         self.step_count = 0
