@@ -286,6 +286,72 @@ def test_item_cdf_buckets_order_the_same_pairs_as_the_device_sort(U, I, deg, B, 
         assert np.array_equal(ja, j3)
 
 
+def test_item_cdf_buckets_on_random_shapes():
+    """40 random CSRs (empty, short, long and full rows; tiny and ragged sizes; any neg_block):
+    bucket layout vs radix layout hold the same pairs, ordered by item, negatives valid and inside
+    the position's item block, same bits when repeated, also through the out-of-LDS path"""
+    import scipy.sparse as sp
+    from recsys_pytorch_amd import rsx
+    from recsys_pytorch_amd.data import csr_to_device
+    rng = np.random.default_rng(123)
+    try:
+        for trial in range(40):
+            U = int(rng.integers(1, 4000))
+            I = int(rng.integers(2, 3000))
+            kind = trial % 4
+            if kind == 0:
+                degs = rng.integers(0, min(I, 6), U)                       # short rows, some empty
+            elif kind == 1:
+                degs = rng.integers(0, min(I, 120), U)                     # beyond the 24-item register test
+            elif kind == 2:
+                degs = np.where(rng.random(U) < 0.05, I, rng.integers(1, min(I, 30) + 1, U))   # some own everything
+            else:
+                degs = np.minimum(I - 1, (rng.pareto(1.0, U) * 3).astype(np.int64))            # heavy tail
+            pop = 1.0 / (1.0 + np.arange(I)) if trial % 2 else np.ones(I)
+            pop = pop / pop.sum()
+            rows = [np.sort(rng.choice(I, int(g), replace=False, p=pop)) for g in degs]
+            indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+            indices = (np.concatenate(rows) if indptr[-1] else np.zeros(0)).astype(np.int32)
+            ip = torch.from_numpy(indptr).cuda()
+            ix = torch.from_numpy(indices if len(indices) else np.zeros(1, np.int32)).cuda()
+            c = int(rng.integers(1, 17))
+            B = U if trial % 3 == 0 else int(rng.integers(1, U + 1))
+            epoch_pos = 0 if B == U else int(rng.integers(0, U - B + 1))
+            cdf = rsx.build_item_cdf(ip, ix, I)
+            sig = rsx.build_signature(ip, ix, c) if trial % 2 else None
+            rsx.lib().rsx_debug_set_sample_sort_cap(16 if trial % 5 == 0 else 0)
+            a = _sample_sorted(ip, ix, I, B, trial, cdf, sig, c=c, key=trial * 2 + 1, epoch_pos=epoch_pos)
+            b = _sample_sorted(ip, ix, I, B, trial, None, sig, c=c, key=trial * 2 + 1, epoch_pos=epoch_pos)
+            a2 = _sample_sorted(ip, ix, I, B, trial, cdf, sig, c=c, key=trial * 2 + 1, epoch_pos=epoch_pos)
+            ctx = f"trial {trial}: U={U} I={I} B={B} c={c}"
+            for x, y in zip(a, a2):
+                live2 = a[1] >= 0
+                assert np.array_equal(x[live2], y[live2]), ctx
+            ua, ia, ja = a
+            live = ia >= 0
+            dead_users = (degs == 0) | (degs >= I)
+            assert len(np.unique(ua)) == B and (~live).sum() == dead_users[ua].sum(), ctx
+            assert np.all(live[:live.sum()]) and np.all(ja[~live] == -1), ctx       # dead rows last
+            assert np.all(np.diff(ia[live]) >= 0), ctx
+            key = lambda u_, i_: np.sort(i_.astype(np.int64) << 32 | u_)
+            assert np.array_equal(key(ua[live], ia[live]), key(b[0][b[1] >= 0], b[1][b[1] >= 0])), ctx
+            nb = -(-I // c)
+            for p in np.flatnonzero(live)[:: max(1, B // 300)]:
+                row = indices[indptr[ua[p]]:indptr[ua[p] + 1]]
+                assert ia[p] in row and ja[p] not in row and 0 <= ja[p] < I, ctx
+            # negatives of one position range share one item block (unless the user owns that block)
+            w = (np.arange(B, dtype=np.int64) * I // B) // c
+            blocks = ja // c
+            bad = 0
+            for ww in np.unique(w[live]):
+                vals, cnt = np.unique(blocks[live & (w == ww)], return_counts=True)
+                bad += cnt.sum() - cnt.max()
+            assert bad <= max(2, 0.2 * live.sum()) or kind == 2, ctx
+            assert nb >= 1
+    finally:
+        rsx.lib().rsx_debug_set_sample_sort_cap(0)
+
+
 def test_item_cdf_buckets_outside_lds_and_rows_without_a_positive():
     """buckets larger than the LDS sort capacity take the in-place path; users with an empty row
     (or owning the whole catalog) come last with i = j = -1"""
