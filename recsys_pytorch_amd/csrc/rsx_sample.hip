@@ -203,14 +203,6 @@ struct __attribute__((packed, aligned(8))) I64Pair { int64_t a, b; };
 
 __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 
-__device__ __forceinline__ int bucket_of(const uint32_t *__restrict__ cdf, uint32_t item, uint32_t u, int64_t I, int nbm)
-{
-    if ((int64_t)item >= I) return nbm;                               // "no positive": own last bucket
-    const uint32_t lo = cdf[item], hi = cdf[item + 1];
-    const uint32_t t = lo + mulhi32((uint32_t)splitmix64(0xC2B2AE3D27D4EB4Full ^ u), hi - lo);
-    return (int)mulhi32(t, (uint32_t)nbm);
-}
-
 __global__ __launch_bounds__(kChunkThreads) void bucket_chunk_kernel(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices, const uint32_t *__restrict__ cdf,
     int64_t U, int64_t I, int64_t piece_lo, int64_t n, uint64_t seed, uint64_t step, int64_t epoch_pos, int hb,
@@ -403,6 +395,7 @@ struct GlobalKeys {
 // negatives of kNegGroup batch positions per thread, advanced in lockstep (one dependent load
 // level at a time: signature, row bounds, each binary-search probe), same draws as draw_negative()
 constexpr int kNegGroup = 4;
+static_assert(kMaxChunks == 2 * kBlock, "bucket_sort_kernel reads two chunk-table entries per thread");
 
 __device__ __forceinline__ void negatives_lockstep(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices, const uint64_t *__restrict__ user_sig,
