@@ -156,6 +156,8 @@ def main():
     g_chunks = list(torch.chunk(eng.G, n_chunks, dim=0))
     q_chunks = list(torch.chunk(eng.Q, n_chunks, dim=0))
 
+    loss_acc = torch.zeros(rsx.RSX_LOSS_SLOTS, dtype=torch.float32, device=dev)
+
     def one_step(ev=None):
         main = torch.cuda.current_stream()
         cur = state["cur"]
@@ -166,7 +168,8 @@ def main():
         u, i, j = buf["t"]
         use_hot = eng.hot is not None
         hot = eng.hot if use_hot else None
-        kw = dict(users_unique=True, hot=hot, neg_block=neg_block, neg_key=buf["key"])
+        # the loss of every batch is accumulated on the device like MF.fit's epoch_loss (models/MF.py:70)
+        kw = dict(users_unique=True, hot=hot, neg_block=neg_block, neg_key=buf["key"], loss_acc=loss_acc)
         if ev is not None:
             ev[0].record()
         if world == 1:
@@ -191,7 +194,7 @@ def main():
             side.wait_event(after_items)
             prefetch(cur ^ 1)                                  # sampler of step t+1 beside the exchange
             if two_pass:
-                rsx.bpr_step(eng.P, eng.Q, eng.G, u, i, j, eng.lr, 1.0 / gb, only="users", **kw)
+                rsx.bpr_step(eng.P, eng.Q, eng.G, u, i, j, eng.lr, 1.0 / gb, only="users", **{**kw, "loss_acc": None})
             buf["free"] = torch.cuda.Event()
             buf["free"].record(main)
             for w, qc, gc in zip(works, q_chunks, g_chunks):
@@ -218,6 +221,7 @@ def main():
     ev_every = 1 if args.steps < 10 else 5
     events = {s: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
               for s in range(0, args.steps, ev_every)}
+    loss_acc.zero_()
     fence()
     t0 = time.perf_counter()
     for s in range(args.steps):
@@ -230,6 +234,8 @@ def main():
     elapsed = float(el.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events.values()]))   # bpr_step_kernel, HIP events
     assert torch.isfinite(P).all() and torch.isfinite(Q).all()
+    mean_loss = float(loss_acc.double().sum()) / (B * args.steps)      # this rank's triplets
+    assert np.isfinite(mean_loss) and 0.0 < mean_loss < 5.0, mean_loss
     replicas_equal = None
     if world > 1:      # every rank applied the same reduced gradient: the item replicas must be identical
         cs = torch.stack([Q.double().sum(), -Q.double().sum()])
@@ -308,6 +314,7 @@ def main():
                        "positives_per_user": args.degree, "item_popularity": args.popularity, "lr": args.lr,
                        "negatives": f"stratified by item block of {neg_block}, batch sorted by positive item" if neg_block else "independent uniform",
                        "sampler": "on device, overlapped on a second HIP stream",
+                       "mean_bpr_loss": mean_loss,
                        **({"item_replicas_identical": replicas_equal} if world > 1 else {}),
                        "hot_items": args.hot, "hot_replicas": args.hot_replicas if args.hot > 0 else 0,
                        "parallelism": (f"user-sharded x{world}, items replicated, 1 all-reduce(G)/step"
