@@ -188,12 +188,15 @@ class MF(BaseModel):
         eval_users = np.asarray(eval_users)
         mask = csr_to_device(eval_pos, self.device) if eval_pos is not None else None
         out_i, out_v = [], []
+        # large catalogs take the fused path, which wants many 8 192-row passes per call (two are in
+        # flight at a time); small ones score a dense [test_batch_size x I] tile like the reference
+        chunk = max(int(test_batch_size), 65536) if self.num_items >= 32768 else int(test_batch_size)
         ws = None
-        for s in range(0, len(eval_users), test_batch_size):
-            users = self._idx(eval_users[s:s + test_batch_size])
+        for s in range(0, len(eval_users), chunk):
+            users = self._idx(eval_users[s:s + chunk])
             if ws is None:
-                ws = torch.empty(min(len(eval_users), test_batch_size, 1024) * self.num_items,
-                                 dtype=torch.float32, device=self.device)
+                need = self._k.lib().rsx_score_topk_workspace(users.numel(), self.num_items) if hasattr(self._k, "lib") else 0
+                ws = torch.empty(max(need, 4) // 4 + 64, dtype=torch.float32, device=self.device)
             r = self._k.score_topk(self._P, self._Q, users, K, mask=mask, want_values=want_values, ws=ws)
             if want_values:
                 out_i.append(r[0].cpu().numpy()); out_v.append(r[1].cpu().numpy())
