@@ -152,7 +152,9 @@ def main():
     # when the exchange takes longer than the user pass plus the sampler (~375 us): expected with
     # the 1 or 3 xGMI links of 2 or 4 GPUs, not with the 7 links of 8 (estimate; RSX_TWO_PASS overrides)
     two_pass = world > 1 and os.environ.get("RSX_TWO_PASS", "1" if world <= 4 else "0") == "1"
-    n_chunks = max(1, int(os.environ.get("RSX_EXCHANGE_CHUNKS", "4"))) if world > 1 else 1
+    # one all-reduce of the whole G by default: RCCL's bus bandwidth still rises with the message size
+    # around 51 MB, which outweighs hiding the apply sweep behind later chunks (RSX_EXCHANGE_CHUNKS > 1)
+    n_chunks = max(1, int(os.environ.get("RSX_EXCHANGE_CHUNKS", "1"))) if world > 1 else 1
     g_chunks = list(torch.chunk(eng.G, n_chunks, dim=0))
     q_chunks = list(torch.chunk(eng.Q, n_chunks, dim=0))
 
@@ -186,8 +188,8 @@ def main():
                 ev[1].record()
             if use_hot:
                 rsx.fold_hot_grad(eng.G, eng.hot)              # the all-reduce needs the folded G
-            # the exchange goes in item-range chunks so that the apply sweep of chunk k runs while the
-            # later chunks are still travelling (only the last chunk's sweep stays exposed)
+            # (optionally in item-range chunks, so that the apply sweep of chunk k runs while the later
+            #  chunks are still travelling)
             works = [dist.all_reduce(c, op=dist.ReduceOp.SUM, async_op=True) for c in g_chunks]
             after_items = torch.cuda.Event()
             after_items.record(main)
@@ -318,7 +320,7 @@ def main():
                        **({"item_replicas_identical": replicas_equal} if world > 1 else {}),
                        "hot_items": args.hot, "hot_replicas": args.hot_replicas if args.hot > 0 else 0,
                        "parallelism": (f"user-sharded x{world}, items replicated, 1 all-reduce(G)/step"
-                                       + f" in {n_chunks} chunks pipelined with the apply sweep"
+                                       + (f" in {n_chunks} chunks pipelined with the apply sweep" if n_chunks > 1 else "")
                                        + (", under the user pass of a two-pass step" if two_pass else "")) if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "bpr_step_blocked_kernel" if neg_block else "bpr_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
