@@ -113,6 +113,64 @@ def test_bpr_step_random_vs_oracle(rsx, oracle_mod, d, B):
     assert np.allclose(losses, ol, rtol=1e-5, atol=1e-6)
 
 
+def test_step_kernels_on_random_shapes(rsx, oracle_mod):
+    """48 random problems through every step path (general / unique users / blocked with any
+    neg_block and key / hot-item replicas / two passes / skipped triplets / sorted or shuffled
+    positions), three steps each, against the CPU oracle"""
+    rng = np.random.default_rng(777)
+    for trial in range(48):
+        d = int(rng.choice([32, 64, 128]))
+        U, I = int(rng.integers(1, 3000)), int(rng.integers(2, 2000))
+        unique = trial % 3 != 0
+        B = int(rng.integers(1, U + 1)) if unique else int(rng.integers(1, 4000))
+        c = int(rng.integers(0, 17)) if unique else 0
+        key = int(rng.integers(0, 2**62)) * (trial % 2)
+        lr = float(rng.choice([0.05, 1.0]))
+        P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+        Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+        orc = oracle_mod.MFOracle(P0, Q0, "sgd", lr)
+        P, Q = torch.from_numpy(P0).cuda(), torch.from_numpy(Q0).cuda()
+        G = torch.zeros_like(Q)
+        hot = rsx.HotItems(torch.from_numpy(rng.integers(0, 100, I)), int(rng.integers(1, min(I, 64) + 1)),
+                           int(rng.choice([1, 4, 16])), d, "cuda") if trial % 4 == 1 else None
+        ws = None if unique else torch.zeros(rsx.bpr_step_workspace(U, B, d), dtype=torch.uint8, device="cuda")
+        ctx = f"trial {trial}: U={U} I={I} d={d} B={B} unique={unique} c={c} hot={hot is not None} lr={lr}"
+        for step in range(3):
+            u = rng.permutation(U)[:B] if unique else rng.integers(0, U, B)
+            pop = rng.integers(0, I, B) if trial % 2 else np.minimum(I - 1, (rng.pareto(1.0, B) * 2).astype(np.int64))
+            i, j = pop.copy(), rng.integers(0, I, B)
+            if trial % 5 == 2:
+                order = np.argsort(i, kind="stable")               # the sampler's order
+                u, i, j = u[order], i[order], j[order]
+            i_dev = i.copy()
+            if trial % 7 == 3:
+                i_dev[rng.random(B) < 0.2] = -1                      # users without a positive: skipped
+            live = i_dev >= 0
+            n_live = int(live.sum())
+            want_loss = orc.step(u[live], i[live], j[live]) if n_live else 0.0
+            # the oracle averages over the live triplets; the device call gets the same 1/n as inv_batch
+            ut, it, jt = (torch.from_numpy(x.astype(np.int32)).cuda() for x in (u, i_dev, j))
+            loss = torch.zeros(rsx.RSX_LOSS_SLOTS, device="cuda")
+            kw = dict(users_unique=unique, ws=ws, hot=hot, neg_block=c, neg_key=key if c else 0)
+            inv = 1.0 / max(n_live, 1)
+            if unique and trial % 6 == 4:
+                rsx.bpr_step(P, Q, G, ut, it, jt, lr, inv, loss_acc=loss, only="items", **kw)
+                rsx.bpr_step(P, Q, G, ut, it, jt, lr, inv, only="users", **kw)
+            else:
+                rsx.bpr_step(P, Q, G, ut, it, jt, lr, inv, loss_acc=loss, **kw)
+            if hot is not None and step % 2 == 0:
+                rsx.fold_hot_grad(G, hot)
+                rsx.apply_item_grad(Q, G, lr)
+            else:
+                rsx.apply_item_grad(Q, G, lr, hot=hot)
+            if n_live:
+                assert abs(float(loss.sum()) / n_live - want_loss) < 2e-5 * max(1.0, abs(want_loss)), ctx
+        scale = lambda a: max(float(np.abs(a).max()), 1e-6)
+        assert np.abs(P.cpu().numpy() - orc.P).max() < REL_TOL * scale(orc.P), ctx
+        assert np.abs(Q.cpu().numpy() - orc.Q).max() < REL_TOL * scale(orc.Q), ctx
+        assert float(G.abs().max()) == 0.0 and (hot is None or float(hot.ghot.abs().max()) == 0.0), ctx
+
+
 def test_bpr_step_unique_users_fast_path_equals_general_path(rsx, oracle_mod):
     rng = np.random.default_rng(5)
     U, I, d, B = 5000, 700, 128, 3001
@@ -282,6 +340,36 @@ def test_fused_score_topk_equals_dense_path(rsx, oracle_mod, d, I, rows, K):
     want = oracle_mod.topk(Sn, K)                                  # and the CPU oracle agrees
     assert np.array_equal(idx.cpu().numpy(), want)
     assert not torch.isinf(val).any()
+
+
+def test_fused_score_topk_on_random_shapes(rsx, oracle_mod):
+    """16 random (d, catalog, rows, K, mask density, score scale) problems around the fused path's
+    thresholds (32 768 items, 8 192 rows per pass, K up to 512): identical to dense scoring + row top-k
+    and to the CPU oracle's order"""
+    from recsys_pytorch_amd.data import synthetic_csr
+    rng = np.random.default_rng(4242)
+    for trial in range(16):
+        d = int(rng.choice([32, 64, 128]))
+        I = int(rng.choice([32_768, 32_769, 40_000, 50_011, 70_003]))
+        rows = int(rng.choice([1, 63, 129, 1024, 3000, 8192, 8193, 9000]))
+        K = int(rng.choice([1, 5, 50, 128, 512]))
+        U = 3000
+        torch.manual_seed(trial)
+        scale = float(rng.choice([0.01, 0.1, 3.0]))
+        P = torch.randn(U, d, device="cuda") * scale
+        Q = torch.randn(I, d, device="cuda") * scale
+        users = torch.randint(0, U, (rows,), device="cuda").to(torch.int32)
+        mask = synthetic_csr(U, I, int(rng.choice([1, 30, 300])), "cuda", seed=trial) if trial % 4 else None
+        idx, val = rsx.score_topk(P, Q, users, K, mask=mask, want_values=True)
+        ctx = f"trial {trial}: d={d} I={I} rows={rows} K={K} mask={mask is not None} scale={scale}"
+        for r0 in range(0, rows, 2048):                       # dense reference in slabs (memory)
+            sl = slice(r0, min(rows, r0 + 2048))
+            S = rsx.score(P, Q, users[sl], mask=mask)
+            ref_i, ref_v = rsx.topk(S, K, want_values=True)
+            assert torch.equal(val[sl], ref_v) and torch.equal(idx[sl], ref_i), ctx
+            if r0 == 0:
+                n = min(64, S.shape[0])
+                assert np.array_equal(idx[:n].cpu().numpy(), oracle_mod.topk(S[:n].cpu().numpy(), K)), ctx
 
 
 def test_fused_score_topk_degenerate_ties_take_the_dense_redo(rsx, oracle_mod):
