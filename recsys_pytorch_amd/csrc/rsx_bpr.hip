@@ -763,7 +763,9 @@ RSX_API int rsx_apply_item_grad(float *Q, float *G, int64_t num_items, int d, fl
         hot = HotMap{hot_slot_dev, G_hot, hot_replicas};
     }
     const int64_t n4 = num_items * d / 4;
-    hipLaunchKernelGGL(apply_item_grad_kernel, dim3((unsigned)grid_1d(n4)), dim3(kBlock), 0,
+    // one trip of four quads per thread when the table is large (an uneven grid-stride tail costs ~25 %)
+    const int64_t blocks = ceil_div64(n4, (int64_t)kBlock * 4);
+    hipLaunchKernelGGL(apply_item_grad_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(kBlock), 0,
                        (hipStream_t)stream, (float4 *)Q, (float4 *)G, n4, lr, hot, d / 4);
     RSX_CHECK_LAUNCH();
     return RSX_OK;
