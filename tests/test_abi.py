@@ -57,3 +57,14 @@ def test_argument_errors_use_the_error_channel(libpath):
     assert L.rsx_bpr_step_workspace(10, 10, 48) < 0          # unsupported d
     rc = L.rsx_apply_item_grad(None, None, 10, 32, 0.1, None, None, 0, None)
     assert rc == -1 and b"null" in L.rsx_last_error()
+    # sampler sizing calls run on the host: shapes are validated, sizes grow with the batch
+    assert L.rsx_bpr_sample_workspace(-1, 10) < 0 and L.rsx_bpr_sample_workspace(10, 0) < 0
+    assert L.rsx_bpr_sample_workspace(0, 10) == 0
+    small, big = L.rsx_bpr_sample_workspace(1000, 100_000), L.rsx_bpr_sample_workspace(1_000_000, 100_000)
+    assert 0 < small < big < (1 << 30)
+    assert L.rsx_bpr_item_cdf_workspace(0) < 0 and L.rsx_bpr_item_cdf_workspace(1000) >= 8000
+    assert L.rsx_score_topk_workspace(-1, 10) < 0 and L.rsx_score_topk_workspace(1024, 100_000) >= 1024 * 100_000 * 4
+    rc = L.rsx_bpr_sample(None, None, 10, 10, 5, 1, 0, 0, 0, 0, 0, None, 0, None, None, None, None, None, None)
+    assert rc == -1 and b"null" in L.rsx_last_error()
+    rc = L.rsx_bpr_build_item_cdf(None, None, 10, 10, None, None, 0, None)
+    assert rc == -1
