@@ -272,7 +272,7 @@ def main():
     if args.score_tiles > 0 and rank == 0:
         tiles, K = args.score_tiles, args.topk
         if os.environ.get("RSX_SCORE_LANES"):
-            rsx.lib().rsx_debug_set_score_lanes(int(os.environ["RSX_SCORE_LANES"]))
+            rsx.set_option("score_lanes", int(os.environ["RSX_SCORE_LANES"]))
         users = torch.arange(1024 * tiles, device=dev, dtype=torch.int32) % U
         ws = torch.empty(rsx.lib().rsx_score_topk_workspace(users.numel(), I) // 4 + 64, dtype=torch.float32, device=dev)
         mask = (indptr, indices)

@@ -70,6 +70,17 @@ int rsx_version(void);
 const char *rsx_last_error(void);
 int rsx_device_info_get(int device, rsx_device_info *out);
 
+/* Process-wide options (the only mutable library state besides the per-device side streams of
+ * rsx_score_topk).  Unknown names and out-of-range values return RSX_E_INVALID.
+ *   "score_lanes"     1..4 (default 2): 8192-row passes of rsx_score_topk in flight, one HIP stream
+ *                     each (the selection kernels of one pass run under the product of another)
+ *   "sample_sort_cap" 0..2048 (default 0 = 2048): pairs a bucket of the sorted sampler may hold and
+ *                     still be sorted in LDS; tests lower it to exercise the out-of-LDS path.  The
+ *                     sampled triplets do not depend on it.
+ * There is no option that skips work: the development ablation switches of the kernels exist only
+ * in the separate dev build (librsx_dev.so, -DRSX_ABLATE), never in librsx.so.                    */
+int rsx_set_option(const char *name, int64_t value);
+
 /* ---- BPR triplet step -------------------------------------------------------
  * Replaces, for the pairwise branch, one iteration of the reference loop
  *   models/MF.py:64-68   zero_grad / process_one_batch / backward / step

@@ -1,6 +1,9 @@
 """Build librsx.so (the C-ABI HIP library) in-tree for gfx950.
 
-    python -m recsys_pytorch_amd.build [--force]
+    python -m recsys_pytorch_amd.build [--force] [--dev]
+
+--dev additionally builds librsx_dev.so with -DRSX_ABLATE (development write/load switches for
+tools/ablate*.py; load it with RSX_LIB=.../librsx_dev.so).  The product library never has them.
 
 hipcc cross-compiles without a GPU.  The .so lands next to this file so it
 travels with the source tree (git-ignored, not gpurun-ignored).
@@ -22,25 +25,30 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def _stale():
-    if not os.path.exists(LIB):
+DEV_LIB = os.path.join(HERE, "librsx_dev.so")
+
+
+def _stale(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + \
         [os.path.join(HERE, "..", "include", "rsx.h"), os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
-        return LIB
+def build(force=False, verbose=False, dev=False):
+    lib = DEV_LIB if dev else LIB
+    if not force and not _stale(lib):
+        return lib
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    objdir = os.path.join(HERE, "build", "dev" if dev else "")
+    os.makedirs(objdir, exist_ok=True)
     procs = []
     for src in sources():
-        obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
-        cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, "-c", src, "-o", obj]
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, *(["-DRSX_ABLATE"] if dev else []), "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))
@@ -48,10 +56,12 @@ def build(force=False, verbose=False):
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib, *objs]
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--dev" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, dev=True))

@@ -27,6 +27,26 @@ int rsx_num_cus()
     return cus[dev];
 }
 
+int g_rsx_score_lanes = 2;
+int g_rsx_sort_cap = 0;
+
+RSX_API int rsx_set_option(const char *name, int64_t value)
+{
+    RSX_CHECK_ARG(name != nullptr, "null option name");
+    if (strcmp(name, "score_lanes") == 0) {
+        RSX_CHECK_ARG(value >= 1 && value <= 4, "score_lanes must be in [1, 4]");
+        g_rsx_score_lanes = (int)value;
+        return RSX_OK;
+    }
+    if (strcmp(name, "sample_sort_cap") == 0) {
+        RSX_CHECK_ARG(value >= 0 && value <= 2048, "sample_sort_cap must be in [0, 2048] (0 = default)");
+        g_rsx_sort_cap = (int)value;
+        return RSX_OK;
+    }
+    rsx_set_error("rsx_set_option: unknown option '%s'", name);
+    return RSX_E_INVALID;
+}
+
 RSX_API int rsx_version(void) { return RSX_ABI_VERSION; }
 
 RSX_API const char *rsx_last_error(void) { return g_err; }

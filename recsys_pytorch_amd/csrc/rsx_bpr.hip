@@ -42,17 +42,6 @@ struct Row {
 #pragma unroll
         for (int c = 0; c < EPL; ++c) v[c] = row[elem(k, c)];
     }
-    // streaming (non-temporal) variants for rows nobody re-reads (measured: no effect)
-    __device__ __forceinline__ void load_nt(const float *row, int k)
-    {
-#pragma unroll
-        for (int c = 0; c < EPL; ++c) v[c] = __builtin_nontemporal_load(row + elem(k, c));
-    }
-    __device__ __forceinline__ void store_nt(float *row, int k) const
-    {
-#pragma unroll
-        for (int c = 0; c < EPL; ++c) __builtin_nontemporal_store(v[c], row + elem(k, c));
-    }
     __device__ __forceinline__ void store(float *row, int k) const
     {
 #pragma unroll
@@ -130,14 +119,20 @@ struct HotMap {
 // MODE 1: users may repeat          -> user deltas summed into GU[owner slot].
 // MODE 2: gradients only            -> dP summed into the dense buffer GU[u] (P untouched);
 //                                      the optimizer sweep (adam_apply_kernel) consumes it.
-template <int D, int MODE>
+// PASS (compile time): which side of the step this launch WRITES.  kPassItems = the item sums
+// (G / replicas), kPassUsers = the user rows; both = the whole step, neither = loss only
+// (RSX_NO_UPDATE).  RSX_ITEMS_ONLY / RSX_USERS_ONLY are the two halves of the two-pass step.
+constexpr int kPassItems = 1, kPassUsers = 2, kPassBoth = 3;
+
+template <int D, int MODE, int PASS>
 __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
     float *__restrict__ P, const float *__restrict__ Q, float *__restrict__ G,
     const int32_t *__restrict__ U_idx, const int32_t *__restrict__ I_idx,
     const int32_t *__restrict__ J_idx, int64_t B, float lr, float inv_batch,
     float *__restrict__ loss_acc, const int32_t *__restrict__ owner, float *__restrict__ GU,
-    HotMap hot, int ablate)
+    HotMap hot)
 {
+    static_assert(MODE == 0 || PASS == kPassBoth, "the split passes exist for the in-place (unique users) mode only");
     constexpr int EPL = D / 32;
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR;
@@ -161,7 +156,7 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
             const float *qi_row = Q + (size_t)i * D;
             const float *qj_row = Q + (size_t)j * D;
             Row<D> p, qi, qj;
-            if (ablate & 8) p.load_nt(prow, k); else p.load(prow, k);
+            p.load(prow, k);
             qi.load(qi_row, k);
             qj.load(qj_row, k);
             float dpos = 0.0f, dneg = 0.0f;
@@ -177,22 +172,26 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
             const float x = dpos - dneg;
             const float sneg = 1.0f / (1.0f + __expf(x));      // sigmoid(-x)
             const float g = -sneg * inv_batch;                 // dL/dx
-            if (k == 0) loss_local += softplus_neg(x);
+            if (loss_acc != nullptr && k == 0) loss_local += softplus_neg(x);
             // item gradients (shared rows): G[i] += g p ; G[j] -= g p
-            float *gi_row = G + (size_t)i * D;
-            if (hot.slot != nullptr) {
-                const int32_t hs = hot.slot[i];
-                if (hs >= 0)
-                    gi_row = hot.ghot + ((size_t)hs * hot.replicas + (size_t)(wave & (hot.replicas - 1))) * D;
+            if constexpr ((PASS & kPassItems) != 0) {
+                float *gi_row = G + (size_t)i * D;
+                if (hot.slot != nullptr) {
+                    const int32_t hs = hot.slot[i];
+                    if (hs >= 0)
+                        gi_row = hot.ghot + ((size_t)hs * hot.replicas + (size_t)(wave & (hot.replicas - 1))) * D;
+                }
+                if (!RSX_ABL(1)) p.atomic_axpy(gi_row, k, g);
+                if (!RSX_ABL(2)) p.atomic_axpy(G + (size_t)j * D, k, -g);
             }
-            if (!(ablate & 1)) p.atomic_axpy(gi_row, k, g);
-            if (!(ablate & 2)) p.atomic_axpy(G + (size_t)j * D, k, -g);
             // user row: P[u] -= lr * g * (qi - qj)
             const float s = -lr * g;
             if constexpr (MODE == 0) {
+                if constexpr ((PASS & kPassUsers) != 0) {
 #pragma unroll
-                for (int c = 0; c < EPL; ++c) p.v[c] = fmaf(s, qi.v[c] - qj.v[c], p.v[c]);
-                if (!(ablate & 4)) { if (ablate & 16) p.store_nt(prow, k); else p.store(prow, k); }
+                    for (int c = 0; c < EPL; ++c) p.v[c] = fmaf(s, qi.v[c] - qj.v[c], p.v[c]);
+                    if (!RSX_ABL(4)) p.store(prow, k);
+                }
             } else {
                 Row<D> dq;
 #pragma unroll
@@ -228,13 +227,14 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
 //    registers, touching G once per run.
 // Neither is a correctness contract: a negative outside the wave's block and an unsorted batch
 // take the global-atomic path / runs of length one, and the sums are the same.
-template <int D>
+template <int D, int PASS>
 __global__ __launch_bounds__(kBlock, 6) void bpr_step_blocked_kernel(
     float *__restrict__ P, const float *__restrict__ Q, float *__restrict__ G,
     const int32_t *__restrict__ U_idx, const int32_t *__restrict__ I_idx,
     const int32_t *__restrict__ J_idx, int64_t B, int64_t num_items, int c, uint64_t neg_key, float lr,
-    float inv_batch, float *__restrict__ loss_acc, HotMap hot, int ablate)
+    float inv_batch, float *__restrict__ loss_acc, HotMap hot)
 {
+    constexpr bool kItems = (PASS & kPassItems) != 0, kUsers = (PASS & kPassUsers) != 0;
     extern __shared__ __attribute__((aligned(16))) float neg_acc[];   // [4 waves][c][D]
     using RowT = Row<D>;
     constexpr int EPL = D / 32;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kBlock, 6) void bpr_step_blocked_kernel(
     // a popular item's run spans hundreds of wavefronts, which all flush into the same row at
     // about the same time (same-line atomics serialise): such rows go to the replicas (HotMap)
 #define RSX_RUN_FLUSH(RI, R)                                                      \
-    if (RI >= 0 && !(ablate & 1)) {                                               \
+    if (kItems && RI >= 0 && !RSX_ABL(1)) {                                       \
         float *grow = G + (size_t)RI * D;                                         \
         if (hot.slot != nullptr) {                                                \
             const int32_t hs = hot.slot[RI];                                      \
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(kBlock, 6) void bpr_step_blocked_kernel(
             const float x = dpos - dneg;
             const float sneg = 1.0f / (1.0f + __expf(x));
             const float g = -sneg * inv_batch;
-            if (k == 0) loss_local += softplus_neg(x);
+            if (loss_acc != nullptr && k == 0) loss_local += softplus_neg(x);
             // positive item: extend its run, or flush the run and start a new one
             if (i != run_item) {
                 RSX_RUN_FLUSH(run_item, run)
@@ -310,19 +310,21 @@ __global__ __launch_bounds__(kBlock, 6) void bpr_step_blocked_kernel(
             for (int cc = 0; cc < EPL; ++cc) run[cc] = fmaf(g, p.v[cc], run[cc]);
             // negative item: the wave's own block goes to LDS, anything else to G
             neg_local = ((int64_t)j >= item_lo && (int64_t)j < item_hi);
-            if (!neg_local && !(ablate & 2)) p.atomic_axpy(G + (size_t)j * D, k, -g);
+            if (kItems && !neg_local && !RSX_ABL(2)) p.atomic_axpy(G + (size_t)j * D, k, -g);
             neg_g = -g;
 #pragma unroll
             for (int cc = 0; cc < EPL; ++cc) pv[cc] = p.v[cc];
-            const float s = -lr * g;
+            if constexpr (kUsers) {
+                const float s = -lr * g;
 #pragma unroll
-            for (int cc = 0; cc < EPL; ++cc) p.v[cc] = fmaf(s, qi.v[cc] - qj.v[cc], p.v[cc]);
-            if (!(ablate & 4)) p.store(P + (size_t)u * D, k);
+                for (int cc = 0; cc < EPL; ++cc) p.v[cc] = fmaf(s, qi.v[cc] - qj.v[cc], p.v[cc]);
+                if (!RSX_ABL(4)) p.store(P + (size_t)u * D, k);
+            }
         }
         // wave-private LDS tile, plain read-modify-write (ds_add_f32 measured ~120 clk per
         // wave instruction).  The lane groups of one wavefront may hit the same row, so they
         // take turns; LDS executes a wavefront's instructions in order.
-        if (!(ablate & 2)) {
+        if (kItems && !RSX_ABL(2)) {
 #pragma unroll
             for (int tt = 0; tt < TPW; ++tt) {
                 if (sub == tt && neg_local) {
@@ -350,8 +352,8 @@ __global__ __launch_bounds__(kBlock, 6) void bpr_step_blocked_kernel(
         const bool live_a = (b < g_hi) && (ia >= 0);
         const bool live_b = (b + 1 < g_hi) && (ib >= 0);
         Row<D> pa, qia, qja, pb, qib, qjb;
-        if (live_a) { pa.load(P + (size_t)ua * D, k); qia.load(Q + (size_t)((ablate & 32) ? 0 : ia) * D, k); qja.load(Q + (size_t)((ablate & 64) ? 1 : ja) * D, k); }
-        if (live_b) { pb.load(P + (size_t)ub * D, k); qib.load(Q + (size_t)((ablate & 32) ? 0 : ib) * D, k); qjb.load(Q + (size_t)((ablate & 64) ? 1 : jb) * D, k); }
+        if (live_a) { pa.load(P + (size_t)ua * D, k); qia.load(Q + (size_t)(RSX_ABL(32) ? 0 : ia) * D, k); qja.load(Q + (size_t)(RSX_ABL(64) ? 1 : ja) * D, k); }
+        if (live_b) { pb.load(P + (size_t)ub * D, k); qib.load(Q + (size_t)(RSX_ABL(32) ? 0 : ib) * D, k); qjb.load(Q + (size_t)(RSX_ABL(64) ? 1 : jb) * D, k); }
         process(live_a, ua, ia, ja, pa, qia, qja);
         process(live_b, ub, ib, jb, pb, qib, qjb);
         ua = una; ia = ina; ja = jna; ub = unb; ib = inb; jb = jnb;
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(kBlock, 6) void bpr_step_blocked_kernel(
     RSX_RUN_FLUSH(run_item, run)     // last run of this lane group
 #undef RSX_RUN_FLUSH
     // flush the block's rows: one global atomic row per touched item
-    const int rows = (int)(item_hi - item_lo);
+    const int rows = kItems ? (int)(item_hi - item_lo) : 0;
     for (int m = sub; m - sub < rows; m += TPW) {
         float v[EPL];
 #pragma unroll
@@ -561,31 +563,41 @@ __global__ __launch_bounds__(kBlock) void fold_hot_kernel(float *__restrict__ G,
     *dst = g;
 }
 
-int g_ablate = 0;       // development only: 1 = skip pos-item atomics, 2 = skip neg-item atomics, 4 = skip P store
-
-template <int D, int MODE>
+template <int D, int MODE, int PASS>
 void launch_step(float *P, const float *Q, float *G, const int32_t *u, const int32_t *i,
                  const int32_t *j, int64_t B, float lr, float inv_batch, float *loss_acc,
-                 const int32_t *owner, float *GU, HotMap hot, int ablate, hipStream_t st)
+                 const int32_t *owner, float *GU, HotMap hot, hipStream_t st)
 {
     const int64_t waves = (B + TPW - 1) / TPW;
     int64_t blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
     const int64_t cap = (int64_t)rsx_num_cus() * 8;   // 8 blocks x 4 waves = 32 waves per CU
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((bpr_step_kernel<D, MODE>), dim3((unsigned)blocks), dim3(kBlock), 0, st, P, Q,
-                       G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot, ablate);
+    hipLaunchKernelGGL((bpr_step_kernel<D, MODE, PASS>), dim3((unsigned)blocks), dim3(kBlock), 0, st, P, Q,
+                       G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot);
 }
 
-template <int MODE>
+template <int MODE, int PASS>
 void dispatch_step(int d, float *P, const float *Q, float *G, const int32_t *u, const int32_t *i,
                    const int32_t *j, int64_t B, float lr, float inv_batch, float *loss_acc,
-                   const int32_t *owner, float *GU, HotMap hot, int ablate, hipStream_t st)
+                   const int32_t *owner, float *GU, HotMap hot, hipStream_t st)
 {
     switch (d) {
-    case 32: launch_step<32, MODE>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot, ablate, st); break;
-    case 64: launch_step<64, MODE>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot, ablate, st); break;
-    default: launch_step<128, MODE>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot, ablate, st); break;
+    case 32: launch_step<32, MODE, PASS>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot, st); break;
+    case 64: launch_step<64, MODE, PASS>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot, st); break;
+    default: launch_step<128, MODE, PASS>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot, st); break;
+    }
+}
+
+template <int PASS>
+void dispatch_blocked(int d, unsigned blocks, size_t lds, hipStream_t st, float *P, const float *Q, float *G,
+                      const int32_t *u, const int32_t *i, const int32_t *j, int64_t B, int64_t num_items,
+                      int c, uint64_t neg_key, float lr, float inv_batch, float *loss_acc, HotMap hot)
+{
+    switch (d) {
+    case 32: hipLaunchKernelGGL((bpr_step_blocked_kernel<32, PASS>), dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u, i, j, B, num_items, c, neg_key, lr, inv_batch, loss_acc, hot); break;
+    case 64: hipLaunchKernelGGL((bpr_step_blocked_kernel<64, PASS>), dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u, i, j, B, num_items, c, neg_key, lr, inv_batch, loss_acc, hot); break;
+    default: hipLaunchKernelGGL((bpr_step_blocked_kernel<128, PASS>), dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u, i, j, B, num_items, c, neg_key, lr, inv_batch, loss_acc, hot); break;
     }
 }
 
@@ -599,8 +611,13 @@ int64_t grid_1d(int64_t n)
 
 }  // namespace
 
-// undocumented tuning hook (bench / tests): select the row layout of bpr_step
-RSX_API int rsx_debug_set_ablation(int mask) { g_ablate = mask; return RSX_OK; }
+#ifdef RSX_ABLATE
+// dev build only (librsx_dev.so): write/load switches for tools/ablate*.py
+RSX_API int rsx_debug_set_ablation(int mask)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_rsx_ablate), &mask, sizeof(int)) == hipSuccess ? RSX_OK : RSX_E_HIP;
+}
+#endif
 
 RSX_API int64_t rsx_bpr_step_workspace(int64_t num_users, int64_t max_batch, int d)
 {
@@ -627,36 +644,34 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
         RSX_CHECK_ARG(hot_replicas >= 1 && (hot_replicas & (hot_replicas - 1)) == 0, "hot_replicas must be a power of two");
         hot = HotMap{hot_slot_dev, G_hot, hot_replicas};
     }
-    if (flags & RSX_NO_UPDATE) {   // loss only: the in-place kernel with every write suppressed
-        dispatch_step<0>(d, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch,
-                         loss_acc, nullptr, nullptr, HotMap{nullptr, nullptr, 1}, /*suppress every write*/ 7, st);
+    if (flags & RSX_NO_UPDATE) {   // loss only: the in-place kernel with neither side written
+        dispatch_step<0, 0>(d, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch, loss_acc, nullptr, nullptr,
+                            HotMap{nullptr, nullptr, 1}, st);
         RSX_CHECK_LAUNCH();
         return RSX_OK;
     }
     RSX_CHECK_ARG(neg_block >= 0 && neg_block <= kMaxNegBlock, "neg_block must be in [0, 16]");
-    // two-pass step: the kernels' write switches (1 positive-item sums, 2 negative-item sums, 4 P store)
-    int ablate = g_ablate;
+    int pass = kPassBoth;          // two-pass step: which side this launch writes
     if (flags & (RSX_ITEMS_ONLY | RSX_USERS_ONLY)) {
         RSX_CHECK_ARG(flags & RSX_USERS_UNIQUE, "RSX_ITEMS_ONLY / RSX_USERS_ONLY need RSX_USERS_UNIQUE");
         RSX_CHECK_ARG((flags & (RSX_ITEMS_ONLY | RSX_USERS_ONLY)) != (RSX_ITEMS_ONLY | RSX_USERS_ONLY), "pick one pass");
-        if (flags & RSX_ITEMS_ONLY) ablate |= 4;
-        if (flags & RSX_USERS_ONLY) { ablate |= 3; loss_acc = nullptr; }
+        if (flags & RSX_ITEMS_ONLY) pass = kPassItems;
+        if (flags & RSX_USERS_ONLY) { pass = kPassUsers; loss_acc = nullptr; }
     }
     if ((flags & RSX_USERS_UNIQUE) && neg_block > 0) {
         const int64_t waves = ceil_div64(num_items, neg_block);
         const unsigned blocks = (unsigned)ceil_div64(waves, kWavesPerBlock);
         const size_t lds = (size_t)kWavesPerBlock * neg_block * d * sizeof(float);
-        switch (d) {
-        case 32: hipLaunchKernelGGL(bpr_step_blocked_kernel<32>, dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u_dev, i_dev, j_dev, batch, num_items, neg_block, neg_key, lr, inv_batch, loss_acc, hot, ablate); break;
-        case 64: hipLaunchKernelGGL(bpr_step_blocked_kernel<64>, dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u_dev, i_dev, j_dev, batch, num_items, neg_block, neg_key, lr, inv_batch, loss_acc, hot, ablate); break;
-        default: hipLaunchKernelGGL(bpr_step_blocked_kernel<128>, dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u_dev, i_dev, j_dev, batch, num_items, neg_block, neg_key, lr, inv_batch, loss_acc, hot, ablate); break;
-        }
+#define RSX_BLOCKED(PASS_) dispatch_blocked<PASS_>(d, blocks, lds, st, P, Q, G, u_dev, i_dev, j_dev, batch, num_items, neg_block, neg_key, lr, inv_batch, loss_acc, hot)
+        if (pass == kPassItems) RSX_BLOCKED(kPassItems); else if (pass == kPassUsers) RSX_BLOCKED(kPassUsers); else RSX_BLOCKED(kPassBoth);
+#undef RSX_BLOCKED
         RSX_CHECK_LAUNCH();
         return RSX_OK;
     }
     if (flags & RSX_USERS_UNIQUE) {
-        dispatch_step<0>(d, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch,
-                         loss_acc, nullptr, nullptr, hot, ablate, st);
+#define RSX_INPLACE(PASS_) dispatch_step<0, PASS_>(d, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch, loss_acc, nullptr, nullptr, hot, st)
+        if (pass == kPassItems) RSX_INPLACE(kPassItems); else if (pass == kPassUsers) RSX_INPLACE(kPassUsers); else RSX_INPLACE(kPassBoth);
+#undef RSX_INPLACE
         RSX_CHECK_LAUNCH();
         return RSX_OK;
     }
@@ -670,8 +685,7 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
     float *GU = (float *)((char *)ws + ((num_users * 4 + 255) / 256) * 256);
     const unsigned g1 = (unsigned)grid_1d(batch);
     hipLaunchKernelGGL(bpr_claim_kernel, dim3(g1), dim3(kBlock), 0, st, u_dev, i_dev, batch, owner);
-    dispatch_step<1>(d, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch,
-                     loss_acc, owner, GU, hot, g_ablate, st);
+    dispatch_step<1, kPassBoth>(d, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch, loss_acc, owner, GU, hot, st);
     const int64_t tpw = 64 / (d / 4);     // bpr_apply_user_kernel: one float4 per lane
     const unsigned g2 = (unsigned)grid_1d((batch + tpw - 1) / tpw * 64);
     switch (d) {
@@ -694,8 +708,8 @@ RSX_API int rsx_bpr_grad(const float *P, const float *Q, float *GP, float *GQ, i
     RSX_CHECK_ARG(batch >= 0 && num_users > 0 && num_items > 0, "negative size");
     if (batch == 0) return RSX_OK;
     RSX_CHECK_ARG(u_dev && i_dev && j_dev, "null index pointer");
-    dispatch_step<2>(d, const_cast<float *>(P), Q, GQ, u_dev, i_dev, j_dev, batch, 0.0f, inv_batch,
-                     loss_acc, nullptr, GP, HotMap{nullptr, nullptr, 1}, 0, (hipStream_t)stream);
+    dispatch_step<2, kPassBoth>(d, const_cast<float *>(P), Q, GQ, u_dev, i_dev, j_dev, batch, 0.0f, inv_batch,
+                                loss_acc, nullptr, GP, HotMap{nullptr, nullptr, 1}, (hipStream_t)stream);
     RSX_CHECK_LAUNCH();
     return RSX_OK;
 }

@@ -39,6 +39,20 @@ __device__ __forceinline__ void rsx_atomic_add(float *p, float v)
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Development ablation switches exist ONLY in the dev build (-DRSX_ABLATE -> librsx_dev.so, built by
+// `python -m recsys_pytorch_amd.build --dev` for tools/ablate*.py).  In the shipped library RSX_ABL()
+// is the constant false: no kernel of librsx.so can be told at run time to drop a store or an atomic.
+#ifdef RSX_ABLATE
+static __constant__ int c_rsx_ablate = 0;
+#define RSX_ABL(mask) ((c_rsx_ablate & (mask)) != 0)
+#else
+#define RSX_ABL(mask) false
+#endif
+
+// process-wide options behind rsx_set_option (include/rsx.h)
+extern int g_rsx_score_lanes;   // passes of the fused scoring path in flight (1..4)
+extern int g_rsx_sort_cap;      // LDS sort capacity of the bucket sampler (test hook for the out-of-LDS path)
+
 // ---- shared by the sampler (rsx_sample.hip) and the step kernels (rsx_bpr.hip) --------------
 constexpr int kMaxNegBlock = 16;
 

@@ -195,7 +195,9 @@ constexpr int kTotalStride = 32;          // bucket totals sit one per 128-B lin
 constexpr int kRangeCap = 256;            // negative-block ranges a bucket's positions may span and still use the LDS table
 static_assert((kMaxBuckets + 4) * 4 + kChunk * 8 <= 64 * 1024, "bucket_chunk_kernel's LDS");
 
-int g_sort_cap = kSortCap;                // test hook: lower it to exercise the out-of-LDS path
+// g_rsx_sort_cap (rsx_set_option "sample_sort_cap"; 0 = kSortCap) lowers the LDS sort capacity so that
+// tests can exercise the out-of-LDS path
+static inline int lds_sort_cap() { return (g_rsx_sort_cap >= 1 && g_rsx_sort_cap <= kSortCap) ? g_rsx_sort_cap : kSortCap; }
 
 // adjacent table entries fetched with one load (dword / qword alignment is enough for global loads)
 struct __attribute__((packed, aligned(4))) U32Pair { uint32_t a, b; };
@@ -744,11 +746,6 @@ RSX_API int rsx_bpr_build_item_cdf(const int64_t *indptr_dev, const int32_t *ind
     return RSX_OK;
 }
 
-RSX_API int rsx_debug_set_sample_sort_cap(int cap)
-{
-    g_sort_cap = (cap >= 1 && cap <= kSortCap) ? cap : kSortCap;
-    return RSX_OK;
-}
 
 RSX_API int rsx_bpr_sample(const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users,
                            int64_t num_items, int64_t batch, uint64_t seed, uint64_t step,
@@ -794,7 +791,7 @@ RSX_API int rsx_bpr_sample(const int64_t *indptr_dev, const int32_t *indices_dev
                                w.pairs, w.table, w.totals);
             hipLaunchKernelGGL(bucket_sort_kernel, dim3(NB), dim3(kBlock), 0, st, indptr_dev, indices_dev,
                                user_sig_dev, num_items, batch, piece_lo, seed, step, neg_block, neg_key, nbm, nblk,
-                               g_sort_cap, w.pairs, w.table, w.totals, u_out, i_out, j_out);
+                               lds_sort_cap(), w.pairs, w.table, w.totals, u_out, i_out, j_out);
         }
         RSX_CHECK_LAUNCH();
         return RSX_OK;

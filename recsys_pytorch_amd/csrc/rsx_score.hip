@@ -13,6 +13,7 @@
 // 32x32 per wavefront (64 accumulator registers), K staged through LDS in
 // chunks of 32 held K-MAJOR ([k][row], leading dimension 129) so that both the
 // transposing ds_write_b32 and the fragment ds_read_b32 are bank-conflict free.
+#include <mutex>
 #include <vector>
 
 #include "rsx_common.h"
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict
                                                          float *__restrict__ cand_val,
                                                          int32_t *__restrict__ cand_idx,
                                                          int32_t *__restrict__ cand_cnt, int cand_cap,
-                                                         uint2 *__restrict__ slots, int ablate)
+                                                         uint2 *__restrict__ slots)
 {
     __shared__ float As[BK * LDT];
     __shared__ float Bs[BK * LDT];
@@ -153,8 +154,8 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict
                 const int site = m * 32 + (r & 3) + 8 * (r >> 2);                // compile-time constant
                 const float t = tau_s[wr * 64 + 4 * hi + site];                  // +inf for rows past the edge
                 const float v0 = acc[m][0][r], v1 = acc[m][1][r];
-                const bool h0 = (col0 < num_items) && (v0 >= t) && !(ablate & 4);
-                const bool h1 = (col1 < num_items) && (v1 >= t) && !(ablate & 4);
+                const bool h0 = (col0 < num_items) && (v0 >= t) && !RSX_ABL(4);
+                const bool h1 = (col1 < num_items) && (v1 >= t) && !RSX_ABL(4);
                 const unsigned long long b0 = __ballot(h0), b1 = __ballot(h1);
                 if ((b0 | b1) == 0ull) continue;                                  // wave-uniform
                 const int cnt0 = __popcll(b0 & half);
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict
                         }
                     }
                 };
-                if (!(ablate & 2)) {
+                if (!RSX_ABL(2)) {
                     if (h0) emit(__popcll(b0 & below), v0, col0);
                     if (h1) emit(cnt0 + __popcll(b1 & below), v1, col1);
                 }
@@ -541,9 +542,7 @@ __global__ __launch_bounds__(MG_THREADS) void merge_candidates_kernel(
     }
 }
 
-int g_score_ablate = 0;   // development only
-constexpr int kMaxLanes = 4;
-int g_score_lanes = 2;    // passes of the fused path in flight (one HIP stream each)
+constexpr int kMaxLanes = 4;   // g_rsx_score_lanes (rsx_set_option "score_lanes"): passes of the fused path in flight
 
 template <bool FILTER>
 int launch_score(const float *P, const int32_t *users, int64_t rows, const float *Q, int64_t cols,
@@ -552,19 +551,50 @@ int launch_score(const float *P, const int32_t *users, int64_t rows, const float
 {
     dim3 grid((unsigned)((cols + BN - 1) / BN), (unsigned)((rows + BM - 1) / BM));
     switch (d) {
-    case 32: hipLaunchKernelGGL((score_tile_kernel<32, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, g_score_ablate); break;
-    case 64: hipLaunchKernelGGL((score_tile_kernel<64, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, g_score_ablate); break;
-    default: hipLaunchKernelGGL((score_tile_kernel<128, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, g_score_ablate); break;
+    case 32: hipLaunchKernelGGL((score_tile_kernel<32, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots); break;
+    case 64: hipLaunchKernelGGL((score_tile_kernel<64, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots); break;
+    default: hipLaunchKernelGGL((score_tile_kernel<128, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots); break;
     }
     return 0;
 }
 
 constexpr int64_t kRowTile = 1024;   // rows scored per pass of rsx_score_topk (evaluator.py:11 batch)
 
+// side streams of the fused path, one set per device, created on first use under a lock
+struct LanePool {
+    std::mutex busy;
+    hipStream_t side[kMaxLanes - 1];
+    hipEvent_t fork, join[kMaxLanes - 1];
+    bool ready = false;
+};
+
+LanePool *lane_pool()
+{
+    static LanePool pools[64];
+    static std::mutex create;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    LanePool &p = pools[dev];
+    std::lock_guard<std::mutex> g(create);
+    if (!p.ready) {
+        bool ok = hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) == hipSuccess;
+        for (int l = 0; ok && l < kMaxLanes - 1; ++l)
+            ok = hipStreamCreateWithFlags(&p.side[l], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&p.join[l], hipEventDisableTiming) == hipSuccess;
+        if (!ok) return nullptr;
+        p.ready = true;
+    }
+    return &p;
+}
+
 }  // namespace
 
-RSX_API int rsx_debug_set_score_ablation(int mask) { g_score_ablate = mask; return RSX_OK; }
-RSX_API int rsx_debug_set_score_lanes(int n) { g_score_lanes = n < 1 ? 1 : (n > kMaxLanes ? kMaxLanes : n); return RSX_OK; }
+#ifdef RSX_ABLATE
+RSX_API int rsx_debug_set_score_ablation(int mask)     // dev build only (librsx_dev.so)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_rsx_ablate), &mask, sizeof(int)) == hipSuccess ? RSX_OK : RSX_E_HIP;
+}
+#endif
 
 RSX_API int rsx_score(const float *P, const int32_t *user_ids_dev, int64_t num_rows, const float *Q,
                       int64_t num_items, int d, const int64_t *mask_indptr_dev,
@@ -710,25 +740,21 @@ RSX_API int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t 
     const int64_t n_tiles = (num_rows + kFusedRows - 1) / kFusedRows;
     // Several passes in flight, one HIP stream each: the selection kernels of one pass (sample
     // top-K, merge; memory / LDS bound) overlap the matrix-core product of the others.
-    const int n_lanes = (int)(n_tiles < g_score_lanes ? n_tiles : g_score_lanes);
+    const int want_lanes = g_rsx_score_lanes < 1 ? 1 : (g_rsx_score_lanes > kMaxLanes ? kMaxLanes : g_rsx_score_lanes);
+    const int n_lanes = (int)(n_tiles < want_lanes ? n_tiles : want_lanes);
     FusedWs lane_ws[kMaxLanes];
     for (int l = 0; l < n_lanes; ++l)
         lane_ws[l] = carve((char *)ws + (l ? (size_t)l * lane_ws[0].bytes : 0), tile_rows, num_rows, num_items, K);
     FusedWs &w = lane_ws[0];                   // overflow list and dense re-do buffers are lane 0's
-    static hipStream_t side_stream[kMaxLanes - 1] = {nullptr, nullptr, nullptr};
-    static hipEvent_t ev_fork = nullptr, ev_join[kMaxLanes - 1] = {nullptr, nullptr, nullptr};
+    // side streams and fork/join events belong to the CURRENT device; one caller at a time per device
+    // uses them (the lock is held until every launch of this call has been queued)
+    LanePool *pool = lane_pool();
+    if (pool == nullptr) { rsx_set_error("rsx_score_topk: could not create the side streams"); return RSX_E_HIP; }
+    std::lock_guard<std::mutex> guard(pool->busy);
+    hipStream_t *side_stream = pool->side;
+    hipEvent_t ev_fork = pool->fork, *ev_join = pool->join;
     hipStream_t lane_st[kMaxLanes] = {st, st, st, st};
-    for (int l = 1; l < n_lanes; ++l) {
-        if (side_stream[l - 1] == nullptr) {
-            if (hipStreamCreateWithFlags(&side_stream[l - 1], hipStreamNonBlocking) != hipSuccess ||
-                (ev_fork == nullptr && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) ||
-                hipEventCreateWithFlags(&ev_join[l - 1], hipEventDisableTiming) != hipSuccess) {
-                rsx_set_error("rsx_score_topk: could not create a side stream");
-                return RSX_E_HIP;
-            }
-        }
-        lane_st[l] = side_stream[l - 1];
-    }
+    for (int l = 1; l < n_lanes; ++l) lane_st[l] = side_stream[l - 1];
     (void)hipMemsetAsync(w.ovf_cnt, 0, 4, st);
     if (n_lanes > 1) {
         (void)hipEventRecord(ev_fork, st);

@@ -1,11 +1,15 @@
 """Interaction data for the BPR-MF path: CSR holders and the synthetic workload.
 
-The reference's dataset/split code (data/dataset.py, data/preprocess.py) is out
-of scope; what the hot path needs from it is only
-`.num_users`, `.num_items`, `.train_data` (scipy CSR) and the eval input/target
-matrices (models/MF.py:16-17,45; main.py:62-63).  `InteractionData` is that
-duck type; `synthetic_csr` builds the BASELINE.json workloads on the device.
+What the hot path needs from the reference's dataset code is only `.num_users`,
+`.num_items`, `.train_data` (scipy CSR) and the eval input/target matrices
+(models/MF.py:16-17,45; main.py:62-63).  `InteractionData` is that duck type;
+`load_uirt` restates the reference's filter / remap / weak holdout split and its
+on-disk cache format (data/dataset.py:92-218,
+data/preprocess.py:12-90); `synthetic_csr` builds the BASELINE.json workloads on
+the device.
 """
+import os
+
 import numpy as np
 import scipy.sparse as sp
 import torch
@@ -28,7 +32,8 @@ class InteractionData:
 
     @property
     def test_input(self):
-        return self.train_data
+        """weak generalisation: the test-time input is train + valid (data/dataset.py:236-241)"""
+        return self.train_data if self.valid_target is None else self.train_data + self.valid_target
 
     @classmethod
     def from_npz(cls, path):
@@ -84,8 +89,47 @@ def synthetic_csr(num_users, num_items, degree, device, seed=2020, popularity="z
     return indptr.contiguous(), items.reshape(-1).to(torch.int32).contiguous()
 
 
+def _cache_subdir(valid_ratio, test_ratio, split_random, min_item_per_user, min_user_per_item, seed):
+    """data/dataset.py:193-207 (holdout / weak): the directory name keys every split parameter"""
+    return "holdout_%.2f_%.2f_weak_%s_minUI_%d_%d_seed%d" % (valid_ratio, test_ratio, "random" if split_random else "time",
+                                                             min_item_per_user, min_user_per_item, seed)
+
+
+CACHE_FILES = ("train.csv", "valid.csv", "test.csv", "user_map", "item_map")
+
+
+def _write_cache(cdir, parts, user_raw, item_raw):
+    """the reference's on-disk cache (data/dataset.py:176-181,214-218): `<part>.csv` rows
+    `user,item,rating,timestamp` with NEW ids, float rating / timestamp as pandas prints them
+    (DataFrame.to_csv(index=False, header=False)), and `user_map` / `item_map` lines "raw, new"."""
+    os.makedirs(cdir, exist_ok=True)
+    for name, (u, it, r, t) in parts.items():
+        with open(os.path.join(cdir, name + ".csv"), "wt") as f:
+            f.write("".join("%d,%d,%r,%r\n" % (a, b, float(c), float(d)) for a, b, c, d in zip(u, it, r, t)))
+    for name, raw in (("user_map", user_raw), ("item_map", item_raw)):
+        with open(os.path.join(cdir, name), "wt") as f:
+            f.write("".join("%d, %d\n" % (int(old), new) for new, old in enumerate(raw)))
+
+
+def _read_cache(cdir):
+    """data/dataset.py:43-66,209-212: id maps give the table sizes, the three csv files the matrices"""
+    sizes = []
+    for name in ("user_map", "item_map"):
+        with open(os.path.join(cdir, name), "rt") as f:
+            sizes.append(sum(1 for line in f if line.strip()))
+    U, I = sizes
+    mats = []
+    for name in ("train", "valid", "test"):
+        raw = np.loadtxt(os.path.join(cdir, name + ".csv"), delimiter=",", dtype=np.float64, ndmin=2)
+        m = sp.csr_matrix((np.ones(len(raw)), (raw[:, 0].astype(np.int64), raw[:, 1].astype(np.int64))), shape=(U, I))
+        m.sum_duplicates()
+        m.data[:] = 1.0                                         # implicit=True: ratings binarised at load
+        mats.append(m)
+    return InteractionData(*mats)
+
+
 def load_uirt(path, separator="\t", min_item_per_user=0, min_user_per_item=0, valid_ratio=0.1,
-              test_ratio=0.2, split_random=True, seed=None):
+              test_ratio=0.2, split_random=True, seed=None, cache_dir=None, cache_seed=1234):
     """Read a `user item rating timestamp` text file and split it like the reference's
     UIRTDataset(protocol='holdout', generalization='weak') does:
 
@@ -94,25 +138,35 @@ def load_uirt(path, separator="\t", min_item_per_user=0, min_user_per_item=0, va
       data/preprocess.py:12-19 weak split: FIRST a "test" part of `valid_ratio` (sic: the two
                                ratios are crossed in the reference, quirk Q8), THEN a "valid"
                                part of `test_ratio` of what is left
-      data/preprocess.py:52-90 per user (ascending id): sort by timestamp, hold out
-                               ceil(ratio * n) interactions chosen with np.random.choice
-                               (split_random) or the last ones
+      data/preprocess.py:52-90 per user (ascending id): sort by timestamp (pandas' default
+                               quicksort: ties in numpy's introsort order), hold out ceil(ratio * n)
+                               interactions chosen with np.random.choice (split_random) or the last
+      data/dataset.py:92-122,176-218  on-disk cache: with `cache_dir` (the reference's default is
+                               'cache') the split is written to / read back from
+                               <dirname(path)>/<cache_dir>/holdout_<v>_<t>_weak_<random|time>_minUI_<a>_<b>_seed<cache_seed>/
+                               {train,valid,test}.csv + user_map + item_map, byte for byte the
+                               files the reference writes (tests/test_loader.py against digests
+                               recorded from the reference's own cache).  `cache_seed` only names
+                               the directory, as in the reference (its `seed` argument, default 1234).
     Ratings are binarised to 1 (implicit=True, data/dataset.py:46-51).  With `seed` the numpy
-    global RNG is seeded first (main.py:30).  On ml-100k this reproduces the reference's
-    per-user train/valid/test SIZES exactly (tests/test_loader.py against the fixture the
-    reference's own loader produced); which interactions are drawn is not bit-identical (pandas'
-    sort of tied timestamps), and SURVEY row f4 does not ask for that.  No on-disk cache is
-    written.  Returns an InteractionData.
+    global RNG is seeded first (main.py:30).  On ml-100k with seed 2020 this reproduces the
+    reference's train/valid/test matrices exactly.  Returns an InteractionData.
     """
+    cdir = None
+    if cache_dir is not None:
+        cdir = os.path.join(os.path.dirname(os.path.abspath(path)), cache_dir,
+                            _cache_subdir(valid_ratio, test_ratio, split_random, min_item_per_user, min_user_per_item, cache_seed))
+        if all(os.path.exists(os.path.join(cdir, f)) for f in CACHE_FILES):     # dataset.py:183-191
+            return _read_cache(cdir)
     raw = np.loadtxt(path, delimiter=separator, dtype=np.float64, ndmin=2)
-    users, items, ts = raw[:, 0].astype(np.int64), raw[:, 1].astype(np.int64), raw[:, 3]
+    users, items, ratings, ts = raw[:, 0].astype(np.int64), raw[:, 1].astype(np.int64), raw[:, 2], raw[:, 3]
     # filter users, then items (dataset.py:131-146)
     uid, ucnt = np.unique(users, return_counts=True)
     keep = np.isin(users, uid[ucnt >= min_item_per_user])
-    users, items, ts = users[keep], items[keep], ts[keep]
+    users, items, ratings, ts = users[keep], items[keep], ratings[keep], ts[keep]
     iid, icnt = np.unique(items, return_counts=True)
     keep = np.isin(items, iid[icnt >= min_user_per_item])
-    users, items, ts = users[keep], items[keep], ts[keep]
+    users, items, ratings, ts = users[keep], items[keep], ratings[keep], ts[keep]
     uid = np.unique(users)                       # ascending raw ids -> 0..U-1 (dataset.py:153-167)
     iid = np.unique(items)
     users = np.searchsorted(uid, users)
@@ -121,13 +175,15 @@ def load_uirt(path, separator="\t", min_item_per_user=0, min_user_per_item=0, va
     if seed is not None:
         np.random.seed(seed)
 
-    def split(us, its, tss, ratio):
-        """data/preprocess.py:52-90 on arrays; returns (kept, held-out) index arrays"""
-        order = np.argsort(us, kind="stable")
+    def split(idx, ratio):
+        """data/preprocess.py:52-90 on the rows `idx` (in frame order); returns (kept, held-out)
+        row ids, each in the order the reference concatenates them"""
+        us = users[idx]
+        order = np.argsort(us, kind="stable")                       # groupby('user'): ascending, rows in frame order
         bounds = np.flatnonzero(np.diff(us[order])) + 1
         keep_idx, out_idx = [], []
-        for grp in np.split(order, bounds):
-            grp = grp[np.argsort(tss[grp], kind="stable")]          # sort_values(by='timestamp')
+        for grp in np.split(idx[order], bounds):
+            grp = grp[np.argsort(ts[grp], kind="quicksort")]        # sort_values(by='timestamp'), pandas' default kind
             n = len(grp)
             n_out = int(np.ceil(ratio * n)) if isinstance(ratio, float) else int(ratio)
             mask = np.ones(n, dtype=bool)
@@ -138,15 +194,15 @@ def load_uirt(path, separator="\t", min_item_per_user=0, min_user_per_item=0, va
             keep_idx.append(grp[mask]); out_idx.append(grp[~mask])
         return np.concatenate(keep_idx), np.concatenate(out_idx)
 
-    all_idx = np.arange(len(users))
-    k1, test = split(users, items, ts, valid_ratio)                 # sic (quirk Q8)
-    k2, valid = split(users[k1], items[k1], ts[k1], test_ratio)
-    train, valid = k1[k2], k1[valid]
+    k1, test = split(np.arange(len(users)), valid_ratio)            # sic (quirk Q8)
+    train, valid = split(k1, test_ratio)
 
     def csr(idx):
         m = sp.csr_matrix((np.ones(len(idx)), (users[idx], items[idx])), shape=(U, I))
         m.sum_duplicates()
         m.data[:] = 1.0
         return m
-    del all_idx
+    if cdir is not None:
+        _write_cache(cdir, {n: (users[ix], items[ix], ratings[ix], ts[ix]) for n, ix in
+                            (("train", train), ("valid", valid), ("test", test))}, uid, iid)
     return InteractionData(csr(train), csr(valid), csr(test))

@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librsx.so")
+# RSX_LIB overrides the library path (development: the -DRSX_ABLATE build librsx_dev.so for tools/ablate*.py)
+LIB_PATH = os.environ.get("RSX_LIB") or os.path.join(_HERE, "librsx.so")
 _lib = None
 
 RSX_USERS_UNIQUE = 1
@@ -27,6 +28,7 @@ SIGNATURES = {
     "rsx_version": (C.c_int, []),
     "rsx_last_error": (C.c_char_p, []),
     "rsx_device_info_get": (C.c_int, [C.c_int, _P]),
+    "rsx_set_option": (C.c_int, [C.c_char_p, _I64]),
     "rsx_bpr_step_workspace": (_I64, [_I64, _I64, _I32]),
     "rsx_bpr_step": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _I64, _I32, _F, _F, _P, _U, _P, _I64,
                                _P, _P, _I32, _I32, _U64, _P]),
@@ -96,6 +98,11 @@ def _stream():
 
 def version():
     return lib().rsx_version()
+
+
+def set_option(name, value):
+    """include/rsx.h:rsx_set_option ("score_lanes", "sample_sort_cap")"""
+    _check(lib().rsx_set_option(name.encode(), int(value)), "rsx_set_option")
 
 
 def device_info(device=0):

@@ -64,16 +64,32 @@ class BPREngine:
         self.hot = None
         self.neg_block = 0          # > 0: negatives stratified by item block, batch sorted by positive item
         self.use_item_cdf = True    # order the batch through the item-CDF buckets (False: device radix sort)
-        self._sample_ws = None
+        self._sample_ws = {}        # sampler scratch, one per stream role ("main" / "side"): never shared
+        self._csr = None            # the CSR tensors the static sampler tables below were built from
+        self._sig = self._cdf = None
         self._bufs = None           # double-buffered triplets for the overlapped sampler
-        self._side = None
+        self._side = None           # ONE side stream for the engine's lifetime
 
     def set_neg_block(self, batch, max_block=8):
         """enable the on-chip gradient summation (blocked negatives + batch sorted by positive
         item, include/rsx.h: neg_block / RSX_SAMPLE_SORT_POS) when every item row gets >= 2
         updates per step; below that there is nothing to combine."""
-        self.neg_block = int(max_block) if batch >= 2 * self.Q.shape[0] else 0
+        nb = int(max_block) if batch >= 2 * self.Q.shape[0] else 0
+        if nb != self.neg_block:
+            self._csr = None        # the user signatures depend on neg_block: rebuild on next use
+        self.neg_block = nb
         return self.neg_block
+
+    def _bind_csr(self, indptr, indices):
+        """static per-CSR sampler tables (user signatures, item CDF).  The engine keeps references to
+        the very tensors they were built from, so `is` identifies the CSR: an address recycled by the
+        caching allocator for ANOTHER CSR can never be mistaken for it (a stale signature would
+        accept positives as negatives)."""
+        if self._csr is not None and self._csr[0] is indptr and self._csr[1] is indices and self._csr[2] == self.neg_block:
+            return
+        self._sig = self.k.build_signature(indptr, indices, self.neg_block) if hasattr(self.k, "build_signature") else None
+        self._cdf = self.k.build_item_cdf(indptr, indices, self.Q.shape[0]) if hasattr(self.k, "build_item_cdf") else None
+        self._csr = (indptr, indices, self.neg_block)
 
     def _neg_key(self, step):
         """per-step key of the negative-block permutation (nonzero); 0 = identity when not sorting"""
@@ -165,10 +181,11 @@ class BPREngine:
         return loss
 
     # -- one step on triplets sampled on the device from this rank's CSR rows -----------
-    def _launch_sample(self, indptr, indices, batch, out, step):
+    def _launch_sample(self, indptr, indices, batch, out, step, role="main"):
         """device sampler (include/rsx.h:rsx_bpr_sample) on the CURRENT stream; users unique
         inside the batch.  A batch never straddles two passes over the user permutation: when
-        fewer than `batch` users remain in the pass, the pass restarts (tail dropped)."""
+        fewer than `batch` users remain in the pass, the pass restarts (tail dropped).
+        `role` names the stream the call is queued on; each role has its own scratch."""
         U = indptr.numel() - 1
         if (self.epoch_pos % U) + batch > U:
             self.epoch_pos = (self.epoch_pos // U + 1) * U
@@ -177,18 +194,14 @@ class BPREngine:
         key = self._neg_key(step)
         if self.neg_block:
             need = self.k.bpr_sample_workspace(batch, self.Q.shape[0])
-            if self._sample_ws is None or self._sample_ws.numel() < need:
-                self._sample_ws = torch.empty(need, dtype=torch.uint8, device=self.Q.device)
-            if getattr(self, "_sig_for", None) != (indptr.data_ptr(), self.neg_block) and hasattr(self.k, "build_signature"):
-                self._sig = self.k.build_signature(indptr, indices, self.neg_block)   # static per CSR
-                self._sig_for = (indptr.data_ptr(), self.neg_block)
-            if getattr(self, "_cdf_for", None) != indptr.data_ptr() and hasattr(self.k, "build_item_cdf"):
-                self._cdf = self.k.build_item_cdf(indptr, indices, self.Q.shape[0])   # static per CSR
-                self._cdf_for = indptr.data_ptr()
-            kw = {"neg_block": self.neg_block, "neg_key": key, "sort_pos": True, "ws": self._sample_ws}
-            if getattr(self, "_sig", None) is not None:
+            ws = self._sample_ws.get(role)
+            if ws is None or ws.numel() < need:
+                ws = self._sample_ws[role] = torch.empty(need, dtype=torch.uint8, device=self.Q.device)
+            self._bind_csr(indptr, indices)
+            kw = {"neg_block": self.neg_block, "neg_key": key, "sort_pos": True, "ws": ws}
+            if self._sig is not None:
                 kw["user_sig"] = self._sig
-            if getattr(self, "_cdf", None) is not None and self.use_item_cdf:
+            if self._cdf is not None and self.use_item_cdf:
                 kw["item_cdf"] = self._cdf
         self.k.bpr_sample(indptr, indices, self.Q.shape[0], batch, self.seed + 7919 * self.user_begin,
                           step, self.epoch_pos, u, i, j, **kw)
@@ -216,9 +229,17 @@ class BPREngine:
         while step t's kernels run (it reads only the CSR, never the tables)."""
         batch = min(int(batch), indptr.numel() - 1)
         main = torch.cuda.current_stream()
-        if self._bufs is None or self._bufs[0]["t"][0].numel() != batch:
+        if self._side is None:
             self._side = torch.cuda.Stream(device=self.Q.device)
-            self._bufs = [{"t": self._triplet_buffers(batch), "ready": None, "free": None, "key": 0} for _ in range(2)]
+        if self._bufs is None or self._bufs[0]["t"][0].numel() != batch:
+            if self._bufs is not None and self._sampled_upto > self.step_count:
+                # a batch of the OLD size was sampled ahead (e.g. before an epoch's short last batch):
+                # give its positions back to the user permutation, and let everything queued on the
+                # side stream finish before its buffers are dropped
+                self.epoch_pos = self._bufs[self._cur]["pos_before"]
+                main.wait_stream(self._side)
+            self._bufs = [{"t": self._triplet_buffers(batch), "ready": None, "free": None, "key": 0, "pos_before": 0}
+                          for _ in range(2)]
             self._cur = 0
             self._sampled_upto = self.step_count          # next step index to sample for
 
@@ -226,8 +247,9 @@ class BPREngine:
             buf = self._bufs[slot]
             if buf["free"] is not None:
                 self._side.wait_event(buf["free"])        # the step that read this buffer is done
+            buf["pos_before"] = self.epoch_pos
             with torch.cuda.stream(self._side):
-                buf["key"] = self._launch_sample(indptr, indices, batch, buf["t"], self._sampled_upto)
+                buf["key"] = self._launch_sample(indptr, indices, batch, buf["t"], self._sampled_upto, role="side")
                 buf["ready"] = torch.cuda.Event()
                 buf["ready"].record(self._side)
             self._sampled_upto += 1

@@ -319,7 +319,7 @@ def test_item_cdf_buckets_on_random_shapes():
             epoch_pos = 0 if B == U else int(rng.integers(0, U - B + 1))
             cdf = rsx.build_item_cdf(ip, ix, I)
             sig = rsx.build_signature(ip, ix, c) if trial % 2 else None
-            rsx.lib().rsx_debug_set_sample_sort_cap(16 if trial % 5 == 0 else 0)
+            rsx.set_option("sample_sort_cap", 16 if trial % 5 == 0 else 0)
             a = _sample_sorted(ip, ix, I, B, trial, cdf, sig, c=c, key=trial * 2 + 1, epoch_pos=epoch_pos)
             b = _sample_sorted(ip, ix, I, B, trial, None, sig, c=c, key=trial * 2 + 1, epoch_pos=epoch_pos)
             a2 = _sample_sorted(ip, ix, I, B, trial, cdf, sig, c=c, key=trial * 2 + 1, epoch_pos=epoch_pos)
@@ -349,7 +349,7 @@ def test_item_cdf_buckets_on_random_shapes():
             assert bad <= max(2, 0.2 * live.sum()) or kind == 2, ctx
             assert nb >= 1
     finally:
-        rsx.lib().rsx_debug_set_sample_sort_cap(0)
+        rsx.set_option("sample_sort_cap", 0)
 
 
 def test_item_cdf_buckets_outside_lds_and_rows_without_a_positive():
@@ -368,7 +368,7 @@ def test_item_cdf_buckets_outside_lds_and_rows_without_a_positive():
     n_dead = int((dense.sum(1) == 0).sum() + (dense.sum(1) == I).sum())
     try:
         for cap in (2048, 64):
-            rsx.lib().rsx_debug_set_sample_sort_cap(cap)
+            rsx.set_option("sample_sort_cap", cap)
             u, i, j = _sample_sorted(ip, ix, I, U, 4, cdf, None, c=4)
             live = i >= 0
             assert (~live).sum() == n_dead and np.all(live[:U - n_dead]) and np.all(j[~live] == -1)
@@ -380,7 +380,7 @@ def test_item_cdf_buckets_outside_lds_and_rows_without_a_positive():
             else:                                                        # same order from both paths
                 assert np.array_equal(first[1], i) and np.array_equal(first[0][live], u[live]) and np.array_equal(first[2], j)
     finally:
-        rsx.lib().rsx_debug_set_sample_sort_cap(0)
+        rsx.set_option("sample_sort_cap", 0)
 
 
 def test_item_cdf_buckets_piecewise_above_two_million_positions():

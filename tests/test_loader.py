@@ -44,8 +44,8 @@ def test_filter_remap_and_split_properties(tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(REF_DATA), reason="reference dataset not present (GPU box)")
 def test_ml100k_split_reproduces_the_reference_fixture():
-    """same file, same seed, same np.random.choice sequence -> the CSR the reference's own loader
-    produced (tests/golden/ml100k_csr.npz, written by oracle/gen_golden.py)"""
+    """same file, same seed, same sort and np.random.choice sequence -> exactly the CSR the
+    reference's own loader produced (tests/golden/ml100k_csr.npz, written by oracle/gen_golden.py)"""
     from recsys_pytorch_amd.data import load_uirt
     ds = load_uirt(REF_DATA, "\t", min_item_per_user=10, min_user_per_item=1, valid_ratio=0.1, test_ratio=0.2,
                    split_random=True, seed=2020)
@@ -53,7 +53,53 @@ def test_ml100k_split_reproduces_the_reference_fixture():
     assert (ds.num_users, ds.num_items) == (int(c["num_users"]), int(c["num_items"]))
     for name, m in (("train", ds.train_data), ("valid", ds.valid_target), ("test", ds.test_target)):
         m.sort_indices()
-        assert m.nnz == len(c[name + "_indices"])
         assert np.array_equal(m.indptr, c[name + "_indptr"])
-        same = np.array_equal(m.indices, c[name + "_indices"].astype(np.int32))
-        print(name, "identical" if same else "same sizes, different draw")
+        assert np.array_equal(m.indices, c[name + "_indices"].astype(np.int32)), name
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DATA), reason="reference dataset not present (GPU box)")
+def test_ml100k_cache_is_byte_identical_to_the_reference_cache(tmp_path):
+    """the on-disk cache format (data/dataset.py:92-122,176-218): same directory name, same five
+    files, same bytes as the reference's own UIRTDataset wrote (digests recorded by
+    oracle/gen_golden_cache.py); a second load reads the cache back to the same matrices"""
+    import hashlib
+    import json
+    import shutil
+    from recsys_pytorch_amd.data import load_uirt
+    want = json.load(open(os.path.join(GOLDEN, "g7_ml100k_cache.json")))
+    work = tmp_path / "ml-100k"
+    work.mkdir()
+    shutil.copy(REF_DATA, work / "u.data")
+    kw = dict(separator="\t", min_item_per_user=10, min_user_per_item=1, valid_ratio=0.1, test_ratio=0.2,
+              split_random=True, cache_dir="cache")
+    ds = load_uirt(str(work / "u.data"), seed=2020, **kw)
+    cdir = work / "cache" / want["cache_subdir"]
+    assert sorted(os.listdir(cdir)) == sorted(want["files"])
+    for name, meta in want["files"].items():
+        raw = open(cdir / name, "rb").read()
+        assert raw.decode().splitlines()[:3] == meta["head"], name
+        assert len(raw) == meta["bytes"] and hashlib.sha256(raw).hexdigest() == meta["sha256"], name
+    os.remove(work / "u.data")                                 # the second load must not need the raw file
+    (work / "u.data").write_text("")
+    again = load_uirt(str(work / "u.data"), seed=None, **kw)
+    for a, b in ((ds.train_data, again.train_data), (ds.valid_target, again.valid_target), (ds.test_target, again.test_target)):
+        assert (a != b).nnz == 0
+    assert (again.test_input != ds.train_data + ds.valid_target).nnz == 0      # dataset.py:236-241
+
+
+def test_cache_round_trip_on_a_toy_file(tmp_path):
+    """runs everywhere (no reference data needed): write, read back, and the file grammar"""
+    from recsys_pytorch_amd.data import load_uirt
+    rng = np.random.default_rng(3)
+    p = str(tmp_path / "toy.data")
+    write_toy(p, rng)
+    kw = dict(separator="\t", min_item_per_user=3, min_user_per_item=1, valid_ratio=0.1, test_ratio=0.2, cache_dir="cache")
+    ds = load_uirt(p, seed=5, split_random=False, **kw)
+    cdir = tmp_path / "cache" / "holdout_0.10_0.20_weak_time_minUI_3_1_seed1234"
+    assert sorted(os.listdir(cdir)) == ["item_map", "test.csv", "train.csv", "user_map", "valid.csv"]
+    line = open(cdir / "train.csv").readline().strip().split(",")
+    assert len(line) == 4 and line[2].endswith(".0") and line[3].endswith(".0") and "." not in line[0]
+    raw, new = open(cdir / "user_map").readline().strip().split(", ")
+    assert int(new) == 0 and int(raw) >= 100
+    again = load_uirt(p, seed=99, split_random=False, **kw)     # served from the cache: seed irrelevant
+    assert (again.train_data != ds.train_data).nnz == 0 and (again.test_target != ds.test_target).nnz == 0

@@ -3,6 +3,7 @@ write/load switches of rsx_debug_set_ablation (1 pos sums, 2 neg sums, 4 P store
 64 Q[j] -> row 1): which part of the kernel the time is sensitive to"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from recsys_pytorch_amd import build as _b; os.environ["RSX_LIB"] = _b.build(dev=True)   # the -DRSX_ABLATE build (built here if run on the build host)
 from recsys_pytorch_amd import rsx
 from recsys_pytorch_amd.data import synthetic_csr
 from recsys_pytorch_amd.sharded import BPREngine
