@@ -4,7 +4,7 @@ G6: golden vectors for LightGCN from the imported reference
 (models/LightGCN.py): normalised adjacency, propagated embeddings for L in {1,2,3}, and Adam
 training steps.  Fixtures are data only.  Asserts the C oracle against the reference on the way.
 
-    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/oracle/gen_golden_lightgcn.py
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/oracle/gen_golden_lightgcn.py [name-filter]
 """
 import os
 import shutil
@@ -89,6 +89,10 @@ def run(name, R, d, L, batches, seed):
 
 def main():
     oracle.build()
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
+    global run
+    run_all = run
+    run = lambda name, *a: run_all(name, *a) if only in name else None
     rng = np.random.default_rng(6)
     R = sp.random(50, 40, density=0.15, format="csr", random_state=np.random.default_rng(1))
     R.data[:] = 1.0
@@ -99,6 +103,14 @@ def main():
     U, I = int(c["num_users"]), int(c["num_items"])
     Rm = sp.csr_matrix((np.ones(len(c["train_indices"])), c["train_indices"].astype(np.int32), c["train_indptr"]), shape=(U, I))
     run("g6_lightgcn_ml100k_d64_L2", Rm, 64, 2, mk(U, I, 256, 6), 31)       # conf/LightGCN.yaml shape
+    # BASELINE configs[4] model shape (d=128, 3 layers) at fixture size, Zipf-ish item degrees
+    rng5 = np.random.default_rng(55)
+    U5, I5 = 200, 150
+    pop = 1.0 / (1.0 + np.arange(I5)); pop /= pop.sum()
+    rows = [np.sort(rng5.choice(I5, 12, replace=False, p=pop)) for _ in range(U5)]
+    R5 = sp.csr_matrix((np.ones(U5 * 12), np.concatenate(rows), np.arange(U5 + 1) * 12), shape=(U5, I5))
+    mk5 = lambda B, T: [(rng5.integers(0, U5, B), rng5.integers(0, I5, B), rng5.integers(0, I5, B)) for _ in range(T)]
+    run("g6_lightgcn_200x150_d128_L3", R5, 128, 3, mk5(128, 6), 41)
 
 
 if __name__ == "__main__":

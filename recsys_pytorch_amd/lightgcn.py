@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from .data import csr_to_device
-from .mf import BaseModel, _get, _pad_dim
+from .mf import BaseModel, _get, _pad_dim, end_of_epoch
 
 
 def normalized_adjacency(train_csr):
@@ -165,23 +165,11 @@ class LightGCN(BaseModel):
                 epoch_loss += batch_loss
                 if verbose and b % 50 == 0:
                     print('(%3d / %3d) loss = %.4f' % (b, num_batches, batch_loss))
-            epoch_summary = {'loss': epoch_loss}
-            if evaluator is not None and epoch >= test_from and epoch % test_step == 0:
-                scores = evaluator.evaluate(self)
-                epoch_summary.update(scores)
-                if loggers is not None:
-                    for logger in loggers:
-                        logger.log_metrics(epoch_summary, epoch=epoch)
-                if early_stop is not None:
-                    is_update, should_stop = early_stop.step(scores, epoch)
-                    if should_stop:
-                        break
-            else:
-                if loggers is not None:
-                    for logger in loggers:
-                        logger.log_metrics(epoch_summary, epoch=epoch)
-        best_score = early_stop.best_score if early_stop is not None else scores
-        return {'scores': best_score}
+            scores, stop = end_of_epoch(self, epoch, {'loss': epoch_loss}, scores, evaluator, early_stop,
+                                        loggers, test_from, test_step)
+            if stop:
+                break
+        return {'scores': early_stop.best_score if early_stop is not None else scores}
 
     # -- models/LightGCN.py:125-150 -------------------------------------------------------------------------
     def predict_batch_users(self, user_ids):

@@ -41,6 +41,23 @@ class BaseModel(nn.Module):
         pass
 
 
+def end_of_epoch(model, epoch, epoch_summary, scores, evaluator, early_stop, loggers, test_from, test_step):
+    """what the reference's fit loops do after every epoch (models/MF.py:75-95, LightGCN.py:93-113):
+    evaluate every `test_step` epochs from `test_from`, log the summary, ask early_stop.
+    Returns (latest scores, should_stop)."""
+    evaluated = evaluator is not None and epoch >= test_from and epoch % test_step == 0
+    if evaluated:
+        scores = evaluator.evaluate(model)
+        epoch_summary.update(scores)
+    if loggers is not None:
+        for logger in loggers:
+            logger.log_metrics(epoch_summary, epoch=epoch)
+    stop = False
+    if evaluated and early_stop is not None:
+        _, stop = early_stop.step(scores, epoch)
+    return scores, stop
+
+
 def _pad_dim(d):
     for p in (32, 64, 128):
         if d <= p:
@@ -146,23 +163,11 @@ class MF(BaseModel):
                 epoch_loss += batch_loss
                 if verbose and b % 50 == 0:
                     print('(%3d / %3d) loss = %.4f' % (b, num_batches, float(batch_loss)))
-            epoch_summary = {'loss': float(epoch_loss)}
-            if evaluator is not None and epoch >= test_from and epoch % test_step == 0:
-                scores = evaluator.evaluate(self)
-                epoch_summary.update(scores)
-                if loggers is not None:
-                    for logger in loggers:
-                        logger.log_metrics(epoch_summary, epoch=epoch)
-                if early_stop is not None:
-                    is_update, should_stop = early_stop.step(scores, epoch)
-                    if should_stop:
-                        break
-            else:
-                if loggers is not None:
-                    for logger in loggers:
-                        logger.log_metrics(epoch_summary, epoch=epoch)
-        best_score = early_stop.best_score if early_stop is not None else scores
-        return {'scores': best_score}
+            scores, stop = end_of_epoch(self, epoch, {'loss': float(epoch_loss)}, scores, evaluator, early_stop,
+                                        loggers, test_from, test_step)
+            if stop:
+                break
+        return {'scores': early_stop.best_score if early_stop is not None else scores}
 
     # -- models/MF.py:109-112 ----------------------------------------------------------------
     def predict_batch_users(self, user_ids):

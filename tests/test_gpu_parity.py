@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import G1_ADAM, G1_SGD, G23, golden, rel_err, split_batches
+from conftest import DELTA_TOL_SMALL_LR, G1_ADAM, G1_SGD, G1_SGD_BIGLR, G23, delta_err, golden, rel_err, split_batches
 
 pytestmark = pytest.mark.gpu
 REL_TOL = 1e-5
@@ -48,14 +48,19 @@ def run_steps(rsx, P0, Q0, batches, lr, unique_flag):
     return P.cpu().numpy(), Q.cpu().numpy(), losses
 
 
-@pytest.mark.parametrize("name", G1_SGD)
+@pytest.mark.parametrize("name", G1_SGD + G1_SGD_BIGLR)
 def test_bpr_step_matches_reference_golden(rsx, name):
-    """20 SGD steps on the reference's own triplets (duplicates inside batches)."""
+    """20 SGD steps on the reference's own triplets (duplicates inside batches).  The north-star
+    bar (tables within 1e-5 relative) AND the same bar on the update: with the large-lr fixtures
+    the 20 steps move the tables by 0.3-0.8 of their magnitude, so 1e-5 of the table is 1e-5 of the
+    update; with lr 0.05 the update is asserted to what fp32 tables can represent of it."""
     g = golden(name)
     batches = list(split_batches(g))
     P, Q, losses = run_steps(rsx, g["P0"], g["Q0"], batches, float(g["lr"]), True)
     assert rel_err(P, g["PT"]) < REL_TOL
     assert rel_err(Q, g["QT"]) < REL_TOL
+    tol = REL_TOL if name in G1_SGD_BIGLR else DELTA_TOL_SMALL_LR
+    assert delta_err(P, g["P0"], g["PT"]) < tol and delta_err(Q, g["Q0"], g["QT"]) < tol
     assert np.allclose(losses, g["loss"], rtol=1e-5, atol=1e-6)
 
 
@@ -80,6 +85,8 @@ def test_adam_as_shipped_matches_reference_golden(rsx, name):
     assert float(GP.abs().max()) == 0.0 and float(GQ.abs().max()) == 0.0
     assert rel_err(P.cpu().numpy(), g["PT"]) < REL_TOL
     assert rel_err(Q.cpu().numpy(), g["QT"]) < REL_TOL
+    # Adam's update is 1.5-4 % of the table: asserted directly, to 1e-4 of the update
+    assert delta_err(P.cpu().numpy(), g["P0"], g["PT"]) < 1e-4 and delta_err(Q.cpu().numpy(), g["Q0"], g["QT"]) < 1e-4
 
 
 def test_first_step_gradients(rsx):

@@ -11,7 +11,7 @@ import torch
 from conftest import GOLDEN, golden, rel_err, split_batches
 
 G6 = ["g6_lightgcn_50x40_d32_L1", "g6_lightgcn_50x40_d32_L2", "g6_lightgcn_50x40_d32_L3",
-      "g6_lightgcn_ml100k_d64_L2"]
+      "g6_lightgcn_ml100k_d64_L2", "g6_lightgcn_200x150_d128_L3"]    # the last: BASELINE configs[4] model shape
 
 
 def graph_of(g):
@@ -132,3 +132,64 @@ def test_hip_lightgcn_fit_and_topk_end_to_end():
     for r in range(64):
         kth = np.sort(pred[r])[::-1][9]
         assert np.all(pred[r][top[r]] >= kth) and np.all(np.isfinite(pred[r][top[r]]))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1500)
+def test_hip_lightgcn_full_size_config5_properties():
+    """BASELINE configs[4] at its full shape: 1M users x 100K items, d=128, 3 layers (nnz(A_hat) =
+    4e7), through properties that hold at any size:
+      * sqrt(degree) is an eigenvector of A_hat = D^-1/2 A D^-1/2 with eigenvalue 1, so tables whose
+        columns all equal sqrt(deg) propagate to themselves (every layer, hence their mean);
+      * A_hat is symmetric: <A x, y> == <x, A y>;
+      * sampled output rows equal an fp64 gather over the CSR row;
+      * one training step (LightGCN.py:83-87): loss = mean softplus(-x) on the propagated tables,
+        Adam's first step moves a parameter by lr |g| / (|g| + eps): never more than lr."""
+    import recsys_pytorch_amd as pkg
+    from recsys_pytorch_amd import rsx
+    from recsys_pytorch_amd.data import synthetic_csr
+    U, I, d, L, deg = 1_000_000, 100_000, 128, 3, 20
+    ip, ix = synthetic_csr(U, I, deg, "cuda", seed=2020)
+    R = sp.csr_matrix((np.ones(U * deg, np.float32), ix.cpu().numpy(), ip.cpu().numpy()), shape=(U, I))
+    ds = types.SimpleNamespace(num_users=U, num_items=I, dataname="c5")
+    torch.manual_seed(5)
+    m = pkg.LightGCN(ds, {"emb_dim": d, "num_layers": L, "node_dropout": 0.0, "split": False, "num_folds": 100,
+                          "reg": 1e-4, "graph_dir": "graph"}, "cuda")
+    g = m.getSparseGraph(R)
+    N = U + I
+    assert g.n == N and int(g.indices.numel()) == 2 * U * deg
+    # eigenvector
+    degs = torch.cat([torch.full((U,), float(deg), device="cuda"), torch.bincount(ix.long(), minlength=I).float()])
+    E0_saved = m._E0.clone()
+    m._E0.copy_(degs.sqrt().unsqueeze(1).expand(N, d))
+    m.update_lightgcn_embedding()
+    assert float((m._out - m._E0).abs().max()) < 2e-5 * float(m._E0.abs().max())
+    # symmetry on random vectors (fp64 inner products)
+    x, y = torch.randn(N, d, device="cuda"), torch.randn(N, d, device="cuda")
+    ax, ay = torch.empty_like(x), torch.empty_like(y)
+    rsx.spmm(g, x, ax); rsx.spmm(g, y, ay)
+    lhs, rhs = float((ax.double() * y.double()).sum()), float((x.double() * ay.double()).sum())
+    assert abs(lhs - rhs) < 1e-6 * max(abs(lhs), abs(rhs), float(ax.double().norm() * y.double().norm()) * 1e-3)
+    # sampled rows against an fp64 gather (users: 20 neighbours; items: up to 1e5+)
+    ipn = g.indptr.cpu().numpy()
+    for r in [0, 1, U - 1, U, U + 1, U + 5, U + 999, N - 1] + list(np.random.default_rng(0).integers(0, N, 24)):
+        lo, hi = int(ipn[r]), int(ipn[r + 1])
+        want = (g.vals[lo:hi].double().unsqueeze(1) * x[g.indices[lo:hi].long()].double()).sum(0)
+        assert float((ax[r].double() - want).abs().max()) < 1e-5 * max(float(want.abs().max()), 1e-3), r
+    del x, y, ax, ay
+    # one training step at the reference's init (N(0, 0.01), LightGCN.py:50-51)
+    m._E0.copy_(E0_saved)
+    B = 65_536
+    rng = np.random.default_rng(7)
+    u, i, j = rng.permutation(U)[:B], rng.integers(0, I, B), rng.integers(0, I, B)
+    m.update_lightgcn_embedding()
+    ut, it, jt = (torch.from_numpy(a).cuda().long() for a in (u, i, j))
+    xs = (m._out[:U][ut].double() * (m._out[U:][it].double() - m._out[U:][jt].double())).sum(1)
+    want_loss = float(torch.nn.functional.softplus(-xs).mean())
+    loss = float(m.train_step(u, i, j))
+    assert abs(loss - want_loss) < 1e-5
+    step = (m._E0 - E0_saved).abs()
+    assert bool(torch.isfinite(m._E0).all())
+    # Adam's first step is lr * g / (|g| + eps): at most lr, and close to lr where |g| >> eps = 1e-8
+    assert float(step.max()) <= 1e-3 * (1 + 1e-3) and float(step.max()) > 0.5e-3
+    assert int((step > 0).any(1).sum()) > B                      # propagation spreads the gradient beyond the batch

@@ -3,10 +3,10 @@ vectors captured from the imported reference (oracle/gen_golden.py).  CPU only."
 import numpy as np
 import pytest
 
-from conftest import G1_ADAM, G1_SGD, G23, golden, rel_err, split_batches
+from conftest import DELTA_TOL_SMALL_LR, G1_ADAM, G1_SGD, G1_SGD_BIGLR, G23, delta_err, golden, rel_err, split_batches
 
 
-@pytest.mark.parametrize("name", G1_SGD + G1_ADAM)
+@pytest.mark.parametrize("name", G1_SGD + G1_SGD_BIGLR + G1_ADAM)
 def test_c_oracle_step_matches_reference(oracle_mod, name):
     g = golden(name)
     m = oracle_mod.MFOracle(g["P0"], g["Q0"], optimizer=str(g["optimizer"]), lr=float(g["lr"]))
@@ -19,6 +19,9 @@ def test_c_oracle_step_matches_reference(oracle_mod, name):
         assert abs(loss - g["loss"][t]) < 1e-5
     assert rel_err(m.P, g["PT"]) < 1e-6
     assert rel_err(m.Q, g["QT"]) < 1e-6
+    # ... and on the update itself (large-lr fixtures: the update is O(1) of the table)
+    tol = 1e-5 if name in G1_SGD_BIGLR else DELTA_TOL_SMALL_LR
+    assert delta_err(m.P, g["P0"], g["PT"]) < tol and delta_err(m.Q, g["Q0"], g["QT"]) < tol
 
 
 @pytest.mark.parametrize("name", [G1_SGD[0], G1_ADAM[0]])
