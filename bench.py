@@ -4,20 +4,31 @@
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one batch of synthetic triplets:
-  device sampling (rsx_bpr_sample, on a second stream, one step ahead) -> rsx_bpr_step
+A "step" is one pass of the hot path over one batch of synthetic triplets, queued by the native
+batch loop (include/rsx.h: rsx_bpr_trainer_run -- the reference's inner loop, models/MF.py:61-72):
+  device sampling (rsx_bpr_sample, on a side stream, one step ahead) -> rsx_bpr_step
   -> [all-reduce of the item gradients over RCCL when N > 1] -> rsx_apply_item_grad.
-Workload = BASELINE.json configs[2] (the d=128 shape the metric is quoted on):
-1M users x 100K items per GPU, d=128, Zipf item popularity, 20 positives/user,
-tables N(0, 0.1^2) resident in HBM before the timed region.  Weak scaling: every
-rank owns its own 1M-user block (user rows sharded, items replicated).
+Headline workload = BASELINE.json configs[2] (the d=128 shape the metric is quoted on): 1M users x
+100K items per GPU, d=128, Zipf item popularity, 20 positives/user, one triplet per user per step
+(the reference's epoch, data/generators.py:182-195), tables N(0, 0.1^2) resident in HBM before the
+timed region.  Weak scaling: every rank owns its own 1M-user block (user rows sharded, items replicated).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel
-(bpr_step_blocked_kernel, or bpr_step_kernel when the batch is < 2x the catalog): algorithmic bytes 24*d per triplet over the
-kernel's average launch duration measured with HIP events on the launch stream.
-`cpu_baseline` is the torch-CPU port of the reference path (oracle/torch_port.py)
-timed on this host on a bounded sample; it is test infrastructure and is used here
-only as the thing-compared-against.
+Prints ONE JSON line (rank 0).
+  roofline      dominant kernel of the headline leg.  `achieved` = ALGORITHMIC bytes (24*d per triplet,
+                SURVEY section 8d) / the kernel's mean duration, HIP events on the launch stream inside the
+                timed region.  The blocked kernel sums item-side gradients on chip, so the algorithmic
+                figure counts row writes that never reach HBM: `frac` can approach or exceed 1.  Next to it
+                therefore `hbm_bytes` (PMC-measured traffic per launch, profiles/traffic.json) with
+                `frac_hbm`, and `compulsory_bytes` (what must cross HBM at least once for this batch:
+                P read + write, every touched Q row read once, every touched G row read + written once)
+                with `frac_compulsory` -- neither can exceed 1.
+  legs          the other section-8d measurements, each with its own roofline: SURVEY's base batch
+                B = 65 536, independent uniform negatives, uniform item popularity, a batch sweep, the
+                configs[1] (d=64) shape, and the configs[3] one-rank slice (1.25M users x 1M items).
+  scoring       full-catalog scores/s (MFMA fp32 roofline).
+  cpu_baseline  the torch-CPU port of the reference path (oracle/torch_port.py; test infrastructure, used
+                here only as the thing compared against) on this host: SGD and as-shipped Adam at the SAME
+                batch as each GPU leg, the 1024 x I scoring tile and top-50.
 """
 import argparse
 import json
@@ -56,37 +67,138 @@ def parse():
     ap.add_argument("--hot", type=int, default=256, help="popular items whose gradient rows are replicated (0 = off)")
     ap.add_argument("--hot-replicas", type=int, default=16)
     ap.add_argument("--neg-block", type=int, default=8, help="item block of the stratified negatives (0 = independent uniform negatives)")
-    ap.add_argument("--small-batch", type=int, default=65_536, help="extra leg at this batch size (0 = off)")
+    ap.add_argument("--no-legs", action="store_true", help="headline only (no section-8d legs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=65_536)
     return ap.parse_args()
 
 
-def cpu_baseline(args):
-    """reference path (dense autograd + optimizer sweep) as ported in oracle/torch_port.py,
-    SGD like the GPU path, same U/I/d, bounded to ~10-30 s of CPU work."""
+def traffic_for(key):
+    """PMC-measured HBM bytes per launch of the leg's dominant kernel, if that leg was profiled"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key, {}).get("hbm_bytes_per_launch")
+    except Exception:       # noqa: BLE001 -- no profile, no traffic figure
+        return None
+
+
+def roofline(kernel, kern_ms, B, I, d, key, two_pass=False):
+    alg = (20 if two_pass else 24) * d * B          # per launch (SURVEY section 8d); the item pass writes no P row
+    touched = min(2 * B, I)
+    compulsory = 8 * d * B + 4 * d * touched + 8 * d * touched
+    hbm = traffic_for(key)
+    per_s = lambda nbytes: nbytes / (kern_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": kernel, "achieved": per_s(alg), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": per_s(alg) / HBM_PEAK_GBS, "traffic": hbm, "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms,
+            "compulsory_bytes": compulsory, "frac_compulsory": per_s(compulsory) / HBM_PEAK_GBS,
+            "hbm_bytes": hbm, "frac_hbm": per_s(hbm) / HBM_PEAK_GBS if hbm else None, "traffic_key": key}
+
+
+def fence(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, warmup, world, rank, popularity, two_pass=None):
+    """one timed region of `steps` native steps; returns the leg record (rank 0 fills the throughput)"""
+    from recsys_pytorch_amd import rsx
+    from recsys_pytorch_amd.sharded import BPREngine
+    U, d = P.shape
+    I = Q.shape[0]
+    dev = P.device
+    B = min(B, U)
+    eng = BPREngine(P, Q, lr, user_begin=rank * U, seed=2020)
+    if two_pass is not None:
+        eng.overlap_exchange = bool(two_pass) and world > 1
+    nb = eng.set_neg_block(B, want_nb) if want_nb > 0 else 0
+    if hot > 0:
+        eng.set_hot_items(torch.bincount(indices.long(), minlength=I), hot, hot_replicas)
+    # the loss of every batch is accumulated on the device like MF.fit's epoch_loss (models/MF.py:70)
+    loss = torch.zeros(rsx.RSX_LOSS_SLOTS, dtype=torch.float32, device=dev)
+    tr = eng.native_trainer(indptr, indices, B, loss_acc=loss)
+    gb = B * world
+    tr.run(warmup, B, gb)
+    loss.zero_()
+    fence(world)
+    t0 = time.perf_counter()
+    tr.run(steps, B, gb, time_every=1 if steps < 10 else 5)     # exactly `steps` steps inside the timed region
+    fence(world)
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    kern_ms, _ = tr.kernel_ms()
+    tr.close()
+    assert torch.isfinite(P).all() and torch.isfinite(Q).all()
+    mean_loss = float(loss.double().sum()) / (B * steps)            # this rank's triplets
+    assert np.isfinite(mean_loss) and 0.0 < mean_loss < 5.0, mean_loss
+    replicas_equal = None
+    if world > 1:      # every rank applied the same reduced gradient: the item replicas must be identical
+        cs = torch.stack([Q.double().sum(), -Q.double().sum()])
+        dist.all_reduce(cs, op=dist.ReduceOp.MAX)
+        replicas_equal = bool(float(cs[0] + cs[1]) == 0.0)          # max(sum) == min(sum)
+        assert replicas_equal, "item replicas diverged"
+    kernel = "bpr_step_blocked_kernel" if nb else "bpr_step_kernel"
+    key = f"U{U}_I{I}_d{d}_B{B}_{popularity}_nb{nb}"
+    return {"batch_per_gpu": B, "global_batch": gb, "value": gb * steps / elapsed, "unit": "triplets/s",
+            "ms_per_step": elapsed / steps * 1e3, "steps": steps, "neg_block": nb, "mean_bpr_loss": mean_loss,
+            "two_pass": bool(eng.overlap_exchange), "item_replicas_identical": replicas_equal,
+            "roofline": roofline(kernel, kern_ms, B, I, d, key, two_pass=eng.overlap_exchange),
+            "frac_of_hbm_roofline_end_to_end": gb / world * steps / elapsed * 24 * d / (HBM_PEAK_GBS * 1e9)}
+
+
+def cpu_baseline(args, U, I, d, batches):
+    """reference path (dense autograd + optimizer sweep) as ported in oracle/torch_port.py on this host,
+    at the SAME batch as each GPU leg (SGD like the GPU path, and Adam as shipped, models/MF.py:30), plus the
+    scoring tile P[users] @ Q.T (models/MF.py:109-112) and top-50 (python/func.py:4-17 via argpartition and
+    func.h:12-31 via the C oracle).  Bounded to ~30 s of CPU work in all."""
+    import oracle
     from oracle.torch_port import TorchMFPort
     cores = min(os.cpu_count() or 1, 64)   # dense fp32 sweeps stop scaling (and regress) past ~64 threads
     torch.set_num_threads(cores)
-    U, I, d, B = args.users, args.items, args.dim, args.cpu_batch
     g = torch.Generator().manual_seed(2020)
     P0 = (torch.randn(U, d, generator=g) * 0.1).numpy()
     Q0 = (torch.randn(I, d, generator=g) * 0.1).numpy()
-    m = TorchMFPort(P0, Q0, optimizer="sgd", lr=args.lr)
     rng = np.random.default_rng(1)
-    mk = lambda: (rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B))
-    for _ in range(2):
-        m.step(*mk())
-    times, t_all = [], time.time()
-    while len(times) < 30 and time.time() - t_all < 15.0:    # ~15 s of CPU work, at least a few steps
-        b = mk()
-        t0 = time.time()
-        m.step(*b)
-        times.append(time.time() - t0)
-    med = float(np.median(times))
-    return {"value": B / med, "unit": "triplets/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} SGD steps of B={B} on U={U} I={I} d={d} (torch CPU port of models/MF.py:64-68, "
-                      f"dense grads + full optimizer sweep), median {med*1e3:.0f} ms/step"}
+    legs = {}
+
+    def timed(fn, budget, max_n):
+        fn()
+        ts, t_all = [], time.time()
+        while len(ts) < max_n and (time.time() - t_all < budget or len(ts) < 2):
+            t0 = time.time()
+            fn()
+            ts.append(time.time() - t0)
+        return float(np.median(ts)), len(ts)
+
+    for opt, lr in (("sgd", args.lr), ("adam", 1e-3)):
+        for B in batches:
+            if opt == "adam" and B != batches[0]:
+                continue
+            m = TorchMFPort(P0, Q0, optimizer=opt, lr=lr)
+            mk = lambda: (rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B))
+            med, n = timed(lambda: m.step(*mk()), 5.0, 20)
+            legs[f"{opt}_B{B}"] = {"value": B / med, "unit": "triplets/s", "ms_per_step": med * 1e3, "steps": n}
+            del m
+    users = rng.integers(0, U, 1024)
+    Pt, Qt = torch.from_numpy(P0), torch.from_numpy(Q0)
+    score = lambda: (Pt[torch.from_numpy(users)] @ Qt.T).numpy()
+    med, n = timed(score, 3.0, 10)
+    legs["score_tile_1024xI"] = {"value": 1024 * I / med, "unit": "scores/s", "ms_per_tile": med * 1e3, "tiles": n}
+    S = score().astype(np.float32)
+    K = args.topk
+    med, n = timed(lambda: np.argpartition(-S, K, axis=1)[:, :K], 3.0, 5)
+    legs["top%d_numpy_argpartition" % K] = {"value": 1024 * I / med, "unit": "scores/s", "ms_per_tile": med * 1e3, "tiles": n}
+    oracle.build(with_ref=False)
+    med, n = timed(lambda: oracle.topk(S, K), 3.0, 5)
+    legs["top%d_cxx_partial_sort_1_thread" % K] = {"value": 1024 * I / med, "unit": "scores/s", "ms_per_tile": med * 1e3, "tiles": n}
+    head = legs[f"sgd_B{batches[0]}"]
+    return {"value": head["value"], "unit": "triplets/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{head['steps']} SGD steps of B={batches[0]} (the headline batch) on U={U} I={I} d={d}: torch CPU port of "
+                      f"models/MF.py:64-68 (dense grads + full optimizer sweep), median {head['ms_per_step']:.0f} ms/step; "
+                      "other legs: same port at the other GPU batches, as-shipped Adam, scoring tile, top-k",
+            "legs": legs}
 
 
 def main():
@@ -111,168 +223,69 @@ def main():
 
     from recsys_pytorch_amd import rsx
     from recsys_pytorch_amd.data import synthetic_csr
-    from recsys_pytorch_amd.sharded import BPREngine
     rsx.lib()
+    if os.environ.get("RSX_SCORE_LANES"):
+        rsx.set_option("score_lanes", int(os.environ["RSX_SCORE_LANES"]))
+
+    def tables(U, I, d, degree, popularity):
+        torch.manual_seed(2020 + rank)
+        P = (torch.randn(U, d, device=dev) * 0.1).contiguous()          # this rank's user block
+        torch.manual_seed(2020)
+        Q = (torch.randn(I, d, device=dev) * 0.1).contiguous()          # replicated item table
+        indptr, indices = synthetic_csr(U, I, degree, dev, seed=2020 + rank, popularity=popularity)
+        return P, Q, indptr, indices
 
     U, I, d, B = args.users, args.items, args.dim, min(args.batch, args.users)
-    torch.manual_seed(2020 + rank)
-    P = (torch.randn(U, d, device=dev) * 0.1).contiguous()          # this rank's user block
-    torch.manual_seed(2020)
-    Q = (torch.randn(I, d, device=dev) * 0.1).contiguous()          # replicated item table
-    indptr, indices = synthetic_csr(U, I, args.degree, dev, seed=2020 + rank, popularity=args.popularity)
-    eng = BPREngine(P, Q, args.lr, user_begin=rank * U, seed=2020)
-    gb = B * world
-    eng.use_item_cdf = os.environ.get("RSX_NO_CDF", "0") != "1"         # development knobs
-    inline_sampler = os.environ.get("RSX_INLINE_SAMPLER", "0") == "1"
-    neg_block = eng.set_neg_block(B, args.neg_block) if args.neg_block > 0 else 0
-    if args.hot > 0:
-        eng.set_hot_items(torch.bincount(indices.long(), minlength=I), args.hot, args.hot_replicas)
-
-    # the sampler of step t+1 runs on a second HIP stream while step t computes (it reads only
-    # the CSR); both are inside the timed region
-    side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("RSX_SIDE_PRIORITY", "0")))
-    if inline_sampler:
-        side = torch.cuda.current_stream()
-    bufs = [{"t": eng._triplet_buffers(B), "ready": None, "free": None, "key": 0} for _ in range(2)]
-    state = {"cur": 0, "next_step": 0}
-
-    def prefetch(slot):
-        buf = bufs[slot]
-        if buf["free"] is not None:
-            side.wait_event(buf["free"])
-        with torch.cuda.stream(side):
-            buf["key"] = eng._launch_sample(indptr, indices, B, buf["t"], state["next_step"])
-            buf["ready"] = torch.cuda.Event()
-            buf["ready"].record(side)
-        state["next_step"] += 1
-
-    side.wait_stream(torch.cuda.current_stream())
-    prefetch(0)
-    # N > 1.  Two-pass step: the all-reduce runs under the user pass.  It pays
-    # when the exchange takes longer than the user pass plus the sampler (~375 us): expected with
-    # the 1 or 3 xGMI links of 2 or 4 GPUs, not with the 7 links of 8 (estimate; RSX_TWO_PASS overrides)
+    # N > 1.  Two-pass step: the all-reduce runs under the user pass.  It pays when the
+    # exchange takes longer than the user pass plus the sampler (~375 us): expected with the 1 or 3 xGMI links
+    # of 2 or 4 GPUs, not with the 7 links of 8 (an estimate until measured; RSX_TWO_PASS overrides)
     two_pass = world > 1 and os.environ.get("RSX_TWO_PASS", "1" if world <= 4 else "0") == "1"
-    # one all-reduce of the whole G by default: RCCL's bus bandwidth still rises with the message size
-    # around 51 MB, which outweighs hiding the apply sweep behind later chunks (RSX_EXCHANGE_CHUNKS > 1)
-    n_chunks = max(1, int(os.environ.get("RSX_EXCHANGE_CHUNKS", "1"))) if world > 1 else 1
-    g_chunks = list(torch.chunk(eng.G, n_chunks, dim=0))
-    q_chunks = list(torch.chunk(eng.Q, n_chunks, dim=0))
+    P, Q, indptr, indices = tables(U, I, d, args.degree, args.popularity)
+    head = step_leg(P, Q, indptr, indices, args.lr, B, args.neg_block, args.hot, args.hot_replicas, args.steps, args.warmup,
+                    world, rank, args.popularity, two_pass=two_pass)
 
-    loss_acc = torch.zeros(rsx.RSX_LOSS_SLOTS, dtype=torch.float32, device=dev)
-
-    def one_step(ev=None):
-        main = torch.cuda.current_stream()
-        cur = state["cur"]
-        buf = bufs[cur]
-        main.wait_event(buf["ready"])
+    # ---- the other section-8d legs: each its own timed region of the same native loop ------------------------
+    legs = {}
+    if not args.no_legs:
+        short = max(10, args.steps // 2)
         if world == 1:
-            prefetch(cur ^ 1)           # sampler of step t+1 runs beside step t's kernel
-        u, i, j = buf["t"]
-        use_hot = eng.hot is not None
-        hot = eng.hot if use_hot else None
-        # the loss of every batch is accumulated on the device like MF.fit's epoch_loss (models/MF.py:70)
-        kw = dict(users_unique=True, hot=hot, neg_block=neg_block, neg_key=buf["key"], loss_acc=loss_acc)
-        if ev is not None:
-            ev[0].record()
-        if world == 1:
-            rsx.bpr_step(eng.P, eng.Q, eng.G, u, i, j, eng.lr, 1.0 / gb, **kw)
-            if ev is not None:
-                ev[1].record()
-            rsx.apply_item_grad(eng.Q, eng.G, eng.lr, hot=hot)      # replicas folded inside the sweep
-        else:
-            # two passes over the same triplets (include/rsx.h RSX_ITEMS_ONLY / RSX_USERS_ONLY): the item
-            # pass completes G, and the one exchange of the step -- all_reduce(G) over RCCL/xGMI -- then
-            # travels under the user pass and the next step's sampler instead of behind the whole kernel
-            rsx.bpr_step(eng.P, eng.Q, eng.G, u, i, j, eng.lr, 1.0 / gb, only="items" if two_pass else None, **kw)
-            if ev is not None:
-                ev[1].record()
-            if use_hot:
-                rsx.fold_hot_grad(eng.G, eng.hot)              # the all-reduce needs the folded G
-            # (optionally in item-range chunks, so that the apply sweep of chunk k runs while the later
-            #  chunks are still travelling)
-            works = [dist.all_reduce(c, op=dist.ReduceOp.SUM, async_op=True) for c in g_chunks]
-            after_items = torch.cuda.Event()
-            after_items.record(main)
-            side.wait_event(after_items)
-            prefetch(cur ^ 1)                                  # sampler of step t+1 beside the exchange
-            if two_pass:
-                rsx.bpr_step(eng.P, eng.Q, eng.G, u, i, j, eng.lr, 1.0 / gb, only="users", **{**kw, "loss_acc": None})
-            buf["free"] = torch.cuda.Event()
-            buf["free"].record(main)
-            for w, qc, gc in zip(works, q_chunks, g_chunks):
-                w.wait()
-                rsx.apply_item_grad(qc, gc, eng.lr)
-        if world == 1:
-            # (an event record between two kernels of this queue costs ~10 us of launch gap: with one
-            #  GPU the triplet buffer is released after the apply sweep, not between kernel and sweep)
-            buf["free"] = torch.cuda.Event()
-            buf["free"].record(main)
-        eng.step_count += 1
-        state["cur"] = cur ^ 1
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        one_step()
-    # HIP events around the step kernel of every 5th timed step (an event pair costs ~9 us of
-    # launch gap on this queue, so bracketing every step would slow the thing being measured)
-    ev_every = 1 if args.steps < 10 else 5
-    events = {s: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for s in range(0, args.steps, ev_every)}
-    loss_acc.zero_()
-    fence()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        one_step(events.get(s))
-    fence()
-    elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in events.values()]))   # bpr_step_kernel, HIP events
-    assert torch.isfinite(P).all() and torch.isfinite(Q).all()
-    mean_loss = float(loss_acc.double().sum()) / (B * args.steps)      # this rank's triplets
-    assert np.isfinite(mean_loss) and 0.0 < mean_loss < 5.0, mean_loss
-    replicas_equal = None
-    if world > 1:      # every rank applied the same reduced gradient: the item replicas must be identical
-        cs = torch.stack([Q.double().sum(), -Q.double().sum()])
-        dist.all_reduce(cs, op=dist.ReduceOp.MAX)
-        replicas_equal = bool(float(cs[0] + cs[1]) == 0.0)    # max(sum) == min(sum)
-        assert replicas_equal, "item replicas diverged"
-
-    # ---- small-batch leg: SURVEY section 8d's base batch (65 536 triplets/step), reported beside
-    # the headline.  Below 2 triplets per item there is nothing to sum on chip: atomic path.
-    small = None
-    if world == 1 and args.small_batch > 0 and args.small_batch < B:
-        eng_s = BPREngine(P, Q, args.lr, seed=2021)
-        if args.hot > 0:
-            eng_s.set_hot_items(torch.bincount(indices.long(), minlength=I), args.hot, args.hot_replicas)
-        n_small = 200
-        for _ in range(10):
-            eng_s.sampled_step_overlapped(indptr, indices, args.small_batch, want_loss=False)
-        torch.cuda.synchronize()
-        ts = time.perf_counter()
-        for _ in range(n_small):
-            eng_s.sampled_step_overlapped(indptr, indices, args.small_batch, want_loss=False)
-        torch.cuda.synchronize()
-        dts = time.perf_counter() - ts
-        small = {"batch": args.small_batch, "value": args.small_batch * n_small / dts, "unit": "triplets/s",
-                 "ms_per_step": dts / n_small * 1e3, "steps": n_small,
-                 "path": "bpr_step_kernel (one atomic row update per item row touched, hot-item replicas)",
-                 "frac_of_hbm_roofline": args.small_batch * n_small / dts * 24 * d / (HBM_PEAK_GBS * 1e9)}
-        assert torch.isfinite(P).all() and torch.isfinite(Q).all()
+            base = 65_536      # SURVEY section 8d's base batch: below 2 triplets per item nothing is summed on chip
+            if base < B:
+                legs["base_batch_65536"] = step_leg(P, Q, indptr, indices, args.lr, base, args.neg_block, args.hot,
+                                                    args.hot_replicas, 200, 10, 1, 0, args.popularity)
+            if args.neg_block > 0:
+                legs["independent_uniform_negatives"] = step_leg(P, Q, indptr, indices, args.lr, B, 0, args.hot, args.hot_replicas,
+                                                                 short, 3, 1, 0, args.popularity)
+            sweep = []
+            for b in (4_096, 16_384, 262_144):
+                if b < B:
+                    r = step_leg(P, Q, indptr, indices, args.lr, b, args.neg_block, args.hot, args.hot_replicas, 100, 10, 1, 0,
+                                 args.popularity)
+                    sweep.append({**{k: r[k] for k in ("batch_per_gpu", "value", "ms_per_step", "neg_block")},
+                                  "kernel_ms": r["roofline"]["kernel_ms"], "frac": r["roofline"]["frac"]})
+            legs["batch_sweep"] = sweep
+            other = "uniform" if args.popularity == "zipf" else "zipf"
+            ip2, ix2 = synthetic_csr(U, I, args.degree, dev, seed=2020, popularity=other)
+            legs[f"{other}_item_popularity"] = step_leg(P, Q, ip2, ix2, args.lr, B, args.neg_block, args.hot, args.hot_replicas,
+                                                        short, 3, 1, 0, other)
+            del ip2, ix2
+            if d != 64:       # BASELINE configs[1]: the same shape at d=64
+                P64, Q64 = (torch.randn(U, 64, device=dev) * 0.1), (torch.randn(I, 64, device=dev) * 0.1)
+                legs["config1_d64"] = step_leg(P64, Q64, indptr, indices, args.lr, B, args.neg_block, args.hot, args.hot_replicas,
+                                               short, 3, 1, 0, args.popularity)
+                del P64, Q64
+        # BASELINE configs[3] as each of its ranks sees it: 1.25M users x 1M items per GPU, 10 positives per
+        # user, B = 1.25M per GPU (B < 2 I: the plain step kernel); with N > 1 the 512 MB all-reduce per step
+        if (args.users, args.items, args.dim) == (1_000_000, 100_000, 128):
+            P4, Q4, ip4, ix4 = tables(1_250_000, 1_000_000, 128, 10, args.popularity)
+            legs["config3_slice_1.25Mx1M"] = step_leg(P4, Q4, ip4, ix4, args.lr, 1_250_000, args.neg_block, args.hot,
+                                                      args.hot_replicas, 10, 2, world, rank, args.popularity, two_pass=two_pass)
+            del P4, Q4, ip4, ix4
 
     # ---- scoring leg (reported beside the headline; its own timed region) ---------------
     scoring = None
     if args.score_tiles > 0 and rank == 0:
         tiles, K = args.score_tiles, args.topk
-        if os.environ.get("RSX_SCORE_LANES"):
-            rsx.set_option("score_lanes", int(os.environ["RSX_SCORE_LANES"]))
         users = torch.arange(1024 * tiles, device=dev, dtype=torch.int32) % U
         ws = torch.empty(rsx.lib().rsx_score_topk_workspace(users.numel(), I) // 4 + 64, dtype=torch.float32, device=dev)
         mask = (indptr, indices)
@@ -293,45 +306,32 @@ def main():
         dist.barrier()
 
     if rank == 0:
-        value = gb * args.steps / elapsed
-        alg_bytes = (20 if two_pass else 24) * d * B               # per launch; item pass: no P write
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-measured HBM bytes per launch, if profiled
-        if os.path.exists(tpath):
-            try:
-                t = json.load(open(tpath))
-                key = f"U{U}_I{I}_d{d}_B{B}_{args.popularity}_nb{neg_block}"
-                traffic = t.get(key, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        nb = head["neg_block"]
         out = {
-            "metric": "bpr_triplet_updates_per_sec", "value": value, "unit": "triplets/s",
+            "metric": "bpr_triplet_updates_per_sec", "value": head["value"], "unit": "triplets/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2]: BPRMF synthetic {U} users/GPU x {I} items, d={d}, "
                                    "on-device negative sampling, SGD",
-                       "users_per_gpu": U, "items": I, "d": d, "batch_per_gpu": B, "global_batch": gb,
+                       "users_per_gpu": U, "items": I, "d": d, "batch_per_gpu": B, "global_batch": head["global_batch"],
                        "positives_per_user": args.degree, "item_popularity": args.popularity, "lr": args.lr,
-                       "negatives": f"stratified by item block of {neg_block}, batch sorted by positive item" if neg_block else "independent uniform",
-                       "sampler": "on device, overlapped on a second HIP stream",
-                       "mean_bpr_loss": mean_loss,
-                       **({"item_replicas_identical": replicas_equal} if world > 1 else {}),
+                       "negatives": f"stratified by item block of {nb}, batch sorted by positive item" if nb else "independent uniform",
+                       "sampler": "on device, one step ahead on a side stream",
+                       "loop": "native (rsx_bpr_trainer_run): no interpreter between the kernels of the timed region",
+                       "mean_bpr_loss": head["mean_bpr_loss"],
+                       **({"item_replicas_identical": head["item_replicas_identical"]} if world > 1 else {}),
                        "hot_items": args.hot, "hot_replicas": args.hot_replicas if args.hot > 0 else 0,
                        "parallelism": (f"user-sharded x{world}, items replicated, 1 all-reduce(G)/step"
-                                       + (f" in {n_chunks} chunks pipelined with the apply sweep" if n_chunks > 1 else "")
-                                       + (", under the user pass of a two-pass step" if two_pass else "")) if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "bpr_step_blocked_kernel" if neg_block else "bpr_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},
+                                       + (", under the user pass of a two-pass step" if head["two_pass"] else "")) if world > 1 else "single GPU"},
+            "roofline": head["roofline"],
         }
-        if small is not None:
-            out["small_batch"] = small
+        if legs:
+            out["legs"] = legs
         if scoring is not None:
             out["scoring"] = scoring
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline(args, U, I, d, [B] + ([65_536] if 65_536 < B else []))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RSX_ABI_VERSION 1
+#define RSX_ABI_VERSION 2
 
 #define RSX_OK 0
 #define RSX_E_INVALID (-1)   /* bad argument (null pointer, unsupported d, K ...) */
@@ -47,11 +47,18 @@ extern "C" {
 /* the all-reduce of G is launched after the item pass and travels under the user pass.          */
 #define RSX_ITEMS_ONLY 4u
 #define RSX_USERS_ONLY 8u
+#define RSX_WIDE_OFFSETS 16u /* address rows with 64-bit offsets even when every table is below 4 GB (where  */
+                             /* 32-bit offsets are used and are faster).  Tables of 4 GB and more always   */
+                             /* take the 64-bit form; the flag exists so that form can be tested at any size */
 
 /* flags for rsx_bpr_sample */
 #define RSX_SAMPLE_SORT_POS 1u /* order the batch by positive item (needs a workspace)       */
 
-#define RSX_LOSS_SLOTS 64   /* loss accumulator is float[RSX_LOSS_SLOTS] (striped atomics) */
+#define RSX_LOSS_SLOTS 2048 /* the loss accumulator is float[RSX_LOSS_SLOTS]; the loss is the SUM of all its entries. */
+                            /* Wavefronts add their partial sums to 64 entries kept one per 128-byte line (index   */
+                            /* 32*s): atomics on one line serialise at ~40 per microsecond, and thousands of       */
+                            /* wavefronts adding into 64 ADJACENT floats (two lines) cost a 65 536-triplet step    */
+                            /* 45 of its 114 microseconds                                                          */
 
 typedef void *rsx_stream_t;
 
@@ -97,7 +104,7 @@ int rsx_set_option(const char *name, int64_t value);
  *         otherwise            : summed per distinct user in `ws`, then applied
  *                                (exact for repeated users)
  *   loss_acc (nullable): float[RSX_LOSS_SLOTS]; sum_b softplus(-x_b) is ADDED,
- *     striped over the slots (loss of the batch = sum(slots) * inv_batch).
+ *     spread over the entries (loss of the batch = sum(all entries) * inv_batch).
  *   inv_batch = 1 / (global batch size)  (the mean of MF.py:105; with user
  *     sharding it is 1/(sum over ranks))
  *   ws / ws_bytes: device scratch, needed only without RSX_USERS_UNIQUE;
@@ -220,6 +227,97 @@ int64_t rsx_bpr_item_cdf_workspace(int64_t num_items);
 int rsx_bpr_build_item_cdf(const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users,
                            int64_t num_items, uint32_t *cdf_out, void *ws, int64_t ws_bytes,
                            rsx_stream_t stream);
+
+/* ---- the native batch loop -----------------------------------------------------------
+ * Replaces the reference's inner training loop and the generator feeding it:
+ *   models/MF.py:61-72         for b, (users, pos, neg) in enumerate(batch_generator):
+ *                                  zero_grad / process_one_batch / backward / optimizer.step
+ *                                  epoch_loss += batch_loss
+ *   data/generators.py:206-224 PairwiseGenerator.__iter__ (permutation, slicing, H2D copies)
+ * rsx_bpr_trainer_run queues n_steps steps on `stream` without returning to the caller's
+ * interpreter in between.  Per step: the sampler of step t+1 runs on the trainer's own side
+ * stream beside the step kernel of step t; then [exchange]; then rsx_apply_item_grad.  Every
+ * kernel is the one behind the stand-alone entry points above, with the same arguments a caller
+ * driving rsx_bpr_sample / rsx_bpr_step / rsx_apply_item_grad by hand would pass (step index t,
+ * the running position in the user permutation, neg_key derived from (seed_key, t)), so n native
+ * steps equal n hand-driven steps.  All device buffers are BORROWED (caller keeps them alive until
+ * the stream has drained and the trainer is destroyed); the trainer owns host state, one side
+ * stream and a few events, bound to the device current at creation.
+ *
+ * config
+ *   P [num_users x d] (this rank's user rows), Q, G [num_items x d] (G zero before the first step)
+ *   indptr / indices     CSR of this rank's users (see rsx_bpr_sample)
+ *   batch                largest batch a run may ask for; triplets = int32 [2][3][batch] scratch
+ *   seed                 sampler seed; seed_key keys the per-step negative-block permutation
+ *   neg_block            0 = independent uniform negatives, plain layout.  c > 0 = sorted layout with
+ *                        stratified negatives and on-chip summation, engaged for runs whose batch is
+ *                        >= 2 * num_items (below that every step of the run takes the plain layout);
+ *                        needs sample_ws of rsx_bpr_sample_workspace(batch, num_items) bytes;
+ *                        user_sig / item_cdf optional accelerators (built for this CSR and neg_block)
+ *   hot_slot / G_hot / hot_items / n_hot / hot_replicas   popular-row replicas or all NULL / 0
+ *   loss_acc             nullable float[RSX_LOSS_SLOTS]: sum of softplus(-x) over ALL triplets of ALL
+ *                        steps is added (epoch_loss of MF.py:70 = sum(slots) / batch for equal batches)
+ *   exchange_begin / exchange_end / exchange_ctx   NULL on one GPU.  With user sharding the caller's
+ *                        collective: exchange_begin(ctx) is called when G (folded) is complete on
+ *                        `stream` and must start its all-reduce(sum) over the ranks; exchange_end(ctx)
+ *                        must make `stream` wait for the reduced G.  Return 0 on success.  Between the
+ *                        two the trainer queues the next step's sampler and, if two_pass != 0, the
+ *                        user half of the step (RSX_ITEMS_ONLY before, RSX_USERS_ONLY under the exchange).
+ *   step0 / epoch_pos0   starting step index and position in the user permutation
+ * rsx_bpr_trainer_run(n_steps, batch <= config batch, global_batch = sum of the ranks' batches,
+ *   time_every): time_every > 0 brackets the step kernel of every time_every-th step with HIP events
+ *   on `stream`; rsx_bpr_trainer_kernel_ms returns their mean once the stream has drained.
+ * rsx_bpr_trainer_state: next step index and the permutation position the next batch starts from.
+ * rsx_bpr_trainer_seek: set both (drops a batch sampled ahead).
+ * rsx_bpr_trainer_last_batch: device pointers of the triplets the most recent step consumed (valid
+ *   until two more steps have been queued) and the neg_block / neg_key it ran with: lets a test
+ *   replay exactly what a native step did.                                                   */
+typedef int (*rsx_exchange_fn)(void *ctx);
+
+typedef struct rsx_bpr_trainer_config {
+    float *P;
+    float *Q;
+    float *G;
+    int64_t num_users;
+    int64_t num_items;
+    int32_t d;
+    float lr;
+    const int64_t *indptr;
+    const int32_t *indices;
+    int64_t batch;
+    uint64_t seed;
+    uint64_t seed_key;
+    int32_t neg_block;
+    int32_t two_pass;
+    void *sample_ws;
+    int64_t sample_ws_bytes;
+    const uint64_t *user_sig;
+    const uint32_t *item_cdf;
+    int32_t *triplets;
+    const int32_t *hot_slot;
+    float *G_hot;
+    const int32_t *hot_items;
+    int32_t n_hot;
+    int32_t hot_replicas;
+    float *loss_acc;
+    rsx_exchange_fn exchange_begin;
+    rsx_exchange_fn exchange_end;
+    void *exchange_ctx;
+    int64_t step0;
+    int64_t epoch_pos0;
+} rsx_bpr_trainer_config;
+
+typedef struct rsx_bpr_trainer rsx_bpr_trainer;
+
+int rsx_bpr_trainer_create(const rsx_bpr_trainer_config *cfg, rsx_bpr_trainer **out);
+void rsx_bpr_trainer_destroy(rsx_bpr_trainer *t);
+int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t batch, int64_t global_batch,
+                        int time_every, rsx_stream_t stream);
+int rsx_bpr_trainer_state(const rsx_bpr_trainer *t, int64_t *step, int64_t *epoch_pos);
+int rsx_bpr_trainer_seek(rsx_bpr_trainer *t, int64_t step, int64_t epoch_pos, rsx_stream_t stream);
+int rsx_bpr_trainer_last_batch(const rsx_bpr_trainer *t, const int32_t **u, const int32_t **i,
+                               const int32_t **j, int64_t *batch, int *neg_block, uint64_t *neg_key);
+int rsx_bpr_trainer_kernel_ms(const rsx_bpr_trainer *t, double *mean_ms, int64_t *count);
 
 /* ---- full-catalog scoring + Top-K ----------------------------------------------
  * Replaces

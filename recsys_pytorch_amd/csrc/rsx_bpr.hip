@@ -32,11 +32,48 @@ constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int LPR = 32;   // lanes per row
 constexpr int TPW = 2;    // lane groups (triplets) per wavefront
 
+//
+// ADDRESSING.  A row is named by a byte offset from its table's base, OffT wide.  OffT = uint32_t
+// (tables below 4 GB, every BASELINE shape per GPU): the base stays in SGPRs and each row costs ONE
+// VGPR and one 32-bit multiply-add -- global_load_dword v, v_off, s[base:base+1] offset:c*128 --
+// instead of a 64-bit pointer pair and 64-bit VALU address math per access (the step kernels were
+// spilling registers into scratch inside the triplet loop, and a spill reload is a VMEM operation
+// that waits behind the previous trip's stores and atomics).  OffT = uint64_t: same code, any size.
+template <int D, typename OffT>
+__device__ __forceinline__ OffT row_off(int32_t row, int k)
+{
+    return (OffT)(uint32_t)row * (OffT)(D * 4) + (OffT)(k * 4);
+}
+template <typename OffT>
+__device__ __forceinline__ float *at(const float *base, OffT off)
+{
+    // (pointer arithmetic, not an integer round trip: the address must stay provably global memory)
+    return reinterpret_cast<float *>(reinterpret_cast<char *>(const_cast<float *>(base)) + off);
+}
+
 template <int D>
 struct Row {
     static constexpr int EPL = D / 32;
     float v[EPL];
     static __device__ __forceinline__ int elem(int k, int c) { return k + 32 * c; }
+    template <typename OffT>
+    __device__ __forceinline__ void load_at(const float *base, OffT off)
+    {
+#pragma unroll
+        for (int c = 0; c < EPL; ++c) v[c] = at(base, off)[32 * c];
+    }
+    template <typename OffT>
+    __device__ __forceinline__ void store_at(float *base, OffT off) const
+    {
+#pragma unroll
+        for (int c = 0; c < EPL; ++c) at(base, off)[32 * c] = v[c];
+    }
+    template <typename OffT>
+    __device__ __forceinline__ void atomic_axpy_at(float *base, OffT off, float s) const
+    {
+#pragma unroll
+        for (int c = 0; c < EPL; ++c) rsx_atomic_add(at(base, off) + 32 * c, s * v[c]);
+    }
     __device__ __forceinline__ void load(const float *row, int k)
     {
 #pragma unroll
@@ -124,7 +161,7 @@ struct HotMap {
 // (RSX_NO_UPDATE).  RSX_ITEMS_ONLY / RSX_USERS_ONLY are the two halves of the two-pass step.
 constexpr int kPassItems = 1, kPassUsers = 2, kPassBoth = 3;
 
-template <int D, int MODE, int PASS>
+template <int D, int MODE, int PASS, typename OffT>
 __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
     float *__restrict__ P, const float *__restrict__ Q, float *__restrict__ G,
     const int32_t *__restrict__ U_idx, const int32_t *__restrict__ I_idx,
@@ -152,13 +189,11 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
         if (bn < B) { un = U_idx[bn]; in = I_idx[bn]; jn = J_idx[bn]; }  // prefetch
         const bool live = (b < B) && (i >= 0);
         if (live) {
-            float *prow = P + (size_t)u * D;
-            const float *qi_row = Q + (size_t)i * D;
-            const float *qj_row = Q + (size_t)j * D;
+            const OffT u_off = row_off<D, OffT>(u, k), i_off = row_off<D, OffT>(i, k), j_off = row_off<D, OffT>(j, k);
             Row<D> p, qi, qj;
-            p.load(prow, k);
-            qi.load(qi_row, k);
-            qj.load(qj_row, k);
+            p.load_at(P, u_off);
+            qi.load_at(Q, i_off);
+            qj.load_at(Q, j_off);
             float dpos = 0.0f, dneg = 0.0f;
 #pragma unroll
             for (int c = 0; c < EPL; ++c) {
@@ -175,14 +210,15 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
             if (loss_acc != nullptr && k == 0) loss_local += softplus_neg(x);
             // item gradients (shared rows): G[i] += g p ; G[j] -= g p
             if constexpr ((PASS & kPassItems) != 0) {
-                float *gi_row = G + (size_t)i * D;
-                if (hot.slot != nullptr) {
-                    const int32_t hs = hot.slot[i];
-                    if (hs >= 0)
-                        gi_row = hot.ghot + ((size_t)hs * hot.replicas + (size_t)(wave & (hot.replicas - 1))) * D;
+                int32_t hs = -1;
+                if (hot.slot != nullptr) hs = hot.slot[i];
+                if (!RSX_ABL(1)) {
+                    if (hs >= 0)       // popular item: one of its private replica rows (a small table: 32-bit offsets)
+                        p.atomic_axpy_at(hot.ghot, row_off<D, uint32_t>(hs * hot.replicas + (int32_t)(wave & (hot.replicas - 1)), k), g);
+                    else
+                        p.atomic_axpy_at(G, i_off, g);
                 }
-                if (!RSX_ABL(1)) p.atomic_axpy(gi_row, k, g);
-                if (!RSX_ABL(2)) p.atomic_axpy(G + (size_t)j * D, k, -g);
+                if (!RSX_ABL(2)) p.atomic_axpy_at(G, j_off, -g);
             }
             // user row: P[u] -= lr * g * (qi - qj)
             const float s = -lr * g;
@@ -190,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
                 if constexpr ((PASS & kPassUsers) != 0) {
 #pragma unroll
                     for (int c = 0; c < EPL; ++c) p.v[c] = fmaf(s, qi.v[c] - qj.v[c], p.v[c]);
-                    if (!RSX_ABL(4)) p.store(prow, k);
+                    if (!RSX_ABL(4)) p.store_at(P, u_off);
                 }
             } else {
                 Row<D> dq;
@@ -208,7 +244,7 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
     }
     if (loss_acc != nullptr) {
         const float w = wave_sum(loss_local);
-        if (lane == 0) rsx_atomic_add(loss_acc + (wave & (RSX_LOSS_SLOTS - 1)), w);
+        if (lane == 0) rsx_atomic_add(loss_acc + (wave & 63) * (RSX_LOSS_SLOTS / 64), w);   // one 128-B line per slot
     }
 }
 
@@ -227,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
 //    registers, touching G once per run.
 // Neither is a correctness contract: a negative outside the wave's block and an unsorted batch
 // take the global-atomic path / runs of length one, and the sums are the same.
-template <int D, int PASS>
+template <int D, int PASS, typename OffT>
 __global__ __launch_bounds__(kBlock, 6) void bpr_step_blocked_kernel(
     float *__restrict__ P, const float *__restrict__ Q, float *__restrict__ G,
     const int32_t *__restrict__ U_idx, const int32_t *__restrict__ I_idx,
@@ -253,8 +289,8 @@ __global__ __launch_bounds__(kBlock, 6) void bpr_step_blocked_kernel(
     const int64_t nom_hi = (nom_lo + c < num_items) ? nom_lo + c : num_items;
     const int64_t b0 = ceil_div64(nom_lo * B, num_items);
     const int64_t b1 = ceil_div64(nom_hi * B, num_items);
-    const int64_t item_lo = neg_block_of(wave, nblocks, neg_key) * c;
-    const int64_t item_hi = (item_lo + c < num_items) ? item_lo + c : num_items;
+    const int32_t item_lo = (int32_t)(neg_block_of(wave, nblocks, neg_key) * c);            // num_items < 2^31
+    const int32_t item_hi = (int32_t)(((int64_t)item_lo + c < num_items) ? (int64_t)item_lo + c : num_items);
     // each lane group walks a contiguous part of [b0, b1)
     const int64_t len = ceil_div64(b1 - b0, TPW);
     const int64_t g_lo = b0 + sub * len;
@@ -270,35 +306,34 @@ __global__ __launch_bounds__(kBlock, 6) void bpr_step_blocked_kernel(
     // about the same time (same-line atomics serialise): such rows go to the replicas (HotMap)
 #define RSX_RUN_FLUSH(RI, R)                                                      \
     if (kItems && RI >= 0 && !RSX_ABL(1)) {                                       \
-        float *grow = G + (size_t)RI * D;                                         \
-        if (hot.slot != nullptr) {                                                \
-            const int32_t hs = hot.slot[RI];                                      \
-            if (hs >= 0) grow = hot.ghot + ((size_t)hs * hot.replicas + (size_t)(wave & (hot.replicas - 1))) * D; \
+        int32_t hs = -1;                                                          \
+        if (hot.slot != nullptr) hs = hot.slot[RI];                               \
+        if (hs >= 0) {                                                            \
+            float *grow = at(hot.ghot, row_off<D, uint32_t>(hs * hot.replicas + (int32_t)(wave & (hot.replicas - 1)), k)); \
+            _Pragma("unroll") for (int cc = 0; cc < EPL; ++cc) rsx_atomic_add(grow + 32 * cc, R[cc]); \
+        } else {                                                                  \
+            float *grow = at(G, row_off<D, OffT>(RI, k));                         \
+            _Pragma("unroll") for (int cc = 0; cc < EPL; ++cc) rsx_atomic_add(grow + 32 * cc, R[cc]); \
         }                                                                         \
-        _Pragma("unroll") for (int cc = 0; cc < EPL; ++cc) rsx_atomic_add(grow + RowT::elem(k, cc), R[cc]); \
     }
 
     // one triplet whose three rows are already in registers
     auto process = [&](bool live, int32_t u, int32_t i, int32_t j, Row<D> &p,
                        const Row<D> &qi, const Row<D> &qj) __attribute__((always_inline)) {
-        bool neg_local = false;
-        float neg_g = 0.0f;
-        float pv[EPL];
+        if (!live) return;
+        float dpos = 0.0f, dneg = 0.0f;
 #pragma unroll
-        for (int cc = 0; cc < EPL; ++cc) pv[cc] = 0.f;
-        if (live) {
-            float dpos = 0.0f, dneg = 0.0f;
-#pragma unroll
-            for (int cc = 0; cc < EPL; ++cc) {
-                dpos = fmaf(p.v[cc], qi.v[cc], dpos);
-                dneg = fmaf(p.v[cc], qj.v[cc], dneg);
-            }
-            dpos = group_sum(dpos);
-            dneg = group_sum(dneg);
-            const float x = dpos - dneg;
-            const float sneg = 1.0f / (1.0f + __expf(x));
-            const float g = -sneg * inv_batch;
-            if (loss_acc != nullptr && k == 0) loss_local += softplus_neg(x);
+        for (int cc = 0; cc < EPL; ++cc) {
+            dpos = fmaf(p.v[cc], qi.v[cc], dpos);
+            dneg = fmaf(p.v[cc], qj.v[cc], dneg);
+        }
+        dpos = group_sum(dpos);
+        dneg = group_sum(dneg);
+        const float x = dpos - dneg;
+        const float sneg = 1.0f / (1.0f + __expf(x));
+        const float g = -sneg * inv_batch;
+        if (loss_acc != nullptr && k == 0) loss_local += softplus_neg(x);
+        if constexpr (kItems) {
             // positive item: extend its run, or flush the run and start a new one
             if (i != run_item) {
                 RSX_RUN_FLUSH(run_item, run)
@@ -308,52 +343,56 @@ __global__ __launch_bounds__(kBlock, 6) void bpr_step_blocked_kernel(
             }
 #pragma unroll
             for (int cc = 0; cc < EPL; ++cc) run[cc] = fmaf(g, p.v[cc], run[cc]);
-            // negative item: the wave's own block goes to LDS, anything else to G
-            neg_local = ((int64_t)j >= item_lo && (int64_t)j < item_hi);
-            if (kItems && !neg_local && !RSX_ABL(2)) p.atomic_axpy(G + (size_t)j * D, k, -g);
-            neg_g = -g;
+            // negative item: the wave's own block goes to its LDS tile, anything else to G.  The tile
+            // is wave-private and updated by plain read-modify-write (ds_add_f32 measured ~120 clk per
+            // wave instruction); the lane groups of one wavefront may hit the same row, so they take
+            // turns -- LDS executes a wavefront's instructions in order.
+            const bool neg_local = (j >= item_lo && j < item_hi);
+            if (!RSX_ABL(2)) {
+                if (!neg_local) p.atomic_axpy_at(G, row_off<D, OffT>(j, k), -g);
 #pragma unroll
-            for (int cc = 0; cc < EPL; ++cc) pv[cc] = p.v[cc];
-            if constexpr (kUsers) {
-                const float s = -lr * g;
+                for (int tt = 0; tt < TPW; ++tt) {
+                    if (sub == tt && neg_local) {
+                        float *cell = acc + ((j - item_lo) * LPR + k) * EPL;   // lane k's EPL floats
+                        float a[EPL];
+                        tile_load<EPL>(cell, a);
 #pragma unroll
-                for (int cc = 0; cc < EPL; ++cc) p.v[cc] = fmaf(s, qi.v[cc] - qj.v[cc], p.v[cc]);
-                if (!RSX_ABL(4)) p.store(P + (size_t)u * D, k);
-            }
-        }
-        // wave-private LDS tile, plain read-modify-write (ds_add_f32 measured ~120 clk per
-        // wave instruction).  The lane groups of one wavefront may hit the same row, so they
-        // take turns; LDS executes a wavefront's instructions in order.
-        if (kItems && !RSX_ABL(2)) {
-#pragma unroll
-            for (int tt = 0; tt < TPW; ++tt) {
-                if (sub == tt && neg_local) {
-                    float *cell = acc + ((size_t)(j - item_lo) * LPR + k) * EPL;   // lane k's EPL floats
-                    float a[EPL];
-                    tile_load<EPL>(cell, a);
-#pragma unroll
-                    for (int cc = 0; cc < EPL; ++cc) a[cc] = fmaf(neg_g, pv[cc], a[cc]);
-                    tile_store<EPL>(cell, a);
+                        for (int cc = 0; cc < EPL; ++cc) a[cc] = fmaf(-g, p.v[cc], a[cc]);
+                        tile_store<EPL>(cell, a);
+                    }
                 }
             }
+        }
+        if constexpr (kUsers) {      // last: p is dead after its update
+            const float s = -lr * g;
+#pragma unroll
+            for (int cc = 0; cc < EPL; ++cc) p.v[cc] = fmaf(s, qi.v[cc] - qj.v[cc], p.v[cc]);
+            if (!RSX_ABL(4)) p.store_at(P, row_off<D, OffT>(u, k));
         }
     };
 
     // two positions per lane group per trip: all six row gathers are in flight together
     // (the gather is latency-bound: ~2 us per dependent trip under load)
+    // The walk is in positions RELATIVE to the lane group's first one (32-bit, like the row offsets):
+    // the index arrays are then read as base (SGPRs) + 32-bit byte offset too.
+    const int32_t n_pos = (int32_t)((g_hi > g_lo) ? g_hi - g_lo : 0);
+    const int32_t n_trip = (int32_t)len;
+    const OffT pos0 = (OffT)g_lo * 4;
+    auto idx = [&](const int32_t *base, int32_t rel) __attribute__((always_inline)) {
+        return *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(base) + (pos0 + (OffT)((uint32_t)rel * 4u)));
+    };
     int32_t ua = -1, ia = -1, ja = -1, ub = -1, ib = -1, jb = -1;
-    if (g_lo < g_hi) { ua = U_idx[g_lo]; ia = I_idx[g_lo]; ja = J_idx[g_lo]; }
-    if (g_lo + 1 < g_hi) { ub = U_idx[g_lo + 1]; ib = I_idx[g_lo + 1]; jb = J_idx[g_lo + 1]; }
-    for (int64_t t = 0; t < len; t += 2) {       // wave-uniform trip count
-        const int64_t b = g_lo + t;
+    if (0 < n_pos) { ua = idx(U_idx, 0); ia = idx(I_idx, 0); ja = idx(J_idx, 0); }
+    if (1 < n_pos) { ub = idx(U_idx, 1); ib = idx(I_idx, 1); jb = idx(J_idx, 1); }
+    for (int32_t t = 0; t < n_trip; t += 2) {       // wave-uniform trip count
         int32_t una = -1, ina = -1, jna = -1, unb = -1, inb = -1, jnb = -1;
-        if (b + 2 < g_hi) { una = U_idx[b + 2]; ina = I_idx[b + 2]; jna = J_idx[b + 2]; }
-        if (b + 3 < g_hi) { unb = U_idx[b + 3]; inb = I_idx[b + 3]; jnb = J_idx[b + 3]; }
-        const bool live_a = (b < g_hi) && (ia >= 0);
-        const bool live_b = (b + 1 < g_hi) && (ib >= 0);
+        if (t + 2 < n_pos) { una = idx(U_idx, t + 2); ina = idx(I_idx, t + 2); jna = idx(J_idx, t + 2); }
+        if (t + 3 < n_pos) { unb = idx(U_idx, t + 3); inb = idx(I_idx, t + 3); jnb = idx(J_idx, t + 3); }
+        const bool live_a = (t < n_pos) && (ia >= 0);
+        const bool live_b = (t + 1 < n_pos) && (ib >= 0);
         Row<D> pa, qia, qja, pb, qib, qjb;
-        if (live_a) { pa.load(P + (size_t)ua * D, k); qia.load(Q + (size_t)(RSX_ABL(32) ? 0 : ia) * D, k); qja.load(Q + (size_t)(RSX_ABL(64) ? 1 : ja) * D, k); }
-        if (live_b) { pb.load(P + (size_t)ub * D, k); qib.load(Q + (size_t)(RSX_ABL(32) ? 0 : ib) * D, k); qjb.load(Q + (size_t)(RSX_ABL(64) ? 1 : jb) * D, k); }
+        if (live_a) { pa.load_at(P, row_off<D, OffT>(ua, k)); qia.load_at(Q, row_off<D, OffT>(RSX_ABL(32) ? 0 : ia, k)); qja.load_at(Q, row_off<D, OffT>(RSX_ABL(64) ? 1 : ja, k)); }
+        if (live_b) { pb.load_at(P, row_off<D, OffT>(ub, k)); qib.load_at(Q, row_off<D, OffT>(RSX_ABL(32) ? 0 : ib, k)); qjb.load_at(Q, row_off<D, OffT>(RSX_ABL(64) ? 1 : jb, k)); }
         process(live_a, ua, ia, ja, pa, qia, qja);
         process(live_b, ub, ib, jb, pb, qib, qjb);
         ua = una; ia = ina; ja = jna; ub = unb; ib = inb; jb = jnb;
@@ -368,21 +407,21 @@ __global__ __launch_bounds__(kBlock, 6) void bpr_step_blocked_kernel(
         for (int cc = 0; cc < EPL; ++cc) v[cc] = 0.f;
         bool nz = false;
         if (m < rows) {
-            tile_load<EPL>(acc + ((size_t)m * LPR + k) * EPL, v);
+            tile_load<EPL>(acc + (m * LPR + k) * EPL, v);
 #pragma unroll
             for (int cc = 0; cc < EPL; ++cc) nz |= (v[cc] != 0.0f);
         }
         const unsigned long long bal = __ballot(nz);
         const unsigned long long gmask = 0xFFFFFFFFull << (sub * 32);
         if (m < rows && (bal & gmask) != 0ull) {
-            float *grow = G + (size_t)(item_lo + m) * D;
+            float *grow = at(G, row_off<D, OffT>(item_lo + m, k));
 #pragma unroll
-            for (int cc = 0; cc < EPL; ++cc) rsx_atomic_add(grow + RowT::elem(k, cc), v[cc]);
+            for (int cc = 0; cc < EPL; ++cc) rsx_atomic_add(grow + 32 * cc, v[cc]);
         }
     }
     if (loss_acc != nullptr) {
         const float w = wave_sum(loss_local);
-        if (lane == 0) rsx_atomic_add(loss_acc + (wave & (RSX_LOSS_SLOTS - 1)), w);
+        if (lane == 0) rsx_atomic_add(loss_acc + (wave & 63) * (RSX_LOSS_SLOTS / 64), w);   // one 128-B line per slot
     }
 }
 
@@ -563,7 +602,14 @@ __global__ __launch_bounds__(kBlock) void fold_hot_kernel(float *__restrict__ G,
     *dst = g;
 }
 
-template <int D, int MODE, int PASS>
+// tables of 4 GB and more need 64-bit row offsets (see ADDRESSING above)
+bool wide_offsets(int64_t num_users, int64_t num_items, int d)
+{
+    const int64_t rows = num_users > num_items ? num_users : num_items;
+    return rows * (int64_t)d * 4 >= (1ll << 32);
+}
+
+template <int D, int MODE, int PASS, typename OffT>
 void launch_step(float *P, const float *Q, float *G, const int32_t *u, const int32_t *i,
                  const int32_t *j, int64_t B, float lr, float inv_batch, float *loss_acc,
                  const int32_t *owner, float *GU, HotMap hot, hipStream_t st)
@@ -573,32 +619,38 @@ void launch_step(float *P, const float *Q, float *G, const int32_t *u, const int
     const int64_t cap = (int64_t)rsx_num_cus() * 8;   // 8 blocks x 4 waves = 32 waves per CU
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((bpr_step_kernel<D, MODE, PASS>), dim3((unsigned)blocks), dim3(kBlock), 0, st, P, Q,
+    hipLaunchKernelGGL((bpr_step_kernel<D, MODE, PASS, OffT>), dim3((unsigned)blocks), dim3(kBlock), 0, st, P, Q,
                        G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot);
 }
 
 template <int MODE, int PASS>
-void dispatch_step(int d, float *P, const float *Q, float *G, const int32_t *u, const int32_t *i,
+void dispatch_step(int d, bool wide, float *P, const float *Q, float *G, const int32_t *u, const int32_t *i,
                    const int32_t *j, int64_t B, float lr, float inv_batch, float *loss_acc,
                    const int32_t *owner, float *GU, HotMap hot, hipStream_t st)
 {
+#define RSX_LAUNCH(D_) do { if (wide) launch_step<D_, MODE, PASS, uint64_t>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot, st); \
+                            else launch_step<D_, MODE, PASS, uint32_t>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot, st); } while (0)
     switch (d) {
-    case 32: launch_step<32, MODE, PASS>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot, st); break;
-    case 64: launch_step<64, MODE, PASS>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot, st); break;
-    default: launch_step<128, MODE, PASS>(P, Q, G, u, i, j, B, lr, inv_batch, loss_acc, owner, GU, hot, st); break;
+    case 32: RSX_LAUNCH(32); break;
+    case 64: RSX_LAUNCH(64); break;
+    default: RSX_LAUNCH(128); break;
     }
+#undef RSX_LAUNCH
 }
 
 template <int PASS>
-void dispatch_blocked(int d, unsigned blocks, size_t lds, hipStream_t st, float *P, const float *Q, float *G,
+void dispatch_blocked(int d, bool wide, unsigned blocks, size_t lds, hipStream_t st, float *P, const float *Q, float *G,
                       const int32_t *u, const int32_t *i, const int32_t *j, int64_t B, int64_t num_items,
                       int c, uint64_t neg_key, float lr, float inv_batch, float *loss_acc, HotMap hot)
 {
+#define RSX_LAUNCH(D_) do { if (wide) hipLaunchKernelGGL((bpr_step_blocked_kernel<D_, PASS, uint64_t>), dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u, i, j, B, num_items, c, neg_key, lr, inv_batch, loss_acc, hot); \
+                            else hipLaunchKernelGGL((bpr_step_blocked_kernel<D_, PASS, uint32_t>), dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u, i, j, B, num_items, c, neg_key, lr, inv_batch, loss_acc, hot); } while (0)
     switch (d) {
-    case 32: hipLaunchKernelGGL((bpr_step_blocked_kernel<32, PASS>), dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u, i, j, B, num_items, c, neg_key, lr, inv_batch, loss_acc, hot); break;
-    case 64: hipLaunchKernelGGL((bpr_step_blocked_kernel<64, PASS>), dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u, i, j, B, num_items, c, neg_key, lr, inv_batch, loss_acc, hot); break;
-    default: hipLaunchKernelGGL((bpr_step_blocked_kernel<128, PASS>), dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u, i, j, B, num_items, c, neg_key, lr, inv_batch, loss_acc, hot); break;
+    case 32: RSX_LAUNCH(32); break;
+    case 64: RSX_LAUNCH(64); break;
+    default: RSX_LAUNCH(128); break;
     }
+#undef RSX_LAUNCH
 }
 
 int64_t grid_1d(int64_t n)
@@ -638,6 +690,7 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
     if (batch == 0) return RSX_OK;
     RSX_CHECK_ARG(u_dev && i_dev && j_dev, "null index pointer");
     hipStream_t st = (hipStream_t)stream;
+    const bool wide = wide_offsets(num_users, num_items, d) || batch >= (1ll << 30) || (flags & RSX_WIDE_OFFSETS) != 0;
     HotMap hot{nullptr, nullptr, 1};
     if (hot_slot_dev != nullptr) {
         RSX_CHECK_ARG(G_hot != nullptr, "hot_slot_dev given without G_hot");
@@ -645,7 +698,7 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
         hot = HotMap{hot_slot_dev, G_hot, hot_replicas};
     }
     if (flags & RSX_NO_UPDATE) {   // loss only: the in-place kernel with neither side written
-        dispatch_step<0, 0>(d, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch, loss_acc, nullptr, nullptr,
+        dispatch_step<0, 0>(d, wide, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch, loss_acc, nullptr, nullptr,
                             HotMap{nullptr, nullptr, 1}, st);
         RSX_CHECK_LAUNCH();
         return RSX_OK;
@@ -662,14 +715,14 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
         const int64_t waves = ceil_div64(num_items, neg_block);
         const unsigned blocks = (unsigned)ceil_div64(waves, kWavesPerBlock);
         const size_t lds = (size_t)kWavesPerBlock * neg_block * d * sizeof(float);
-#define RSX_BLOCKED(PASS_) dispatch_blocked<PASS_>(d, blocks, lds, st, P, Q, G, u_dev, i_dev, j_dev, batch, num_items, neg_block, neg_key, lr, inv_batch, loss_acc, hot)
+#define RSX_BLOCKED(PASS_) dispatch_blocked<PASS_>(d, wide, blocks, lds, st, P, Q, G, u_dev, i_dev, j_dev, batch, num_items, neg_block, neg_key, lr, inv_batch, loss_acc, hot)
         if (pass == kPassItems) RSX_BLOCKED(kPassItems); else if (pass == kPassUsers) RSX_BLOCKED(kPassUsers); else RSX_BLOCKED(kPassBoth);
 #undef RSX_BLOCKED
         RSX_CHECK_LAUNCH();
         return RSX_OK;
     }
     if (flags & RSX_USERS_UNIQUE) {
-#define RSX_INPLACE(PASS_) dispatch_step<0, PASS_>(d, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch, loss_acc, nullptr, nullptr, hot, st)
+#define RSX_INPLACE(PASS_) dispatch_step<0, PASS_>(d, wide, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch, loss_acc, nullptr, nullptr, hot, st)
         if (pass == kPassItems) RSX_INPLACE(kPassItems); else if (pass == kPassUsers) RSX_INPLACE(kPassUsers); else RSX_INPLACE(kPassBoth);
 #undef RSX_INPLACE
         RSX_CHECK_LAUNCH();
@@ -685,7 +738,7 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
     float *GU = (float *)((char *)ws + ((num_users * 4 + 255) / 256) * 256);
     const unsigned g1 = (unsigned)grid_1d(batch);
     hipLaunchKernelGGL(bpr_claim_kernel, dim3(g1), dim3(kBlock), 0, st, u_dev, i_dev, batch, owner);
-    dispatch_step<1, kPassBoth>(d, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch, loss_acc, owner, GU, hot, st);
+    dispatch_step<1, kPassBoth>(d, wide, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch, loss_acc, owner, GU, hot, st);
     const int64_t tpw = 64 / (d / 4);     // bpr_apply_user_kernel: one float4 per lane
     const unsigned g2 = (unsigned)grid_1d((batch + tpw - 1) / tpw * 64);
     switch (d) {
@@ -708,7 +761,7 @@ RSX_API int rsx_bpr_grad(const float *P, const float *Q, float *GP, float *GQ, i
     RSX_CHECK_ARG(batch >= 0 && num_users > 0 && num_items > 0, "negative size");
     if (batch == 0) return RSX_OK;
     RSX_CHECK_ARG(u_dev && i_dev && j_dev, "null index pointer");
-    dispatch_step<2, kPassBoth>(d, const_cast<float *>(P), Q, GQ, u_dev, i_dev, j_dev, batch, 0.0f, inv_batch,
+    dispatch_step<2, kPassBoth>(d, wide_offsets(num_users, num_items, d), const_cast<float *>(P), Q, GQ, u_dev, i_dev, j_dev, batch, 0.0f, inv_batch,
                                 loss_acc, nullptr, GP, HotMap{nullptr, nullptr, 1}, (hipStream_t)stream);
     RSX_CHECK_LAUNCH();
     return RSX_OK;

@@ -1,0 +1,272 @@
+// rsx_train.hip -- the native batch loop of one epoch of BPR-MF training on one GPU.
+//
+// Replaces the reference's inner loop (models/MF.py:61-72)
+//     for b, (batch_users, batch_pos, batch_neg) in enumerate(batch_generator):
+//         self.optimizer.zero_grad(); loss = self.process_one_batch(...); loss.backward(); self.optimizer.step()
+//         epoch_loss += batch_loss
+// together with the generator that feeds it (data/generators.py:206-224).  One call queues n
+// steps on the caller's stream without returning to the interpreter in between:
+//     sampler of step t+1 (side stream)  ||  step kernel of step t  ->  [exchange of G]  ->  apply
+// Every kernel is the one behind the stand-alone entry points (rsx_bpr_sample, rsx_bpr_step,
+// rsx_fold_hot_grad, rsx_apply_item_grad): a run of n steps equals n hand-driven steps.
+// The trainer owns only host state (step counter, position in the user permutation, a side
+// stream, events); every device buffer is borrowed from the caller.
+#include <vector>
+
+#include "rsx_common.h"
+
+struct rsx_bpr_trainer {
+    rsx_bpr_trainer_config c;
+    int device = 0;
+    hipStream_t side = nullptr;
+    hipEvent_t ready[2] = {nullptr, nullptr};    // slot sampled (recorded on side)
+    hipEvent_t freed[2] = {nullptr, nullptr};    // slot consumed (recorded on the run stream)
+    hipEvent_t fork = nullptr;                   // run stream -> side ordering
+    bool freed_valid[2] = {false, false};
+    int64_t step = 0;                            // next step to CONSUME
+    int64_t epoch_pos = 0;                       // next position of the user permutation to SAMPLE
+    int cur = 0;                                 // slot the next step consumes
+    bool prefetched = false;                     // slot `cur` holds the batch of step `step`
+    int64_t slot_batch[2] = {0, 0};
+    int64_t slot_pos_before[2] = {0, 0};
+    uint64_t slot_key[2] = {0, 0};
+    int slot_nb[2] = {0, 0};
+    int last = -1;                               // slot consumed by the most recent step
+    // live timing of the step kernel (HIP events on the run stream, every `time_every`-th step)
+    std::vector<hipEvent_t> t0, t1;
+    size_t timed = 0;
+};
+
+namespace {
+
+int32_t *slot_ptr(const rsx_bpr_trainer *t, int slot, int which)
+{
+    return t->c.triplets + ((size_t)slot * 3 + which) * (size_t)t->c.batch;
+}
+
+// per-step key of the negative-block permutation (nonzero).  Same function as
+// recsys_pytorch_amd/sharded.py:BPREngine._neg_key, so that a native run and hand-driven steps
+// draw the same triplets.
+uint64_t neg_key_for(uint64_t seed, int64_t step)
+{
+    uint64_t z = seed * 0x9E3779B97F4A7C15ull + (uint64_t)(step + 1) * 0xD1B54A32D192ED03ull;
+    z ^= z >> 31;
+    return z | 1ull;
+}
+
+int effective_neg_block(const rsx_bpr_trainer *t, int64_t batch)
+{
+    return (t->c.neg_block > 0 && batch >= 2 * t->c.num_items) ? t->c.neg_block : 0;
+}
+
+#define RSX_TRY(call) do { int rc__ = (call); if (rc__ != RSX_OK) return rc__; } while (0)
+#define RSX_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (call);                                                               \
+        if (e__ != hipSuccess) {                                                               \
+            rsx_set_error("%s: %s failed: %s", __func__, #call, hipGetErrorString(e__));       \
+            return RSX_E_HIP;                                                                  \
+        }                                                                                      \
+    } while (0)
+
+// queue the sampler of step `step_index` into `slot` on the side stream
+int launch_sample(rsx_bpr_trainer *t, int slot, int64_t step_index, int64_t batch)
+{
+    const rsx_bpr_trainer_config &c = t->c;
+    // a batch never straddles two passes over the user permutation (tail of a pass is dropped)
+    t->slot_pos_before[slot] = t->epoch_pos;
+    if ((t->epoch_pos % c.num_users) + batch > c.num_users) t->epoch_pos = (t->epoch_pos / c.num_users + 1) * c.num_users;
+    const int nb = effective_neg_block(t, batch);
+    const uint64_t key = nb ? neg_key_for(c.seed_key, step_index) : 0ull;
+    if (t->freed_valid[slot]) RSX_HIP(hipStreamWaitEvent(t->side, t->freed[slot], 0));
+    RSX_TRY(rsx_bpr_sample(c.indptr, c.indices, c.num_users, c.num_items, batch, c.seed, (uint64_t)step_index,
+                           t->epoch_pos, nb, key, nb ? RSX_SAMPLE_SORT_POS : 0u, nb ? c.sample_ws : nullptr,
+                           nb ? c.sample_ws_bytes : 0, nb ? c.user_sig : nullptr, nb ? c.item_cdf : nullptr,
+                           slot_ptr(t, slot, 0), slot_ptr(t, slot, 1), slot_ptr(t, slot, 2), (rsx_stream_t)t->side));
+    RSX_HIP(hipEventRecord(t->ready[slot], t->side));
+    t->epoch_pos += batch;
+    t->slot_batch[slot] = batch;
+    t->slot_key[slot] = key;
+    t->slot_nb[slot] = nb;
+    return RSX_OK;
+}
+
+}  // namespace
+
+RSX_API int rsx_bpr_trainer_create(const rsx_bpr_trainer_config *cfg, rsx_bpr_trainer **out)
+{
+    RSX_CHECK_ARG(cfg != nullptr && out != nullptr, "null pointer");
+    RSX_CHECK_ARG(cfg->P && cfg->Q && cfg->G && cfg->indptr && cfg->indices && cfg->triplets, "null device pointer");
+    RSX_CHECK_ARG(rsx_dim_ok(cfg->d), "d must be 32, 64 or 128");
+    RSX_CHECK_ARG(cfg->num_users > 0 && cfg->num_items > 0 && cfg->batch > 0 && cfg->batch <= cfg->num_users,
+                  "batch must be in [1, num_users]");
+    RSX_CHECK_ARG(cfg->neg_block >= 0 && cfg->neg_block <= kMaxNegBlock, "neg_block must be in [0, 16]");
+    RSX_CHECK_ARG(cfg->neg_block == 0 || (cfg->sample_ws != nullptr &&
+                  cfg->sample_ws_bytes >= rsx_bpr_sample_workspace(cfg->batch, cfg->num_items)),
+                  "neg_block > 0 needs a sampler workspace of rsx_bpr_sample_workspace(batch, num_items) bytes");
+    RSX_CHECK_ARG((cfg->hot_slot == nullptr) == (cfg->G_hot == nullptr) && (cfg->hot_slot == nullptr) == (cfg->hot_items == nullptr),
+                  "hot_slot, G_hot and hot_items go together");
+    RSX_CHECK_ARG((cfg->exchange_begin == nullptr) == (cfg->exchange_end == nullptr), "exchange_begin and exchange_end go together");
+    RSX_CHECK_ARG(cfg->step0 >= 0 && cfg->epoch_pos0 >= 0, "negative start state");
+    rsx_bpr_trainer *t = new (std::nothrow) rsx_bpr_trainer();
+    if (t == nullptr) { rsx_set_error("rsx_bpr_trainer_create: out of memory"); return RSX_E_INVALID; }
+    t->c = *cfg;
+    t->step = cfg->step0;
+    t->epoch_pos = cfg->epoch_pos0;
+    bool ok = hipGetDevice(&t->device) == hipSuccess &&
+              hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&t->fork, hipEventDisableTiming) == hipSuccess;
+    for (int s = 0; ok && s < 2; ++s)
+        ok = hipEventCreateWithFlags(&t->ready[s], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&t->freed[s], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        rsx_set_error("rsx_bpr_trainer_create: could not create the side stream / events");
+        rsx_bpr_trainer_destroy(t);
+        return RSX_E_HIP;
+    }
+    *out = t;
+    return RSX_OK;
+}
+
+RSX_API void rsx_bpr_trainer_destroy(rsx_bpr_trainer *t)
+{
+    if (t == nullptr) return;
+    if (t->side) { (void)hipStreamSynchronize(t->side); (void)hipStreamDestroy(t->side); }
+    for (int s = 0; s < 2; ++s) {
+        if (t->ready[s]) (void)hipEventDestroy(t->ready[s]);
+        if (t->freed[s]) (void)hipEventDestroy(t->freed[s]);
+    }
+    if (t->fork) (void)hipEventDestroy(t->fork);
+    for (hipEvent_t e : t->t0) (void)hipEventDestroy(e);
+    for (hipEvent_t e : t->t1) (void)hipEventDestroy(e);
+    delete t;
+}
+
+RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t batch, int64_t global_batch,
+                                int time_every, rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(t != nullptr, "null trainer");
+    RSX_CHECK_ARG(n_steps >= 0 && batch > 0 && batch <= t->c.batch, "batch must be in [1, config batch]");
+    RSX_CHECK_ARG(global_batch >= batch, "global_batch is the sum of the ranks' batches");
+    RSX_CHECK_ARG(time_every >= 0, "time_every must be >= 0");
+    if (n_steps == 0) return RSX_OK;
+    const rsx_bpr_trainer_config &c = t->c;
+    hipStream_t st = (hipStream_t)stream;
+    const float inv_batch = 1.0f / (float)global_batch;
+    const bool sharded = c.exchange_begin != nullptr;
+    const bool hot = c.hot_slot != nullptr;
+    t->timed = 0;
+    if (t->prefetched && t->slot_batch[t->cur] != batch) {
+        // a batch of another size was sampled ahead (e.g. before an epoch's short last batch): hand its
+        // positions back to the user permutation; the side stream is drained before the slot is reused
+        t->epoch_pos = t->slot_pos_before[t->cur];
+        t->prefetched = false;
+        RSX_HIP(hipEventRecord(t->fork, t->side));
+        RSX_HIP(hipStreamWaitEvent(st, t->fork, 0));
+    }
+    if (!t->prefetched) {
+        // the sampler reads only the CSR, but it must not start before earlier work of the run stream
+        // that may still read the triplet buffers (a previous run's last step)
+        RSX_HIP(hipEventRecord(t->fork, st));
+        RSX_HIP(hipStreamWaitEvent(t->side, t->fork, 0));
+        RSX_TRY(launch_sample(t, t->cur, t->step, batch));
+        t->prefetched = true;
+    }
+    for (int64_t s = 0; s < n_steps; ++s) {
+        const int cur = t->cur, nxt = cur ^ 1;
+        RSX_HIP(hipStreamWaitEvent(st, t->ready[cur], 0));
+        if (!sharded) RSX_TRY(launch_sample(t, nxt, t->step + 1, batch));      // beside this step's kernel
+        const int32_t *u = slot_ptr(t, cur, 0), *i = slot_ptr(t, cur, 1), *j = slot_ptr(t, cur, 2);
+        const int nb = t->slot_nb[cur];
+        const uint64_t key = t->slot_key[cur];
+        const bool timed = time_every > 0 && (s % time_every) == 0;
+        if (timed) {
+            if (t->timed == t->t0.size()) {
+                hipEvent_t a, b;
+                RSX_HIP(hipEventCreate(&a));
+                RSX_HIP(hipEventCreate(&b));
+                t->t0.push_back(a); t->t1.push_back(b);
+            }
+            RSX_HIP(hipEventRecord(t->t0[t->timed], st));
+        }
+        const unsigned f = RSX_USERS_UNIQUE | ((sharded && c.two_pass) ? RSX_ITEMS_ONLY : 0u);
+        RSX_TRY(rsx_bpr_step(c.P, c.Q, c.G, c.num_users, c.num_items, u, i, j, batch, c.d, c.lr, inv_batch, c.loss_acc, f,
+                             nullptr, 0, c.hot_slot, c.G_hot, c.hot_replicas, nb, key, stream));
+        if (timed) { RSX_HIP(hipEventRecord(t->t1[t->timed], st)); ++t->timed; }
+        if (!sharded) {
+            RSX_TRY(rsx_apply_item_grad(c.Q, c.G, c.num_items, c.d, c.lr, c.hot_slot, c.G_hot, c.hot_replicas, stream));
+        } else {
+            // the one exchange of the step: the item gradients, summed over the ranks by the caller's
+            // collective (RCCL all-reduce through torch.distributed in this package).  It needs the
+            // folded G; with two passes it travels under the user pass and the next step's sampler.
+            if (hot) RSX_TRY(rsx_fold_hot_grad(c.G, c.G_hot, c.hot_items, c.n_hot, c.hot_replicas, c.d, stream));
+            if (c.exchange_begin(c.exchange_ctx) != 0) { rsx_set_error("rsx_bpr_trainer_run: exchange_begin failed"); return RSX_E_INVALID; }
+            RSX_HIP(hipEventRecord(t->fork, st));
+            RSX_HIP(hipStreamWaitEvent(t->side, t->fork, 0));
+            RSX_TRY(launch_sample(t, nxt, t->step + 1, batch));               // beside the exchange
+            if (c.two_pass)
+                RSX_TRY(rsx_bpr_step(c.P, c.Q, c.G, c.num_users, c.num_items, u, i, j, batch, c.d, c.lr, inv_batch, nullptr,
+                                     RSX_USERS_UNIQUE | RSX_USERS_ONLY, nullptr, 0, c.hot_slot, c.G_hot, c.hot_replicas, nb,
+                                     key, stream));
+            if (c.exchange_end(c.exchange_ctx) != 0) { rsx_set_error("rsx_bpr_trainer_run: exchange_end failed"); return RSX_E_INVALID; }
+            RSX_TRY(rsx_apply_item_grad(c.Q, c.G, c.num_items, c.d, c.lr, nullptr, nullptr, 0, stream));
+        }
+        RSX_HIP(hipEventRecord(t->freed[cur], st));
+        t->freed_valid[cur] = true;
+        t->last = cur;
+        t->cur = nxt;
+        ++t->step;
+    }
+    return RSX_OK;
+}
+
+RSX_API int rsx_bpr_trainer_state(const rsx_bpr_trainer *t, int64_t *step, int64_t *epoch_pos)
+{
+    RSX_CHECK_ARG(t != nullptr, "null trainer");
+    if (step) *step = t->step;
+    // position the NEXT un-sampled batch starts from, as if nothing had been sampled ahead
+    if (epoch_pos) *epoch_pos = t->prefetched ? t->slot_pos_before[t->cur] : t->epoch_pos;
+    return RSX_OK;
+}
+
+RSX_API int rsx_bpr_trainer_seek(rsx_bpr_trainer *t, int64_t step, int64_t epoch_pos, rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(t != nullptr && step >= 0 && epoch_pos >= 0, "bad state");
+    if (t->prefetched) {     // drop the batch sampled ahead; order the side stream before later work
+        RSX_HIP(hipEventRecord(t->fork, t->side));
+        RSX_HIP(hipStreamWaitEvent((hipStream_t)stream, t->fork, 0));
+        t->prefetched = false;
+    }
+    t->step = step;
+    t->epoch_pos = epoch_pos;
+    return RSX_OK;
+}
+
+RSX_API int rsx_bpr_trainer_last_batch(const rsx_bpr_trainer *t, const int32_t **u, const int32_t **i,
+                                       const int32_t **j, int64_t *batch, int *neg_block, uint64_t *neg_key)
+{
+    RSX_CHECK_ARG(t != nullptr, "null trainer");
+    RSX_CHECK_ARG(t->last >= 0, "no step has run yet");
+    if (u) *u = slot_ptr(t, t->last, 0);
+    if (i) *i = slot_ptr(t, t->last, 1);
+    if (j) *j = slot_ptr(t, t->last, 2);
+    if (batch) *batch = t->slot_batch[t->last];
+    if (neg_block) *neg_block = t->slot_nb[t->last];
+    if (neg_key) *neg_key = t->slot_key[t->last];
+    return RSX_OK;
+}
+
+RSX_API int rsx_bpr_trainer_kernel_ms(const rsx_bpr_trainer *t, double *mean_ms, int64_t *count)
+{
+    RSX_CHECK_ARG(t != nullptr && mean_ms != nullptr, "null pointer");
+    double sum = 0.0;
+    for (size_t k = 0; k < t->timed; ++k) {
+        float ms = 0.f;
+        RSX_HIP(hipEventSynchronize(t->t1[k]));
+        RSX_HIP(hipEventElapsedTime(&ms, t->t0[k], t->t1[k]));
+        sum += ms;
+    }
+    *mean_ms = t->timed ? sum / (double)t->timed : 0.0;
+    if (count) *count = (int64_t)t->timed;
+    return RSX_OK;
+}

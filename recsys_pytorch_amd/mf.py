@@ -152,14 +152,34 @@ class MF(BaseModel):
         if self.optimizer_name == "sgd":
             self._engine.set_neg_block(batch_size)   # on-chip gradient summation when batch >= 2 * items
         scores = None
+        # SGD on the HIP library: the batch loop itself is native (include/rsx.h: rsx_bpr_trainer_run),
+        # Python is re-entered once per epoch (or every 50 batches when verbose, for the progress line)
+        native = self.optimizer_name == "sgd" and hasattr(self._k, "BPRTrainer")
+        acc = torch.zeros(self._k.RSX_LOSS_SLOTS, dtype=torch.float32, device=self.device)
+        trainer = self._engine.native_trainer(indptr, indices, batch_size, loss_acc=acc) if native else None
         for epoch in range(1, num_epochs + 1):
             self.train()
             epoch_loss = torch.zeros((), dtype=torch.float32, device=self.device)
             self._engine.epoch_pos = (epoch - 1) * n_data
-            for b in range(num_batches):
+            if native:
+                trainer.seek(self._engine.step_count, self._engine.epoch_pos)
+                b = 0
+                while b < num_batches:
+                    bsz = min(batch_size, n_data - b * batch_size)
+                    full_left = (n_data - b * batch_size) // batch_size
+                    n = 1 if bsz < batch_size else (min(50, full_left) if verbose else full_left)
+                    acc.zero_()
+                    trainer.run(n, bsz)
+                    chunk_loss = acc.sum() / bsz                    # sum over the n batches of their mean losses
+                    epoch_loss += chunk_loss
+                    if verbose:
+                        print('(%3d / %3d) loss = %.4f' % (b, num_batches, float(chunk_loss) / n))
+                    b += n
+                self._engine.adopt(trainer)
+            for b in range(num_batches if not native else 0):
                 bsz = min(batch_size, n_data - b * batch_size)
-                acc = self._engine.sampled_step(indptr, indices, bsz)
-                batch_loss = acc.sum() / bsz
+                step_acc = self._engine.sampled_step(indptr, indices, bsz)
+                batch_loss = step_acc.sum() / bsz
                 epoch_loss += batch_loss
                 if verbose and b % 50 == 0:
                     print('(%3d / %3d) loss = %.4f' % (b, num_batches, float(batch_loss)))

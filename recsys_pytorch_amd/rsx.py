@@ -18,8 +18,9 @@ RSX_USERS_UNIQUE = 1
 RSX_NO_UPDATE = 2
 RSX_ITEMS_ONLY = 4
 RSX_USERS_ONLY = 8
+RSX_WIDE_OFFSETS = 16
 RSX_SAMPLE_SORT_POS = 1
-RSX_LOSS_SLOTS = 64
+RSX_LOSS_SLOTS = 2048
 SUPPORTED_DIMS = (32, 64, 128)
 
 # symbol -> (restype, argtypes); mirrors include/rsx.h one to one
@@ -47,6 +48,13 @@ SIGNATURES = {
     "rsx_bpr_build_signature": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "rsx_bpr_item_cdf_workspace": (_I64, [_I64]),
     "rsx_bpr_build_item_cdf": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _I64, _P]),
+    "rsx_bpr_trainer_create": (C.c_int, [_P, _P]),
+    "rsx_bpr_trainer_destroy": (None, [_P]),
+    "rsx_bpr_trainer_run": (C.c_int, [_P, _I64, _I64, _I64, _I32, _P]),
+    "rsx_bpr_trainer_state": (C.c_int, [_P, _P, _P]),
+    "rsx_bpr_trainer_seek": (C.c_int, [_P, _I64, _I64, _P]),
+    "rsx_bpr_trainer_last_batch": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "rsx_bpr_trainer_kernel_ms": (C.c_int, [_P, _P, _P]),
     "rsx_score": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P, _P, _P, _P]),
     "rsx_topk": (C.c_int, [_P, _I64, _I64, _I32, _P, _P, _P]),
     "rsx_score_topk_workspace": (_I64, [_I64, _I64]),
@@ -139,7 +147,7 @@ def fold_hot_grad(G, hot):
 
 
 def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False, ws=None,
-             no_update=False, hot=None, neg_block=0, neg_key=0, only=None):
+             no_update=False, hot=None, neg_block=0, neg_key=0, only=None, wide_offsets=False):
     """One batch of include/rsx.h:rsx_bpr_step.  u, i, j: int32 device tensors.
     only = "items" | "users": one pass of the two-pass step (RSX_ITEMS_ONLY / RSX_USERS_ONLY)."""
     d = P.shape[1]
@@ -150,7 +158,7 @@ def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False,
         _dev(j, torch.int32, "j"), u.numel(), d, float(lr), float(inv_batch),
         _dev(loss_acc, torch.float32, "loss_acc") if loss_acc is not None else None,
         (RSX_USERS_UNIQUE if users_unique else 0) | (RSX_NO_UPDATE if no_update else 0)
-        | {None: 0, "items": RSX_ITEMS_ONLY, "users": RSX_USERS_ONLY}[only],
+        | {None: 0, "items": RSX_ITEMS_ONLY, "users": RSX_USERS_ONLY}[only] | (RSX_WIDE_OFFSETS if wide_offsets else 0),
         C.c_void_p(ws.data_ptr()) if ws is not None else None,
         ws.numel() * ws.element_size() if ws is not None else 0,
         _dev(hot.slot, torch.int32, "hot slot") if hot is not None else None,
@@ -285,6 +293,112 @@ def bpr_sample(indptr, indices, num_items, batch, seed, step, epoch_pos, u_out, 
         _dev(item_cdf, torch.int32, "item_cdf") if item_cdf is not None else None,
         _dev(u_out, torch.int32, "u_out"), _dev(i_out, torch.int32, "i_out"),
         _dev(j_out, torch.int32, "j_out"), _stream()), "rsx_bpr_sample")
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+class TrainerConfig(C.Structure):
+    """include/rsx.h:rsx_bpr_trainer_config, field for field"""
+    _fields_ = [("P", _P), ("Q", _P), ("G", _P), ("num_users", _I64), ("num_items", _I64), ("d", C.c_int32),
+                ("lr", _F), ("indptr", _P), ("indices", _P), ("batch", _I64), ("seed", _U64), ("seed_key", _U64),
+                ("neg_block", C.c_int32), ("two_pass", C.c_int32), ("sample_ws", _P), ("sample_ws_bytes", _I64),
+                ("user_sig", _P), ("item_cdf", _P), ("triplets", _P), ("hot_slot", _P), ("G_hot", _P),
+                ("hot_items", _P), ("n_hot", C.c_int32), ("hot_replicas", C.c_int32), ("loss_acc", _P),
+                ("exchange_begin", EXCHANGE_FN), ("exchange_end", EXCHANGE_FN), ("exchange_ctx", _P),
+                ("step0", _I64), ("epoch_pos0", _I64)]
+
+
+class BPRTrainer:
+    """The native batch loop (include/rsx.h: rsx_bpr_trainer_*): n steps of sampler || step kernel ->
+    [exchange] -> apply per call, queued from C++ on torch's current stream.  Keeps every tensor it
+    borrows alive."""
+
+    def __init__(self, P, Q, G, indptr, indices, lr, batch, seed, seed_key, neg_block=0, hot=None, user_sig=None,
+                 item_cdf=None, loss_acc=None, exchange=None, two_pass=False, step0=0, epoch_pos0=0):
+        dev = P.device
+        self.batch = int(batch)
+        self.triplets = torch.empty(2 * 3 * self.batch, dtype=torch.int32, device=dev)
+        self.sample_ws = None
+        if neg_block:
+            self.sample_ws = torch.empty(bpr_sample_workspace(self.batch, Q.shape[0]), dtype=torch.uint8, device=dev)
+        self._keep = (P, Q, G, indptr, indices, hot, user_sig, item_cdf, loss_acc)
+        ptr = lambda t, dt, name: _dev(t, dt, name) if t is not None else None
+        self._cb = (None, None)
+        if exchange is not None:                       # (begin, end) callables; exceptions become error codes
+            def wrap(fn):
+                def call(_ctx):
+                    try:
+                        fn()
+                        return 0
+                    except Exception as e:             # noqa: BLE001 -- must not unwind through the C frames
+                        self._exc = e
+                        return 1
+                return EXCHANGE_FN(call)
+            self._cb = (wrap(exchange[0]), wrap(exchange[1]))
+        self._exc = None
+        cfg = TrainerConfig(
+            P=_dev(P, torch.float32, "P"), Q=_dev(Q, torch.float32, "Q"), G=_dev(G, torch.float32, "G"),
+            num_users=P.shape[0], num_items=Q.shape[0], d=P.shape[1], lr=float(lr),
+            indptr=_dev(indptr, torch.int64, "indptr"), indices=_dev(indices, torch.int32, "indices"),
+            batch=self.batch, seed=int(seed) & (2**64 - 1), seed_key=int(seed_key) & (2**64 - 1),
+            neg_block=int(neg_block), two_pass=int(bool(two_pass)),
+            sample_ws=C.c_void_p(self.sample_ws.data_ptr()) if self.sample_ws is not None else None,
+            sample_ws_bytes=self.sample_ws.numel() if self.sample_ws is not None else 0,
+            user_sig=ptr(user_sig, torch.int64, "user_sig"), item_cdf=ptr(item_cdf, torch.int32, "item_cdf"),
+            triplets=_dev(self.triplets, torch.int32, "triplets"),
+            hot_slot=ptr(hot.slot if hot else None, torch.int32, "hot slot"),
+            G_hot=ptr(hot.ghot if hot else None, torch.float32, "ghot"),
+            hot_items=ptr(hot.items if hot else None, torch.int32, "hot items"),
+            n_hot=hot.n if hot else 0, hot_replicas=hot.replicas if hot else 0,
+            loss_acc=ptr(loss_acc, torch.float32, "loss_acc"),
+            exchange_begin=self._cb[0] or EXCHANGE_FN(), exchange_end=self._cb[1] or EXCHANGE_FN(), exchange_ctx=None,
+            step0=int(step0), epoch_pos0=int(epoch_pos0))
+        self._h = C.c_void_p()
+        _check(lib().rsx_bpr_trainer_create(C.byref(cfg), C.byref(self._h)), "rsx_bpr_trainer_create")
+
+    def run(self, n_steps, batch=None, global_batch=None, time_every=0):
+        batch = self.batch if batch is None else int(batch)
+        rc = lib().rsx_bpr_trainer_run(self._h, int(n_steps), batch, int(global_batch or batch), int(time_every), _stream())
+        if self._exc is not None:
+            e, self._exc = self._exc, None
+            raise e
+        _check(rc, "rsx_bpr_trainer_run")
+
+    def state(self):
+        step, pos = C.c_int64(), C.c_int64()
+        _check(lib().rsx_bpr_trainer_state(self._h, C.byref(step), C.byref(pos)), "rsx_bpr_trainer_state")
+        return step.value, pos.value
+
+    def seek(self, step, epoch_pos):
+        _check(lib().rsx_bpr_trainer_seek(self._h, int(step), int(epoch_pos), _stream()), "rsx_bpr_trainer_seek")
+
+    def last_batch(self):
+        """(u, i, j) views of the triplets the most recent step consumed, its neg_block and neg_key"""
+        pu, pi, pj = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        b, nb, key = C.c_int64(), C.c_int(), C.c_uint64()
+        _check(lib().rsx_bpr_trainer_last_batch(self._h, C.byref(pu), C.byref(pi), C.byref(pj), C.byref(b), C.byref(nb),
+                                                C.byref(key)), "rsx_bpr_trainer_last_batch")
+        base, es = self.triplets.data_ptr(), 4
+        view = lambda p: self.triplets[(p.value - base) // es:(p.value - base) // es + b.value]
+        return view(pu), view(pi), view(pj), nb.value, key.value
+
+    def kernel_ms(self):
+        """mean duration of the timed step kernels of the last run (waits for them)"""
+        ms, n = C.c_double(), C.c_int64()
+        _check(lib().rsx_bpr_trainer_kernel_ms(self._h, C.byref(ms), C.byref(n)), "rsx_bpr_trainer_kernel_ms")
+        return ms.value, n.value
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().rsx_bpr_trainer_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                              # noqa: BLE001 -- interpreter shutdown
+            pass
 
 
 def _mask_ptrs(mask):

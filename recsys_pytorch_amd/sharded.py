@@ -269,6 +269,38 @@ class BPREngine:
         self._cur = cur ^ 1
         return loss
 
+    # -- the native batch loop (include/rsx.h: rsx_bpr_trainer_*) ---------------------------------
+    def native_trainer(self, indptr, indices, batch, loss_acc=None):
+        """C++ loop over this engine's tables and sampler state: `trainer.run(n)` equals n calls of
+        sampled_step_overlapped (same triplets: same seed, step indices, permutation positions and
+        per-step keys) without returning to Python between kernels.  When sharded, the exchange is
+        this engine's all-reduce(G) handed in as a pair of callbacks.  SGD only."""
+        if self.optimizer != "sgd":
+            raise ValueError("the native loop runs the SGD step; optimizer='adam' steps through BPREngine.step")
+        batch = min(int(batch), indptr.numel() - 1)
+        if self.neg_block:
+            self._bind_csr(indptr, indices)
+        exchange = None
+        if self.sharded:
+            pending = []
+
+            def begin():        # G (folded) is complete on the current stream: start the all-reduce
+                pending.append(dist.all_reduce(self.G, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+            def end():          # the current stream waits for the reduced G
+                pending.pop().wait()
+            exchange = (begin, end)
+        return self.k.BPRTrainer(self.P, self.Q, self.G, indptr, indices, self.lr, batch,
+                                 seed=self.seed + 7919 * self.user_begin, seed_key=self.seed, neg_block=self.neg_block,
+                                 hot=self.hot, user_sig=self._sig if self.neg_block else None,
+                                 item_cdf=self._cdf if (self.neg_block and self.use_item_cdf) else None,
+                                 loss_acc=loss_acc, exchange=exchange, two_pass=self.overlap_exchange,
+                                 step0=self.step_count, epoch_pos0=self.epoch_pos)
+
+    def adopt(self, trainer):
+        """take over the step counter and permutation position a native run has reached"""
+        self.step_count, self.epoch_pos = trainer.state()
+
     # -- replay of GLOBAL-id triplets: each rank keeps the triplets of its own users -----
     def route(self, u_global, i, j):
         lo, hi = self.user_begin, self.user_begin + self.P.shape[0]

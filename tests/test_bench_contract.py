@@ -1,4 +1,4 @@
-"""bench.py prints ONE JSON line with the driver's contract fields (+ roofline, cpu_baseline, scoring)."""
+"""bench.py prints ONE JSON line with the driver's contract fields (+ roofline, legs, cpu_baseline, scoring)."""
 import json
 import os
 import subprocess
@@ -9,28 +9,54 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def run_bench(cmd, env=None):
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=500, cwd=ROOT, env={**os.environ, **(env or {})})
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
 def test_bench_json_contract_small_shape():
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--users", "60000",
-           "--items", "40000", "--batch", "60000", "--score-tiles", "1", "--cpu-batch", "4096", "--small-batch", "8192"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=500, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout
-    d = json.loads(lines[0])
+    d = run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--users", "80000",
+                   "--items", "30000", "--batch", "80000", "--score-tiles", "1"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "scoring"):
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "scoring", "legs"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "bpr_step_blocked_kernel"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r and r["kernel_ms"] > 0
+    assert 0 < r["frac_compulsory"] <= 1.0 and r["compulsory_bytes"] < r["algorithmic_bytes_per_launch"]
     assert abs(d["value"] - d["config"]["global_batch"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    legs = d["legs"]
+    assert legs["base_batch_65536"]["neg_block"] == 8 and legs["base_batch_65536"]["roofline"]["kernel_ms"] > 0     # 65536 >= 2 * 30000
+    assert legs["independent_uniform_negatives"]["neg_block"] == 0
+    assert legs["independent_uniform_negatives"]["roofline"]["kernel"] == "bpr_step_kernel"
+    assert [s["batch_per_gpu"] for s in legs["batch_sweep"]] == [4096, 16384] and legs["uniform_item_popularity"]["value"] > 0
+    assert legs["config1_d64"]["value"] > 0 and "config3_slice_1.25Mx1M" not in legs       # only beside the default shape
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
-    assert d["small_batch"]["batch"] == 8192 and d["small_batch"]["value"] > 0
+    assert {"sgd_B80000", "sgd_B65536", "adam_B80000", "score_tile_1024xI", "top50_numpy_argpartition",
+            "top50_cxx_partial_sort_1_thread"} <= set(c["legs"])
     s = d["scoring"]["roofline"]
     assert s["bound"] == "mfma" and s["peak"] == 157.3
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("two_pass", ["0", "1"])
+def test_bench_two_ranks_on_one_gpu(two_pass):
+    """the N > 1 code path of bench.py (torch.distributed.run, native loop with the exchange callbacks) with two
+    ranks sharing the box's GPU and gloo moving G: not a performance number, a does-it-run-and-agree check"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + (os.getpid() + 31 + int(two_pass)) % 2000), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--steps", "4", "--warmup", "1", "--users", "120000", "--batch", "120000", "--items", "30000", "--score-tiles", "0", "--no-legs"]
+    d = run_bench(cmd, env={"RSX_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "RSX_TWO_PASS": two_pass})
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 240000 and d["config"]["item_replicas_identical"] is True
+    assert ("two-pass" in d["config"]["parallelism"]) == (two_pass == "1")
+    assert abs(d["value"] - 240000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]

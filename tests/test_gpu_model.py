@@ -535,6 +535,124 @@ def test_overlapped_sampler_equals_inline_sampler():
     assert torch.allclose(out[0][0], out[1][0], rtol=0, atol=1e-6) and torch.allclose(out[0][1], out[1][1], rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("U,I,B,hot", [(60_000, 3_000, 20_000, True), (30_000, 40_000, 8_192, False)])
+def test_native_trainer_equals_hand_driven_steps(U, I, B, hot):
+    """rsx_bpr_trainer_run (C++ loop: sampler on its side stream || step -> apply) against the same
+    steps driven from Python: same triplets (seed, step index, permutation position, per-step key),
+    across several run() calls, a pass boundary of the user permutation and a change of batch size"""
+    from recsys_pytorch_amd import rsx
+    from recsys_pytorch_amd.data import synthetic_csr
+    from recsys_pytorch_amd.sharded import BPREngine
+    d = 128
+    ip, ix = synthetic_csr(U, I, 10, "cuda", seed=5)
+    outs = []
+    for mode in ("python", "native"):
+        torch.manual_seed(9)
+        P = torch.randn(U, d, device="cuda") * 0.1
+        Q = torch.randn(I, d, device="cuda") * 0.1
+        eng = BPREngine(P, Q, 0.05)
+        nb = eng.set_neg_block(B, 8)
+        assert nb == (8 if B >= 2 * I else 0)
+        if hot:
+            eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 64, 4)
+        total = 0.0
+        if mode == "python":
+            for n, bsz in ((7, B), (2, B // 3), (1, B)):
+                for _ in range(n):
+                    total += float(eng.sampled_step_overlapped(ip, ix, bsz).sum())
+        else:
+            acc = torch.zeros(rsx.RSX_LOSS_SLOTS, device="cuda")
+            tr = eng.native_trainer(ip, ix, B, loss_acc=acc)
+            tr.run(3); tr.run(4)
+            tr.run(2, B // 3)
+            tr.run(1, B)
+            torch.cuda.synchronize()
+            total = float(acc.sum())
+            eng.adopt(tr)
+            tr.close()
+        torch.cuda.synchronize()
+        # (the Python-driven engine's epoch_pos already counts the batch it sampled ahead)
+        pos = eng.epoch_pos if mode == "native" else eng._bufs[eng._cur]["pos_before"]
+        outs.append((P.clone(), Q.clone(), total, eng.step_count, pos))
+    (Pa, Qa, la, sa, pa), (Pb, Qb, lb, sb, pb) = outs
+    assert (sa, pa) == (sb, pb) and sa == 10
+    assert abs(la - lb) < 1e-5 * abs(la)
+    # fp32 atomics reorder sums between runs: compare to rounding, not bitwise
+    assert torch.allclose(Pa, Pb, rtol=0, atol=1e-6) and torch.allclose(Qa, Qb, rtol=0, atol=1e-6)
+
+
+def test_native_trainer_steps_replay_through_the_oracle(oracle_mod):
+    """what a native step consumed (rsx_bpr_trainer_last_batch) replayed on the CPU oracle; state and seek"""
+    from recsys_pytorch_amd import rsx
+    from recsys_pytorch_amd.data import synthetic_csr
+    from recsys_pytorch_amd.sharded import BPREngine
+    U, I, d, B = 9_000, 2_000, 64, 4_000
+    ip, ix = synthetic_csr(U, I, 8, "cuda", seed=2)
+    torch.manual_seed(4)
+    P = torch.randn(U, d, device="cuda") * 0.1
+    Q = torch.randn(I, d, device="cuda") * 0.1
+    orc = oracle_mod.MFOracle(P.cpu().numpy(), Q.cpu().numpy(), "sgd", 0.05)
+    eng = BPREngine(P, Q, 0.05)
+    assert eng.set_neg_block(B, 8) == 8
+    acc = torch.zeros(rsx.RSX_LOSS_SLOTS, device="cuda")
+    tr = eng.native_trainer(ip, ix, B, loss_acc=acc)
+    ipn, ixn = ip.cpu().numpy(), ix.cpu().numpy()
+    seen = []
+    for t in range(4):
+        acc.zero_()
+        tr.run(1)
+        torch.cuda.synchronize()
+        u, i, j, nb, key = tr.last_batch()
+        un, inn, jn = u.cpu().numpy(), i.cpu().numpy(), j.cpu().numpy()
+        assert nb == 8 and key != 0 and len(np.unique(un)) == B and np.all(np.diff(inn) >= 0)
+        for a, b_, c_ in list(zip(un, inn, jn))[::97]:
+            row = ixn[ipn[a]:ipn[a + 1]]
+            assert b_ in row and c_ not in row
+        assert abs(float(acc.sum()) / B - orc.step(un, inn, jn)) < 1e-5
+        seen.append(un)
+        # two batches fit a pass of 9000 users; the third starts the next pass (tail of 1000 dropped)
+        assert tr.state() == [(1, 4000), (2, 8000), (3, 13000), (4, 17000)][t]
+    assert len(np.unique(np.concatenate(seen[:2]))) == 2 * B             # one pass: no user twice
+    assert rel_err(P.cpu().numpy(), orc.P) < 1e-5 and rel_err(Q.cpu().numpy(), orc.Q) < 1e-5
+    # seek back to the start: the same batch again (counter-based sampler)
+    tr.seek(0, 0)
+    tr.run(1)
+    torch.cuda.synchronize()
+    assert np.array_equal(tr.last_batch()[0].cpu().numpy(), seen[0]) and tr.state()[0] == 1
+    tr.close()
+    with pytest.raises(rsx.RsxError):
+        rsx.BPRTrainer(P, Q, eng.G, ip, ix, 0.05, batch=U + 1, seed=1, seed_key=1)      # batch > users
+
+
+def test_fit_runs_twice_with_different_csrs(ml100k):
+    """the static sampler tables (user signatures, item CDF) are bound to the CSR tensors of each
+    fit(): a second fit() on ANOTHER interaction matrix must not see the first one's (a stale
+    signature would accept positives as negatives)"""
+    import scipy.sparse as sp
+    import recsys_pytorch_amd as pkg
+    from recsys_pytorch_amd.data import csr_to_device
+    rng = np.random.default_rng(0)
+    U, I = 4000, 600
+    mats = []
+    for _ in range(2):
+        dense = rng.random((U, I)) < 0.02
+        dense[np.arange(U), rng.integers(0, I, U)] = True
+        mats.append(sp.csr_matrix(dense.astype(np.float32)))
+    ds = [pkg.InteractionData(m) for m in mats]
+    m = pkg.MF(ds[0], dict(HP, hidden_dim=32, lr=0.5), "cuda")
+    cfg = types.SimpleNamespace(batch_size=2000, num_epochs=2, verbose=0, test_from=1, test_step=1)   # 2000 >= 2 * 600: sorted layout
+    for k in range(2):
+        m.fit(ds[k], cfg)
+        eng = m._engine
+        assert eng.neg_block == 8 and eng._csr is not None
+        ip, ix = csr_to_device(mats[k], "cuda")
+        assert torch.equal(eng._csr[0], ip) and torch.equal(eng._csr[1], ix)          # bound to THIS fit's CSR
+        u, i, j = eng.sample(eng._csr[0], eng._csr[1], 2000)
+        dense = np.asarray(mats[k].todense()) > 0
+        un, inn, jn = u.cpu().numpy(), i.cpu().numpy(), j.cpu().numpy()
+        assert dense[un, inn].all() and not dense[un, jn].any()
+
+
 def test_blocked_kernel_is_exact_on_foreign_triplets(oracle_mod):
     """neg_block set but the triplets do NOT follow the sampler contract: still exact"""
     from recsys_pytorch_amd import rsx

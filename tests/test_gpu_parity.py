@@ -158,7 +158,8 @@ def test_step_kernels_on_random_shapes(rsx, oracle_mod):
             # the oracle averages over the live triplets; the device call gets the same 1/n as inv_batch
             ut, it, jt = (torch.from_numpy(x.astype(np.int32)).cuda() for x in (u, i_dev, j))
             loss = torch.zeros(rsx.RSX_LOSS_SLOTS, device="cuda")
-            kw = dict(users_unique=unique, ws=ws, hot=hot, neg_block=c, neg_key=key if c else 0)
+            # (odd trials address rows with 64-bit offsets, the form tables of 4 GB and more take)
+            kw = dict(users_unique=unique, ws=ws, hot=hot, neg_block=c, neg_key=key if c else 0, wide_offsets=bool(trial & 1))
             inv = 1.0 / max(n_live, 1)
             if unique and trial % 6 == 4:
                 rsx.bpr_step(P, Q, G, ut, it, jt, lr, inv, loss_acc=loss, only="items", **kw)

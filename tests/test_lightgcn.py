@@ -163,7 +163,11 @@ def test_hip_lightgcn_full_size_config5_properties():
     E0_saved = m._E0.clone()
     m._E0.copy_(degs.sqrt().unsqueeze(1).expand(N, d))
     m.update_lightgcn_embedding()
-    assert float((m._out - m._E0).abs().max()) < 2e-5 * float(m._E0.abs().max())
+    # (the most popular item row sums ~7e5 equal positive terms in fp32: equal addends round the same
+    #  way, so the error grows linearly, ~2e-4 relative there -- in any summation order, the reference's
+    #  sequential torch.sparse.mm included)
+    assert float(((m._out - m._E0).abs() / m._E0.abs()).max()) < 1e-3
+    assert float(((m._out - m._E0).abs() / m._E0.abs())[:U].max()) < 1e-4          # user rows: 20 neighbours, fed by those item rows
     # symmetry on random vectors (fp64 inner products)
     x, y = torch.randn(N, d, device="cuda"), torch.randn(N, d, device="cuda")
     ax, ay = torch.empty_like(x), torch.empty_like(y)

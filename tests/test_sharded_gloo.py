@@ -160,3 +160,56 @@ def test_two_ranks_on_hip_kernels_with_the_exchange_under_the_user_pass(oracle_m
     err = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
     assert np.array_equal(out[0][3], out[1][3]), "item replicas diverged"
     assert err(P, single.P) < 1e-5 and err(out[0][3], single.Q) < 1e-5
+
+
+def _gpu_sampled_worker(rank, world, port, mode, U, I, d, B, steps, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from recsys_pytorch_amd.data import synthetic_csr
+    from recsys_pytorch_amd.sharded import BPREngine
+    dev = torch.device("cuda", 0)                      # both ranks share the one GPU of the test box
+    ip, ix = synthetic_csr(U, I, 10, dev, seed=40 + rank)          # this rank's block of users
+    torch.manual_seed(100 + rank)
+    P = torch.randn(U, d, device=dev) * 0.1
+    torch.manual_seed(7)
+    Q = torch.randn(I, d, device=dev) * 0.1
+    eng = BPREngine(P, Q, 0.05, user_begin=rank * U, seed=11)
+    eng.set_neg_block(B, 8)
+    eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 32, 4)
+    if mode == "python":
+        for _ in range(steps):
+            eng.sampled_step_overlapped(ip, ix, B, global_batch=world * B, want_loss=False)
+    else:
+        tr = eng.native_trainer(ip, ix, B)
+        tr.run(steps, B, global_batch=world * B)
+        torch.cuda.synchronize()
+        eng.adopt(tr)
+        tr.close()
+    torch.cuda.synchronize()
+    # (the Python-driven engine's epoch_pos already counts the batch it sampled ahead)
+    pos = eng.epoch_pos if mode == "native" else eng._bufs[eng._cur]["pos_before"]
+    out[(mode, rank)] = (P.cpu().numpy(), Q.cpu().numpy(), eng.step_count, pos)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("B,I", [(6000, 2500), (3000, 4000)])
+def test_two_ranks_native_loop_with_exchange_callbacks_equals_python_driven(B, I):
+    """user-sharded SAMPLED steps, two processes on the HIP kernels: the native loop (exchange handed
+    in as callbacks, all-reduce of G under the user pass) against the Python-driven engine on the
+    same triplets; item replicas identical across the ranks in both"""
+    U, d, steps = 9000, 64, 5
+    mgr = mp.Manager()
+    out = mgr.dict()
+    for k, mode in enumerate(("python", "native")):
+        port = 29500 + (os.getpid() + 13 + 17 * k + B) % 2000
+        mp.spawn(_gpu_sampled_worker, args=(2, port, mode, U, I, d, B, steps, out), nprocs=2, join=True)
+    for mode in ("python", "native"):
+        assert np.array_equal(out[(mode, 0)][1], out[(mode, 1)][1]), f"item replicas diverged ({mode})"
+    for r in range(2):
+        Pp, Qp, sp_, pp = out[("python", r)]
+        Pn, Qn, sn, pn = out[("native", r)]
+        assert (sp_, pp) == (sn, pn) and sn == steps
+        assert np.abs(Pp - Pn).max() < 1e-6 and np.abs(Qp - Qn).max() < 1e-6
