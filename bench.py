@@ -107,7 +107,10 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     I = Q.shape[0]
     dev = P.device
     B = min(B, U)
-    eng = BPREngine(P, Q, lr, user_begin=rank * U, seed=2020)
+    # N > 1 exchange of the item gradients: all_reduce(G) (default) or RSX_EXCHANGE=scatter_gather
+    # (reduce_scatter -> own item shard applied -> all_gather of the updated rows; sharded.py)
+    eng = BPREngine(P, Q, lr, user_begin=rank * U, seed=2020, exchange=os.environ.get("RSX_EXCHANGE", "allreduce"))
+    Q = eng.Q                                            # (scatter_gather may re-home the item table)
     if two_pass is not None:
         eng.overlap_exchange = bool(two_pass) and world > 1
     nb = eng.set_neg_block(B, want_nb) if want_nb > 0 else 0
@@ -143,7 +146,8 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     key = f"U{U}_I{I}_d{d}_B{B}_{popularity}_nb{nb}"
     return {"batch_per_gpu": B, "global_batch": gb, "value": gb * steps / elapsed, "unit": "triplets/s",
             "ms_per_step": elapsed / steps * 1e3, "steps": steps, "neg_block": nb, "mean_bpr_loss": mean_loss,
-            "two_pass": bool(eng.overlap_exchange), "item_replicas_identical": replicas_equal,
+            "two_pass": bool(eng.overlap_exchange), "exchange": eng.exchange if world > 1 else None,
+            "item_replicas_identical": replicas_equal, "_Q": Q,
             "roofline": roofline(kernel, kern_ms, B, I, d, key, two_pass=eng.overlap_exchange),
             "frac_of_hbm_roofline_end_to_end": gb / world * steps / elapsed * 24 * d / (HBM_PEAK_GBS * 1e9)}
 
@@ -243,42 +247,48 @@ def main():
     P, Q, indptr, indices = tables(U, I, d, args.degree, args.popularity)
     head = step_leg(P, Q, indptr, indices, args.lr, B, args.neg_block, args.hot, args.hot_replicas, args.steps, args.warmup,
                     world, rank, args.popularity, two_pass=two_pass)
+    Q = head.pop("_Q")
 
     # ---- the other section-8d legs: each its own timed region of the same native loop ------------------------
+    def leg(*a, **k):
+        r = step_leg(*a, **k)
+        r.pop("_Q")
+        return r
+
     legs = {}
     if not args.no_legs:
         short = max(10, args.steps // 2)
         if world == 1:
             base = 65_536      # SURVEY section 8d's base batch: below 2 triplets per item nothing is summed on chip
             if base < B:
-                legs["base_batch_65536"] = step_leg(P, Q, indptr, indices, args.lr, base, args.neg_block, args.hot,
+                legs["base_batch_65536"] = leg(P, Q, indptr, indices, args.lr, base, args.neg_block, args.hot,
                                                     args.hot_replicas, 200, 10, 1, 0, args.popularity)
             if args.neg_block > 0:
-                legs["independent_uniform_negatives"] = step_leg(P, Q, indptr, indices, args.lr, B, 0, args.hot, args.hot_replicas,
+                legs["independent_uniform_negatives"] = leg(P, Q, indptr, indices, args.lr, B, 0, args.hot, args.hot_replicas,
                                                                  short, 3, 1, 0, args.popularity)
             sweep = []
             for b in (4_096, 16_384, 262_144):
                 if b < B:
-                    r = step_leg(P, Q, indptr, indices, args.lr, b, args.neg_block, args.hot, args.hot_replicas, 100, 10, 1, 0,
+                    r = leg(P, Q, indptr, indices, args.lr, b, args.neg_block, args.hot, args.hot_replicas, 100, 10, 1, 0,
                                  args.popularity)
                     sweep.append({**{k: r[k] for k in ("batch_per_gpu", "value", "ms_per_step", "neg_block")},
                                   "kernel_ms": r["roofline"]["kernel_ms"], "frac": r["roofline"]["frac"]})
             legs["batch_sweep"] = sweep
             other = "uniform" if args.popularity == "zipf" else "zipf"
             ip2, ix2 = synthetic_csr(U, I, args.degree, dev, seed=2020, popularity=other)
-            legs[f"{other}_item_popularity"] = step_leg(P, Q, ip2, ix2, args.lr, B, args.neg_block, args.hot, args.hot_replicas,
+            legs[f"{other}_item_popularity"] = leg(P, Q, ip2, ix2, args.lr, B, args.neg_block, args.hot, args.hot_replicas,
                                                         short, 3, 1, 0, other)
             del ip2, ix2
             if d != 64:       # BASELINE configs[1]: the same shape at d=64
                 P64, Q64 = (torch.randn(U, 64, device=dev) * 0.1), (torch.randn(I, 64, device=dev) * 0.1)
-                legs["config1_d64"] = step_leg(P64, Q64, indptr, indices, args.lr, B, args.neg_block, args.hot, args.hot_replicas,
+                legs["config1_d64"] = leg(P64, Q64, indptr, indices, args.lr, B, args.neg_block, args.hot, args.hot_replicas,
                                                short, 3, 1, 0, args.popularity)
                 del P64, Q64
         # BASELINE configs[3] as each of its ranks sees it: 1.25M users x 1M items per GPU, 10 positives per
         # user, B = 1.25M per GPU (B < 2 I: the plain step kernel); with N > 1 the 512 MB all-reduce per step
         if (args.users, args.items, args.dim) == (1_000_000, 100_000, 128):
             P4, Q4, ip4, ix4 = tables(1_250_000, 1_000_000, 128, 10, args.popularity)
-            legs["config3_slice_1.25Mx1M"] = step_leg(P4, Q4, ip4, ix4, args.lr, 1_250_000, args.neg_block, args.hot,
+            legs["config3_slice_1.25Mx1M"] = leg(P4, Q4, ip4, ix4, args.lr, 1_250_000, args.neg_block, args.hot,
                                                       args.hot_replicas, 10, 2, world, rank, args.popularity, two_pass=two_pass)
             del P4, Q4, ip4, ix4
 
@@ -322,7 +332,9 @@ def main():
                        "mean_bpr_loss": head["mean_bpr_loss"],
                        **({"item_replicas_identical": head["item_replicas_identical"]} if world > 1 else {}),
                        "hot_items": args.hot, "hot_replicas": args.hot_replicas if args.hot > 0 else 0,
-                       "parallelism": (f"user-sharded x{world}, items replicated, 1 all-reduce(G)/step"
+                       "parallelism": (f"user-sharded x{world}, items replicated, "
+                                       + ("1 all-reduce(G)/step" if head["exchange"] == "allreduce" else
+                                          "reduce-scatter(G) + own item shard applied + all-gather(Q rows) per step")
                                        + (", under the user pass of a two-pass step" if head["two_pass"] else "")) if world > 1 else "single GPU"},
             "roofline": head["roofline"],
         }

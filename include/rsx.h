@@ -51,6 +51,13 @@ extern "C" {
                              /* 32-bit offsets are used and are faster).  Tables of 4 GB and more always   */
                              /* take the 64-bit form; the flag exists so that form can be tested at any size */
 
+#define RSX_DETERMINISTIC 32u /* bit-reproducible step for bisecting (needs RSX_USERS_UNIQUE and a workspace of   */
+                              /* rsx_bpr_step_det_workspace bytes): no atomics; every item row sums its incidences */
+                              /* in ascending batch position -- the order of autograd's index_add on the CPU --    */
+                              /* after a stable device sort of the 2B (item, position) incidences; the loss is     */
+                              /* summed by one workgroup in a fixed order.  Same step, to rounding, as the default */
+                              /* path; slower (a debugging aid).  hot_slot_dev / neg_block are ignored.            */
+
 /* flags for rsx_bpr_sample */
 #define RSX_SAMPLE_SORT_POS 1u /* order the batch by positive item (needs a workspace)       */
 
@@ -129,6 +136,7 @@ int rsx_set_option(const char *name, int64_t value);
  *     With hot_slot_dev the runs of popular items are flushed into the replicas.
  */
 int64_t rsx_bpr_step_workspace(int64_t num_users, int64_t max_batch, int d);
+int64_t rsx_bpr_step_det_workspace(int64_t batch, int64_t num_items);   /* scratch of RSX_DETERMINISTIC */
 
 int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, int64_t num_items,
                  const int32_t *u_dev, const int32_t *i_dev, const int32_t *j_dev, int64_t batch,
@@ -263,6 +271,9 @@ int rsx_bpr_build_item_cdf(const int64_t *indptr_dev, const int32_t *indices_dev
  *                        must make `stream` wait for the reduced G.  Return 0 on success.  Between the
  *                        two the trainer queues the next step's sampler and, if two_pass != 0, the
  *                        user half of the step (RSX_ITEMS_ONLY before, RSX_USERS_ONLY under the exchange).
+ *   exchange_applies     != 0: exchange_end also UPDATES Q and leaves G zero (e.g. reduce-scatter of G,
+ *                        each rank applying its own shard of item rows, all-gather of the updated rows);
+ *                        the trainer then does not call rsx_apply_item_grad itself.
  *   step0 / epoch_pos0   starting step index and position in the user permutation
  * rsx_bpr_trainer_run(n_steps, batch <= config batch, global_batch = sum of the ranks' batches,
  *   time_every): time_every > 0 brackets the step kernel of every time_every-th step with HIP events
@@ -303,6 +314,8 @@ typedef struct rsx_bpr_trainer_config {
     rsx_exchange_fn exchange_begin;
     rsx_exchange_fn exchange_end;
     void *exchange_ctx;
+    int32_t exchange_applies;
+    int32_t reserved0;
     int64_t step0;
     int64_t epoch_pos0;
 } rsx_bpr_trainer_config;

@@ -704,6 +704,12 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
         return RSX_OK;
     }
     RSX_CHECK_ARG(neg_block >= 0 && neg_block <= kMaxNegBlock, "neg_block must be in [0, 16]");
+    if (flags & RSX_DETERMINISTIC) {
+        RSX_CHECK_ARG(flags & RSX_USERS_UNIQUE, "RSX_DETERMINISTIC needs RSX_USERS_UNIQUE");
+        RSX_CHECK_ARG(!(flags & (RSX_ITEMS_ONLY | RSX_USERS_ONLY)), "RSX_DETERMINISTIC runs the whole step");
+        return rsx_bpr_step_deterministic(P, Q, G, num_items, u_dev, i_dev, j_dev, batch, d, lr, inv_batch, loss_acc, ws,
+                                          ws_bytes, st);
+    }
     int pass = kPassBoth;          // two-pass step: which side this launch writes
     if (flags & (RSX_ITEMS_ONLY | RSX_USERS_ONLY)) {
         RSX_CHECK_ARG(flags & RSX_USERS_UNIQUE, "RSX_ITEMS_ONLY / RSX_USERS_ONLY need RSX_USERS_UNIQUE");

@@ -53,6 +53,11 @@ static __constant__ int c_rsx_ablate = 0;
 extern int g_rsx_score_lanes;   // passes of the fused scoring path in flight (1..4)
 extern int g_rsx_sort_cap;      // LDS sort capacity of the bucket sampler (test hook for the out-of-LDS path)
 
+// rsx_det.hip: the deterministic form of the step (RSX_DETERMINISTIC); arguments validated by rsx_bpr_step
+int rsx_bpr_step_deterministic(float *P, const float *Q, float *G, int64_t num_items, const int32_t *u_dev,
+                               const int32_t *i_dev, const int32_t *j_dev, int64_t batch, int d, float lr, float inv_batch,
+                               float *loss_acc, void *ws, int64_t ws_bytes, hipStream_t st);
+
 // ---- shared by the sampler (rsx_sample.hip) and the step kernels (rsx_bpr.hip) --------------
 constexpr int kMaxNegBlock = 16;
 

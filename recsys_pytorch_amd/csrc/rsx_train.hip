@@ -209,7 +209,8 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
                                      RSX_USERS_UNIQUE | RSX_USERS_ONLY, nullptr, 0, c.hot_slot, c.G_hot, c.hot_replicas, nb,
                                      key, stream));
             if (c.exchange_end(c.exchange_ctx) != 0) { rsx_set_error("rsx_bpr_trainer_run: exchange_end failed"); return RSX_E_INVALID; }
-            RSX_TRY(rsx_apply_item_grad(c.Q, c.G, c.num_items, c.d, c.lr, nullptr, nullptr, 0, stream));
+            if (!c.exchange_applies)
+                RSX_TRY(rsx_apply_item_grad(c.Q, c.G, c.num_items, c.d, c.lr, nullptr, nullptr, 0, stream));
         }
         RSX_HIP(hipEventRecord(t->freed[cur], st));
         t->freed_valid[cur] = true;

@@ -16,6 +16,9 @@ Divergences from the reference, all documented in DESIGN.md:
   * triplets: sampled on the device every step (include/rsx.h:rsx_bpr_sample), true
     BPR sampling, instead of PairwiseGenerator's once-per-fit host sampling with its
     quirks (data/generators.py:165,182-185).  `train_step` replays explicit triplets.
+  * hparams['neg_block'] (default 8; 0 = off): when a batch holds >= 2 triplets per item the sampler
+    orders it by positive item and stratifies the negatives by item block so that the step kernel can
+    sum item gradients on chip; tests/test_gpu_model.py checks it trains as well.
   * pointwise branch (MF.py:48-51,101-102) is outside the hot path: NotImplementedError.
   * hidden_dim is padded to 32/64/128 columns of zeros internally (they stay zero).
 """
@@ -87,6 +90,8 @@ class MF(BaseModel):
         self.optimizer_name = opt
         self.lr = float(_get(hparams, "lr", 0.05 if opt == "sgd" else 1e-3))
         self.seed = int(_get(hparams, "seed", 2020))
+        # item block of the stratified negatives; 0 = independent uniform negatives always
+        self.neg_block = int(_get(hparams, "neg_block", 8))
         self.device = torch.device(device)
         self._dpad = _pad_dim(self.hidden_dim)
         d = self.hidden_dim
@@ -149,8 +154,8 @@ class MF(BaseModel):
         # (data/generators.py:182-195); the last batch of an epoch is short, not dropped (:213)
         n_data = self.num_users
         num_batches = int(np.ceil(n_data / batch_size))
-        if self.optimizer_name == "sgd":
-            self._engine.set_neg_block(batch_size)   # on-chip gradient summation when batch >= 2 * items
+        if self.optimizer_name == "sgd":     # on-chip gradient summation when batch >= 2 * items
+            self._engine.set_neg_block(batch_size if self.neg_block > 0 else 0, max(self.neg_block, 1))
         scores = None
         # SGD on the HIP library: the batch loop itself is native (include/rsx.h: rsx_bpr_trainer_run),
         # Python is re-entered once per epoch (or every 50 batches when verbose, for the progress line)

@@ -19,6 +19,7 @@ RSX_NO_UPDATE = 2
 RSX_ITEMS_ONLY = 4
 RSX_USERS_ONLY = 8
 RSX_WIDE_OFFSETS = 16
+RSX_DETERMINISTIC = 32
 RSX_SAMPLE_SORT_POS = 1
 RSX_LOSS_SLOTS = 2048
 SUPPORTED_DIMS = (32, 64, 128)
@@ -31,6 +32,7 @@ SIGNATURES = {
     "rsx_device_info_get": (C.c_int, [C.c_int, _P]),
     "rsx_set_option": (C.c_int, [C.c_char_p, _I64]),
     "rsx_bpr_step_workspace": (_I64, [_I64, _I64, _I32]),
+    "rsx_bpr_step_det_workspace": (_I64, [_I64, _I64]),
     "rsx_bpr_step": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, _I64, _I32, _F, _F, _P, _U, _P, _I64,
                                _P, _P, _I32, _I32, _U64, _P]),
     "rsx_fold_hot_grad": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P]),
@@ -126,6 +128,13 @@ def bpr_step_workspace(num_users, max_batch, d):
     return n
 
 
+def bpr_step_det_workspace(batch, num_items):
+    n = lib().rsx_bpr_step_det_workspace(batch, num_items)
+    if n < 0:
+        raise RsxError("rsx_bpr_step_det_workspace: invalid shape")
+    return n
+
+
 class HotItems:
     """Replicated gradient rows for the most popular items (include/rsx.h: hot_slot_dev)."""
 
@@ -147,7 +156,7 @@ def fold_hot_grad(G, hot):
 
 
 def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False, ws=None,
-             no_update=False, hot=None, neg_block=0, neg_key=0, only=None, wide_offsets=False):
+             no_update=False, hot=None, neg_block=0, neg_key=0, only=None, wide_offsets=False, deterministic=False):
     """One batch of include/rsx.h:rsx_bpr_step.  u, i, j: int32 device tensors.
     only = "items" | "users": one pass of the two-pass step (RSX_ITEMS_ONLY / RSX_USERS_ONLY)."""
     d = P.shape[1]
@@ -158,7 +167,8 @@ def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False,
         _dev(j, torch.int32, "j"), u.numel(), d, float(lr), float(inv_batch),
         _dev(loss_acc, torch.float32, "loss_acc") if loss_acc is not None else None,
         (RSX_USERS_UNIQUE if users_unique else 0) | (RSX_NO_UPDATE if no_update else 0)
-        | {None: 0, "items": RSX_ITEMS_ONLY, "users": RSX_USERS_ONLY}[only] | (RSX_WIDE_OFFSETS if wide_offsets else 0),
+        | {None: 0, "items": RSX_ITEMS_ONLY, "users": RSX_USERS_ONLY}[only] | (RSX_WIDE_OFFSETS if wide_offsets else 0)
+        | (RSX_DETERMINISTIC if deterministic else 0),
         C.c_void_p(ws.data_ptr()) if ws is not None else None,
         ws.numel() * ws.element_size() if ws is not None else 0,
         _dev(hot.slot, torch.int32, "hot slot") if hot is not None else None,
@@ -306,7 +316,7 @@ class TrainerConfig(C.Structure):
                 ("user_sig", _P), ("item_cdf", _P), ("triplets", _P), ("hot_slot", _P), ("G_hot", _P),
                 ("hot_items", _P), ("n_hot", C.c_int32), ("hot_replicas", C.c_int32), ("loss_acc", _P),
                 ("exchange_begin", EXCHANGE_FN), ("exchange_end", EXCHANGE_FN), ("exchange_ctx", _P),
-                ("step0", _I64), ("epoch_pos0", _I64)]
+                ("exchange_applies", C.c_int32), ("reserved0", C.c_int32), ("step0", _I64), ("epoch_pos0", _I64)]
 
 
 class BPRTrainer:
@@ -315,7 +325,7 @@ class BPRTrainer:
     borrows alive."""
 
     def __init__(self, P, Q, G, indptr, indices, lr, batch, seed, seed_key, neg_block=0, hot=None, user_sig=None,
-                 item_cdf=None, loss_acc=None, exchange=None, two_pass=False, step0=0, epoch_pos0=0):
+                 item_cdf=None, loss_acc=None, exchange=None, two_pass=False, exchange_applies=False, step0=0, epoch_pos0=0):
         dev = P.device
         self.batch = int(batch)
         self.triplets = torch.empty(2 * 3 * self.batch, dtype=torch.int32, device=dev)
@@ -353,7 +363,7 @@ class BPRTrainer:
             n_hot=hot.n if hot else 0, hot_replicas=hot.replicas if hot else 0,
             loss_acc=ptr(loss_acc, torch.float32, "loss_acc"),
             exchange_begin=self._cb[0] or EXCHANGE_FN(), exchange_end=self._cb[1] or EXCHANGE_FN(), exchange_ctx=None,
-            step0=int(step0), epoch_pos0=int(epoch_pos0))
+            exchange_applies=int(bool(exchange_applies)), reserved0=0, step0=int(step0), epoch_pos0=int(epoch_pos0))
         self._h = C.c_void_p()
         _check(lib().rsx_bpr_trainer_create(C.byref(cfg), C.byref(self._h)), "rsx_bpr_trainer_create")
 

@@ -33,7 +33,8 @@ class BPREngine:
     Q       : [I x d] fp32, replicated
     """
 
-    def __init__(self, P_local, Q, lr, kernels=None, group=None, user_begin=0, seed=2020, optimizer="sgd"):
+    def __init__(self, P_local, Q, lr, kernels=None, group=None, user_begin=0, seed=2020, optimizer="sgd",
+                 exchange="allreduce"):
         if kernels is None:
             from . import rsx as kernels   # the HIP path; raises if librsx.so is missing
         self.k = kernels
@@ -61,6 +62,18 @@ class BPREngine:
             self.mQ, self.vQ = torch.zeros_like(Q), torch.zeros_like(Q)
         elif optimizer != "sgd":
             raise ValueError(optimizer)
+        # how the ranks exchange the item gradients of a step:
+        #   "allreduce"      all_reduce(G), then every rank applies the identical Q -= lr*G
+        #   "scatter_gather" reduce_scatter(G) -> each rank applies ITS shard of item rows -> all_gather of
+        #                    the updated Q rows.  Every item row is computed by exactly one rank and copied
+        #                    to the others: the replicas are identical by construction, whatever order the
+        #                    collective sums in, and the apply sweep shrinks to 1/W of the table per rank.
+        if exchange not in ("allreduce", "scatter_gather"):
+            raise ValueError(exchange)
+        self.exchange = exchange if (self.sharded and optimizer == "sgd") else "allreduce"
+        self._work = None
+        if self.exchange == "scatter_gather":
+            self._setup_item_shards()
         self.hot = None
         self.neg_block = 0          # > 0: negatives stratified by item block, batch sorted by positive item
         self.use_item_cdf = True    # order the batch through the item-CDF buckets (False: device radix sort)
@@ -103,6 +116,50 @@ class BPREngine:
         """spread the gradients of the `num_hot` most popular items over `replicas` private rows
         (contention relief at the atomic unit, include/rsx.h:rsx_bpr_step hot_slot_dev)"""
         self.hot = self.k.HotItems(item_counts, num_hot, replicas, self.Q.shape[1], self.Q.device) if num_hot > 0 else None
+
+    # -- the exchange of a step's item gradients ------------------------------------------------
+    def _setup_item_shards(self):
+        """equal item shards for reduce_scatter / all_gather: the tables are re-homed into buffers padded
+        to W * ceil(I / W) rows (self.Q / self.G stay [I x d] views of them; a caller that allocated Q
+        must go on using ENGINE.Q, which is the same storage only when I divides evenly)"""
+        W, r = self.world, dist.get_rank(self.group)
+        I, d = self.Q.shape
+        self._shard = (I + W - 1) // W
+        rows = self._shard * W
+        if rows != I:
+            Qp = torch.zeros(rows, d, dtype=self.Q.dtype, device=self.Q.device)
+            Qp[:I] = self.Q
+            self.Q = Qp[:I]
+        else:
+            Qp = self.Q
+        self._Qp = Qp
+        self._Gp = torch.zeros(rows, d, dtype=self.Q.dtype, device=self.Q.device)
+        self.G = self._Gp[:I]
+        self._mine = slice(r * self._shard, (r + 1) * self._shard)
+
+    def _exchange_begin(self):
+        """G (folded) is complete on the current stream: start the collective"""
+        if self.exchange == "allreduce":
+            self._work = dist.all_reduce(self.G, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            return
+        try:        # in place: this rank's shard of G receives the sum over the ranks
+            self._work = dist.reduce_scatter_tensor(self._Gp[self._mine], self._Gp, op=dist.ReduceOp.SUM, group=self.group,
+                                                    async_op=True)
+        except RuntimeError:    # a backend without reduce_scatter (gloo, in the CPU tests): same shard via all_reduce
+            self._work = dist.all_reduce(self._Gp, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _exchange_end(self):
+        """the current stream waits for the exchange; with "scatter_gather" this also applies the own shard
+        and gathers the updated item rows, so no apply sweep follows"""
+        self._work.wait()
+        self._work = None
+        if self.exchange == "allreduce":
+            return
+        m = self._mine
+        self.k.apply_item_grad(self._Qp[m], self._Gp[m], self.lr)          # Q -= lr*G on the own rows; zeroes them in G
+        self._Gp[:m.start].zero_()                                         # the other shards hold this rank's partial sums
+        self._Gp[m.stop:].zero_()
+        dist.all_gather_into_tensor(self._Qp, self._Qp[m], group=self.group)   # in place: every rank's updated rows
 
     # -- helpers ---------------------------------------------------------------
     def _workspace(self, batch):
@@ -153,14 +210,15 @@ class BPREngine:
                                 users_unique=True, only="items", **kw)
                 if "hot" in kw:
                     self.k.fold_hot_grad(self.G, self.hot)
-            work = dist.all_reduce(self.G, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._exchange_begin()
             if B > 0:
                 self.k.bpr_step(self.P, self.Q, self.G, u_local, i, j, self.lr, 1.0 / gb,
                                 users_unique=True, only="users", **kw)
-            work.wait()
+            self._exchange_end()
             if want_loss:
                 dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.group)
-            self.k.apply_item_grad(self.Q, self.G, self.lr)
+            if self.exchange == "allreduce":
+                self.k.apply_item_grad(self.Q, self.G, self.lr)
             self.step_count += 1
             return loss
         if B > 0:
@@ -170,12 +228,13 @@ class BPREngine:
                 self.k.fold_hot_grad(self.G, self.hot)      # the all-reduce needs the folded G
         if self.sharded:
             # the one exchange of the step: item gradients, summed over ranks (RCCL over xGMI)
-            dist.all_reduce(self.G, op=dist.ReduceOp.SUM, group=self.group)
+            self._exchange_begin()
+            self._exchange_end()
             if want_loss:
                 dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.group)
         if self.hot is not None and not self.sharded:
             self.k.apply_item_grad(self.Q, self.G, self.lr, hot=self.hot)   # replicas folded in the sweep
-        else:
+        elif self.exchange == "allreduce":
             self.k.apply_item_grad(self.Q, self.G, self.lr)
         self.step_count += 1
         return loss
@@ -280,21 +339,13 @@ class BPREngine:
         batch = min(int(batch), indptr.numel() - 1)
         if self.neg_block:
             self._bind_csr(indptr, indices)
-        exchange = None
-        if self.sharded:
-            pending = []
-
-            def begin():        # G (folded) is complete on the current stream: start the all-reduce
-                pending.append(dist.all_reduce(self.G, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-
-            def end():          # the current stream waits for the reduced G
-                pending.pop().wait()
-            exchange = (begin, end)
+        exchange = (self._exchange_begin, self._exchange_end) if self.sharded else None
         return self.k.BPRTrainer(self.P, self.Q, self.G, indptr, indices, self.lr, batch,
                                  seed=self.seed + 7919 * self.user_begin, seed_key=self.seed, neg_block=self.neg_block,
                                  hot=self.hot, user_sig=self._sig if self.neg_block else None,
                                  item_cdf=self._cdf if (self.neg_block and self.use_item_cdf) else None,
                                  loss_acc=loss_acc, exchange=exchange, two_pass=self.overlap_exchange,
+                                 exchange_applies=self.exchange == "scatter_gather",
                                  step0=self.step_count, epoch_pos0=self.epoch_pos)
 
     def adopt(self, trainer):

@@ -49,14 +49,16 @@ def test_bench_json_contract_small_shape():
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("two_pass", ["0", "1"])
-def test_bench_two_ranks_on_one_gpu(two_pass):
+@pytest.mark.parametrize("two_pass,exchange", [("0", "allreduce"), ("1", "allreduce"), ("1", "scatter_gather")])
+def test_bench_two_ranks_on_one_gpu(two_pass, exchange):
     """the N > 1 code path of bench.py (torch.distributed.run, native loop with the exchange callbacks) with two
     ranks sharing the box's GPU and gloo moving G: not a performance number, a does-it-run-and-agree check"""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29500 + (os.getpid() + 31 + int(two_pass)) % 2000), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--master-port", str(29500 + (os.getpid() + 31 + int(two_pass) + 7 * len(exchange)) % 2000), os.path.join(ROOT, "bench.py"), "--gpus", "2",
            "--steps", "4", "--warmup", "1", "--users", "120000", "--batch", "120000", "--items", "30000", "--score-tiles", "0", "--no-legs"]
-    d = run_bench(cmd, env={"RSX_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "RSX_TWO_PASS": two_pass})
+    d = run_bench(cmd, env={"RSX_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "RSX_TWO_PASS": two_pass,
+                                "RSX_EXCHANGE": exchange})
+    assert ("reduce-scatter" in d["config"]["parallelism"]) == (exchange == "scatter_gather")
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 240000 and d["config"]["item_replicas_identical"] is True
     assert ("two-pass" in d["config"]["parallelism"]) == (two_pass == "1")
     assert abs(d["value"] - 240000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]

@@ -653,6 +653,47 @@ def test_fit_runs_twice_with_different_csrs(ml100k):
         assert dense[un, inn].all() and not dense[un, jn].any()
 
 
+@pytest.mark.timeout(900)
+def test_stratified_sorted_sampler_trains_as_well_as_independent_negatives():
+    """the layout the headline number rests on (batch ordered by positive item, negatives stratified by
+    item block, B >= 2 I) against independent uniform negatives on a planted-factor dataset: same
+    model, same number of steps, two seeds each -- ranking quality (NDCG@10 on held-out positives)
+    must agree within the seed-to-seed noise, and both must be far above an untrained model"""
+    import scipy.sparse as sp
+    import recsys_pytorch_amd as pkg
+    rng = np.random.default_rng(42)
+    U, I, k_true, n_pos, n_held = 40_000, 2_000, 16, 20, 5
+    A, Bm = rng.standard_normal((U, k_true)), rng.standard_normal((I, k_true))
+    pop = 0.8 * np.log1p(np.arange(I)[::-1])                                   # popular head, like the bench CSR
+    train_rows, test_rows = [], []
+    for lo in range(0, U, 4000):
+        aff = A[lo:lo + 4000] @ Bm.T + pop + rng.gumbel(size=(4000, I)) * 1.5
+        top = np.argpartition(-aff, n_pos, axis=1)[:, :n_pos]
+        for r in top:
+            r = rng.permutation(r)
+            test_rows.append(np.sort(r[:n_held])); train_rows.append(np.sort(r[n_held:]))
+    mk = lambda rows, n: sp.csr_matrix((np.ones(U * n), np.concatenate(rows), np.arange(U + 1) * n), shape=(U, I))
+    ds = pkg.InteractionData(mk(train_rows, n_pos - n_held), mk(test_rows, n_held), mk(test_rows, n_held))
+    ev = pkg.Evaluator(ds.valid_input, ds.valid_target, "holdout", [10])
+    cfg = types.SimpleNamespace(batch_size=U, num_epochs=150, verbose=0, test_from=150, test_step=150)   # B = U = 20 I
+    res = {}
+    for nb in (8, 0):
+        for seed in (1, 2):
+            torch.manual_seed(seed)
+            m = pkg.MF(ds, dict(HP, hidden_dim=32, lr=0.1 * U, neg_block=nb, seed=seed), "cuda")
+            with torch.no_grad():
+                m._P.mul_(0.1); m._Q.mul_(0.1)
+            if (nb, seed) == (8, 1):
+                untrained = ev.evaluate(m)["NDCG@10"]
+            out = m.fit(ds, cfg, evaluator=ev)["scores"]["NDCG@10"]
+            assert m._engine.neg_block == nb                                      # the layout under test really ran
+            res[(nb, seed)] = float(out)
+    a, b = [res[(8, 1)], res[(8, 2)]], [res[(0, 1)], res[(0, 2)]]
+    noise = max(abs(a[0] - a[1]), abs(b[0] - b[1]))
+    assert min(a + b) > max(5 * untrained, 0.05), (res, untrained)              # both learn the planted structure
+    assert abs(np.mean(a) - np.mean(b)) < max(3 * noise, 0.03 * np.mean(b)), (res, untrained)
+
+
 def test_blocked_kernel_is_exact_on_foreign_triplets(oracle_mod):
     """neg_block set but the triplets do NOT follow the sampler contract: still exact"""
     from recsys_pytorch_amd import rsx

@@ -179,6 +179,47 @@ def test_step_kernels_on_random_shapes(rsx, oracle_mod):
         assert float(G.abs().max()) == 0.0 and (hot is None or float(hot.ghot.abs().max()) == 0.0), ctx
 
 
+@pytest.mark.parametrize("d,U,I,B", [(128, 5000, 700, 4000), (64, 3000, 90, 3000), (32, 200, 1500, 77)])
+def test_deterministic_step_is_bit_reproducible_and_matches_the_oracle(rsx, oracle_mod, d, U, I, B):
+    """RSX_DETERMINISTIC: no atomics, fixed summation order (ascending batch position per item row):
+    two runs from the same state agree BIT FOR BIT (the atomic path does not), the result equals the
+    oracle / the atomic path to rounding, skipped triplets are skipped, the loss is reproducible too"""
+    rng = np.random.default_rng(d + B)
+    P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+    w = 1.0 / np.arange(1, I + 1); w /= w.sum()
+    u, i, j = rng.permutation(U)[:B], rng.choice(I, B, p=w), rng.integers(0, I, B)     # heavy duplicate items
+    i_dev = i.copy()
+    i_dev[rng.random(B) < 0.05] = -1
+    live = i_dev >= 0
+    orc = oracle_mod.MFOracle(P0, Q0, "sgd", 0.5)
+    want_loss = orc.step(u[live], i[live], j[live])
+    ut, it, jt = (torch.from_numpy(x.astype(np.int32)).cuda() for x in (u, i_dev, j))
+    ws = torch.empty(rsx.bpr_step_det_workspace(B, I), dtype=torch.uint8, device="cuda")
+    runs = []
+    for rep in range(3):
+        P, Q = torch.from_numpy(P0).cuda(), torch.from_numpy(Q0).cuda()
+        G = torch.zeros_like(Q)
+        loss = torch.zeros(rsx.RSX_LOSS_SLOTS, device="cuda")
+        rsx.bpr_step(P, Q, G, ut, it, jt, 0.5, 1.0 / live.sum(), loss_acc=loss, users_unique=True, deterministic=True, ws=ws)
+        runs.append((P.clone(), G.clone(), loss.clone()))
+        rsx.apply_item_grad(Q, G, 0.5)
+    for P_, G_, l_ in runs[1:]:
+        assert torch.equal(P_, runs[0][0]) and torch.equal(G_, runs[0][1]) and torch.equal(l_, runs[0][2])
+    assert abs(float(runs[0][2].sum()) / live.sum() - want_loss) < 1e-5
+    assert rel_err(runs[0][0].cpu().numpy(), orc.P) < REL_TOL and rel_err(Q.cpu().numpy(), orc.Q) < REL_TOL
+    # against the default (atomic) path on the same triplets
+    P, Q = torch.from_numpy(P0).cuda(), torch.from_numpy(Q0).cuda()
+    G = torch.zeros_like(Q)
+    rsx.bpr_step(P, Q, G, ut, it, jt, 0.5, 1.0 / live.sum(), users_unique=True)
+    assert torch.equal(P, runs[0][0])                                   # the user side has no reduction: identical
+    assert rel_err(G.cpu().numpy(), runs[0][1].cpu().numpy()) < 1e-6
+    with pytest.raises(rsx.RsxError):                                   # needs unique users and its workspace
+        rsx.bpr_step(P, Q, G, ut, it, jt, 0.5, 1.0, deterministic=True, ws=ws)
+    with pytest.raises(rsx.RsxError):
+        rsx.bpr_step(P, Q, G, ut, it, jt, 0.5, 1.0, users_unique=True, deterministic=True)
+
+
 def test_bpr_step_unique_users_fast_path_equals_general_path(rsx, oracle_mod):
     rng = np.random.default_rng(5)
     U, I, d, B = 5000, 700, 128, 3001

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def _worker(rank, world, port, P0, Q0, batches, lr, out, unique=False):
+def _worker(rank, world, port, P0, Q0, batches, lr, out, unique=False, exchange="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import cpu_kernels
@@ -23,7 +23,8 @@ def _worker(rank, world, port, P0, Q0, batches, lr, out, unique=False):
     lo, hi = user_block(P0.shape[0], rank, world)
     P = torch.from_numpy(P0[lo:hi].copy())
     Q = torch.from_numpy(Q0.copy())
-    eng = BPREngine(P, Q, lr, kernels=cpu_kernels, user_begin=lo)
+    eng = BPREngine(P, Q, lr, kernels=cpu_kernels, user_begin=lo, exchange=exchange)
+    Q = eng.Q                                           # "scatter_gather" may re-home the item table (padding)
     losses, sums = [], []
     for (u, i, j) in batches:
         ul, il, jl = eng.route(torch.from_numpy(u), torch.from_numpy(i), torch.from_numpy(j))
@@ -36,7 +37,10 @@ def _worker(rank, world, port, P0, Q0, batches, lr, out, unique=False):
 
 
 @pytest.mark.timeout(300)
-def test_two_ranks_equal_one_process(oracle_mod):
+@pytest.mark.parametrize("exchange", ["allreduce", "scatter_gather"])
+def test_two_ranks_equal_one_process(oracle_mod, exchange):
+    """exchange = all_reduce(G) + identical apply, or reduce_scatter(G) -> own item shard applied ->
+    all_gather of the updated rows (97 items on 2 ranks: the padded-shard path)"""
     rng = np.random.default_rng(9)
     U, I, d, B, T, lr = 301, 97, 64, 200, 5, 0.05
     P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
@@ -49,7 +53,7 @@ def test_two_ranks_equal_one_process(oracle_mod):
     mgr = mp.Manager()
     out = mgr.dict()
     port = 29500 + os.getpid() % 2000
-    mp.spawn(_worker, args=(world, port, P0, Q0, batches, lr, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, P0, Q0, batches, lr, out, False, exchange), nprocs=world, join=True)
     P = np.zeros_like(P0)
     for r in range(world):
         lo, hi, Pr, Qr, losses, sums = out[r]
@@ -62,7 +66,8 @@ def test_two_ranks_equal_one_process(oracle_mod):
 
 
 @pytest.mark.timeout(300)
-def test_two_ranks_with_the_exchange_under_the_user_pass_equal_one_process(oracle_mod):
+@pytest.mark.parametrize("exchange", ["allreduce", "scatter_gather"])
+def test_two_ranks_with_the_exchange_under_the_user_pass_equal_one_process(oracle_mod, exchange):
     """batches with unique users take the two-pass step (item pass -> async all-reduce of G ->
     user pass, BPREngine.overlap_exchange): same step as one launch"""
     rng = np.random.default_rng(10)
@@ -76,7 +81,7 @@ def test_two_ranks_with_the_exchange_under_the_user_pass_equal_one_process(oracl
     mgr = mp.Manager()
     out = mgr.dict()
     port = 29500 + (os.getpid() + 3) % 2000
-    mp.spawn(_worker, args=(2, port, P0, Q0, batches, lr, out, True), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, P0, Q0, batches, lr, out, True, exchange), nprocs=2, join=True)
     P = np.zeros_like(P0)
     for r in range(2):
         lo, hi, Pr, Qr, losses, sums = out[r]
@@ -87,7 +92,7 @@ def test_two_ranks_with_the_exchange_under_the_user_pass_equal_one_process(oracl
     assert err(P, single.P) < 1e-5 and err(out[0][3], single.Q) < 1e-5
 
 
-def _gpu_worker(rank, world, port, P0, Q0, batches, lr, out, unique=False):
+def _gpu_worker(rank, world, port, P0, Q0, batches, lr, out, unique=False, exchange="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from recsys_pytorch_amd.sharded import BPREngine, user_block
@@ -95,7 +100,8 @@ def _gpu_worker(rank, world, port, P0, Q0, batches, lr, out, unique=False):
     lo, hi = user_block(P0.shape[0], rank, world)
     P = torch.from_numpy(P0[lo:hi].copy()).to(dev)
     Q = torch.from_numpy(Q0.copy()).to(dev)
-    eng = BPREngine(P, Q, lr, user_begin=lo)            # default kernels: the HIP library
+    eng = BPREngine(P, Q, lr, user_begin=lo, exchange=exchange)     # default kernels: the HIP library
+    Q = eng.Q
     if unique:
         eng.set_hot_items(torch.bincount(torch.from_numpy(np.concatenate([b[1] for b in batches])), minlength=Q0.shape[0]), 16, 4)
     losses = []
@@ -114,7 +120,8 @@ def _gpu_worker(rank, world, port, P0, Q0, batches, lr, out, unique=False):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
-def test_two_ranks_on_hip_kernels_equal_one_process(oracle_mod):
+@pytest.mark.parametrize("exchange", ["allreduce", "scatter_gather"])
+def test_two_ranks_on_hip_kernels_equal_one_process(oracle_mod, exchange):
     """same check with the real HIP kernels: two processes (sharing the box's GPU, gloo for the
     all-reduce) on their own triplets == one process on the concatenated batch"""
     rng = np.random.default_rng(19)
@@ -127,7 +134,7 @@ def test_two_ranks_on_hip_kernels_equal_one_process(oracle_mod):
     mgr = mp.Manager()
     out = mgr.dict()
     port = 29500 + (os.getpid() + 7) % 2000
-    mp.spawn(_gpu_worker, args=(2, port, P0, Q0, batches, lr, out), nprocs=2, join=True)
+    mp.spawn(_gpu_worker, args=(2, port, P0, Q0, batches, lr, out, False, exchange), nprocs=2, join=True)
     P = np.zeros_like(P0)
     for r in range(2):
         lo, hi, Pr, Qr, losses = out[r]
@@ -140,9 +147,10 @@ def test_two_ranks_on_hip_kernels_equal_one_process(oracle_mod):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
-def test_two_ranks_on_hip_kernels_with_the_exchange_under_the_user_pass(oracle_mod):
+@pytest.mark.parametrize("exchange", ["allreduce", "scatter_gather"])
+def test_two_ranks_on_hip_kernels_with_the_exchange_under_the_user_pass(oracle_mod, exchange):
     rng = np.random.default_rng(29)
-    U, I, d, B, T, lr = 4001, 1500, 128, 3000, 4, 0.05
+    U, I, d, B, T, lr = 4001, 1501, 128, 3000, 4, 0.05
     P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
     Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
     batches = [(rng.permutation(U)[:B], (rng.integers(0, I, B) ** 2) // I, rng.integers(0, I, B)) for _ in range(T)]
@@ -151,7 +159,7 @@ def test_two_ranks_on_hip_kernels_with_the_exchange_under_the_user_pass(oracle_m
     mgr = mp.Manager()
     out = mgr.dict()
     port = 29500 + (os.getpid() + 11) % 2000
-    mp.spawn(_gpu_worker, args=(2, port, P0, Q0, batches, lr, out, True), nprocs=2, join=True)
+    mp.spawn(_gpu_worker, args=(2, port, P0, Q0, batches, lr, out, True, exchange), nprocs=2, join=True)
     P = np.zeros_like(P0)
     for r in range(2):
         lo, hi, Pr, Qr, losses = out[r]
@@ -162,7 +170,7 @@ def test_two_ranks_on_hip_kernels_with_the_exchange_under_the_user_pass(oracle_m
     assert err(P, single.P) < 1e-5 and err(out[0][3], single.Q) < 1e-5
 
 
-def _gpu_sampled_worker(rank, world, port, mode, U, I, d, B, steps, out):
+def _gpu_sampled_worker(rank, world, port, mode, U, I, d, B, steps, out, exchange="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from recsys_pytorch_amd.data import synthetic_csr
@@ -173,7 +181,8 @@ def _gpu_sampled_worker(rank, world, port, mode, U, I, d, B, steps, out):
     P = torch.randn(U, d, device=dev) * 0.1
     torch.manual_seed(7)
     Q = torch.randn(I, d, device=dev) * 0.1
-    eng = BPREngine(P, Q, 0.05, user_begin=rank * U, seed=11)
+    eng = BPREngine(P, Q, 0.05, user_begin=rank * U, seed=11, exchange=exchange)
+    Q = eng.Q
     eng.set_neg_block(B, 8)
     eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 32, 4)
     if mode == "python":
@@ -195,8 +204,8 @@ def _gpu_sampled_worker(rank, world, port, mode, U, I, d, B, steps, out):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("B,I", [(6000, 2500), (3000, 4000)])
-def test_two_ranks_native_loop_with_exchange_callbacks_equals_python_driven(B, I):
+@pytest.mark.parametrize("B,I,exchange", [(6000, 2500, "allreduce"), (3000, 4000, "allreduce"), (6000, 2501, "scatter_gather")])
+def test_two_ranks_native_loop_with_exchange_callbacks_equals_python_driven(B, I, exchange):
     """user-sharded SAMPLED steps, two processes on the HIP kernels: the native loop (exchange handed
     in as callbacks, all-reduce of G under the user pass) against the Python-driven engine on the
     same triplets; item replicas identical across the ranks in both"""
@@ -205,7 +214,7 @@ def test_two_ranks_native_loop_with_exchange_callbacks_equals_python_driven(B, I
     out = mgr.dict()
     for k, mode in enumerate(("python", "native")):
         port = 29500 + (os.getpid() + 13 + 17 * k + B) % 2000
-        mp.spawn(_gpu_sampled_worker, args=(2, port, mode, U, I, d, B, steps, out), nprocs=2, join=True)
+        mp.spawn(_gpu_sampled_worker, args=(2, port, mode, U, I, d, B, steps, out, exchange), nprocs=2, join=True)
     for mode in ("python", "native"):
         assert np.array_equal(out[(mode, 0)][1], out[(mode, 1)][1]), f"item replicas diverged ({mode})"
     for r in range(2):
