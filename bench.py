@@ -142,7 +142,8 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
         dist.all_reduce(cs, op=dist.ReduceOp.MAX)
         replicas_equal = bool(float(cs[0] + cs[1]) == 0.0)          # max(sum) == min(sum)
         assert replicas_equal, "item replicas diverged"
-    kernel = "bpr_step_blocked_kernel" if nb else "bpr_step_kernel"
+    # (the walk of the blocked kernel without its negative-side LDS tile when only the positives are ordered)
+    kernel = "bpr_step_blocked_kernel" if nb else ("bpr_step_blocked_kernel<TILE=false>" if eng._sorts(B) else "bpr_step_kernel")
     key = f"U{U}_I{I}_d{d}_B{B}_{popularity}_nb{nb}"
     return {"batch_per_gpu": B, "global_batch": gb, "value": gb * steps / elapsed, "unit": "triplets/s",
             "ms_per_step": elapsed / steps * 1e3, "steps": steps, "neg_block": nb, "mean_bpr_loss": mean_loss,

@@ -58,6 +58,12 @@ extern "C" {
                               /* summed by one workgroup in a fixed order.  Same step, to rounding, as the default */
                               /* path; slower (a debugging aid).  hot_slot_dev / neg_block are ignored.            */
 
+#define RSX_BATCH_SORTED 64u  /* the batch is ordered by positive item (rsx_bpr_sample with RSX_SAMPLE_SORT_POS; needs  */
+                              /* RSX_USERS_UNIQUE; ignored when neg_block > 0, which implies it).  Every lane group then */
+                              /* walks a contiguous range of positions and sums runs of equal positive items in         */
+                              /* registers: one update of G per run instead of one per triplet.  A hint, not a          */
+                              /* contract: on an unordered batch the runs are simply of length one.                     */
+
 /* flags for rsx_bpr_sample */
 #define RSX_SAMPLE_SORT_POS 1u /* order the batch by positive item (needs a workspace)       */
 
@@ -271,6 +277,9 @@ int rsx_bpr_build_item_cdf(const int64_t *indptr_dev, const int32_t *indices_dev
  *                        must make `stream` wait for the reduced G.  Return 0 on success.  Between the
  *                        two the trainer queues the next step's sampler and, if two_pass != 0, the
  *                        user half of the step (RSX_ITEMS_ONLY before, RSX_USERS_ONLY under the exchange).
+ *   sort_min_batch       > 0: runs whose batch is at least this large but below 2 * num_items (where neg_block does
+ *                        not engage) still order the batch by positive item (RSX_SAMPLE_SORT_POS with independent
+ *                        uniform negatives) and step with RSX_BATCH_SORTED; needs sample_ws like neg_block
  *   exchange_applies     != 0: exchange_end also UPDATES Q and leaves G zero (e.g. reduce-scatter of G,
  *                        each rank applying its own shard of item rows, all-gather of the updated rows);
  *                        the trainer then does not call rsx_apply_item_grad itself.
@@ -315,7 +324,7 @@ typedef struct rsx_bpr_trainer_config {
     rsx_exchange_fn exchange_end;
     void *exchange_ctx;
     int32_t exchange_applies;
-    int32_t reserved0;
+    int32_t sort_min_batch;
     int64_t step0;
     int64_t epoch_pos0;
 } rsx_bpr_trainer_config;

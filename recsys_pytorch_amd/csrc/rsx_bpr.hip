@@ -263,34 +263,48 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
 //    registers, touching G once per run.
 // Neither is a correctness contract: a negative outside the wave's block and an unsorted batch
 // take the global-atomic path / runs of length one, and the sums are the same.
-template <int D, int PASS, typename OffT>
-__global__ __launch_bounds__(kBlock, 6) void bpr_step_blocked_kernel(
+#ifndef RSX_BLOCKED_WAVES
+#define RSX_BLOCKED_WAVES 6     // wavefronts per SIMD the blocked kernel is compiled for
+#endif
+// TILE = false is the same walk without the negative-side LDS tile, for batches that are ordered by
+// positive item but too small for blocked negatives (B < 2 I: fewer than two updates per item row, so the
+// negative side has nothing to sum): wavefront w owns the positions [w * span, (w + 1) * span), positive runs
+// are summed in registers (Zipf positives at B = 65 536: 65K row updates become ~25K), negatives go to G one by one.
+template <int D, int PASS, typename OffT, bool TILE>
+__global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_kernel(
     float *__restrict__ P, const float *__restrict__ Q, float *__restrict__ G,
     const int32_t *__restrict__ U_idx, const int32_t *__restrict__ I_idx,
-    const int32_t *__restrict__ J_idx, int64_t B, int64_t num_items, int c, uint64_t neg_key, float lr,
+    const int32_t *__restrict__ J_idx, int64_t B, int64_t num_items, int c, int64_t span, uint64_t neg_key, float lr,
     float inv_batch, float *__restrict__ loss_acc, HotMap hot)
 {
     constexpr bool kItems = (PASS & kPassItems) != 0, kUsers = (PASS & kPassUsers) != 0;
     extern __shared__ __attribute__((aligned(16))) float neg_acc[];   // [4 waves][c][D]
-    using RowT = Row<D>;
     constexpr int EPL = D / 32;
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR;
     const int k = lane % LPR;
     const int wib = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wib;
-    const int64_t nblocks = ceil_div64(num_items, c);
-    if (wave >= nblocks) return;
-    float *acc = neg_acc + (size_t)wib * c * D;
-    for (int e = lane; e < c * D; e += 64) acc[e] = 0.0f;
-
-    // batch positions of this wavefront, and the item block its negatives come from
-    const int64_t nom_lo = wave * c;
-    const int64_t nom_hi = (nom_lo + c < num_items) ? nom_lo + c : num_items;
-    const int64_t b0 = ceil_div64(nom_lo * B, num_items);
-    const int64_t b1 = ceil_div64(nom_hi * B, num_items);
-    const int32_t item_lo = (int32_t)(neg_block_of(wave, nblocks, neg_key) * c);            // num_items < 2^31
-    const int32_t item_hi = (int32_t)(((int64_t)item_lo + c < num_items) ? (int64_t)item_lo + c : num_items);
+    float *acc = nullptr;
+    int64_t b0, b1;
+    int32_t item_lo = 0, item_hi = 0;                // the item block of this wavefront's negatives (TILE)
+    if constexpr (TILE) {
+        const int64_t nblocks = ceil_div64(num_items, c);
+        if (wave >= nblocks) return;
+        acc = neg_acc + (size_t)wib * c * D;
+        for (int e = lane; e < c * D; e += 64) acc[e] = 0.0f;
+        // batch positions of this wavefront, and the item block its negatives come from
+        const int64_t nom_lo = wave * c;
+        const int64_t nom_hi = (nom_lo + c < num_items) ? nom_lo + c : num_items;
+        b0 = ceil_div64(nom_lo * B, num_items);
+        b1 = ceil_div64(nom_hi * B, num_items);
+        item_lo = (int32_t)(neg_block_of(wave, nblocks, neg_key) * c);            // num_items < 2^31
+        item_hi = (int32_t)(((int64_t)item_lo + c < num_items) ? (int64_t)item_lo + c : num_items);
+    } else {
+        b0 = wave * span;
+        if (b0 >= B) return;
+        b1 = (b0 + span < B) ? b0 + span : B;
+    }
     // each lane group walks a contiguous part of [b0, b1)
     const int64_t len = ceil_div64(b1 - b0, TPW);
     const int64_t g_lo = b0 + sub * len;
@@ -347,11 +361,11 @@ __global__ __launch_bounds__(kBlock, 6) void bpr_step_blocked_kernel(
             // is wave-private and updated by plain read-modify-write (ds_add_f32 measured ~120 clk per
             // wave instruction); the lane groups of one wavefront may hit the same row, so they take
             // turns -- LDS executes a wavefront's instructions in order.
-            const bool neg_local = (j >= item_lo && j < item_hi);
+            const bool neg_local = TILE && (j >= item_lo && j < item_hi);
             if (!RSX_ABL(2)) {
                 if (!neg_local) p.atomic_axpy_at(G, row_off<D, OffT>(j, k), -g);
 #pragma unroll
-                for (int tt = 0; tt < TPW; ++tt) {
+                for (int tt = 0; TILE && tt < TPW; ++tt) {
                     if (sub == tt && neg_local) {
                         float *cell = acc + ((j - item_lo) * LPR + k) * EPL;   // lane k's EPL floats
                         float a[EPL];
@@ -400,7 +414,7 @@ __global__ __launch_bounds__(kBlock, 6) void bpr_step_blocked_kernel(
     RSX_RUN_FLUSH(run_item, run)     // last run of this lane group
 #undef RSX_RUN_FLUSH
     // flush the block's rows: one global atomic row per touched item
-    const int rows = kItems ? (int)(item_hi - item_lo) : 0;
+    const int rows = (kItems && TILE) ? (int)(item_hi - item_lo) : 0;
     for (int m = sub; m - sub < rows; m += TPW) {
         float v[EPL];
 #pragma unroll
@@ -638,13 +652,13 @@ void dispatch_step(int d, bool wide, float *P, const float *Q, float *G, const i
 #undef RSX_LAUNCH
 }
 
-template <int PASS>
+template <int PASS, bool TILE>
 void dispatch_blocked(int d, bool wide, unsigned blocks, size_t lds, hipStream_t st, float *P, const float *Q, float *G,
                       const int32_t *u, const int32_t *i, const int32_t *j, int64_t B, int64_t num_items,
-                      int c, uint64_t neg_key, float lr, float inv_batch, float *loss_acc, HotMap hot)
+                      int c, int64_t span, uint64_t neg_key, float lr, float inv_batch, float *loss_acc, HotMap hot)
 {
-#define RSX_LAUNCH(D_) do { if (wide) hipLaunchKernelGGL((bpr_step_blocked_kernel<D_, PASS, uint64_t>), dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u, i, j, B, num_items, c, neg_key, lr, inv_batch, loss_acc, hot); \
-                            else hipLaunchKernelGGL((bpr_step_blocked_kernel<D_, PASS, uint32_t>), dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u, i, j, B, num_items, c, neg_key, lr, inv_batch, loss_acc, hot); } while (0)
+#define RSX_LAUNCH(D_) do { if (wide) hipLaunchKernelGGL((bpr_step_blocked_kernel<D_, PASS, uint64_t, TILE>), dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u, i, j, B, num_items, c, span, neg_key, lr, inv_batch, loss_acc, hot); \
+                            else hipLaunchKernelGGL((bpr_step_blocked_kernel<D_, PASS, uint32_t, TILE>), dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u, i, j, B, num_items, c, span, neg_key, lr, inv_batch, loss_acc, hot); } while (0)
     switch (d) {
     case 32: RSX_LAUNCH(32); break;
     case 64: RSX_LAUNCH(64); break;
@@ -721,9 +735,22 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
         const int64_t waves = ceil_div64(num_items, neg_block);
         const unsigned blocks = (unsigned)ceil_div64(waves, kWavesPerBlock);
         const size_t lds = (size_t)kWavesPerBlock * neg_block * d * sizeof(float);
-#define RSX_BLOCKED(PASS_) dispatch_blocked<PASS_>(d, wide, blocks, lds, st, P, Q, G, u_dev, i_dev, j_dev, batch, num_items, neg_block, neg_key, lr, inv_batch, loss_acc, hot)
+#define RSX_BLOCKED(PASS_) dispatch_blocked<PASS_, true>(d, wide, blocks, lds, st, P, Q, G, u_dev, i_dev, j_dev, batch, num_items, neg_block, 0, neg_key, lr, inv_batch, loss_acc, hot)
         if (pass == kPassItems) RSX_BLOCKED(kPassItems); else if (pass == kPassUsers) RSX_BLOCKED(kPassUsers); else RSX_BLOCKED(kPassBoth);
 #undef RSX_BLOCKED
+        RSX_CHECK_LAUNCH();
+        return RSX_OK;
+    }
+    if ((flags & RSX_USERS_UNIQUE) && (flags & RSX_BATCH_SORTED)) {
+        // one round of wavefronts: as many as fit the chip at once (6 per SIMD), each with an even share
+        // of the positions, at least 8 (two trips of two positions per lane group)
+        const int64_t slots = (int64_t)rsx_num_cus() * 4 * RSX_BLOCKED_WAVES;
+        int64_t span = 2 * ceil_div64(batch, 2 * slots);
+        if (span < 8) span = 8;
+        const unsigned blocks = (unsigned)ceil_div64(ceil_div64(batch, span), kWavesPerBlock);
+#define RSX_RUNS(PASS_) dispatch_blocked<PASS_, false>(d, wide, blocks, 0, st, P, Q, G, u_dev, i_dev, j_dev, batch, num_items, 0, span, 0, lr, inv_batch, loss_acc, hot)
+        if (pass == kPassItems) RSX_RUNS(kPassItems); else if (pass == kPassUsers) RSX_RUNS(kPassUsers); else RSX_RUNS(kPassBoth);
+#undef RSX_RUNS
         RSX_CHECK_LAUNCH();
         return RSX_OK;
     }

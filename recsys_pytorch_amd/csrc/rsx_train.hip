@@ -31,6 +31,7 @@ struct rsx_bpr_trainer {
     int64_t slot_pos_before[2] = {0, 0};
     uint64_t slot_key[2] = {0, 0};
     int slot_nb[2] = {0, 0};
+    bool slot_sorted[2] = {false, false};        // ordered by positive item without blocked negatives
     int last = -1;                               // slot consumed by the most recent step
     // live timing of the step kernel (HIP events on the run stream, every `time_every`-th step)
     std::vector<hipEvent_t> t0, t1;
@@ -77,17 +78,19 @@ int launch_sample(rsx_bpr_trainer *t, int slot, int64_t step_index, int64_t batc
     t->slot_pos_before[slot] = t->epoch_pos;
     if ((t->epoch_pos % c.num_users) + batch > c.num_users) t->epoch_pos = (t->epoch_pos / c.num_users + 1) * c.num_users;
     const int nb = effective_neg_block(t, batch);
+    const bool sorted = nb > 0 || (c.sort_min_batch > 0 && batch >= c.sort_min_batch);
     const uint64_t key = nb ? neg_key_for(c.seed_key, step_index) : 0ull;
     if (t->freed_valid[slot]) RSX_HIP(hipStreamWaitEvent(t->side, t->freed[slot], 0));
     RSX_TRY(rsx_bpr_sample(c.indptr, c.indices, c.num_users, c.num_items, batch, c.seed, (uint64_t)step_index,
-                           t->epoch_pos, nb, key, nb ? RSX_SAMPLE_SORT_POS : 0u, nb ? c.sample_ws : nullptr,
-                           nb ? c.sample_ws_bytes : 0, nb ? c.user_sig : nullptr, nb ? c.item_cdf : nullptr,
+                           t->epoch_pos, nb, key, sorted ? RSX_SAMPLE_SORT_POS : 0u, sorted ? c.sample_ws : nullptr,
+                           sorted ? c.sample_ws_bytes : 0, nb ? c.user_sig : nullptr, sorted ? c.item_cdf : nullptr,
                            slot_ptr(t, slot, 0), slot_ptr(t, slot, 1), slot_ptr(t, slot, 2), (rsx_stream_t)t->side));
     RSX_HIP(hipEventRecord(t->ready[slot], t->side));
     t->epoch_pos += batch;
     t->slot_batch[slot] = batch;
     t->slot_key[slot] = key;
     t->slot_nb[slot] = nb;
+    t->slot_sorted[slot] = sorted && nb == 0;
     return RSX_OK;
 }
 
@@ -101,9 +104,9 @@ RSX_API int rsx_bpr_trainer_create(const rsx_bpr_trainer_config *cfg, rsx_bpr_tr
     RSX_CHECK_ARG(cfg->num_users > 0 && cfg->num_items > 0 && cfg->batch > 0 && cfg->batch <= cfg->num_users,
                   "batch must be in [1, num_users]");
     RSX_CHECK_ARG(cfg->neg_block >= 0 && cfg->neg_block <= kMaxNegBlock, "neg_block must be in [0, 16]");
-    RSX_CHECK_ARG(cfg->neg_block == 0 || (cfg->sample_ws != nullptr &&
+    RSX_CHECK_ARG((cfg->neg_block == 0 && cfg->sort_min_batch <= 0) || (cfg->sample_ws != nullptr &&
                   cfg->sample_ws_bytes >= rsx_bpr_sample_workspace(cfg->batch, cfg->num_items)),
-                  "neg_block > 0 needs a sampler workspace of rsx_bpr_sample_workspace(batch, num_items) bytes");
+                  "neg_block / sort_min_batch need a sampler workspace of rsx_bpr_sample_workspace(batch, num_items) bytes");
     RSX_CHECK_ARG((cfg->hot_slot == nullptr) == (cfg->G_hot == nullptr) && (cfg->hot_slot == nullptr) == (cfg->hot_items == nullptr),
                   "hot_slot, G_hot and hot_items go together");
     RSX_CHECK_ARG((cfg->exchange_begin == nullptr) == (cfg->exchange_end == nullptr), "exchange_begin and exchange_end go together");
@@ -189,7 +192,8 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
             }
             RSX_HIP(hipEventRecord(t->t0[t->timed], st));
         }
-        const unsigned f = RSX_USERS_UNIQUE | ((sharded && c.two_pass) ? RSX_ITEMS_ONLY : 0u);
+        const unsigned sorted_flag = t->slot_sorted[cur] ? RSX_BATCH_SORTED : 0u;
+        const unsigned f = RSX_USERS_UNIQUE | sorted_flag | ((sharded && c.two_pass) ? RSX_ITEMS_ONLY : 0u);
         RSX_TRY(rsx_bpr_step(c.P, c.Q, c.G, c.num_users, c.num_items, u, i, j, batch, c.d, c.lr, inv_batch, c.loss_acc, f,
                              nullptr, 0, c.hot_slot, c.G_hot, c.hot_replicas, nb, key, stream));
         if (timed) { RSX_HIP(hipEventRecord(t->t1[t->timed], st)); ++t->timed; }
@@ -206,7 +210,7 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
             RSX_TRY(launch_sample(t, nxt, t->step + 1, batch));               // beside the exchange
             if (c.two_pass)
                 RSX_TRY(rsx_bpr_step(c.P, c.Q, c.G, c.num_users, c.num_items, u, i, j, batch, c.d, c.lr, inv_batch, nullptr,
-                                     RSX_USERS_UNIQUE | RSX_USERS_ONLY, nullptr, 0, c.hot_slot, c.G_hot, c.hot_replicas, nb,
+                                     RSX_USERS_UNIQUE | RSX_USERS_ONLY | sorted_flag, nullptr, 0, c.hot_slot, c.G_hot, c.hot_replicas, nb,
                                      key, stream));
             if (c.exchange_end(c.exchange_ctx) != 0) { rsx_set_error("rsx_bpr_trainer_run: exchange_end failed"); return RSX_E_INVALID; }
             if (!c.exchange_applies)

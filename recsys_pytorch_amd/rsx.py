@@ -20,6 +20,7 @@ RSX_ITEMS_ONLY = 4
 RSX_USERS_ONLY = 8
 RSX_WIDE_OFFSETS = 16
 RSX_DETERMINISTIC = 32
+RSX_BATCH_SORTED = 64
 RSX_SAMPLE_SORT_POS = 1
 RSX_LOSS_SLOTS = 2048
 SUPPORTED_DIMS = (32, 64, 128)
@@ -156,7 +157,7 @@ def fold_hot_grad(G, hot):
 
 
 def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False, ws=None,
-             no_update=False, hot=None, neg_block=0, neg_key=0, only=None, wide_offsets=False, deterministic=False):
+             no_update=False, hot=None, neg_block=0, neg_key=0, only=None, wide_offsets=False, deterministic=False, batch_sorted=False):
     """One batch of include/rsx.h:rsx_bpr_step.  u, i, j: int32 device tensors.
     only = "items" | "users": one pass of the two-pass step (RSX_ITEMS_ONLY / RSX_USERS_ONLY)."""
     d = P.shape[1]
@@ -168,7 +169,7 @@ def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False,
         _dev(loss_acc, torch.float32, "loss_acc") if loss_acc is not None else None,
         (RSX_USERS_UNIQUE if users_unique else 0) | (RSX_NO_UPDATE if no_update else 0)
         | {None: 0, "items": RSX_ITEMS_ONLY, "users": RSX_USERS_ONLY}[only] | (RSX_WIDE_OFFSETS if wide_offsets else 0)
-        | (RSX_DETERMINISTIC if deterministic else 0),
+        | (RSX_DETERMINISTIC if deterministic else 0) | (RSX_BATCH_SORTED if batch_sorted else 0),
         C.c_void_p(ws.data_ptr()) if ws is not None else None,
         ws.numel() * ws.element_size() if ws is not None else 0,
         _dev(hot.slot, torch.int32, "hot slot") if hot is not None else None,
@@ -316,7 +317,7 @@ class TrainerConfig(C.Structure):
                 ("user_sig", _P), ("item_cdf", _P), ("triplets", _P), ("hot_slot", _P), ("G_hot", _P),
                 ("hot_items", _P), ("n_hot", C.c_int32), ("hot_replicas", C.c_int32), ("loss_acc", _P),
                 ("exchange_begin", EXCHANGE_FN), ("exchange_end", EXCHANGE_FN), ("exchange_ctx", _P),
-                ("exchange_applies", C.c_int32), ("reserved0", C.c_int32), ("step0", _I64), ("epoch_pos0", _I64)]
+                ("exchange_applies", C.c_int32), ("sort_min_batch", C.c_int32), ("step0", _I64), ("epoch_pos0", _I64)]
 
 
 class BPRTrainer:
@@ -325,12 +326,12 @@ class BPRTrainer:
     borrows alive."""
 
     def __init__(self, P, Q, G, indptr, indices, lr, batch, seed, seed_key, neg_block=0, hot=None, user_sig=None,
-                 item_cdf=None, loss_acc=None, exchange=None, two_pass=False, exchange_applies=False, step0=0, epoch_pos0=0):
+                 item_cdf=None, loss_acc=None, exchange=None, two_pass=False, exchange_applies=False, sort_min_batch=0, step0=0, epoch_pos0=0):
         dev = P.device
         self.batch = int(batch)
         self.triplets = torch.empty(2 * 3 * self.batch, dtype=torch.int32, device=dev)
         self.sample_ws = None
-        if neg_block:
+        if neg_block or sort_min_batch:
             self.sample_ws = torch.empty(bpr_sample_workspace(self.batch, Q.shape[0]), dtype=torch.uint8, device=dev)
         self._keep = (P, Q, G, indptr, indices, hot, user_sig, item_cdf, loss_acc)
         ptr = lambda t, dt, name: _dev(t, dt, name) if t is not None else None
@@ -363,7 +364,7 @@ class BPRTrainer:
             n_hot=hot.n if hot else 0, hot_replicas=hot.replicas if hot else 0,
             loss_acc=ptr(loss_acc, torch.float32, "loss_acc"),
             exchange_begin=self._cb[0] or EXCHANGE_FN(), exchange_end=self._cb[1] or EXCHANGE_FN(), exchange_ctx=None,
-            exchange_applies=int(bool(exchange_applies)), reserved0=0, step0=int(step0), epoch_pos0=int(epoch_pos0))
+            exchange_applies=int(bool(exchange_applies)), sort_min_batch=int(sort_min_batch), step0=int(step0), epoch_pos0=int(epoch_pos0))
         self._h = C.c_void_p()
         _check(lib().rsx_bpr_trainer_create(C.byref(cfg), C.byref(self._h)), "rsx_bpr_trainer_create")
 

@@ -26,6 +26,21 @@ def user_block(num_users, rank, world):
     return begin, min(begin + per, num_users)
 
 
+def pick_neg_block(num_items, max_block, wave_slots):
+    """item block of the stratified negatives.  The blocked step kernel runs one wavefront per block,
+    each ~100 us long, so its duration is ceil(waves / resident slots) ROUNDS: 12 500 wavefronts on 6 144
+    slots take three rounds for two rounds' worth of work (measured: c = 8 -> 347 us, c = 6 -> 323 us at
+    I = 100K on 256 CUs).  Pick the c in [2, max_block] whose last round is fullest; ties go to the
+    larger block (fewer wavefronts, fewer partial-run flushes)."""
+    best, best_eff = max(1, min(2, max_block)), -1.0
+    for c in range(2, max(2, max_block) + 1):
+        waves = -(-num_items // c)
+        eff = waves / (-(-waves // wave_slots) * wave_slots)
+        if eff >= best_eff - 1e-9:
+            best, best_eff = c, max(eff, best_eff)
+    return best
+
+
 class BPREngine:
     """Owns the step sequence  sample/replay -> bpr_step -> all-reduce(G) -> apply.
 
@@ -77,6 +92,14 @@ class BPREngine:
         self.hot = None
         self.neg_block = 0          # > 0: negatives stratified by item block, batch sorted by positive item
         self.use_item_cdf = True    # order the batch through the item-CDF buckets (False: device radix sort)
+        # Sampled batches of at least this many triplets are ordered by positive item also when the negatives are
+        # NOT blocked (neg_block == 0: independent uniform negatives), and the step then sums runs of equal
+        # positives in registers (include/rsx.h: RSX_BATCH_SORTED).  Default: from 2 triplets per item on, like
+        # neg_block.  Measured on MI355X (I = 100K, d = 128, Zipf): B = 1M 963 -> 647 us per step; below that it
+        # does not pay -- at B = 65 536 / 262 144 the step kernel gains nothing (64 vs 70 us, 173 us) while the
+        # ordering sampler (built for million-triplet batches: 16 workgroups at 65 536) takes 114 / 222 us and
+        # becomes the critical path (step 101 -> 132 us, 190 -> 244 us).  0 = never.
+        self.sorted_min_batch = 2 * Q.shape[0]
         self._sample_ws = {}        # sampler scratch, one per stream role ("main" / "side"): never shared
         self._csr = None            # the CSR tensors the static sampler tables below were built from
         self._sig = self._cdf = None
@@ -86,12 +109,22 @@ class BPREngine:
     def set_neg_block(self, batch, max_block=8):
         """enable the on-chip gradient summation (blocked negatives + batch sorted by positive
         item, include/rsx.h: neg_block / RSX_SAMPLE_SORT_POS) when every item row gets >= 2
-        updates per step; below that there is nothing to combine."""
-        nb = int(max_block) if batch >= 2 * self.Q.shape[0] else 0
+        updates per step; below that there is nothing to combine.  The block size c <= max_block
+        is picked so that the step kernel's ceil(I / c) wavefronts fill the chip's resident
+        wavefront slots in whole rounds (`pick_neg_block`)."""
+        nb = pick_neg_block(self.Q.shape[0], int(max_block), self._wave_slots()) if batch >= 2 * self.Q.shape[0] else 0
         if nb != self.neg_block:
             self._csr = None        # the user signatures depend on neg_block: rebuild on next use
         self.neg_block = nb
         return self.neg_block
+
+    def _wave_slots(self):
+        """wavefronts of the blocked step kernel resident at a time: CUs x 4 SIMDs x 6 (csrc/rsx_bpr.hip)"""
+        try:
+            dev = self.Q.device.index or 0
+            return int(self.k.device_info(dev)["compute_units"]) * 24
+        except Exception:           # noqa: BLE001 -- a kernels stand-in without device_info (CPU tests)
+            return 256 * 24
 
     def _bind_csr(self, indptr, indices):
         """static per-CSR sampler tables (user signatures, item CDF).  The engine keeps references to
@@ -100,7 +133,8 @@ class BPREngine:
         accept positives as negatives)."""
         if self._csr is not None and self._csr[0] is indptr and self._csr[1] is indices and self._csr[2] == self.neg_block:
             return
-        self._sig = self.k.build_signature(indptr, indices, self.neg_block) if hasattr(self.k, "build_signature") else None
+        self._sig = (self.k.build_signature(indptr, indices, self.neg_block)
+                     if (self.neg_block and hasattr(self.k, "build_signature")) else None)
         self._cdf = self.k.build_item_cdf(indptr, indices, self.Q.shape[0]) if hasattr(self.k, "build_item_cdf") else None
         self._csr = (indptr, indices, self.neg_block)
 
@@ -178,8 +212,13 @@ class BPREngine:
         return int(self._count.item())
 
     # -- one step on explicit triplets (local user ids) ---------------------------
+    def _sorts(self, batch):
+        """is a sampled batch of this size ordered by positive item (blocked negatives or not)?"""
+        return bool(self.neg_block) or bool(self.sorted_min_batch and batch >= self.sorted_min_batch
+                                            and hasattr(self.k, "build_item_cdf"))
+
     def step(self, u_local, i, j, global_batch=None, users_unique=False, want_loss=True, neg_block=0,
-             neg_key=0):
+             neg_key=0, batch_sorted=False):
         """returns the device tensor of loss slots (sum_b softplus(-x_b) striped) or None"""
         B = int(u_local.numel())
         gb = self._global_batch(B, global_batch)
@@ -201,6 +240,8 @@ class BPREngine:
         kw = {"hot": self.hot} if self.hot is not None else {}
         if neg_block:
             kw["neg_block"], kw["neg_key"] = neg_block, neg_key
+        elif batch_sorted and users_unique:
+            kw["batch_sorted"] = True
         if self.sharded and users_unique and self.overlap_exchange:
             # two passes over the same triplets (include/rsx.h: RSX_ITEMS_ONLY / RSX_USERS_ONLY): the
             # item pass completes G, whose all-reduce then runs while the user pass updates P --
@@ -251,7 +292,7 @@ class BPREngine:
         u, i, j = out
         kw = {}
         key = self._neg_key(step)
-        if self.neg_block:
+        if self._sorts(batch):
             need = self.k.bpr_sample_workspace(batch, self.Q.shape[0])
             ws = self._sample_ws.get(role)
             if ws is None or ws.numel() < need:
@@ -281,7 +322,7 @@ class BPREngine:
     def sampled_step(self, indptr, indices, batch, global_batch=None, want_loss=True):
         u, i, j = self.sample(indptr, indices, batch)
         return self.step(u, i, j, global_batch=global_batch, users_unique=True, want_loss=want_loss,
-                         neg_block=self.neg_block, neg_key=self.last_neg_key)
+                         neg_block=self.neg_block, neg_key=self.last_neg_key, batch_sorted=self._sorts(batch))
 
     def sampled_step_overlapped(self, indptr, indices, batch, global_batch=None, want_loss=True):
         """same result as sampled_step, but the sampler of step t+1 runs on a second HIP stream
@@ -322,7 +363,7 @@ class BPREngine:
         prefetch(cur ^ 1)                                  # sampler of the next step, concurrently
         u, i, j = buf["t"]
         loss = self.step(u, i, j, global_batch=global_batch, users_unique=True, want_loss=want_loss,
-                         neg_block=self.neg_block, neg_key=buf["key"])
+                         neg_block=self.neg_block, neg_key=buf["key"], batch_sorted=self._sorts(batch))
         buf["free"] = torch.cuda.Event()
         buf["free"].record(main)
         self._cur = cur ^ 1
@@ -337,13 +378,15 @@ class BPREngine:
         if self.optimizer != "sgd":
             raise ValueError("the native loop runs the SGD step; optimizer='adam' steps through BPREngine.step")
         batch = min(int(batch), indptr.numel() - 1)
-        if self.neg_block:
+        sort_min = int(self.sorted_min_batch) if (self.sorted_min_batch and not self.neg_block) else 0
+        if self.neg_block or sort_min:
             self._bind_csr(indptr, indices)
         exchange = (self._exchange_begin, self._exchange_end) if self.sharded else None
         return self.k.BPRTrainer(self.P, self.Q, self.G, indptr, indices, self.lr, batch,
                                  seed=self.seed + 7919 * self.user_begin, seed_key=self.seed, neg_block=self.neg_block,
                                  hot=self.hot, user_sig=self._sig if self.neg_block else None,
-                                 item_cdf=self._cdf if (self.neg_block and self.use_item_cdf) else None,
+                                 item_cdf=self._cdf if ((self.neg_block or sort_min) and self.use_item_cdf) else None,
+                                 sort_min_batch=sort_min,
                                  loss_acc=loss_acc, exchange=exchange, two_pass=self.overlap_exchange,
                                  exchange_applies=self.exchange == "scatter_gather",
                                  step0=self.step_count, epoch_pos0=self.epoch_pos)

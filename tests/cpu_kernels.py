@@ -17,7 +17,7 @@ def bpr_step_workspace(num_users, max_batch, d):
 
 
 def bpr_step(P, Q, G, u, i, j, lr, inv_batch, loss_acc=None, users_unique=False, ws=None, no_update=False,
-             hot=None, neg_block=0, neg_key=0, only=None, wide_offsets=False, deterministic=False):
+             hot=None, neg_block=0, neg_key=0, only=None, wide_offsets=False, deterministic=False, batch_sorted=False):
     """same contract as include/rsx.h:rsx_bpr_step, on host tensors: G += dQ (scaled by
     inv_batch), P -= lr*dP, loss slots += sum softplus(-x)."""
     Pn, Qn = P.numpy(), Q.numpy()

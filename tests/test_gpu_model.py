@@ -437,7 +437,7 @@ def _full_size_step_check(U, I, d, B, deg, want_neg_block, hot=True):
     P0 = P.clone()
     eng = BPREngine(P, Q, lr)
     nb = eng.set_neg_block(B, 8)
-    assert nb == want_neg_block, (nb, want_neg_block)            # which step path engages at this shape
+    assert (nb > 0) == (want_neg_block > 0) and nb <= 8, (nb, want_neg_block)   # which step path engages at this shape
     if hot:
         eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 256, 16)
     u, i, j = eng.sample(ip, ix, B)
@@ -510,6 +510,38 @@ def test_base_batch_65536_on_the_headline_tables():
     _full_size_step_check(1_000_000, 100_000, 128, 65_536, 20, want_neg_block=0)
 
 
+def test_sorted_runs_layout_replays_through_oracle(oracle_mod):
+    """B below 2 triplets per item: the sampler still orders the batch by positive item (independent uniform
+    negatives) and the step sums runs of equal positives in registers (RSX_BATCH_SORTED): dump, replay on the oracle"""
+    from recsys_pytorch_amd.data import synthetic_csr
+    from recsys_pytorch_amd.sharded import BPREngine
+    U, I, d, B = 60_000, 50_000, 128, 20_000
+    ip, ix = synthetic_csr(U, I, 12, "cuda", seed=4)
+    torch.manual_seed(8)
+    P = torch.randn(U, d, device="cuda") * 0.1
+    Q = torch.randn(I, d, device="cuda") * 0.1
+    orc = oracle_mod.MFOracle(P.cpu().numpy(), Q.cpu().numpy(), "sgd", 0.05)
+    eng = BPREngine(P, Q, 0.05)
+    eng.sorted_min_batch = 16384                      # (default: 2 * I; lowered to take this layout at a small size)
+    assert eng.set_neg_block(B, 8) == 0 and eng._sorts(B) and not eng._sorts(1000)
+    eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 64, 4)
+    ipn, ixn = ip.cpu().numpy(), ix.cpu().numpy()
+    jh = np.zeros(I)
+    for s in range(3):
+        u, i, j = eng.sample(ip, ix, B)
+        un, inn, jn = u.cpu().numpy(), i.cpu().numpy(), j.cpu().numpy()
+        assert len(np.unique(un)) == B and np.all(np.diff(inn) >= 0)          # unique users, ordered by positive item
+        for a, b_, c_ in list(zip(un, inn, jn))[::211]:
+            row = ixn[ipn[a]:ipn[a + 1]]
+            assert b_ in row and c_ not in row
+        jh += np.bincount(jn, minlength=I)
+        lo = orc.step(un, inn, jn)
+        acc = eng.step(u, i, j, users_unique=True, batch_sorted=True)
+        assert abs(float(acc.sum()) / B - lo) < 1e-5
+    assert rel_err(P.cpu().numpy(), orc.P) < 1e-5 and rel_err(Q.cpu().numpy(), orc.Q) < 1e-5
+    assert jh.max() <= 12                                                     # negatives: independent uniform, not stratified
+
+
 def test_overlapped_sampler_equals_inline_sampler():
     """sampling one step ahead on a second stream must not change a single bit"""
     from recsys_pytorch_amd.data import synthetic_csr
@@ -523,7 +555,7 @@ def test_overlapped_sampler_equals_inline_sampler():
         Q = torch.randn(I, d, device="cuda") * 0.1
         eng = BPREngine(P, Q, 0.05)
         eng.set_neg_block(B, 8)
-        assert eng.neg_block == 8
+        assert 2 <= eng.neg_block <= 8
         losses = []
         for _ in range(7):   # crosses a pass boundary of the user permutation (3 batches per pass)
             fn = eng.sampled_step if mode == "inline" else eng.sampled_step_overlapped
@@ -535,7 +567,7 @@ def test_overlapped_sampler_equals_inline_sampler():
     assert torch.allclose(out[0][0], out[1][0], rtol=0, atol=1e-6) and torch.allclose(out[0][1], out[1][1], rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize("U,I,B,hot", [(60_000, 3_000, 20_000, True), (30_000, 40_000, 8_192, False)])
+@pytest.mark.parametrize("U,I,B,hot", [(60_000, 3_000, 20_000, True), (30_000, 40_000, 8_192, False), (70_000, 40_000, 30_000, True)])
 def test_native_trainer_equals_hand_driven_steps(U, I, B, hot):
     """rsx_bpr_trainer_run (C++ loop: sampler on its side stream || step -> apply) against the same
     steps driven from Python: same triplets (seed, step index, permutation position, per-step key),
@@ -545,6 +577,7 @@ def test_native_trainer_equals_hand_driven_steps(U, I, B, hot):
     from recsys_pytorch_amd.sharded import BPREngine
     d = 128
     ip, ix = synthetic_csr(U, I, 10, "cuda", seed=5)
+    # (third case: 16 384 <= B < 2 I -- batch ordered by positive item, runs summed in registers, no blocked negatives)
     outs = []
     for mode in ("python", "native"):
         torch.manual_seed(9)
@@ -552,7 +585,9 @@ def test_native_trainer_equals_hand_driven_steps(U, I, B, hot):
         Q = torch.randn(I, d, device="cuda") * 0.1
         eng = BPREngine(P, Q, 0.05)
         nb = eng.set_neg_block(B, 8)
-        assert nb == (8 if B >= 2 * I else 0)
+        assert (2 <= nb <= 8) if B >= 2 * I else nb == 0
+        if (U, I, B) == (70_000, 40_000, 30_000):
+            eng.sorted_min_batch = 16384                  # the ordered layout without blocked negatives
         if hot:
             eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 64, 4)
         total = 0.0
@@ -593,7 +628,7 @@ def test_native_trainer_steps_replay_through_the_oracle(oracle_mod):
     Q = torch.randn(I, d, device="cuda") * 0.1
     orc = oracle_mod.MFOracle(P.cpu().numpy(), Q.cpu().numpy(), "sgd", 0.05)
     eng = BPREngine(P, Q, 0.05)
-    assert eng.set_neg_block(B, 8) == 8
+    assert 2 <= eng.set_neg_block(B, 8) <= 8
     acc = torch.zeros(rsx.RSX_LOSS_SLOTS, device="cuda")
     tr = eng.native_trainer(ip, ix, B, loss_acc=acc)
     ipn, ixn = ip.cpu().numpy(), ix.cpu().numpy()
@@ -604,7 +639,7 @@ def test_native_trainer_steps_replay_through_the_oracle(oracle_mod):
         torch.cuda.synchronize()
         u, i, j, nb, key = tr.last_batch()
         un, inn, jn = u.cpu().numpy(), i.cpu().numpy(), j.cpu().numpy()
-        assert nb == 8 and key != 0 and len(np.unique(un)) == B and np.all(np.diff(inn) >= 0)
+        assert nb == eng.neg_block and key != 0 and len(np.unique(un)) == B and np.all(np.diff(inn) >= 0)
         for a, b_, c_ in list(zip(un, inn, jn))[::97]:
             row = ixn[ipn[a]:ipn[a + 1]]
             assert b_ in row and c_ not in row
@@ -644,7 +679,7 @@ def test_fit_runs_twice_with_different_csrs(ml100k):
     for k in range(2):
         m.fit(ds[k], cfg)
         eng = m._engine
-        assert eng.neg_block == 8 and eng._csr is not None
+        assert 2 <= eng.neg_block <= 8 and eng._csr is not None
         ip, ix = csr_to_device(mats[k], "cuda")
         assert torch.equal(eng._csr[0], ip) and torch.equal(eng._csr[1], ix)          # bound to THIS fit's CSR
         u, i, j = eng.sample(eng._csr[0], eng._csr[1], 2000)
@@ -686,7 +721,7 @@ def test_stratified_sorted_sampler_trains_as_well_as_independent_negatives():
             if (nb, seed) == (8, 1):
                 untrained = ev.evaluate(m)["NDCG@10"]
             out = m.fit(ds, cfg, evaluator=ev)["scores"]["NDCG@10"]
-            assert m._engine.neg_block == nb                                      # the layout under test really ran
+            assert (m._engine.neg_block > 0) == (nb > 0)                          # the layout under test really ran
             res[(nb, seed)] = float(out)
     a, b = [res[(8, 1)], res[(8, 2)]], [res[(0, 1)], res[(0, 2)]]
     noise = max(abs(a[0] - a[1]), abs(b[0] - b[1]))

@@ -12,6 +12,8 @@ Q = torch.randn(I, d, device=dev) * 0.1
 ip, ix = synthetic_csr(U, I, 20, dev)
 users = torch.arange(1024 * tiles, device=dev, dtype=torch.int32)
 rsx.set_option("score_lanes", int(os.environ.get("LANES", 1)))
+if os.environ.get("ABL"):      # development write switches: needs RSX_LIB=.../librsx_dev.so
+    rsx.lib().rsx_debug_set_score_ablation(int(os.environ["ABL"]))
 for _ in range(2):
     top = rsx.score_topk(P, Q, users, K, mask=(ip, ix))
 torch.cuda.synchronize()

@@ -1,0 +1,24 @@
+"""tools/step_prof.py [B] [neg_block] [steps] : the native loop on the bench workload for a few steps -- the thing
+rocprofv3 wraps in tools/pmc_groups.py (no timing of its own)"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from recsys_pytorch_amd import rsx
+from recsys_pytorch_amd.data import synthetic_csr
+from recsys_pytorch_amd.sharded import BPREngine
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+nbw = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+U, I, d = int(os.environ.get("USERS", 1_000_000)), int(os.environ.get("ITEMS", 100_000)), int(os.environ.get("DIM", 128))
+dev = torch.device("cuda")
+torch.manual_seed(2020)
+P = torch.randn(U, d, device=dev) * 0.1
+Q = torch.randn(I, d, device=dev) * 0.1
+ip, ix = synthetic_csr(U, I, int(os.environ.get("DEG", 20)), dev, popularity=os.environ.get("POP", "zipf"))
+eng = BPREngine(P, Q, 0.05)
+if nbw:
+    eng.set_neg_block(B, nbw)
+eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 256, 16)
+loss = torch.zeros(rsx.RSX_LOSS_SLOTS, device=dev)
+tr = eng.native_trainer(ip, ix, B, loss_acc=loss)
+tr.run(steps)
+torch.cuda.synchronize()
