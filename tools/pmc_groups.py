@@ -35,7 +35,8 @@ for gi, grp in enumerate(groups):
     dur = json.load(open(d + "_o_durations.json")) if os.path.exists(d + "_o_durations.json") else {}
     for k, v in c.items():
         if any(p in k for p in pats):
-            key = k.split("(")[0].split("::")[-1][-60:] + ("<" + k.split("<")[1].split(">")[0] + ">" if "<" in k else "")
+            name = k.replace("(anonymous namespace)::", "").replace("void ", "")
+            key = name.split("(")[0].strip()              # kernel name with its template arguments, without the parameter list
             res.setdefault(key, {}).update({a: round(b, 1) for a, b in v.items()})
             if k in dur:
                 res[key].setdefault("mean_us", []).append(round(dur[k]["mean_ns"] / 1e3, 1))
