@@ -93,13 +93,14 @@ class BPREngine:
         self.neg_block = 0          # > 0: negatives stratified by item block, batch sorted by positive item
         self.use_item_cdf = True    # order the batch through the item-CDF buckets (False: device radix sort)
         # Sampled batches of at least this many triplets are ordered by positive item also when the negatives are
-        # NOT blocked (neg_block == 0: independent uniform negatives), and the step then sums runs of equal
-        # positives in registers (include/rsx.h: RSX_BATCH_SORTED).  Default: from 2 triplets per item on, like
-        # neg_block.  Measured on MI355X (I = 100K, d = 128, Zipf): B = 1M 963 -> 647 us per step; below that it
-        # does not pay -- at B = 65 536 / 262 144 the step kernel gains nothing (64 vs 70 us, 173 us) while the
+        # NOT blocked (neg_block == 0 asked for, or B < 2 I), and the step then sums runs of equal positives in
+        # registers (include/rsx.h: RSX_BATCH_SORTED).  Default: from 2 triplets per item on, like neg_block, and
+        # in any case from 2^19 triplets on.  Measured on MI355X (d = 128, Zipf): I = 100K, B = 1M, independent
+        # negatives 963 -> 650 us per step; configs[3] slice (I = 1M, B = 1.25M) 1454 -> 1183 us.  Small batches
+        # do not pay: at B = 65 536 / 262 144 (I = 100K) the step kernel gains nothing (64 vs 70 us, 173 us) while the
         # ordering sampler (built for million-triplet batches: 16 workgroups at 65 536) takes 114 / 222 us and
         # becomes the critical path (step 101 -> 132 us, 190 -> 244 us).  0 = never.
-        self.sorted_min_batch = 2 * Q.shape[0]
+        self.sorted_min_batch = min(2 * Q.shape[0], 1 << 19)
         self._sample_ws = {}        # sampler scratch, one per stream role ("main" / "side"): never shared
         self._csr = None            # the CSR tensors the static sampler tables below were built from
         self._sig = self._cdf = None

@@ -7,16 +7,18 @@ from recsys_pytorch_amd.data import synthetic_csr
 from recsys_pytorch_amd.sharded import BPREngine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 nbw = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-U, I, d = 1_000_000, int(os.environ.get("ITEMS", 100_000)), int(os.environ.get("DIM", 128))
+U, I, d = int(os.environ.get("USERS", 1_000_000)), int(os.environ.get("ITEMS", 100_000)), int(os.environ.get("DIM", 128))
 dev = torch.device("cuda")
 P = torch.randn(U, d, device=dev) * 0.1
 Q = torch.randn(I, d, device=dev) * 0.1
-ip, ix = synthetic_csr(U, I, 20, dev, popularity=os.environ.get("POP", "zipf"))
+ip, ix = synthetic_csr(U, I, int(os.environ.get("DEG", 20)), dev, popularity=os.environ.get("POP", "zipf"))
 eng = BPREngine(P, Q, 0.05)
+if os.environ.get("SORTED_MIN"):
+    eng.sorted_min_batch = int(os.environ["SORTED_MIN"])
 nb = eng.set_neg_block(B, nbw) if nbw else 0
 eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 256, 16)
 u, i, j = eng.sample(ip, ix, B)
-kw = dict(users_unique=True, hot=eng.hot, neg_block=nb, neg_key=eng.last_neg_key)
+kw = dict(users_unique=True, hot=eng.hot, neg_block=nb, neg_key=eng.last_neg_key, batch_sorted=eng._sorts(B) and not nb)
 loss = torch.zeros(rsx.RSX_LOSS_SLOTS, device=dev)
 for with_loss in (True, False):
     ts = []
