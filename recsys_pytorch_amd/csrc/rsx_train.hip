@@ -116,8 +116,14 @@ RSX_API int rsx_bpr_trainer_create(const rsx_bpr_trainer_config *cfg, rsx_bpr_tr
     t->c = *cfg;
     t->step = cfg->step0;
     t->epoch_pos = cfg->epoch_pos0;
+    // The sampler is the background producer: it has a whole step of slack, so its stream gets the LOWEST
+    // priority and its workgroups fill the slots the step kernel leaves free (measured beside the 1M-triplet
+    // step kernel: that kernel 348 -> 326 us, step 386 -> 372 us, same box; highest priority: no gain)
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);        // lo = numerically largest = least urgent
+    const int prio = prio_lo;
     bool ok = hipGetDevice(&t->device) == hipSuccess &&
-              hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, prio) == hipSuccess &&
               hipEventCreateWithFlags(&t->fork, hipEventDisableTiming) == hipSuccess;
     for (int s = 0; ok && s < 2; ++s)
         ok = hipEventCreateWithFlags(&t->ready[s], hipEventDisableTiming) == hipSuccess &&
