@@ -261,7 +261,8 @@ int rsx_bpr_build_item_cdf(const int64_t *indptr_dev, const int32_t *indices_dev
  * config
  *   P [num_users x d] (this rank's user rows), Q, G [num_items x d] (G zero before the first step)
  *   indptr / indices     CSR of this rank's users (see rsx_bpr_sample)
- *   batch                largest batch a run may ask for; triplets = int32 [2][3][batch] scratch
+ *   batch                largest batch a run may ask for; triplets = int32 [RSX_TRAINER_SLOTS][3][batch] scratch
+ *                        (the batch being consumed and the ones sampled ahead)
  *   seed                 sampler seed; seed_key keys the per-step negative-block permutation
  *   neg_block            0 = independent uniform negatives, plain layout.  c > 0 = sorted layout with
  *                        stratified negatives and on-chip summation, engaged for runs whose batch is
@@ -290,8 +291,9 @@ int rsx_bpr_build_item_cdf(const int64_t *indptr_dev, const int32_t *indices_dev
  * rsx_bpr_trainer_state: next step index and the permutation position the next batch starts from.
  * rsx_bpr_trainer_seek: set both (drops a batch sampled ahead).
  * rsx_bpr_trainer_last_batch: device pointers of the triplets the most recent step consumed (valid
- *   until two more steps have been queued) and the neg_block / neg_key it ran with: lets a test
+ *   until the next rsx_bpr_trainer_run) and the neg_block / neg_key it ran with: lets a test
  *   replay exactly what a native step did.                                                   */
+#define RSX_TRAINER_SLOTS 3
 typedef int (*rsx_exchange_fn)(void *ctx);
 
 typedef struct rsx_bpr_trainer_config {

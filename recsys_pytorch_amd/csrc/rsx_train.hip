@@ -19,19 +19,25 @@ struct rsx_bpr_trainer {
     rsx_bpr_trainer_config c;
     int device = 0;
     hipStream_t side = nullptr;
-    hipEvent_t ready[2] = {nullptr, nullptr};    // slot sampled (recorded on side)
-    hipEvent_t freed[2] = {nullptr, nullptr};    // slot consumed (recorded on the run stream)
+    // ring of RSX_TRAINER_SLOTS triplet buffers: the one being consumed and the batches sampled ahead.  Two
+    // ahead, not one: with one, the step kernel's launch waits on an event the side stream has recorded only
+    // microseconds before, and that cross-stream hand-over showed as a 11-12 us hole in front of EVERY step
+    // kernel in the rocprofv3 time line (11 % of a 65 536-triplet step); an event that completed a whole step
+    // earlier costs nothing.
+    static constexpr int S = RSX_TRAINER_SLOTS;
+    hipEvent_t ready[S] = {};                    // slot sampled (recorded on side)
+    hipEvent_t freed[S] = {};                    // slot consumed (recorded on the run stream)
     hipEvent_t fork = nullptr;                   // run stream -> side ordering
-    bool freed_valid[2] = {false, false};
+    bool freed_valid[S] = {};
     int64_t step = 0;                            // next step to CONSUME
     int64_t epoch_pos = 0;                       // next position of the user permutation to SAMPLE
     int cur = 0;                                 // slot the next step consumes
-    bool prefetched = false;                     // slot `cur` holds the batch of step `step`
-    int64_t slot_batch[2] = {0, 0};
-    int64_t slot_pos_before[2] = {0, 0};
-    uint64_t slot_key[2] = {0, 0};
-    int slot_nb[2] = {0, 0};
-    bool slot_sorted[2] = {false, false};        // ordered by positive item without blocked negatives
+    int ahead = 0;                               // slots cur, cur+1, ... (mod S) hold the batches of steps step, step+1, ...
+    int64_t slot_batch[S] = {};
+    int64_t slot_pos_before[S] = {};
+    uint64_t slot_key[S] = {};
+    int slot_nb[S] = {};
+    bool slot_sorted[S] = {};                    // ordered by positive item without blocked negatives
     int last = -1;                               // slot consumed by the most recent step
     // live timing of the step kernel (HIP events on the run stream, every `time_every`-th step)
     std::vector<hipEvent_t> t0, t1;
@@ -54,6 +60,12 @@ uint64_t neg_key_for(uint64_t seed, int64_t step)
     z ^= z >> 31;
     return z | 1ull;
 }
+
+// The trainer's events only order kernels of ONE device across its two streams; nobody on the host or on
+// another device inspects memory through them.  Without hipEventDisableSystemFence every hipEventRecord on
+// the run stream is a system-scope release -- a write-back of the L2s, which the apply sweep has just
+// filled with 100 MB of dirty item rows -- and showed as an 11-12 us hole in front of every step kernel.
+constexpr unsigned kOrderOnly = hipEventDisableTiming | hipEventDisableSystemFence;
 
 int effective_neg_block(const rsx_bpr_trainer *t, int64_t batch)
 {
@@ -124,10 +136,10 @@ RSX_API int rsx_bpr_trainer_create(const rsx_bpr_trainer_config *cfg, rsx_bpr_tr
     const int prio = prio_lo;
     bool ok = hipGetDevice(&t->device) == hipSuccess &&
               hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, prio) == hipSuccess &&
-              hipEventCreateWithFlags(&t->fork, hipEventDisableTiming) == hipSuccess;
-    for (int s = 0; ok && s < 2; ++s)
-        ok = hipEventCreateWithFlags(&t->ready[s], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&t->freed[s], hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&t->fork, kOrderOnly) == hipSuccess;
+    for (int s = 0; ok && s < rsx_bpr_trainer::S; ++s)
+        ok = hipEventCreateWithFlags(&t->ready[s], kOrderOnly) == hipSuccess &&
+             hipEventCreateWithFlags(&t->freed[s], kOrderOnly) == hipSuccess;
     if (!ok) {
         rsx_set_error("rsx_bpr_trainer_create: could not create the side stream / events");
         rsx_bpr_trainer_destroy(t);
@@ -141,7 +153,7 @@ RSX_API void rsx_bpr_trainer_destroy(rsx_bpr_trainer *t)
 {
     if (t == nullptr) return;
     if (t->side) { (void)hipStreamSynchronize(t->side); (void)hipStreamDestroy(t->side); }
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < rsx_bpr_trainer::S; ++s) {
         if (t->ready[s]) (void)hipEventDestroy(t->ready[s]);
         if (t->freed[s]) (void)hipEventDestroy(t->freed[s]);
     }
@@ -165,26 +177,35 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
     const bool sharded = c.exchange_begin != nullptr;
     const bool hot = c.hot_slot != nullptr;
     t->timed = 0;
-    if (t->prefetched && t->slot_batch[t->cur] != batch) {
-        // a batch of another size was sampled ahead (e.g. before an epoch's short last batch): hand its
-        // positions back to the user permutation; the side stream is drained before the slot is reused
+    constexpr int S = rsx_bpr_trainer::S;
+    if (t->ahead > 0 && t->slot_batch[t->cur] != batch) {
+        // batches of another size were sampled ahead (e.g. before an epoch's short last batch): hand their
+        // positions back to the user permutation; the side stream is drained before the slots are reused
         t->epoch_pos = t->slot_pos_before[t->cur];
-        t->prefetched = false;
+        t->ahead = 0;
         RSX_HIP(hipEventRecord(t->fork, t->side));
         RSX_HIP(hipStreamWaitEvent(st, t->fork, 0));
     }
-    if (!t->prefetched) {
+    if (t->ahead == 0) {
         // the sampler reads only the CSR, but it must not start before earlier work of the run stream
         // that may still read the triplet buffers (a previous run's last step)
         RSX_HIP(hipEventRecord(t->fork, st));
         RSX_HIP(hipStreamWaitEvent(t->side, t->fork, 0));
         RSX_TRY(launch_sample(t, t->cur, t->step, batch));
-        t->prefetched = true;
+        t->ahead = 1;
     }
+    // keep the ring full: sample the batches of the steps after the one being consumed
+    auto top_up = [&]() -> int {
+        while (t->ahead < S) {
+            RSX_TRY(launch_sample(t, (t->cur + t->ahead) % S, t->step + t->ahead, batch));
+            ++t->ahead;
+        }
+        return RSX_OK;
+    };
     for (int64_t s = 0; s < n_steps; ++s) {
-        const int cur = t->cur, nxt = cur ^ 1;
+        const int cur = t->cur;
         RSX_HIP(hipStreamWaitEvent(st, t->ready[cur], 0));
-        if (!sharded) RSX_TRY(launch_sample(t, nxt, t->step + 1, batch));      // beside this step's kernel
+        if (!sharded) RSX_TRY(top_up());                                       // beside this step's kernel
         const int32_t *u = slot_ptr(t, cur, 0), *i = slot_ptr(t, cur, 1), *j = slot_ptr(t, cur, 2);
         const int nb = t->slot_nb[cur];
         const uint64_t key = t->slot_key[cur];
@@ -213,7 +234,7 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
             if (c.exchange_begin(c.exchange_ctx) != 0) { rsx_set_error("rsx_bpr_trainer_run: exchange_begin failed"); return RSX_E_INVALID; }
             RSX_HIP(hipEventRecord(t->fork, st));
             RSX_HIP(hipStreamWaitEvent(t->side, t->fork, 0));
-            RSX_TRY(launch_sample(t, nxt, t->step + 1, batch));               // beside the exchange
+            RSX_TRY(top_up());                                                 // beside the exchange
             if (c.two_pass)
                 RSX_TRY(rsx_bpr_step(c.P, c.Q, c.G, c.num_users, c.num_items, u, i, j, batch, c.d, c.lr, inv_batch, nullptr,
                                      RSX_USERS_UNIQUE | RSX_USERS_ONLY | sorted_flag, nullptr, 0, c.hot_slot, c.G_hot, c.hot_replicas, nb,
@@ -225,7 +246,8 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
         RSX_HIP(hipEventRecord(t->freed[cur], st));
         t->freed_valid[cur] = true;
         t->last = cur;
-        t->cur = nxt;
+        t->cur = (cur + 1) % S;
+        --t->ahead;
         ++t->step;
     }
     return RSX_OK;
@@ -236,17 +258,17 @@ RSX_API int rsx_bpr_trainer_state(const rsx_bpr_trainer *t, int64_t *step, int64
     RSX_CHECK_ARG(t != nullptr, "null trainer");
     if (step) *step = t->step;
     // position the NEXT un-sampled batch starts from, as if nothing had been sampled ahead
-    if (epoch_pos) *epoch_pos = t->prefetched ? t->slot_pos_before[t->cur] : t->epoch_pos;
+    if (epoch_pos) *epoch_pos = t->ahead > 0 ? t->slot_pos_before[t->cur] : t->epoch_pos;
     return RSX_OK;
 }
 
 RSX_API int rsx_bpr_trainer_seek(rsx_bpr_trainer *t, int64_t step, int64_t epoch_pos, rsx_stream_t stream)
 {
     RSX_CHECK_ARG(t != nullptr && step >= 0 && epoch_pos >= 0, "bad state");
-    if (t->prefetched) {     // drop the batch sampled ahead; order the side stream before later work
+    if (t->ahead > 0) {      // drop the batches sampled ahead; order the side stream before later work
         RSX_HIP(hipEventRecord(t->fork, t->side));
         RSX_HIP(hipStreamWaitEvent((hipStream_t)stream, t->fork, 0));
-        t->prefetched = false;
+        t->ahead = 0;
     }
     t->step = step;
     t->epoch_pos = epoch_pos;

@@ -23,6 +23,7 @@ RSX_DETERMINISTIC = 32
 RSX_BATCH_SORTED = 64
 RSX_SAMPLE_SORT_POS = 1
 RSX_LOSS_SLOTS = 2048
+RSX_TRAINER_SLOTS = 3
 SUPPORTED_DIMS = (32, 64, 128)
 
 # symbol -> (restype, argtypes); mirrors include/rsx.h one to one
@@ -329,7 +330,7 @@ class BPRTrainer:
                  item_cdf=None, loss_acc=None, exchange=None, two_pass=False, exchange_applies=False, sort_min_batch=0, step0=0, epoch_pos0=0):
         dev = P.device
         self.batch = int(batch)
-        self.triplets = torch.empty(2 * 3 * self.batch, dtype=torch.int32, device=dev)
+        self.triplets = torch.empty(RSX_TRAINER_SLOTS * 3 * self.batch, dtype=torch.int32, device=dev)
         self.sample_ws = None
         if neg_block or sort_min_batch:
             self.sample_ws = torch.empty(bpr_sample_workspace(self.batch, Q.shape[0]), dtype=torch.uint8, device=dev)
