@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--hot-replicas", type=int, default=16)
     ap.add_argument("--neg-block", type=int, default=8, help="item block of the stratified negatives (0 = independent uniform negatives)")
     ap.add_argument("--no-legs", action="store_true", help="headline only (no section-8d legs)")
+    ap.add_argument("--no-lightgcn", action="store_true", help="skip the BASELINE configs[4] leg (LightGCN propagation + step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -151,6 +152,51 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
             "item_replicas_identical": replicas_equal, "_Q": Q,
             "roofline": roofline(kernel, kern_ms, B, I, d, key, two_pass=eng.overlap_exchange),
             "frac_of_hbm_roofline_end_to_end": gb / world * steps / elapsed * 24 * d / (HBM_PEAK_GBS * 1e9)}
+
+
+def lightgcn_leg(U, I, d, indptr, indices, dev, layers=3, batch=65_536):
+    """models/LightGCN.py:174-202 (propagation) and :83-87 (one training step: full-graph propagation, BPR gradient on
+    the propagated tables, the same products on the gradient, dense Adam) at the BASELINE configs[4] shape.
+    Roofline of the propagation product Y = A_hat X: algorithmic bytes nnz * (4 d + 8) + 2 N d 4."""
+    import types
+    import scipy.sparse as sp
+    import recsys_pytorch_amd as pkg
+    from recsys_pytorch_amd import rsx
+    t0 = time.perf_counter()
+    R = sp.csr_matrix((np.ones(indices.numel(), np.float32), indices.cpu().numpy(), indptr.cpu().numpy()), shape=(U, I))
+    ds = types.SimpleNamespace(num_users=U, num_items=I, dataname="synthetic")
+    m = pkg.LightGCN(ds, {"emb_dim": d, "num_layers": layers, "node_dropout": 0.0, "split": False, "num_folds": 1,
+                          "reg": 0.0, "graph_dir": "graph"}, dev)
+    g = m.getSparseGraph(R)
+    build_s = time.perf_counter() - t0
+    nnz, N = int(g.vals.numel()), U + I
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t1) / n
+    t_spmm = timed(lambda: rsx.spmm(g, m._E0, m._ta, S_acc=m._out), 10)
+    u = torch.randperm(U, device=dev)[:batch].int()
+    i = torch.randint(0, I, (batch,), device=dev).int()
+    j = torch.randint(0, I, (batch,), device=dev).int()
+    t_step = timed(lambda: m.train_step(u, i, j), 5)
+    assert torch.isfinite(m._E0).all()
+    alg = nnz * (4 * d + 8) + 2 * N * d * 4
+    compulsory = nnz * 8 + 2 * N * d * 4      # every embedding row once, the CSR once, the output once
+    return {"workload": f"BASELINE configs[4]: LightGCN {U} x {I}, d={d}, {layers} layers, nnz(A_hat)={nnz}",
+            "propagation_ms_per_product": t_spmm * 1e3, "train_step_ms": t_step * 1e3, "batch": batch,
+            "value": batch / t_step, "unit": "triplets/s",
+            "graph_build_host_s": build_s,
+            "roofline": {"bound": "hbm", "kernel": "spmm_csr_kernel", "achieved": alg / t_spmm / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": alg / t_spmm / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg,
+                         "kernel_ms": t_spmm * 1e3, "compulsory_bytes": compulsory,
+                         "frac_compulsory": compulsory / t_spmm / 1e9 / HBM_PEAK_GBS,
+                         "note": "the algorithmic figure counts every neighbour row (a gather of nnz rows); rows that are "
+                                 "re-read hit L2/MALL, so the HBM side only has to move compulsory_bytes"}}
 
 
 def cpu_baseline(args, U, I, d, batches):
@@ -292,6 +338,10 @@ def main():
             legs["config3_slice_1.25Mx1M"] = leg(P4, Q4, ip4, ix4, args.lr, 1_250_000, args.neg_block, args.hot,
                                                       args.hot_replicas, 10, 2, world, rank, args.popularity, two_pass=two_pass)
             del P4, Q4, ip4, ix4
+
+    # ---- BASELINE configs[4]: LightGCN on the same interaction graph, d=128, 3 layers -----
+    if world == 1 and not args.no_legs and not args.no_lightgcn and (args.users, args.items, args.dim) == (1_000_000, 100_000, 128):
+        legs["config4_lightgcn"] = lightgcn_leg(U, I, d, indptr, indices, dev)
 
     # ---- scoring leg (reported beside the headline; its own timed region) ---------------
     scoring = None
