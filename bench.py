@@ -93,9 +93,12 @@ def roofline(kernel, kern_ms, B, I, d, key, two_pass=False):
             "hbm_bytes": hbm, "frac_hbm": per_s(hbm) / HBM_PEAK_GBS if hbm else None, "traffic_key": key}
 
 
+SHARDED = False     # a process group is up: N > 1, or RSX_FORCE_SHARDED=1 (the exchange path over a group of one rank)
+
+
 def fence(world):
     torch.cuda.synchronize()
-    if world > 1:
+    if SHARDED:
         dist.barrier()
     torch.cuda.synchronize()
 
@@ -110,10 +113,11 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     B = min(B, U)
     # N > 1 exchange of the item gradients: all_reduce(G) (default) or RSX_EXCHANGE=scatter_gather
     # (reduce_scatter -> own item shard applied -> all_gather of the updated rows; sharded.py)
-    eng = BPREngine(P, Q, lr, user_begin=rank * U, seed=2020, exchange=os.environ.get("RSX_EXCHANGE", "allreduce"))
+    eng = BPREngine(P, Q, lr, user_begin=rank * U, seed=2020, exchange=os.environ.get("RSX_EXCHANGE", "allreduce"),
+                    force_sharded=SHARDED)
     Q = eng.Q                                            # (scatter_gather may re-home the item table)
     if two_pass is not None:
-        eng.overlap_exchange = bool(two_pass) and world > 1
+        eng.overlap_exchange = bool(two_pass) and SHARDED
     nb = eng.set_neg_block(B, want_nb) if want_nb > 0 else 0
     if hot > 0:
         eng.set_hot_items(torch.bincount(indices.long(), minlength=I), hot, hot_replicas)
@@ -129,7 +133,7 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     fence(world)
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
+    if SHARDED:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     kern_ms, _ = tr.kernel_ms()
@@ -138,7 +142,7 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     mean_loss = float(loss.double().sum()) / (B * steps)            # this rank's triplets
     assert np.isfinite(mean_loss) and 0.0 < mean_loss < 5.0, mean_loss
     replicas_equal = None
-    if world > 1:      # every rank applied the same reduced gradient: the item replicas must be identical
+    if SHARDED:        # every rank applied the same reduced gradient: the item replicas must be identical
         cs = torch.stack([Q.double().sum(), -Q.double().sum()])
         dist.all_reduce(cs, op=dist.ReduceOp.MAX)
         replicas_equal = bool(float(cs[0] + cs[1]) == 0.0)          # max(sum) == min(sum)
@@ -148,7 +152,7 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     key = f"U{U}_I{I}_d{d}_B{B}_{popularity}_nb{nb}"
     return {"batch_per_gpu": B, "global_batch": gb, "value": gb * steps / elapsed, "unit": "triplets/s",
             "ms_per_step": elapsed / steps * 1e3, "steps": steps, "neg_block": nb, "mean_bpr_loss": mean_loss,
-            "two_pass": bool(eng.overlap_exchange), "exchange": eng.exchange if world > 1 else None,
+            "two_pass": bool(eng.overlap_exchange), "exchange": eng.exchange if SHARDED else None,
             "item_replicas_identical": replicas_equal, "_Q": Q,
             "roofline": roofline(kernel, kern_ms, B, I, d, key, two_pass=eng.overlap_exchange),
             "frac_of_hbm_roofline_end_to_end": gb / world * steps / elapsed * 24 * d / (HBM_PEAK_GBS * 1e9)}
@@ -264,13 +268,17 @@ def main():
     ndev = max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank % ndev)
     dev = torch.device("cuda", local_rank % ndev)
-    if world > 1:
+    global SHARDED
+    SHARDED = world > 1 or os.environ.get("RSX_FORCE_SHARDED") == "1"
+    if SHARDED:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         backend = os.environ.get("RSX_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; gloo only to
         if backend == "nccl":                                   # smoke-test the N>1 code path on one GPU
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from recsys_pytorch_amd import rsx
     from recsys_pytorch_amd.data import synthetic_csr
@@ -290,7 +298,7 @@ def main():
     # N > 1.  Two-pass step: the all-reduce runs under the user pass.  It pays when the
     # exchange takes longer than the user pass plus the sampler (~375 us): expected with the 1 or 3 xGMI links
     # of 2 or 4 GPUs, not with the 7 links of 8 (an estimate until measured; RSX_TWO_PASS overrides)
-    two_pass = world > 1 and os.environ.get("RSX_TWO_PASS", "1" if world <= 4 else "0") == "1"
+    two_pass = SHARDED and os.environ.get("RSX_TWO_PASS", "1" if world <= 4 else "0") == "1"
     P, Q, indptr, indices = tables(U, I, d, args.degree, args.popularity)
     head = step_leg(P, Q, indptr, indices, args.lr, B, args.neg_block, args.hot, args.hot_replicas, args.steps, args.warmup,
                     world, rank, args.popularity, two_pass=two_pass)
@@ -363,7 +371,7 @@ def main():
                                 "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": n_scores * 2 * d / dt / 1e12 / MFMA_F32_PEAK_TFLOPS},
                    "topk_rows": int(top.shape[0])}
-    if world > 1:
+    if SHARDED:
         dist.barrier()
 
     if rank == 0:
@@ -381,12 +389,12 @@ def main():
                        "sampler": "on device, one step ahead on a side stream",
                        "loop": "native (rsx_bpr_trainer_run): no interpreter between the kernels of the timed region",
                        "mean_bpr_loss": head["mean_bpr_loss"],
-                       **({"item_replicas_identical": head["item_replicas_identical"]} if world > 1 else {}),
+                       **({"item_replicas_identical": head["item_replicas_identical"]} if SHARDED else {}),
                        "hot_items": args.hot, "hot_replicas": args.hot_replicas if args.hot > 0 else 0,
                        "parallelism": (f"user-sharded x{world}, items replicated, "
                                        + ("1 all-reduce(G)/step" if head["exchange"] == "allreduce" else
                                           "reduce-scatter(G) + own item shard applied + all-gather(Q rows) per step")
-                                       + (", under the user pass of a two-pass step" if head["two_pass"] else "")) if world > 1 else "single GPU"},
+                                       + (", under the user pass of a two-pass step" if head["two_pass"] else "")) if SHARDED else "single GPU"},
             "roofline": head["roofline"],
         }
         if legs:
@@ -396,7 +404,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, U, I, d, [B] + ([65_536] if 65_536 < B else []))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if SHARDED:
         dist.destroy_process_group()
 
 

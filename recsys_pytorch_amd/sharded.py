@@ -49,7 +49,7 @@ class BPREngine:
     """
 
     def __init__(self, P_local, Q, lr, kernels=None, group=None, user_begin=0, seed=2020, optimizer="sgd",
-                 exchange="allreduce"):
+                 exchange="allreduce", force_sharded=False):
         if kernels is None:
             from . import rsx as kernels   # the HIP path; raises if librsx.so is missing
         self.k = kernels
@@ -58,7 +58,9 @@ class BPREngine:
         self.lr = float(lr)
         self.group = group
         self.world = dist.get_world_size(group) if (group is not None or dist.is_initialized()) else 1
-        self.sharded = self.world > 1
+        # force_sharded: take the exchange path with a group of ONE rank too (how the RCCL collectives, their
+        # streams and the trainer's callbacks are exercised on a one-GPU box; tests/test_sharded_gloo.py)
+        self.sharded = self.world > 1 or (bool(force_sharded) and dist.is_initialized())
         # sharded + unique users: all-reduce(G) travels under the user pass of a two-pass step.  It pays
         # when the exchange is slower than that pass (few xGMI links: 2 or 4 GPUs)
         self.overlap_exchange = self.sharded and self.world <= 4

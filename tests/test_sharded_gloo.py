@@ -222,3 +222,63 @@ def test_two_ranks_native_loop_with_exchange_callbacks_equals_python_driven(B, I
         Pn, Qn, sn, pn = out[("native", r)]
         assert (sp_, pp) == (sn, pn) and sn == steps
         assert np.abs(Pp - Pn).max() < 1e-6 and np.abs(Qp - Qn).max() < 1e-6
+
+
+def _rccl_one_rank_worker(rank, port, U, I, d, B, steps, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)          # "nccl" IS RCCL on ROCm
+    from recsys_pytorch_amd.data import synthetic_csr
+    from recsys_pytorch_amd.sharded import BPREngine
+    ip, ix = synthetic_csr(U, I, 10, dev, seed=40)
+
+    def run(force, exchange, two_pass, mode):
+        torch.manual_seed(100)
+        P = torch.randn(U, d, device=dev) * 0.1
+        torch.manual_seed(7)
+        Q = torch.randn(I, d, device=dev) * 0.1
+        eng = BPREngine(P, Q, 0.05, seed=11, exchange=exchange, force_sharded=force)
+        eng.overlap_exchange = bool(two_pass) and force
+        eng.set_neg_block(B, 8)
+        eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 32, 4)
+        if mode == "python":
+            for _ in range(steps):
+                eng.sampled_step_overlapped(ip, ix, B, global_batch=B, want_loss=False)
+        else:
+            tr = eng.native_trainer(ip, ix, B)
+            tr.run(steps, B, global_batch=B)
+            torch.cuda.synchronize()
+            tr.close()
+        torch.cuda.synchronize()
+        return P.cpu().numpy(), eng.Q.cpu().numpy()
+
+    res = {"plain": run(False, "allreduce", False, "native")}
+    for exchange in ("allreduce", "scatter_gather"):
+        for two_pass in (False, True):
+            for mode in ("native", "python"):
+                res[(exchange, two_pass, mode)] = run(True, exchange, two_pass, mode)
+    out.update(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("B,I", [(6000, 2500), (3000, 4001)])
+def test_exchange_over_rccl_with_one_rank_equals_the_unsharded_step(B, I):
+    """the exchange path on the REAL collective library: a process group of one rank over RCCL (all a
+    one-GPU box offers), BPREngine(force_sharded=True).  all_reduce / reduce_scatter + all_gather over one
+    rank are identities, so every schedule (exchange kind x one/two-pass x native loop / Python-driven)
+    must reproduce the unsharded step: what this checks is the ordering between the trainer's
+    streams, the collective's stream and the callbacks (a collective that started before G was complete,
+    or an apply that ran before the collective ended, shows up as a different table)"""
+    U, d, steps = 9000, 64, 5
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29500 + (os.getpid() + 29 + B) % 2000
+    mp.spawn(_rccl_one_rank_worker, args=(port, U, I, d, B, steps, out), nprocs=1, join=True)
+    P0, Q0 = out["plain"]
+    assert len(out) == 9
+    for key, (P, Q) in out.items():
+        assert np.abs(P - P0).max() < 1e-6 and np.abs(Q - Q0).max() < 1e-6, key

@@ -4,6 +4,8 @@
 #include <stdio.h>
 #include <stdint.h>
 #include <vector>
+#include <stdlib.h>
+#include <utility>
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1;}}while(0)
 
 // each 32-lane half-wave owns one random row of 128 floats (512 B); MODE selects the op
@@ -41,6 +43,12 @@ __global__ __launch_bounds__(256) void k(float* G, const int* rows, int64_t n)
             for (int c = 0; c < 4; ++c) __hip_atomic_fetch_add(row + kk + 32 * c, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (MODE == 10) {
             for (int c = 0; c < 4; ++c) row[kk + 32 * c] += 1.0f;
+        } else if (MODE == 11) {  // plain RMW with streaming (nt) loads and stores
+            for (int c = 0; c < 4; ++c) { float v = __builtin_nontemporal_load(row + kk + 32 * c); __builtin_nontemporal_store(v + 1.0f, row + kk + 32 * c); }
+        } else if (MODE == 12) {  // loads only (sum kept alive)
+            float a = 0.f;
+            for (int c = 0; c < 4; ++c) a += row[kk + 32 * c];
+            if (a == 123.456f) row[0] = a;
         } else if (MODE == 7) {   // packed bf16 atomics: 2 x (2 bf16 per dword)... use pk_add_f16 via builtin if available
             for (int c = 0; c < 2; ++c) {
                 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -51,19 +59,27 @@ __global__ __launch_bounds__(256) void k(float* G, const int* rows, int64_t n)
     }
 }
 
-int main()
+int main(int argc, char** argv)
 {
-    const int64_t I = 100000, n = 2000000;
+    // atomic_bench [rows of the table] [row accesses per launch]; accesses <= rows: a permutation (every row once)
+    const int64_t I = argc > 1 ? atoll(argv[1]) : 100000, n = argc > 2 ? atoll(argv[2]) : 2000000;
+    printf("table %lld rows x 512 B, %lld row accesses per launch%s\n", (long long)I, (long long)n, n <= I ? " (each row at most once)" : "");
     float* G; int* rows;
     CK(hipMalloc(&G, I * 128 * 4)); CK(hipMemset(G, 0, I * 128 * 4));
     std::vector<int> h(n); uint64_t s = 88172645463325252ull;
+    if (n <= I) {
+        std::vector<int> perm(I);
+        for (int64_t q = 0; q < I; ++q) perm[q] = (int)q;
+        for (int64_t q = I - 1; q > 0; --q) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; std::swap(perm[q], perm[s % (q + 1)]); }
+        for (int64_t q = 0; q < n; ++q) h[q] = perm[q];
+    } else
     for (auto& x : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; x = (int)(s % I); }
     CK(hipMalloc(&rows, n * 4)); CK(hipMemcpy(rows, h.data(), n * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const char* names[] = {"f32 atomic x4 (512B/row)", "u64 atomic x2 (512B/row)", "u32 atomic x4", "f64 atomic x2", "plain RMW x4", "f32 atomic wg-scope x4", "plain store x4", "pk f16 atomic x2 (256B/row)", "f32 atomic, row%8 == own XCD", "f32 atomic, row%8 == other XCD", "plain RMW, row%8 == own XCD"};
+    const char* names[] = {"f32 atomic x4 (512B/row)", "u64 atomic x2 (512B/row)", "u32 atomic x4", "f64 atomic x2", "plain RMW x4", "f32 atomic wg-scope x4", "plain store x4", "pk f16 atomic x2 (256B/row)", "f32 atomic, row%8 == own XCD", "f32 atomic, row%8 == other XCD", "plain RMW, row%8 == own XCD", "plain RMW x4, nt", "loads only x4"};
 #define RUN(M) { for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(k<M>, dim3(2048), dim3(256), 0, 0, G, rows, n); \
     hipEventRecord(e0); for (int it = 0; it < 10; ++it) hipLaunchKernelGGL(k<M>, dim3(2048), dim3(256), 0, 0, G, rows, n); hipEventRecord(e1); hipEventSynchronize(e1); \
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10; printf("%-32s %8.1f us  %7.1f M rows/s\n", names[M], ms * 1e3, n / ms / 1e3); }
-    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10)
+    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12)
     return 0;
 }
