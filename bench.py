@@ -118,6 +118,9 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     Q = eng.Q                                            # (scatter_gather may re-home the item table)
     if two_pass is not None:
         eng.overlap_exchange = bool(two_pass) and SHARDED
+    # OPT-IN, never the default: RSX_STALE_EXCHANGE=1 lets a step's exchange travel under the NEXT step kernel (item
+    # table one step stale: not the reference's batch-synchronous step; flagged in the JSON line)
+    eng.stale_exchange = SHARDED and os.environ.get("RSX_STALE_EXCHANGE") == "1"
     nb = eng.set_neg_block(B, want_nb) if want_nb > 0 else 0
     if hot > 0:
         eng.set_hot_items(torch.bincount(indices.long(), minlength=I), hot, hot_replicas)
@@ -152,7 +155,8 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     key = f"U{U}_I{I}_d{d}_B{B}_{popularity}_nb{nb}"
     return {"batch_per_gpu": B, "global_batch": gb, "value": gb * steps / elapsed, "unit": "triplets/s",
             "ms_per_step": elapsed / steps * 1e3, "steps": steps, "neg_block": nb, "mean_bpr_loss": mean_loss,
-            "two_pass": bool(eng.overlap_exchange), "exchange": eng.exchange if SHARDED else None,
+            "two_pass": bool(eng.overlap_exchange) and not eng.stale_exchange, "exchange": eng.exchange if SHARDED else None,
+            "stale_exchange": bool(eng.stale_exchange),
             "item_replicas_identical": replicas_equal, "_Q": Q,
             "roofline": roofline(kernel, kern_ms, B, I, d, key, two_pass=eng.overlap_exchange),
             "frac_of_hbm_roofline_end_to_end": gb / world * steps / elapsed * 24 * d / (HBM_PEAK_GBS * 1e9)}
@@ -394,7 +398,10 @@ def main():
                        "parallelism": (f"user-sharded x{world}, items replicated, "
                                        + ("1 all-reduce(G)/step" if head["exchange"] == "allreduce" else
                                           "reduce-scatter(G) + own item shard applied + all-gather(Q rows) per step")
-                                       + (", under the user pass of a two-pass step" if head["two_pass"] else "")) if SHARDED else "single GPU"},
+                                       + (", under the user pass of a two-pass step" if head["two_pass"] else "")
+                                       + (", ONE STEP STALE (opt-in RSX_STALE_EXCHANGE: the exchange travels under the next step "
+                                          "kernel; not the reference's synchronous step)" if head["stale_exchange"] else ""))
+                                      if SHARDED else "single GPU"},
             "roofline": head["roofline"],
         }
         if legs:

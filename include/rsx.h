@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RSX_ABI_VERSION 2
+#define RSX_ABI_VERSION 3
 
 #define RSX_OK 0
 #define RSX_E_INVALID (-1)   /* bad argument (null pointer, unsupported d, K ...) */
@@ -285,6 +285,15 @@ int rsx_bpr_build_item_cdf(const int64_t *indptr_dev, const int32_t *indices_dev
  *                        each rank applying its own shard of item rows, all-gather of the updated rows);
  *                        the trainer then does not call rsx_apply_item_grad itself.
  *   step0 / epoch_pos0   starting step index and position in the user permutation
+ *   stale_exchange / G_alt   OPT-IN, needs the exchange callbacks and a second zeroed [num_items x d] buffer.
+ *                        != 0: the exchange of step t's item gradients travels under the step kernel of
+ *                        step t+1, which therefore reads an item table that lacks step t's update (ONE STEP
+ *                        STALE: no longer the reference's batch-synchronous step, MF.py:64-68; user rows are
+ *                        never stale).  The steps of a trainer alternate between G (first) and G_alt; the
+ *                        callbacks come in the order begin(t), end(t-1), begin(t+1), end(t), ...: begin starts
+ *                        the collective on the buffer of the step just computed, end finishes the OLDEST one in
+ *                        flight.  Every rsx_bpr_trainer_run ends the last exchange and applies it before it
+ *                        returns, so nothing is left unapplied between calls.  two_pass is ignored.
  * rsx_bpr_trainer_run(n_steps, batch <= config batch, global_batch = sum of the ranks' batches,
  *   time_every): time_every > 0 brackets the step kernel of every time_every-th step with HIP events
  *   on `stream`; rsx_bpr_trainer_kernel_ms returns their mean once the stream has drained.
@@ -329,6 +338,8 @@ typedef struct rsx_bpr_trainer_config {
     int32_t sort_min_batch;
     int64_t step0;
     int64_t epoch_pos0;
+    float *G_alt;
+    int32_t stale_exchange;
 } rsx_bpr_trainer_config;
 
 typedef struct rsx_bpr_trainer rsx_bpr_trainer;

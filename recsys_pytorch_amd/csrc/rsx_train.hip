@@ -39,6 +39,7 @@ struct rsx_bpr_trainer {
     int slot_nb[S] = {};
     bool slot_sorted[S] = {};                    // ordered by positive item without blocked negatives
     int last = -1;                               // slot consumed by the most recent step
+    bool flip = false;                           // stale_exchange: the next step accumulates into G_alt
     // live timing of the step kernel (HIP events on the run stream, every `time_every`-th step)
     std::vector<hipEvent_t> t0, t1;
     size_t timed = 0;
@@ -123,6 +124,8 @@ RSX_API int rsx_bpr_trainer_create(const rsx_bpr_trainer_config *cfg, rsx_bpr_tr
                   "hot_slot, G_hot and hot_items go together");
     RSX_CHECK_ARG((cfg->exchange_begin == nullptr) == (cfg->exchange_end == nullptr), "exchange_begin and exchange_end go together");
     RSX_CHECK_ARG(cfg->step0 >= 0 && cfg->epoch_pos0 >= 0, "negative start state");
+    RSX_CHECK_ARG(!cfg->stale_exchange || (cfg->exchange_begin != nullptr && cfg->G_alt != nullptr && cfg->G_alt != cfg->G),
+                  "stale_exchange needs the exchange callbacks and a second gradient buffer G_alt");
     rsx_bpr_trainer *t = new (std::nothrow) rsx_bpr_trainer();
     if (t == nullptr) { rsx_set_error("rsx_bpr_trainer_create: out of memory"); return RSX_E_INVALID; }
     t->c = *cfg;
@@ -176,6 +179,7 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
     const float inv_batch = 1.0f / (float)global_batch;
     const bool sharded = c.exchange_begin != nullptr;
     const bool hot = c.hot_slot != nullptr;
+    const bool stale = sharded && c.stale_exchange != 0;
     t->timed = 0;
     constexpr int S = rsx_bpr_trainer::S;
     if (t->ahead > 0 && t->slot_batch[t->cur] != batch) {
@@ -220,8 +224,13 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
             RSX_HIP(hipEventRecord(t->t0[t->timed], st));
         }
         const unsigned sorted_flag = t->slot_sorted[cur] ? RSX_BATCH_SORTED : 0u;
-        const unsigned f = RSX_USERS_UNIQUE | sorted_flag | ((sharded && c.two_pass) ? RSX_ITEMS_ONLY : 0u);
-        RSX_TRY(rsx_bpr_step(c.P, c.Q, c.G, c.num_users, c.num_items, u, i, j, batch, c.d, c.lr, inv_batch, c.loss_acc, f,
+        const bool two_pass = sharded && c.two_pass && !stale;
+        const unsigned f = RSX_USERS_UNIQUE | sorted_flag | (two_pass ? RSX_ITEMS_ONLY : 0u);
+        // one-step-stale exchange: the steps of this trainer alternate between the two gradient buffers, G first
+        float *const Gs = (stale && t->flip) ? c.G_alt : c.G;
+        if (stale) t->flip = !t->flip;
+        float *const Gprev = (Gs == c.G) ? c.G_alt : c.G;
+        RSX_TRY(rsx_bpr_step(c.P, c.Q, Gs, c.num_users, c.num_items, u, i, j, batch, c.d, c.lr, inv_batch, c.loss_acc, f,
                              nullptr, 0, c.hot_slot, c.G_hot, c.hot_replicas, nb, key, stream));
         if (timed) { RSX_HIP(hipEventRecord(t->t1[t->timed], st)); ++t->timed; }
         if (!sharded) {
@@ -230,18 +239,33 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
             // the one exchange of the step: the item gradients, summed over the ranks by the caller's
             // collective (RCCL all-reduce through torch.distributed in this package).  It needs the
             // folded G; with two passes it travels under the user pass and the next step's sampler.
-            if (hot) RSX_TRY(rsx_fold_hot_grad(c.G, c.G_hot, c.hot_items, c.n_hot, c.hot_replicas, c.d, stream));
+            if (hot) RSX_TRY(rsx_fold_hot_grad(Gs, c.G_hot, c.hot_items, c.n_hot, c.hot_replicas, c.d, stream));
             if (c.exchange_begin(c.exchange_ctx) != 0) { rsx_set_error("rsx_bpr_trainer_run: exchange_begin failed"); return RSX_E_INVALID; }
             RSX_HIP(hipEventRecord(t->fork, st));
             RSX_HIP(hipStreamWaitEvent(t->side, t->fork, 0));
             RSX_TRY(top_up());                                                 // beside the exchange
-            if (c.two_pass)
+            if (stale) {
+                // this step's exchange stays in flight under the NEXT step kernel; what is finished and applied
+                // now is the exchange of the step before (nothing before the first step of a run)
+                if (s > 0) {
+                    if (c.exchange_end(c.exchange_ctx) != 0) { rsx_set_error("rsx_bpr_trainer_run: exchange_end failed"); return RSX_E_INVALID; }
+                    if (!c.exchange_applies)
+                        RSX_TRY(rsx_apply_item_grad(c.Q, Gprev, c.num_items, c.d, c.lr, nullptr, nullptr, 0, stream));
+                }
+                if (s + 1 == n_steps) {      // drain: a run leaves nothing unapplied
+                    if (c.exchange_end(c.exchange_ctx) != 0) { rsx_set_error("rsx_bpr_trainer_run: exchange_end failed"); return RSX_E_INVALID; }
+                    if (!c.exchange_applies)
+                        RSX_TRY(rsx_apply_item_grad(c.Q, Gs, c.num_items, c.d, c.lr, nullptr, nullptr, 0, stream));
+                }
+            } else {
+            if (two_pass)
                 RSX_TRY(rsx_bpr_step(c.P, c.Q, c.G, c.num_users, c.num_items, u, i, j, batch, c.d, c.lr, inv_batch, nullptr,
                                      RSX_USERS_UNIQUE | RSX_USERS_ONLY | sorted_flag, nullptr, 0, c.hot_slot, c.G_hot, c.hot_replicas, nb,
                                      key, stream));
             if (c.exchange_end(c.exchange_ctx) != 0) { rsx_set_error("rsx_bpr_trainer_run: exchange_end failed"); return RSX_E_INVALID; }
             if (!c.exchange_applies)
                 RSX_TRY(rsx_apply_item_grad(c.Q, c.G, c.num_items, c.d, c.lr, nullptr, nullptr, 0, stream));
+            }
         }
         RSX_HIP(hipEventRecord(t->freed[cur], st));
         t->freed_valid[cur] = true;

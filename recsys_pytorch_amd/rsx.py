@@ -318,7 +318,8 @@ class TrainerConfig(C.Structure):
                 ("user_sig", _P), ("item_cdf", _P), ("triplets", _P), ("hot_slot", _P), ("G_hot", _P),
                 ("hot_items", _P), ("n_hot", C.c_int32), ("hot_replicas", C.c_int32), ("loss_acc", _P),
                 ("exchange_begin", EXCHANGE_FN), ("exchange_end", EXCHANGE_FN), ("exchange_ctx", _P),
-                ("exchange_applies", C.c_int32), ("sort_min_batch", C.c_int32), ("step0", _I64), ("epoch_pos0", _I64)]
+                ("exchange_applies", C.c_int32), ("sort_min_batch", C.c_int32), ("step0", _I64), ("epoch_pos0", _I64),
+                ("G_alt", _P), ("stale_exchange", C.c_int32)]
 
 
 class BPRTrainer:
@@ -327,14 +328,15 @@ class BPRTrainer:
     borrows alive."""
 
     def __init__(self, P, Q, G, indptr, indices, lr, batch, seed, seed_key, neg_block=0, hot=None, user_sig=None,
-                 item_cdf=None, loss_acc=None, exchange=None, two_pass=False, exchange_applies=False, sort_min_batch=0, step0=0, epoch_pos0=0):
+                 item_cdf=None, loss_acc=None, exchange=None, two_pass=False, exchange_applies=False, sort_min_batch=0, step0=0, epoch_pos0=0,
+                 G_alt=None):
         dev = P.device
         self.batch = int(batch)
         self.triplets = torch.empty(RSX_TRAINER_SLOTS * 3 * self.batch, dtype=torch.int32, device=dev)
         self.sample_ws = None
         if neg_block or sort_min_batch:
             self.sample_ws = torch.empty(bpr_sample_workspace(self.batch, Q.shape[0]), dtype=torch.uint8, device=dev)
-        self._keep = (P, Q, G, indptr, indices, hot, user_sig, item_cdf, loss_acc)
+        self._keep = (P, Q, G, indptr, indices, hot, user_sig, item_cdf, loss_acc, G_alt)
         ptr = lambda t, dt, name: _dev(t, dt, name) if t is not None else None
         self._cb = (None, None)
         if exchange is not None:                       # (begin, end) callables; exceptions become error codes
@@ -365,7 +367,8 @@ class BPRTrainer:
             n_hot=hot.n if hot else 0, hot_replicas=hot.replicas if hot else 0,
             loss_acc=ptr(loss_acc, torch.float32, "loss_acc"),
             exchange_begin=self._cb[0] or EXCHANGE_FN(), exchange_end=self._cb[1] or EXCHANGE_FN(), exchange_ctx=None,
-            exchange_applies=int(bool(exchange_applies)), sort_min_batch=int(sort_min_batch), step0=int(step0), epoch_pos0=int(epoch_pos0))
+            exchange_applies=int(bool(exchange_applies)), sort_min_batch=int(sort_min_batch), step0=int(step0), epoch_pos0=int(epoch_pos0),
+            G_alt=ptr(G_alt, torch.float32, "G_alt"), stale_exchange=int(G_alt is not None))   # opt-in: one step stale
         self._h = C.c_void_p()
         _check(lib().rsx_bpr_trainer_create(C.byref(cfg), C.byref(self._h)), "rsx_bpr_trainer_create")
 

@@ -89,6 +89,13 @@ class BPREngine:
             raise ValueError(exchange)
         self.exchange = exchange if (self.sharded and optimizer == "sgd") else "allreduce"
         self._work = None
+        # OPT-IN (native loop only): the exchange of step t travels under the step kernel of step t+1, which
+        # then reads an item table WITHOUT step t's update -- one step stale, not the reference's
+        # batch-synchronous step (models/MF.py:64-68); include/rsx.h: stale_exchange.  Reported separately.
+        self.stale_exchange = False
+        self._G_alt = self._Gp_alt = None
+        self._pending = []          # exchanges begun and not ended, oldest first: (work, gradient buffer)
+        self._begin_step = 0        # exchanges begun by the current native trainer (picks the buffer by parity)
         if self.exchange == "scatter_gather":
             self._setup_item_shards()
         self.hot = None
@@ -174,28 +181,43 @@ class BPREngine:
         self.G = self._Gp[:I]
         self._mine = slice(r * self._shard, (r + 1) * self._shard)
 
+    def _stale_buffers(self):
+        """the second gradient buffer of the one-step-stale exchange (same shape and padding as the first)"""
+        if self._G_alt is None:
+            if self.exchange == "scatter_gather":
+                self._Gp_alt = torch.zeros_like(self._Gp)
+                self._G_alt = self._Gp_alt[:self.Q.shape[0]]
+            else:
+                self._G_alt = torch.zeros_like(self.G)
+        return self._G_alt
+
     def _exchange_begin(self):
-        """G (folded) is complete on the current stream: start the collective"""
+        """the gradient buffer of this step (folded) is complete on the current stream: start the collective.
+        Begun exchanges queue up (one deep normally, two with stale_exchange) and end oldest first."""
+        alt = self.stale_exchange and (self._begin_step & 1)
+        self._begin_step += 1
         if self.exchange == "allreduce":
-            self._work = dist.all_reduce(self.G, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            G = self._G_alt if alt else self.G
+            self._pending.append((dist.all_reduce(G, op=dist.ReduceOp.SUM, group=self.group, async_op=True), G))
             return
+        Gp = self._Gp_alt if alt else self._Gp
         try:        # in place: this rank's shard of G receives the sum over the ranks
-            self._work = dist.reduce_scatter_tensor(self._Gp[self._mine], self._Gp, op=dist.ReduceOp.SUM, group=self.group,
-                                                    async_op=True)
+            work = dist.reduce_scatter_tensor(Gp[self._mine], Gp, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         except RuntimeError:    # a backend without reduce_scatter (gloo, in the CPU tests): same shard via all_reduce
-            self._work = dist.all_reduce(self._Gp, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work = dist.all_reduce(Gp, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append((work, Gp))
 
     def _exchange_end(self):
-        """the current stream waits for the exchange; with "scatter_gather" this also applies the own shard
-        and gathers the updated item rows, so no apply sweep follows"""
-        self._work.wait()
-        self._work = None
+        """the current stream waits for the OLDEST exchange in flight; with "scatter_gather" this also applies the
+        own shard and gathers the updated item rows, so no apply sweep follows"""
+        work, Gp = self._pending.pop(0)
+        work.wait()
         if self.exchange == "allreduce":
             return
         m = self._mine
-        self.k.apply_item_grad(self._Qp[m], self._Gp[m], self.lr)          # Q -= lr*G on the own rows; zeroes them in G
-        self._Gp[:m.start].zero_()                                         # the other shards hold this rank's partial sums
-        self._Gp[m.stop:].zero_()
+        self.k.apply_item_grad(self._Qp[m], Gp[m], self.lr)                # Q -= lr*G on the own rows; zeroes them in G
+        Gp[:m.start].zero_()                                               # the other shards hold this rank's partial sums
+        Gp[m.stop:].zero_()
         dist.all_gather_into_tensor(self._Qp, self._Qp[m], group=self.group)   # in place: every rank's updated rows
 
     # -- helpers ---------------------------------------------------------------
@@ -385,6 +407,9 @@ class BPREngine:
         if self.neg_block or sort_min:
             self._bind_csr(indptr, indices)
         exchange = (self._exchange_begin, self._exchange_end) if self.sharded else None
+        stale = bool(self.stale_exchange) and self.sharded
+        self._pending.clear()
+        self._begin_step = 0                        # the trainer alternates G / G_alt, G first
         return self.k.BPRTrainer(self.P, self.Q, self.G, indptr, indices, self.lr, batch,
                                  seed=self.seed + 7919 * self.user_begin, seed_key=self.seed, neg_block=self.neg_block,
                                  hot=self.hot, user_sig=self._sig if self.neg_block else None,
@@ -392,7 +417,8 @@ class BPREngine:
                                  sort_min_batch=sort_min,
                                  loss_acc=loss_acc, exchange=exchange, two_pass=self.overlap_exchange,
                                  exchange_applies=self.exchange == "scatter_gather",
-                                 step0=self.step_count, epoch_pos0=self.epoch_pos)
+                                 step0=self.step_count, epoch_pos0=self.epoch_pos,
+                                 **({"G_alt": self._stale_buffers()} if stale else {}))
 
     def adopt(self, trainer):
         """take over the step counter and permutation position a native run has reached"""

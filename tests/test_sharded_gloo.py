@@ -253,7 +253,54 @@ def _rccl_one_rank_worker(rank, port, U, I, d, B, steps, out):
         torch.cuda.synchronize()
         return P.cpu().numpy(), eng.Q.cpu().numpy()
 
+    def run_stale(exchange, lr=20.0):
+        """native loop with the opt-in one-step-stale exchange, and the same recurrence driven by hand on the same
+        triplets: step t's kernel reads the item table WITHOUT the update of step t-1 (applied right after it)"""
+        from recsys_pytorch_amd import rsx
+        def tables():
+            torch.manual_seed(100)
+            P = torch.randn(U, d, device=dev) * 0.1
+            torch.manual_seed(7)
+            return P, torch.randn(I, d, device=dev) * 0.1
+        P, Q = tables()
+        eng = BPREngine(P, Q, lr, seed=11, exchange=exchange, force_sharded=True)
+        eng.stale_exchange = True
+        eng.set_neg_block(B, 8)
+        eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 32, 4)
+        tr = eng.native_trainer(ip, ix, B)
+        tr.run(2, B, global_batch=B)            # two calls: every run drains its last exchange
+        tr.run(steps - 2, B, global_batch=B)
+        torch.cuda.synchronize()
+        tr.close()
+        assert not eng._pending
+
+        def by_hand(stale):
+            P2, Q2 = tables()
+            ref = BPREngine(P2, Q2, lr, seed=11)
+            ref.set_neg_block(B, 8)
+            ref.set_hot_items(torch.bincount(ix.long(), minlength=I), 32, 4)
+            G = [ref.G, torch.zeros_like(ref.G)]
+            for lo, hi in ((0, 2), (2, steps)):
+                for t in range(hi - lo):
+                    u, i, j = ref.sample(ip, ix, B)
+                    rsx.bpr_step(P2, Q2, G[t & 1], u, i, j, lr, 1.0 / B, users_unique=True, hot=ref.hot,
+                                 neg_block=ref.neg_block, neg_key=ref.last_neg_key)
+                    rsx.fold_hot_grad(G[t & 1], ref.hot)
+                    ref.step_count += 1
+                    if not stale:
+                        rsx.apply_item_grad(Q2, G[t & 1], lr)           # the synchronous step
+                    elif t > 0:
+                        rsx.apply_item_grad(Q2, G[(t - 1) & 1], lr)     # after the NEXT step's kernel
+                if stale:
+                    rsx.apply_item_grad(Q2, G[(hi - lo - 1) & 1], lr)   # end of a run: drained
+            torch.cuda.synchronize()
+            return P2.cpu().numpy(), Q2.cpu().numpy()
+
+        return (P.cpu().numpy(), eng.Q.cpu().numpy()), by_hand(True), by_hand(False)
+
     res = {"plain": run(False, "allreduce", False, "native")}
+    for exchange in ("allreduce", "scatter_gather"):
+        res[("stale", exchange)], res[("stale_ref", exchange)], res[("stale_sync", exchange)] = run_stale(exchange)
     for exchange in ("allreduce", "scatter_gather"):
         for two_pass in (False, True):
             for mode in ("native", "python"):
@@ -279,6 +326,15 @@ def test_exchange_over_rccl_with_one_rank_equals_the_unsharded_step(B, I):
     port = 29500 + (os.getpid() + 29 + B) % 2000
     mp.spawn(_rccl_one_rank_worker, args=(port, U, I, d, B, steps, out), nprocs=1, join=True)
     P0, Q0 = out["plain"]
-    assert len(out) == 9
+    assert len(out) == 15
     for key, (P, Q) in out.items():
+        if key[0] in ("stale", "stale_ref", "stale_sync"):
+            continue
         assert np.abs(P - P0).max() < 1e-6 and np.abs(Q - Q0).max() < 1e-6, key
+    # the opt-in one-step-stale exchange: equal to its own recurrence driven by hand, and NOT the synchronous step
+    for exchange in ("allreduce", "scatter_gather"):
+        (P, Q), (Pr, Qr), (Ps, Qs) = out[("stale", exchange)], out[("stale_ref", exchange)], out[("stale_sync", exchange)]
+        scale = np.abs(Qr - Q0).max()          # lr = 20: the five updates are O(0.1) of the table
+        assert scale > 1e-2
+        assert np.abs(P - Pr).max() < 1e-5 * scale and np.abs(Q - Qr).max() < 1e-5 * scale, exchange
+        assert np.abs(Q - Qs).max() > 1e-3 * scale, "the stale recurrence cannot be told from the synchronous step"
