@@ -86,3 +86,24 @@ def test_argument_errors_use_the_error_channel(libpath):
     assert rc == -1 and b"null" in L.rsx_last_error()
     rc = L.rsx_bpr_build_item_cdf(None, None, 10, 10, None, None, 0, None)
     assert rc == -1
+
+
+def test_trainer_config_binding_mirrors_the_header_struct(libpath, tmp_path):
+    """recsys_pytorch_amd/rsx.py:TrainerConfig against include/rsx.h:rsx_bpr_trainer_config: same fields in the same
+    order, and the same size and offsets as the C compiler lays them out (a probe compiled from the header)"""
+    import subprocess
+    from recsys_pytorch_amd import rsx
+    text = open(os.path.join(ROOT, "include", "rsx.h")).read()
+    body = re.search(r"typedef struct rsx_bpr_trainer_config \{(.*?)\} rsx_bpr_trainer_config;", text, flags=re.S).group(1)
+    fields = [re.search(r"(\w+);", line).group(1) for line in body.splitlines() if ";" in line]
+    assert fields == [f[0] for f in rsx.TrainerConfig._fields_]
+    probe = tmp_path / "probe.c"
+    probe.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rsx.h"\nint main(void) {\n'
+                     + 'printf("%zu\\n", sizeof(rsx_bpr_trainer_config));\n'
+                     + "".join(f'printf("%zu\\n", offsetof(rsx_bpr_trainer_config, {f}));\n' for f in fields)
+                     + "return 0; }\n")
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(probe), "-o", str(exe)])
+    nums = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+    assert nums[0] == ctypes.sizeof(rsx.TrainerConfig)
+    assert nums[1:] == [getattr(rsx.TrainerConfig, f).offset for f in fields]
