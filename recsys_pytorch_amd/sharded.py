@@ -245,6 +245,8 @@ class BPREngine:
     def step(self, u_local, i, j, global_batch=None, users_unique=False, want_loss=True, neg_block=0,
              neg_key=0, batch_sorted=False):
         """returns the device tensor of loss slots (sum_b softplus(-x_b) striped) or None"""
+        if self.stale_exchange and self.sharded:
+            raise ValueError("stale_exchange is a schedule of the native loop (native_trainer); step() is synchronous")
         B = int(u_local.numel())
         gb = self._global_batch(B, global_batch)
         loss = None
