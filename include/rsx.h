@@ -179,6 +179,18 @@ int rsx_bpr_grad(const float *P, const float *Q, float *GP, float *GQ, int64_t n
 int rsx_adam_apply(float *W, float *M, float *V, float *G, int64_t n, float lr, float beta1,
                    float beta2, float eps, int64_t t, rsx_stream_t stream);
 
+/* rsx_pointwise_grad: the POINTWISE branch of the reference model (models/MF.py:99-102 with hparams['pointwise'] = True;
+ * "widening" row beyond SURVEY section 8f).  Batch of n (user, item, rating) entries -- users and items repeat, as in the
+ * batches of data/generators.py:105-130 -- x_b = <P[u_b], Q[i_b]>, loss = mean_b l(x_b, y_b) with
+ *   loss_kind 0: F.binary_cross_entropy_with_logits (hparams['loss_func'] != 'mse', MF.py:21)   dl/dx = sigmoid(x) - y
+ *   loss_kind 1: F.mse_loss                                                                      dl/dx = 2 (x - y)
+ * Dense gradients like rsx_bpr_grad: GP[u_b] += dl/dx * inv_n * Q[i_b], GQ[i_b] += dl/dx * inv_n * P[u_b] (tables
+ * untouched; both buffers zero between steps); loss_acc (nullable, RSX_LOSS_SLOTS floats) += sum_b l_b, striped.
+ * Then rsx_adam_apply on both tables (the optimizer as shipped, MF.py:30) or rsx_apply_item_grad on both (SGD). */
+int rsx_pointwise_grad(const float *P, const float *Q, float *GP, float *GQ, int64_t num_users, int64_t num_items,
+                       const int32_t *u_dev, const int32_t *i_dev, const float *y_dev, int64_t n, int d,
+                       float inv_n, int loss_kind, float *loss_acc, rsx_stream_t stream);
+
 /* rsx_pair_score: r[b] = <P[u[b]], Q[i[b]]>   (models/MF.py:38-42, MF.forward)            */
 int rsx_pair_score(const float *P, const float *Q, const int32_t *u_dev, const int32_t *i_dev,
                    int64_t n, int d, float *r_out, rsx_stream_t stream);

@@ -71,6 +71,16 @@ def lib():
                                              C.c_int, _i64p, _i64p, _i64p, C.c_int64, C.c_int, C.c_float,
                                              C.c_float, C.c_float, C.c_float, C.c_int64, _f32p, _f32p, _f32p,
                                              _f32p, _f32p, C.POINTER(C.c_double)]
+        L.orc_pointwise_grad.restype = None
+        L.orc_pointwise_grad.argtypes = [_f32p, _f32p, _i64p, _i64p, _f32p, C.c_int64, C.c_int, C.c_int, _f32p, _f32p,
+                                         C.POINTER(C.c_double)]
+        L.orc_pointwise_step_sgd.restype = None
+        L.orc_pointwise_step_sgd.argtypes = [_f32p, _f32p, C.c_int64, C.c_int64, _i64p, _i64p, _f32p, C.c_int64, C.c_int,
+                                             C.c_int, C.c_float, _f32p, _f32p, C.POINTER(C.c_double)]
+        L.orc_pointwise_step_adam.restype = None
+        L.orc_pointwise_step_adam.argtypes = [_f32p, _f32p, C.c_int64, C.c_int64, _i64p, _i64p, _f32p, C.c_int64, C.c_int,
+                                              C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64,
+                                              _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.POINTER(C.c_double)]
         _LIB = L
     return _LIB
 
@@ -129,6 +139,27 @@ class MFOracle:
                                     len(u), self.d, self.lr, self.betas[0], self.betas[1],
                                     self.eps, self.t, self.mP, self.vP, self.mQ, self.vQ,
                                     self._gP, self._gQ, C.byref(loss))
+        return loss.value
+
+    # the pointwise branch (models/MF.py:99-102): loss_kind "ce" (binary_cross_entropy_with_logits) or "mse"
+    def pointwise_grad(self, u, i, y, loss_kind="ce"):
+        gP, gQ = np.zeros_like(self.P), np.zeros_like(self.Q)
+        loss = C.c_double(0)
+        lib().orc_pointwise_grad(self.P, self.Q, _i64(u), _i64(i), np.ascontiguousarray(y, np.float32), len(u), self.d,
+                                 int(loss_kind == "mse"), gP, gQ, C.byref(loss))
+        return gP, gQ, loss.value
+
+    def pointwise_step(self, u, i, y, loss_kind="ce"):
+        loss = C.c_double(0)
+        self.t += 1
+        y = np.ascontiguousarray(y, np.float32)
+        if self.optimizer == "sgd":
+            lib().orc_pointwise_step_sgd(self.P, self.Q, self.U, self.I, _i64(u), _i64(i), y, len(u), self.d,
+                                         int(loss_kind == "mse"), self.lr, self._gP, self._gQ, C.byref(loss))
+        else:
+            lib().orc_pointwise_step_adam(self.P, self.Q, self.U, self.I, _i64(u), _i64(i), y, len(u), self.d,
+                                          int(loss_kind == "mse"), self.lr, self.betas[0], self.betas[1], self.eps,
+                                          self.t, self.mP, self.vP, self.mQ, self.vQ, self._gP, self._gQ, C.byref(loss))
         return loss.value
 
     def score(self, users):

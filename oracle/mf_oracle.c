@@ -137,6 +137,65 @@ ORC_EXPORT void orc_bpr_step_adam(float *P, float *Q, int64_t U, int64_t I,
     orc_adam_apply(Q, mQ, vQ, gQ, I * d, lr, b1, b2, eps, t);
 }
 
+/* ---- the POINTWISE branch: models/MF.py:99-102 with hparams['pointwise'] = True -----------------
+ * loss = loss_func(forward(users, items), ratings), loss_func = F.mse_loss when hparams['loss_func'] == 'mse',
+ * else F.binary_cross_entropy_with_logits (MF.py:21); both with reduction 'mean'.  x_b = <P[u_b], Q[i_b]>:
+ *   ce : l_b = max(x,0) - x y + log(1 + exp(-|x|))   (torch's stable form)   dl/dx = sigmoid(x) - y
+ *   mse: l_b = (x - y)^2                                                       dl/dx = 2 (x - y)
+ * dense grads like the pairwise branch (nn.Embedding(sparse=False)): dP[u_b] += dl/dx / n * Q[i_b],
+ * dQ[i_b] += dl/dx / n * P[u_b]; users AND items repeat inside a batch (data/generators.py:105-130 puts
+ * batch_size interactions plus one sampled negative for EVERY user into each batch).  loss_kind 0 = ce, 1 = mse. */
+ORC_EXPORT void orc_pointwise_grad(const float *P, const float *Q, const int64_t *u, const int64_t *i,
+                                   const float *y, int64_t n, int d, int loss_kind, float *gP, float *gQ,
+                                   double *loss_out)
+{
+    double acc = 0.0;
+    const float invn = 1.0f / (float)n;
+    for (int64_t b = 0; b < n; ++b) {
+        const float *pu = P + u[b] * d;
+        const float *qi = Q + i[b] * d;
+        const float x = orc_dot(pu, qi, d);
+        float g;
+        if (loss_kind == 1) {
+            acc += (double)((x - y[b]) * (x - y[b]));
+            g = 2.0f * (x - y[b]) * invn;
+        } else {
+            acc += (double)(fmaxf(x, 0.0f) - x * y[b] + log1pf(expf(-fabsf(x))));
+            g = (1.0f / (1.0f + expf(-x)) - y[b]) * invn;
+        }
+        float *gpu = gP + u[b] * d;
+        float *gqi = gQ + i[b] * d;
+        for (int k = 0; k < d; ++k) {
+            gpu[k] += g * qi[k];
+            gqi[k] += g * pu[k];
+        }
+    }
+    if (loss_out) *loss_out = n > 0 ? acc / (double)n : 0.0;
+}
+
+ORC_EXPORT void orc_pointwise_step_sgd(float *P, float *Q, int64_t U, int64_t I, const int64_t *u, const int64_t *i,
+                                       const float *y, int64_t n, int d, int loss_kind, float lr,
+                                       float *gP, float *gQ, double *loss_out)
+{
+    memset(gP, 0, sizeof(float) * (size_t)U * d);
+    memset(gQ, 0, sizeof(float) * (size_t)I * d);
+    orc_pointwise_grad(P, Q, u, i, y, n, d, loss_kind, gP, gQ, loss_out);
+    for (int64_t k = 0; k < U * d; ++k) P[k] -= lr * gP[k];
+    for (int64_t k = 0; k < I * d; ++k) Q[k] -= lr * gQ[k];
+}
+
+ORC_EXPORT void orc_pointwise_step_adam(float *P, float *Q, int64_t U, int64_t I, const int64_t *u, const int64_t *i,
+                                        const float *y, int64_t n, int d, int loss_kind, float lr, float b1, float b2,
+                                        float eps, int64_t t, float *mP, float *vP, float *mQ, float *vQ,
+                                        float *gP, float *gQ, double *loss_out)
+{
+    memset(gP, 0, sizeof(float) * (size_t)U * d);
+    memset(gQ, 0, sizeof(float) * (size_t)I * d);
+    orc_pointwise_grad(P, Q, u, i, y, n, d, loss_kind, gP, gQ, loss_out);
+    orc_adam_apply(P, mP, vP, gP, U * d, lr, b1, b2, eps, t);
+    orc_adam_apply(Q, mQ, vQ, gQ, I * d, lr, b1, b2, eps, t);
+}
+
 /* ---- full-catalog scoring: models/MF.py:109-112 --------------------------
  * S[r, :] = P[users[r]] @ Q.T  (fp32), out row-major [Bu x I].               */
 ORC_EXPORT void orc_score(const float *P, const int64_t *users, int64_t Bu,

@@ -455,6 +455,54 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
     }
 }
 
+// ---- the pointwise branch of the reference model (models/MF.py:99-102 with hparams['pointwise'] = True) -------------
+// loss = loss_func(<P[u], Q[i]>, rating), mean over the batch; loss_func = F.binary_cross_entropy_with_logits
+// (KIND 0; hparams['loss_func'] != 'mse') or F.mse_loss (KIND 1), MF.py:21.  Dense gradients like rsx_bpr_grad:
+// users AND items repeat inside a batch (the reference's generator adds one negative for every user to every batch,
+// data/generators.py:119-124), so both sides go through atomics into GP / GQ.
+template <int D, int KIND, typename OffT>
+__global__ __launch_bounds__(kBlock) void pointwise_grad_kernel(const float *__restrict__ P, const float *__restrict__ Q,
+                                                                float *__restrict__ GP, float *__restrict__ GQ,
+                                                                const int32_t *__restrict__ U_idx,
+                                                                const int32_t *__restrict__ I_idx,
+                                                                const float *__restrict__ Y, int64_t n, float inv_n,
+                                                                float *__restrict__ loss_acc)
+{
+    constexpr int EPL = D / 32;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR;
+    const int k = lane % LPR;
+    const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock * TPW;
+    float loss_local = 0.0f;
+    for (int64_t b = wave * TPW + sub; b - sub < n; b += stride) {      // wave-uniform trip count
+        if (b >= n) continue;
+        const OffT u_off = row_off<D, OffT>(U_idx[b], k), i_off = row_off<D, OffT>(I_idx[b], k);
+        const float y = Y[b];
+        Row<D> p, q;
+        p.load_at(P, u_off);
+        q.load_at(Q, i_off);
+        float x = 0.0f;
+#pragma unroll
+        for (int c = 0; c < EPL; ++c) x = fmaf(p.v[c], q.v[c], x);
+        x = group_sum(x);
+        float g;
+        if constexpr (KIND == 1) {
+            g = 2.0f * (x - y) * inv_n;
+            if (loss_acc != nullptr && k == 0) loss_local += (x - y) * (x - y);
+        } else {
+            g = (1.0f / (1.0f + __expf(-x)) - y) * inv_n;
+            if (loss_acc != nullptr && k == 0) loss_local += fmaxf(x, 0.0f) - x * y + log1pf(__expf(-fabsf(x)));
+        }
+        q.atomic_axpy_at(GP, u_off, g);
+        p.atomic_axpy_at(GQ, i_off, g);
+    }
+    if (loss_acc != nullptr) {
+        const float w = wave_sum(loss_local);
+        if (lane == 0) rsx_atomic_add(loss_acc + (wave & 63) * (RSX_LOSS_SLOTS / 64), w);
+    }
+}
+
 // claim: the first triplet (by CAS winner) of each distinct user owns that user's delta slot
 __global__ __launch_bounds__(kBlock) void bpr_claim_kernel(const int32_t *__restrict__ U_idx,
                                                            const int32_t *__restrict__ I_idx,
@@ -812,6 +860,34 @@ RSX_API int rsx_bpr_grad(const float *P, const float *Q, float *GP, float *GQ, i
     RSX_CHECK_ARG(u_dev && i_dev && j_dev, "null index pointer");
     dispatch_step<2, kPassBoth>(d, wide_offsets(num_users, num_items, d), const_cast<float *>(P), Q, GQ, u_dev, i_dev, j_dev, batch, 0.0f, inv_batch,
                                 loss_acc, nullptr, GP, HotMap{nullptr, nullptr, 1}, (hipStream_t)stream);
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+}
+
+RSX_API int rsx_pointwise_grad(const float *P, const float *Q, float *GP, float *GQ, int64_t num_users, int64_t num_items,
+                               const int32_t *u_dev, const int32_t *i_dev, const float *y_dev, int64_t n, int d,
+                               float inv_n, int loss_kind, float *loss_acc, rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(P && Q && GP && GQ, "null table pointer");
+    RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64 or 128");
+    RSX_CHECK_ARG(n >= 0 && num_users > 0 && num_items > 0, "negative size");
+    RSX_CHECK_ARG(loss_kind == 0 || loss_kind == 1, "loss_kind: 0 = binary cross entropy with logits, 1 = mean squared error");
+    if (n == 0) return RSX_OK;
+    RSX_CHECK_ARG(u_dev && i_dev && y_dev, "null batch pointer");
+    const bool wide = wide_offsets(num_users, num_items, d);
+    const unsigned g = (unsigned)grid_1d(ceil_div64(n, TPW) * 64);
+    hipStream_t st = (hipStream_t)stream;
+#define RSX_PW(D_, K_) do { if (wide) hipLaunchKernelGGL((pointwise_grad_kernel<D_, K_, uint64_t>), dim3(g), dim3(kBlock), 0, st, P, Q, GP, GQ, u_dev, i_dev, y_dev, n, inv_n, loss_acc); \
+                            else hipLaunchKernelGGL((pointwise_grad_kernel<D_, K_, uint32_t>), dim3(g), dim3(kBlock), 0, st, P, Q, GP, GQ, u_dev, i_dev, y_dev, n, inv_n, loss_acc); } while (0)
+    switch (d * 2 + loss_kind) {
+    case 64: RSX_PW(32, 0); break;
+    case 65: RSX_PW(32, 1); break;
+    case 128: RSX_PW(64, 0); break;
+    case 129: RSX_PW(64, 1); break;
+    case 256: RSX_PW(128, 0); break;
+    default: RSX_PW(128, 1); break;
+    }
+#undef RSX_PW
     RSX_CHECK_LAUNCH();
     return RSX_OK;
 }

@@ -40,6 +40,7 @@ SIGNATURES = {
     "rsx_fold_hot_grad": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P]),
     "rsx_apply_item_grad": (C.c_int, [_P, _P, _I64, _I32, _F, _P, _P, _I32, _P]),
     "rsx_bpr_grad": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _I64, _I32, _F, _P, _P]),
+    "rsx_pointwise_grad": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _I64, _I32, _F, _I32, _P, _P]),
     "rsx_adam_apply": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I64, _P]),
     "rsx_spmm_plan": (_I64, [_P, _I64, _I32, _P, _P, _P]),
     "rsx_spmm_csr": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
@@ -195,6 +196,16 @@ def bpr_grad(P, Q, GP, GQ, u, i, j, inv_batch, loss_acc=None):
         _dev(GQ, torch.float32, "GQ"), P.shape[0], Q.shape[0], _dev(u, torch.int32, "u"),
         _dev(i, torch.int32, "i"), _dev(j, torch.int32, "j"), u.numel(), P.shape[1], float(inv_batch),
         _dev(loss_acc, torch.float32, "loss_acc") if loss_acc is not None else None, _stream()), "rsx_bpr_grad")
+
+
+def pointwise_grad(P, Q, GP, GQ, u, i, y, inv_n, loss_func="ce", loss_acc=None):
+    """dense gradients of one POINTWISE batch (models/MF.py:99-102, hparams['pointwise']); loss_func "ce"
+    (binary_cross_entropy_with_logits) or "mse"; tables untouched"""
+    _check(lib().rsx_pointwise_grad(
+        _dev(P, torch.float32, "P"), _dev(Q, torch.float32, "Q"), _dev(GP, torch.float32, "GP"),
+        _dev(GQ, torch.float32, "GQ"), P.shape[0], Q.shape[0], _dev(u, torch.int32, "u"), _dev(i, torch.int32, "i"),
+        _dev(y, torch.float32, "y"), u.numel(), P.shape[1], float(inv_n), int(loss_func == "mse"),
+        _dev(loss_acc, torch.float32, "loss_acc") if loss_acc is not None else None, _stream()), "rsx_pointwise_grad")
 
 
 def adam_apply(W, M, V, G, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):

@@ -53,6 +53,18 @@ G1_SGD = ["g1_sgd_200x100_d32_b64", "g1_sgd_ml100k_d32_b256",
           "g1_sgd_500x300_d64_b257", "g1_sgd_400x250_d128_b512"]
 G1_ADAM = ["g1b_adam_200x100_d32_b64", "g1b_adam_ml100k_d32_b256"]
 G23 = [n.replace("g1_sgd", "g23") for n in G1_SGD]
+# G8: the pointwise branch (models/MF.py:99-102), oracle/gen_golden_pointwise.py
+G8_POINTWISE = ["g8_pointwise_ce_sgd_300x200_d32", "g8_pointwise_mse_sgd_200x150_d64", "g8_pointwise_ce_adam_250x120_d128",
+                "g8_pointwise_ce_adam_generator_120x90_d32"]
+
+
+def split_pointwise(g):
+    """yield (u, i, y) batches from a g8* fixture."""
+    off = 0
+    for n in g["batch_len"]:
+        n = int(n)
+        yield g["u"][off:off + n].astype(np.int64), g["i"][off:off + n].astype(np.int64), g["y"][off:off + n].astype(np.float32)
+        off += n
 
 
 @pytest.fixture(scope="session")

@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import DELTA_TOL_SMALL_LR, G1_ADAM, G1_SGD, G1_SGD_BIGLR, G23, delta_err, golden, rel_err, split_batches
+from conftest import (DELTA_TOL_SMALL_LR, G1_ADAM, G1_SGD, G1_SGD_BIGLR, G23, G8_POINTWISE, delta_err, golden, rel_err,
+                      split_batches, split_pointwise)
 
 pytestmark = pytest.mark.gpu
 REL_TOL = 1e-5
@@ -86,6 +87,33 @@ def test_adam_as_shipped_matches_reference_golden(rsx, name):
     assert rel_err(P.cpu().numpy(), g["PT"]) < REL_TOL
     assert rel_err(Q.cpu().numpy(), g["QT"]) < REL_TOL
     # Adam's update is 1.5-4 % of the table: asserted directly, to 1e-4 of the update
+    assert delta_err(P.cpu().numpy(), g["P0"], g["PT"]) < 1e-4 and delta_err(Q.cpu().numpy(), g["Q0"], g["QT"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", G8_POINTWISE)
+def test_pointwise_branch_matches_reference_golden(rsx, name):
+    """models/MF.py:99-102 with hparams['pointwise'] = True: rsx_pointwise_grad (ce / mse) + the as-shipped Adam or the
+    SGD sweep, against the reference's own steps (random batches with repeated users and items; the batches of the
+    reference's PointwiseGenerator)"""
+    g = golden(name)
+    opt, lf, lr = str(g["optimizer"]), str(g["loss_func"]), float(g["lr"])
+    P, Q = dev(g["P0"]), dev(g["Q0"])
+    GP, GQ = torch.zeros_like(P), torch.zeros_like(Q)
+    mP, vP, mQ, vQ = (torch.zeros_like(t) for t in (P, P, Q, Q))
+    for t, (u, i, y) in enumerate(split_pointwise(g)):
+        acc = torch.zeros(rsx.RSX_LOSS_SLOTS, dtype=torch.float32, device="cuda")
+        rsx.pointwise_grad(P, Q, GP, GQ, dev(u, torch.int32), dev(i, torch.int32), dev(y, torch.float32), 1.0 / len(u),
+                           loss_func=lf, loss_acc=acc)
+        if t == 0:
+            assert rel_err(GP.cpu().numpy(), g["gP1"]) < REL_TOL and rel_err(GQ.cpu().numpy(), g["gQ1"]) < REL_TOL
+        if opt == "adam":
+            rsx.adam_apply(Q, mQ, vQ, GQ, lr, t + 1)
+            rsx.adam_apply(P, mP, vP, GP, lr, t + 1)
+        else:
+            rsx.apply_item_grad(Q, GQ, lr)          # the sweep is table-agnostic: theta -= lr * grad; grad = 0
+            rsx.apply_item_grad(P, GP, lr)
+        assert abs(float(acc.sum()) / len(u) - g["loss"][t]) < 1e-5 * max(1.0, abs(g["loss"][t]))
+    assert float(GP.abs().max()) == 0.0 and float(GQ.abs().max()) == 0.0
     assert delta_err(P.cpu().numpy(), g["P0"], g["PT"]) < 1e-4 and delta_err(Q.cpu().numpy(), g["Q0"], g["QT"]) < 1e-4
 
 

@@ -3,7 +3,8 @@ vectors captured from the imported reference (oracle/gen_golden.py).  CPU only."
 import numpy as np
 import pytest
 
-from conftest import DELTA_TOL_SMALL_LR, G1_ADAM, G1_SGD, G1_SGD_BIGLR, G23, delta_err, golden, rel_err, split_batches
+from conftest import (DELTA_TOL_SMALL_LR, G1_ADAM, G1_SGD, G1_SGD_BIGLR, G23, G8_POINTWISE, delta_err, golden, rel_err,
+                      split_batches, split_pointwise)
 
 
 @pytest.mark.parametrize("name", G1_SGD + G1_SGD_BIGLR + G1_ADAM)
@@ -85,6 +86,22 @@ def test_c_oracle_holdout_metrics(oracle_mod):
     mean = res.mean(0, dtype=np.float32)
     assert np.allclose(mean, g["scores_py"], atol=1e-6)  # Evaluator.evaluate dict (python backend)
     assert np.allclose(mean, g["scores_cy"], atol=1e-6)
+
+
+@pytest.mark.parametrize("name", G8_POINTWISE)
+def test_c_oracle_pointwise_branch_matches_reference(oracle_mod, name):
+    """models/MF.py:99-102 with hparams['pointwise'] = True (ce / mse, SGD-swapped and as-shipped Adam, random batches and
+    the reference PointwiseGenerator's own): first-step dense gradients, every loss, final tables"""
+    g = golden(name)
+    opt, lf = str(g["optimizer"]), str(g["loss_func"])
+    orc = oracle_mod.MFOracle(g["P0"], g["Q0"], optimizer=opt, lr=float(g["lr"]))
+    for t, (u, i, y) in enumerate(split_pointwise(g)):
+        if t == 0:
+            gP, gQ, _ = orc.pointwise_grad(u, i, y, lf)
+            assert rel_err(gP, g["gP1"]) < 2e-6 and rel_err(gQ, g["gQ1"]) < 2e-6
+        loss = orc.pointwise_step(u, i, y, lf)
+        assert abs(loss - g["loss"][t]) < 1e-5 * max(1.0, abs(g["loss"][t]))
+    assert delta_err(orc.P, g["P0"], g["PT"]) < 1e-4 and delta_err(orc.Q, g["Q0"], g["QT"]) < 1e-4
 
 
 def test_g5_reference_sampler_quirks():
