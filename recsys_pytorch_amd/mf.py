@@ -19,7 +19,11 @@ Divergences from the reference, all documented in DESIGN.md:
   * hparams['neg_block'] (default 8; 0 = off): when a batch holds >= 2 triplets per item the sampler
     orders it by positive item and stratifies the negatives by item block so that the step kernel can
     sum item gradients on chip; tests/test_gpu_model.py checks it trains as well.
-  * pointwise branch (MF.py:48-51,101-102) is outside the hot path: NotImplementedError.
+  * hparams['pointwise'] = True (MF.py:48-51,101-102): the pointwise branch, hparams['loss_func'] 'mse' or anything
+    else = binary cross entropy with logits (MF.py:21).  Batches are the reference generator's (data/generators.py:
+    105-130: batch_size interactions of a per-epoch permutation PLUS one uniformly drawn negative, rating 0, for EVERY
+    user of the matrix -- its sample_negatives ignores the batch it is handed), assembled on the device; the gradient
+    of a batch is rsx_pointwise_grad, the update the as-shipped Adam or the SGD sweep.
   * hidden_dim is padded to 32/64/128 columns of zeros internally (they stay zero).
 """
 import numpy as np
@@ -82,8 +86,7 @@ class MF(BaseModel):
         self.num_items = dataset.num_items
         self.hidden_dim = int(hparams["hidden_dim"])
         self.pointwise = bool(hparams["pointwise"])
-        if self.pointwise:
-            raise NotImplementedError("pointwise MF (models/MF.py:48-51) is outside the BPR hot path")
+        self.loss_func = "mse" if _get(hparams, "loss_func", "ce") == "mse" else "ce"          # models/MF.py:21
         opt = _get(hparams, "optimizer", "sgd")
         if opt not in ("sgd", "adam"):
             raise ValueError("optimizer must be 'sgd' (north star) or 'adam' (as shipped, models/MF.py:30)")
@@ -130,6 +133,12 @@ class MF(BaseModel):
 
     # -- models/MF.py:99-107: the loss of one batch (no update) ---------------------------
     def process_one_batch(self, users, items, ratings):
+        if self.pointwise:                       # MF.py:101-102: loss_func(forward(users, items), ratings)
+            x = self.forward(users, items)
+            y = torch.as_tensor(ratings).to(device=self.device, dtype=torch.float32)
+            if self.loss_func == "mse":
+                return ((x - y) ** 2).mean()
+            return (x.clamp_min(0) - x * y + torch.log1p(torch.exp(-x.abs()))).mean()
         u, i, j = self._idx(users), self._idx(items), self._idx(ratings)
         acc = torch.zeros(self._k.RSX_LOSS_SLOTS, dtype=torch.float32, device=self.device)
         self._k.bpr_step(self._P, self._Q, None, u, i, j, 0.0, 1.0, loss_acc=acc, no_update=True)
@@ -137,6 +146,11 @@ class MF(BaseModel):
 
     # -- models/MF.py:64-68: zero_grad + loss + backward + optimizer.step, fused ------------
     def train_step(self, users, pos, neg, users_unique=False):
+        if self.pointwise:                       # (users, items, ratings): users and items may repeat
+            u, i = self._idx(users), self._idx(pos)
+            y = torch.as_tensor(neg).to(device=self.device, dtype=torch.float32).contiguous()
+            acc = self._engine.pointwise_step(u, i, y, self.loss_func)
+            return acc.sum() / max(1, u.numel())
         u, i, j = self._idx(users), self._idx(pos), self._idx(neg)
         acc = self._engine.step(u, i, j, users_unique=users_unique)
         return acc.sum() / max(1, u.numel())
@@ -150,6 +164,9 @@ class MF(BaseModel):
         verbose = _get(exp_config, "verbose", 0)
         test_from = int(_get(exp_config, "test_from", 1))
         test_step = int(_get(exp_config, "test_step", 1))
+        if self.pointwise:
+            return self._fit_pointwise(train_matrix, indptr, indices, batch_size, num_epochs, verbose, test_from, test_step,
+                                       evaluator, early_stop, loggers)
         # one triplet per user per epoch, like PairwiseGenerator(num_positives_per_user=1)
         # (data/generators.py:182-195); the last batch of an epoch is short, not dropped (:213)
         n_data = self.num_users
@@ -185,6 +202,50 @@ class MF(BaseModel):
                 bsz = min(batch_size, n_data - b * batch_size)
                 step_acc = self._engine.sampled_step(indptr, indices, bsz)
                 batch_loss = step_acc.sum() / bsz
+                epoch_loss += batch_loss
+                if verbose and b % 50 == 0:
+                    print('(%3d / %3d) loss = %.4f' % (b, num_batches, float(batch_loss)))
+            scores, stop = end_of_epoch(self, epoch, {'loss': float(epoch_loss)}, scores, evaluator, early_stop,
+                                        loggers, test_from, test_step)
+            if stop:
+                break
+        return {'scores': early_stop.best_score if early_stop is not None else scores}
+
+    def _fit_pointwise(self, train_matrix, indptr, indices, batch_size, num_epochs, verbose, test_from, test_step,
+                       evaluator, early_stop, loggers):
+        """models/MF.py:48-51 + the batches of data/generators.py:58-130 (PointwiseGenerator(return_rating=True,
+        num_negatives=1, shuffle=True)): all interactions once per epoch in a fresh permutation, batch_size at a time, and
+        EVERY batch extended by one uniformly drawn negative (rating 0) per user of the matrix."""
+        dev = self.device
+        counts = (indptr[1:] - indptr[:-1])
+        users_all = torch.repeat_interleave(torch.arange(self.num_users, device=dev, dtype=torch.int32), counts)
+        items_all = indices.to(torch.int32)
+        csr = train_matrix.tocsr()
+        csr.sort_indices()                       # the order csr_to_device stores the row in
+        ratings_all = torch.as_tensor(np.asarray(csr.data, dtype=np.float32)).to(dev)
+        n_data = int(items_all.numel())
+        num_batches = int(np.ceil(n_data / batch_size))
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(self.seed)
+        eng = self._engine
+        zeros = torch.zeros(self.num_users, dtype=torch.float32, device=dev)
+        scores = None
+        for epoch in range(1, num_epochs + 1):
+            self.train()
+            epoch_loss = torch.zeros((), dtype=torch.float32, device=dev)
+            perm = torch.randperm(n_data, device=dev, generator=gen)                  # generators.py:107
+            for b in range(num_batches):
+                idx = perm[b * batch_size:(b + 1) * batch_size]
+                # one negative for every user: the pairwise sampler over a batch of ALL users draws, per user, a negative
+                # uniform over the items outside the user's row -- the distribution of generators.py:87-91
+                eng.epoch_pos = 0
+                nu, _, nj = eng.sample(indptr, indices, self.num_users)
+                eng.step_count += 1              # a fresh draw next batch
+                u = torch.cat([users_all[idx], nu])
+                i = torch.cat([items_all[idx], nj])
+                y = torch.cat([ratings_all[idx], zeros])
+                acc = eng.pointwise_step(u, i, y, self.loss_func, count_step=False)
+                batch_loss = acc.sum() / u.numel()
                 epoch_loss += batch_loss
                 if verbose and b % 50 == 0:
                     print('(%3d / %3d) loss = %.4f' % (b, num_batches, float(batch_loss)))

@@ -307,6 +307,30 @@ class BPREngine:
         self.step_count += 1
         return loss
 
+    # -- one step of the POINTWISE branch (models/MF.py:99-102, hparams['pointwise']) -----------
+    def pointwise_step(self, u, i, y, loss_func="ce", count_step=True):
+        """(user, item, rating) batch, users and items may repeat: dense gradients (rsx_pointwise_grad) + the as-shipped
+        Adam or the SGD sweep over both tables.  One GPU (the pointwise branch is not user-sharded)."""
+        if self.sharded:
+            raise ValueError("the pointwise branch runs on one GPU")
+        if getattr(self, "GP", None) is None:
+            self.GP = torch.zeros_like(self.P)
+        loss = self._loss
+        loss.zero_()
+        n = int(u.numel())
+        if n > 0:
+            self.k.pointwise_grad(self.P, self.Q, self.GP, self.G, u, i, y, 1.0 / n, loss_func=loss_func, loss_acc=loss)
+        if count_step:
+            self.step_count += 1
+        self._pw_t = getattr(self, "_pw_t", 0) + 1
+        if self.optimizer == "adam":
+            self.k.adam_apply(self.Q, self.mQ, self.vQ, self.G, self.lr, self._pw_t)
+            self.k.adam_apply(self.P, self.mP, self.vP, self.GP, self.lr, self._pw_t)
+        else:
+            self.k.apply_item_grad(self.Q, self.G, self.lr)      # table-agnostic sweep: theta -= lr * grad; grad = 0
+            self.k.apply_item_grad(self.P, self.GP, self.lr)
+        return loss
+
     # -- one step on triplets sampled on the device from this rank's CSR rows -----------
     def _launch_sample(self, indptr, indices, batch, out, step, role="main"):
         """device sampler (include/rsx.h:rsx_bpr_sample) on the CURRENT stream; users unique

@@ -133,6 +133,45 @@ def test_fit_with_evaluator_end_to_end(ml100k):
     assert after["NDCG@10"] > before["NDCG@10"] + 0.05           # and ranking quality goes up (CPU oracle run: 0.013 -> 0.19)
 
 
+@pytest.mark.parametrize("name", ["g8_pointwise_ce_adam_generator_120x90_d32", "g8_pointwise_mse_sgd_200x150_d64"])
+def test_pointwise_model_replays_the_reference_batches(name):
+    """MF(hparams['pointwise'] = True).train_step on the reference's own (user, item, rating) batches -- those of its
+    PointwiseGenerator included -- ends at the reference's tables (models/MF.py:64-68,99-102)"""
+    import recsys_pytorch_amd as pkg
+    from conftest import delta_err, golden, split_pointwise
+    g = golden(name)
+    U, d = g["P0"].shape
+    ds = types.SimpleNamespace(num_users=U, num_items=g["Q0"].shape[0])
+    m = pkg.MF(ds, {"hidden_dim": d, "pointwise": True, "loss_func": str(g["loss_func"]), "optimizer": str(g["optimizer"]),
+                    "lr": float(g["lr"])}, "cuda")
+    m.load_tables(g["P0"], g["Q0"])
+    for t, (u, i, y) in enumerate(split_pointwise(g)):
+        want = float(m.process_one_batch(u, i, y))                   # the loss alone (no update) ...
+        loss = float(m.train_step(u, i, y))                          # ... equals the loss of the step
+        assert abs(loss - g["loss"][t]) < 1e-5 * max(1.0, abs(g["loss"][t])) and abs(want - loss) < 1e-5 * max(1.0, abs(loss))
+    P, Q = m.user_embedding.weight.cpu().numpy(), m.item_embedding.weight.cpu().numpy()
+    assert delta_err(P, g["P0"], g["PT"]) < 1e-4 and delta_err(Q, g["Q0"], g["QT"]) < 1e-4
+
+
+def test_pointwise_fit_end_to_end(ml100k):
+    """hparams['pointwise'] = True through MF.fit: the reference generator's batches (batch_size interactions + one
+    negative per user, data/generators.py:105-130) assembled on the device; cross entropy goes down, ranking goes up"""
+    import recsys_pytorch_amd as pkg
+    torch.manual_seed(2020)
+    ev = pkg.Evaluator(ml100k.valid_input, ml100k.valid_target, "holdout", [10])
+    m = pkg.MF(ml100k, {"hidden_dim": 32, "pointwise": True, "loss_func": "ce", "optimizer": "adam", "lr": 5e-3}, "cuda")
+    with torch.no_grad():
+        m._P.mul_(0.1); m._Q.mul_(0.1)
+    logged = []
+    logger = types.SimpleNamespace(log_metrics=lambda d, epoch: logged.append((epoch, dict(d))))
+    cfg = types.SimpleNamespace(batch_size=2048, num_epochs=6, verbose=0, test_from=6, test_step=1)
+    before = ev.evaluate(m)
+    after = m.fit(ml100k, cfg, evaluator=ev, loggers=[logger])["scores"]
+    assert [e for e, _ in logged] == list(range(1, 7))
+    assert logged[-1][1]["loss"] < logged[0][1]["loss"]
+    assert after["NDCG@10"] > before["NDCG@10"] + 0.03
+
+
 def test_device_sampler_properties(ml100k):
     from recsys_pytorch_amd import rsx
     from recsys_pytorch_amd.data import csr_to_device

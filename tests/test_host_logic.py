@@ -94,5 +94,8 @@ def test_registry_and_interface_names():
     for name in ("forward", "fit", "predict", "embeddings", "process_one_batch", "predict_batch_users"):
         assert callable(getattr(cls, name))
     assert issubclass(cls, pkg.BaseModel) and issubclass(pkg.BaseModel, torch.nn.Module)
-    with pytest.raises(NotImplementedError):
-        cls(type("D", (), {"num_users": 4, "num_items": 4})(), {"hidden_dim": 8, "pointwise": True, "loss_func": "ce"}, "cpu")
+    # the constructor reads the reference's three hparams (models/MF.py:19-21); pointwise / loss_func select the branch
+    import cpu_kernels
+    m = cls(type("D", (), {"num_users": 4, "num_items": 4})(), {"hidden_dim": 8, "pointwise": True, "loss_func": "mse"}, "cpu",
+            kernels=cpu_kernels)
+    assert m.pointwise and m.loss_func == "mse"
