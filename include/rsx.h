@@ -434,6 +434,15 @@ int rsx_eval_holdout(int64_t users_num, const int32_t *rankings, int max_k, cons
                      int K_len, const int64_t *truth_indptr, const int32_t *truth_indices,
                      float *results);
 
+/* ---- leave-one-out metrics (HOST function, host pointers; widening row f6) -----------------
+ * Replaces evaluation/backend/cython/include/loo.h:19-85 (evaluate_loo) and its python twin
+ * evaluation/backend/python/loo.py:11-32: ONE held-out item per user (the first target, loo.h:31);
+ * hit_at = its 1-based position in the user's ranking (max_k + 1 when absent);
+ * HR@K = [K >= hit_at], NDCG@K = 1 / log2(hit_at + 1) if K >= hit_at else 0.
+ * truth: int32 [users_num]; results: float [users_num x 2*K_len], layout [user][metric*K_len + k], metrics HR, NDCG. */
+int rsx_eval_loo(int64_t users_num, const int32_t *rankings, int max_k, const int32_t *Ks, int K_len,
+                 const int32_t *truth, float *results);
+
 #ifdef __cplusplus
 }
 #endif

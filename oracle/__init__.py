@@ -61,6 +61,8 @@ def lib():
         L.orc_topk.argtypes = [_f32p, C.c_int64, C.c_int64, C.c_int, _i32p]
         L.orc_holdout.restype = None
         L.orc_holdout.argtypes = [C.c_int64, _i32p, C.c_int, _i32p, C.c_int, _i64p, _i32p, _f32p]
+        L.orc_loo.restype = None
+        L.orc_loo.argtypes = [C.c_int64, _i32p, C.c_int, _i32p, C.c_int, _i32p, _f32p]
         L.orc_spmm_csr.restype = None
         L.orc_spmm_csr.argtypes = [_i64p, _i32p, _f32p, _f32p, _f32p, C.c_int64, C.c_int]
         L.orc_lightgcn_propagate.restype = None
@@ -97,6 +99,9 @@ def ref_lib():
         R.ref_top_k_array_index.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, _i32p]
         R.ref_evaluate_holdout.restype = None
         R.ref_evaluate_holdout.argtypes = [C.c_int, _i32p, C.c_int, _i32p, C.c_int, _i64p, _i32p, _f32p]
+        if hasattr(R, "ref_evaluate_loo"):
+            R.ref_evaluate_loo.restype = None
+            R.ref_evaluate_loo.argtypes = [C.c_int, _i32p, C.c_int, _i32p, C.c_int, _i32p, _f32p]
         _REF = R
     return _REF
 
@@ -209,6 +214,20 @@ def holdout(rankings, Ks, t_indptr, t_indices, use_ref=False):
         ref_lib().ref_evaluate_holdout(n, rankings, rankings.shape[1], Ks, len(Ks), tp, ti, res)
     else:
         lib().orc_holdout(n, rankings, rankings.shape[1], Ks, len(Ks), tp, ti, res)
+    return res
+
+
+def loo(rankings, Ks, truth, use_ref=False):
+    """HR / NDCG of the leave-one-out protocol, [users x 2*len(Ks)] (loo.h:19-85); truth: one item per user"""
+    rankings = np.ascontiguousarray(rankings, np.int32)
+    Ks = np.ascontiguousarray(Ks, np.int32)
+    truth = np.ascontiguousarray(truth, np.int32)
+    n = rankings.shape[0]
+    res = np.zeros((n, 2 * len(Ks)), dtype=np.float32)
+    if use_ref:
+        ref_lib().ref_evaluate_loo(n, rankings, rankings.shape[1], Ks, len(Ks), truth, res)
+    else:
+        lib().orc_loo(n, rankings, rankings.shape[1], Ks, len(Ks), truth, res)
     return res
 
 

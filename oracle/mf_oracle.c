@@ -308,6 +308,26 @@ ORC_EXPORT void orc_holdout(int64_t users_num, const int32_t *rankings, int max_
     }
 }
 
+/* ---- leave-one-out metrics: evaluation/backend/cython/include/loo.h:19-85 (python twin
+ * evaluation/backend/python/loo.py:11-32).  One held-out item per user (truth_len = 1: only the FIRST target counts,
+ * loo.h:31, loo.py:20): hit_at = 1-based position of that item in the user's ranking, max_k + 1 when absent;
+ * HR@K = [K >= hit_at], NDCG@K = 1 / log2(hit_at + 1) when K >= hit_at else 0.
+ * results layout [user][metric*K_len + k], metrics = HR, NDCG (loo.h:64-84).                                   */
+ORC_EXPORT void orc_loo(int64_t users_num, const int32_t *rankings, int max_k, const int32_t *Ks, int K_len,
+                        const int32_t *truth, float *results)
+{
+    for (int64_t uid = 0; uid < users_num; ++uid) {
+        const int32_t *rk = rankings + uid * max_k;
+        int hit_at = max_k + 1;
+        for (int p = 0; p < max_k; ++p) if (rk[p] == truth[uid]) { hit_at = p + 1; break; }
+        float *res = results + uid * 2 * K_len;
+        for (int q = 0; q < K_len; ++q) {
+            if (Ks[q] >= hit_at) { res[q] = 1.0f; res[K_len + q] = (float)(1 / log2(hit_at + 1)); }
+            else { res[q] = 0.0f; res[K_len + q] = 0.0f; }
+        }
+    }
+}
+
 /* ==== LightGCN (BASELINE config 5) ==================================
  * models/LightGCN.py:174-202 (_lightgcn_embedding): all_emb = cat(user_w, item_w);
  * L times all_emb = A_hat @ all_emb (torch.sparse.mm, :196); output = mean over the L+1 layers

@@ -5,12 +5,14 @@
 // copied into this repository):
 //   evaluation/backend/cython/include/func.h:22     c_top_k_array_index
 //   evaluation/backend/cython/include/holdout.h:20  evaluate_holdout
+//   evaluation/backend/cython/include/loo.h:19      evaluate_loo
 // Built only when /root/reference exists (oracle/Makefile target `ref`), output
 // oracle/_ref/libref_eval.so (git-ignored, travels to the GPU box prebuilt).
 // Used to pin oracle/mf_oracle.c (orc_topk / orc_holdout) and as the
 // "reference" CPU baseline for top-k.
 #include "func.h"
 #include "holdout.h"
+#include "loo.h"
 
 extern "C" {
 
@@ -33,6 +35,15 @@ void ref_evaluate_holdout(int users_num, int *rankings, int max_k, int *Ks, int 
         gt_num[u] = (int)(t_indptr[u + 1] - t_indptr[u]);
     }
     evaluate_holdout(users_num, rankings, max_k, Ks, K_len, gt.data(), gt_num.data(), results);
+}
+
+// one held-out item per user; the int** table as loo_func.pyx builds it
+__attribute__((visibility("default")))
+void ref_evaluate_loo(int users_num, int *rankings, int max_k, int *Ks, int K_len, int *truth, float *results)
+{
+    std::vector<int *> gt(users_num);
+    for (int u = 0; u < users_num; ++u) gt[u] = truth + u;
+    evaluate_loo(users_num, rankings, max_k, Ks, K_len, gt.data(), results);
 }
 
 }

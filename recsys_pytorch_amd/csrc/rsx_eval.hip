@@ -42,3 +42,25 @@ RSX_API int rsx_eval_holdout(int64_t users_num, const int32_t *rankings, int max
     }
     return RSX_OK;
 }
+
+RSX_API int rsx_eval_loo(int64_t users_num, const int32_t *rankings, int max_k, const int32_t *Ks, int K_len,
+                         const int32_t *truth, float *results)
+{
+    RSX_CHECK_ARG(rankings && Ks && truth && results, "null pointer");
+    RSX_CHECK_ARG(users_num >= 0 && max_k > 0 && K_len > 0, "bad shape");
+    for (int q = 0; q < K_len; ++q) RSX_CHECK_ARG(Ks[q] >= 1 && Ks[q] <= max_k, "K outside [1, max_k]");
+    for (int64_t uid = 0; uid < users_num; ++uid) {
+        const int32_t *rk = rankings + uid * max_k;
+        int hit_at = max_k + 1;                                   // 1-based position of the held-out item
+        for (int p = 0; p < max_k; ++p)
+            if (rk[p] == truth[uid]) { hit_at = p + 1; break; }
+        float *res = results + uid * 2 * K_len;
+        const float gain = (float)(1.0 / std::log2((double)hit_at + 1.0));
+        for (int q = 0; q < K_len; ++q) {
+            const bool hit = Ks[q] >= hit_at;
+            res[q] = hit ? 1.0f : 0.0f;
+            res[K_len + q] = hit ? gain : 0.0f;
+        }
+    }
+    return RSX_OK;
+}

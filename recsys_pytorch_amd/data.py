@@ -89,10 +89,14 @@ def synthetic_csr(num_users, num_items, degree, device, seed=2020, popularity="z
     return indptr.contiguous(), items.reshape(-1).to(torch.int32).contiguous()
 
 
-def _cache_subdir(valid_ratio, test_ratio, split_random, min_item_per_user, min_user_per_item, seed):
-    """data/dataset.py:193-207 (holdout / weak): the directory name keys every split parameter"""
-    return "holdout_%.2f_%.2f_weak_%s_minUI_%d_%d_seed%d" % (valid_ratio, test_ratio, "random" if split_random else "time",
-                                                             min_item_per_user, min_user_per_item, seed)
+def _cache_subdir(valid_ratio, test_ratio, split_random, min_item_per_user, min_user_per_item, seed,
+                  protocol="holdout", leave_k=1):
+    """data/dataset.py:210-220 (weak generalisation): the directory name keys every split parameter"""
+    how = "random" if split_random else "time"
+    if protocol == "leave_one_out":
+        return "loo_%d_weak_%s_minUI_%d_%d_seed%d" % (leave_k, how, min_item_per_user, min_user_per_item, seed)
+    return "holdout_%.2f_%.2f_weak_%s_minUI_%d_%d_seed%d" % (valid_ratio, test_ratio, how, min_item_per_user,
+                                                             min_user_per_item, seed)
 
 
 CACHE_FILES = ("train.csv", "valid.csv", "test.csv", "user_map", "item_map")
@@ -129,7 +133,8 @@ def _read_cache(cdir):
 
 
 def load_uirt(path, separator="\t", min_item_per_user=0, min_user_per_item=0, valid_ratio=0.1,
-              test_ratio=0.2, split_random=True, seed=None, cache_dir=None, cache_seed=1234):
+              test_ratio=0.2, split_random=True, seed=None, cache_dir=None, cache_seed=1234,
+              protocol="holdout", leave_k=1):
     """Read a `user item rating timestamp` text file and split it like the reference's
     UIRTDataset(protocol='holdout', generalization='weak') does:
 
@@ -148,6 +153,9 @@ def load_uirt(path, separator="\t", min_item_per_user=0, min_user_per_item=0, va
                                files the reference writes (tests/test_loader.py against digests
                                recorded from the reference's own cache).  `cache_seed` only names
                                the directory, as in the reference (its `seed` argument, default 1234).
+    protocol='leave_one_out' (data/dataset.py:170-179): the same two splits with COUNTS instead of ratios -- `leave_k`
+    interactions per user held out for "test", then `leave_k` of the rest for "valid" (preprocess.py:60-63); cache
+    directory `loo_<k>_weak_<random|time>_minUI_<a>_<b>_seed<cache_seed>` (dataset.py:214-215).
     Ratings are binarised to 1 (implicit=True, data/dataset.py:46-51).  With `seed` the numpy
     global RNG is seeded first (main.py:30).  On ml-100k with seed 2020 this reproduces the
     reference's train/valid/test matrices exactly.  Returns an InteractionData.
@@ -155,7 +163,8 @@ def load_uirt(path, separator="\t", min_item_per_user=0, min_user_per_item=0, va
     cdir = None
     if cache_dir is not None:
         cdir = os.path.join(os.path.dirname(os.path.abspath(path)), cache_dir,
-                            _cache_subdir(valid_ratio, test_ratio, split_random, min_item_per_user, min_user_per_item, cache_seed))
+                            _cache_subdir(valid_ratio, test_ratio, split_random, min_item_per_user, min_user_per_item, cache_seed,
+                                          protocol, leave_k))
         if all(os.path.exists(os.path.join(cdir, f)) for f in CACHE_FILES):     # dataset.py:183-191
             return _read_cache(cdir)
     raw = np.loadtxt(path, delimiter=separator, dtype=np.float64, ndmin=2)
@@ -194,8 +203,11 @@ def load_uirt(path, separator="\t", min_item_per_user=0, min_user_per_item=0, va
             keep_idx.append(grp[mask]); out_idx.append(grp[~mask])
         return np.concatenate(keep_idx), np.concatenate(out_idx)
 
-    k1, test = split(np.arange(len(users)), valid_ratio)            # sic (quirk Q8)
-    train, valid = split(k1, test_ratio)
+    if protocol not in ("holdout", "leave_one_out"):
+        raise ValueError(f"{protocol} is not a valid protocol.")                 # dataset.py:189-190
+    first, second = (int(leave_k), int(leave_k)) if protocol == "leave_one_out" else (float(valid_ratio), float(test_ratio))
+    k1, test = split(np.arange(len(users)), first)                  # sic (quirk Q8)
+    train, valid = split(k1, second)
 
     def csr(idx):
         m = sp.csr_matrix((np.ones(len(idx)), (users[idx], items[idx])), shape=(U, I))

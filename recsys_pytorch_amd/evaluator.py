@@ -1,4 +1,4 @@
-"""Host-side mirror of evaluation/evaluator.py:10-54 for the holdout protocol.
+"""Host-side mirror of evaluation/evaluator.py:10-54 (holdout and leave_one_out protocols).
 
     Evaluator(eval_input, eval_target, protocol, ks).evaluate(model) -> {'Prec@5': ...}
 
@@ -10,7 +10,10 @@ Here the [U x I] score matrix never leaves the device: `model.predict_topk`
 metric loop is the C++ host function rsx_eval_holdout behind the C ABI.
 Top-K runs over ALL U rows, including users without targets, as the reference
 does (evaluator.py:31-37); such users are skipped in the mean
-(the reference would divide by zero there).  leave_one_out is out of scope.
+(the reference would divide by zero there).
+protocol 'leave_one_out' (evaluation/backend/__init__.py:18-21 routes it to loo.h:19-85 / loo.py:11-32): HR@K and
+NDCG@K of ONE held-out item per user -- the FIRST target of the user's row (loo.py:20 `target[u][0]`); the metric
+loop is rsx_eval_loo.  A user without a target makes the reference raise IndexError there; such users are skipped.
 """
 from collections.abc import Iterable
 
@@ -18,6 +21,7 @@ import numpy as np
 import scipy.sparse as sp
 
 HOLDOUT_METRICS = ['Prec', 'Recall', 'NDCG']   # evaluation/backend/__init__.py:1
+LOO_METRICS = ['HR', 'NDCG']                   # evaluation/backend/__init__.py:2
 
 
 class Evaluator:
@@ -28,9 +32,8 @@ class Evaluator:
         self.eval_input = eval_input
         self.eval_target = sp.csr_matrix(eval_target)
         self.eval_target.sort_indices()
-        if protocol != 'holdout':
-            raise NotImplementedError("only the holdout protocol is on the accelerated path "
-                                      "(leave_one_out: SURVEY section 2 row 9, out of scope)")
+        if protocol not in ('holdout', 'leave_one_out'):          # evaluation/backend/__init__.py:18-21
+            raise KeyError(protocol)
         self.protocol = protocol
 
     def evaluate(self, model, mean=True):
@@ -44,10 +47,17 @@ class Evaluator:
             import torch
             output = model.predict(eval_users, self.eval_input, self.batch_size)
             pred = rsx.topk(torch.from_numpy(output.astype(np.float32)).cuda(), self.max_k).cpu().numpy()
-        res = rsx.eval_holdout(pred, self.top_k, self.eval_target.indptr, self.eval_target.indices)
         has_target = np.diff(self.eval_target.indptr) > 0
+        if self.protocol == 'leave_one_out':
+            first = np.minimum(self.eval_target.indptr[:-1], max(len(self.eval_target.indices) - 1, 0))
+            truth = np.where(has_target, self.eval_target.indices[first] if len(self.eval_target.indices) else -1, -1)
+            res = rsx.eval_loo(pred, self.top_k, truth)
+            metrics = LOO_METRICS
+        else:
+            res = rsx.eval_holdout(pred, self.top_k, self.eval_target.indptr, self.eval_target.indices)
+            metrics = HOLDOUT_METRICS
         scores = {}
-        for m, metric in enumerate(HOLDOUT_METRICS):
+        for m, metric in enumerate(metrics):
             for q, k in enumerate(self.top_k):
                 col = res[has_target, m * len(self.top_k) + q]
                 scores['%s@%d' % (metric, k)] = np.mean(col, dtype=np.float32) if mean else col.tolist()

@@ -47,6 +47,7 @@ SIGNATURES = {
     "rsx_scale": (C.c_int, [_P, _I64, _F, _P]),
     "rsx_pair_score": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P]),
     "rsx_eval_holdout": (C.c_int, [_I64, _P, _I32, _P, _I32, _P, _P, _P]),
+    "rsx_eval_loo": (C.c_int, [_I64, _P, _I32, _P, _I32, _P, _P]),
     "rsx_bpr_sample_workspace": (_I64, [_I64, _I64]),
     "rsx_bpr_sample": (C.c_int, [_P, _P, _I64, _I64, _I64, _U64, _U64, _I64, _I32, _U64, _U, _P, _I64,
                                  _P, _P, _P, _P, _P, _P]),
@@ -275,6 +276,21 @@ def eval_holdout(rankings, ks, truth_indptr, truth_indices):
     res = np.zeros((n, 3 * len(ks)), dtype=np.float32)
     _check(lib().rsx_eval_holdout(n, rankings.ctypes.data, max_k, ks.ctypes.data, len(ks),
                                   tp.ctypes.data, ti.ctypes.data, res.ctypes.data), "rsx_eval_holdout")
+    return res
+
+
+def eval_loo(rankings, ks, truth):
+    """HOST function: numpy in, numpy out (include/rsx.h:rsx_eval_loo); truth = one held-out item per ranked user"""
+    import numpy as np
+    rankings = np.ascontiguousarray(rankings, dtype=np.int32)
+    ks = np.ascontiguousarray(ks, dtype=np.int32)
+    truth = np.ascontiguousarray(truth, dtype=np.int32)
+    n, max_k = rankings.shape
+    if len(truth) != n:
+        raise RsxError("truth must hold one item per ranked user")
+    res = np.zeros((n, 2 * len(ks)), dtype=np.float32)
+    _check(lib().rsx_eval_loo(n, rankings.ctypes.data, max_k, ks.ctypes.data, len(ks), truth.ctypes.data,
+                              res.ctypes.data), "rsx_eval_loo")
     return res
 
 

@@ -172,6 +172,29 @@ def test_pointwise_fit_end_to_end(ml100k):
     assert after["NDCG@10"] > before["NDCG@10"] + 0.03
 
 
+def test_leave_one_out_evaluator_equals_the_reference():
+    """Evaluator(protocol='leave_one_out') on the reference's own leave-one-out split of ml-100k and a seeded model
+    (fixture G9): the HR / NDCG means the reference's Evaluator returned"""
+    import scipy.sparse as sp
+    import recsys_pytorch_amd as pkg
+    from conftest import golden
+    g = golden("g9_loo_eval_ml100k")
+    U, I = int(g["num_users"]), int(g["num_items"])
+    csr = lambda part: sp.csr_matrix((np.ones(len(g[part + "_indices"])), g[part + "_indices"].astype(np.int64),
+                                      g[part + "_indptr"]), shape=(U, I))
+    ds = pkg.InteractionData(csr("train"), csr("valid"), csr("test"))
+    m = pkg.MF(ds, {"hidden_dim": 32, "pointwise": False, "loss_func": "ce"}, "cuda")
+    m.load_tables(g["P0"], g["Q0"])
+    ev = pkg.Evaluator(ds.valid_input, ds.valid_target, "leave_one_out", [int(k) for k in g["ks"]])
+    got = ev.evaluate(m)
+    want = dict(zip([str(n) for n in g["score_names"]], g["score_values"]))
+    assert set(got) == set(want) == {"HR@1", "HR@5", "HR@10", "NDCG@1", "NDCG@5", "NDCG@10"}
+    for k in want:      # a near-tie at a cut-off can move one user's hit across it: 1 / 943 = 1.1e-3
+        assert abs(float(got[k]) - want[k]) < 1.5e-3, (k, got[k], want[k])
+    with pytest.raises(KeyError):
+        pkg.Evaluator(ds.valid_input, ds.valid_target, "hold_user_out", [5])
+
+
 def test_device_sampler_properties(ml100k):
     from recsys_pytorch_amd import rsx
     from recsys_pytorch_amd.data import csr_to_device

@@ -31,6 +31,29 @@ def test_eval_holdout_matches_reference_native(oracle_mod):
     assert np.allclose(a, b, atol=1e-6)
 
 
+def test_eval_loo_matches_reference_golden(oracle_mod):
+    """rsx_eval_loo against what the reference's Evaluator(protocol='leave_one_out') accumulated per user
+    (evaluation/backend/python/loo.py:11-32) on its own rankings, and against its loo.h compiled in oracle/_ref"""
+    from recsys_pytorch_amd import rsx
+    g = golden("g9_loo_eval_ml100k")
+    ks = [int(k) for k in g["ks"]]
+    truth = g["valid_indices"][g["valid_indptr"][:-1]].astype(np.int32)
+    res = rsx.eval_loo(g["topk10"], ks, truth)
+    assert np.allclose(res, g["per_user"], atol=1e-6)
+    assert np.allclose(res, oracle_mod.loo(g["topk10"], ks, truth), atol=1e-6)
+    means = dict(zip([str(n) for n in g["score_names"]], g["score_values"]))
+    for m, metric in enumerate(("HR", "NDCG")):
+        for q, k in enumerate(ks):
+            assert abs(float(np.mean(res[:, m * len(ks) + q], dtype=np.float32)) - means["%s@%d" % (metric, k)]) < 1e-6
+    if oracle_mod.ref_lib() is not None and hasattr(oracle_mod.ref_lib(), "ref_evaluate_loo"):
+        rng = np.random.default_rng(4)
+        rk = np.stack([rng.permutation(300)[:20] for _ in range(500)]).astype(np.int32)
+        t = rng.integers(0, 300, 500).astype(np.int32)
+        assert np.allclose(rsx.eval_loo(rk, [1, 7, 20], t), oracle_mod.loo(rk, [1, 7, 20], t, use_ref=True), atol=1e-6)
+    with pytest.raises(rsx.RsxError):
+        rsx.eval_loo(np.zeros((2, 5), np.int32), [6], np.zeros(2, np.int32))
+
+
 def test_eval_holdout_rejects_bad_k():
     from recsys_pytorch_amd import rsx
     with pytest.raises(rsx.RsxError):

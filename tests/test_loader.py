@@ -87,6 +87,36 @@ def test_ml100k_cache_is_byte_identical_to_the_reference_cache(tmp_path):
     assert (again.test_input != ds.train_data + ds.valid_target).nnz == 0      # dataset.py:236-241
 
 
+@pytest.mark.skipif(not os.path.exists(REF_DATA), reason="reference dataset not present (GPU box)")
+def test_ml100k_leave_one_out_split_and_cache_equal_the_reference(tmp_path):
+    """protocol='leave_one_out', leave_k=1 (data/dataset.py:170-179,214-215): the cache directory and the bytes of its
+    five files as the reference's UIRTDataset wrote them, and the same train / valid / test matrices
+    (oracle/gen_golden_loo.py)"""
+    import hashlib
+    import json
+    import shutil
+    import scipy.sparse as sp
+    from recsys_pytorch_amd.data import load_uirt
+    want = json.load(open(os.path.join(GOLDEN, "g9_ml100k_loo_cache.json")))
+    g = np.load(os.path.join(GOLDEN, "g9_loo_eval_ml100k.npz"))
+    work = tmp_path / "ml-100k"
+    work.mkdir()
+    shutil.copy(REF_DATA, work / "u.data")
+    ds = load_uirt(str(work / "u.data"), separator="\t", min_item_per_user=10, min_user_per_item=1, split_random=True,
+                   cache_dir="cache", seed=2020, protocol="leave_one_out", leave_k=1)
+    cdir = work / "cache" / want["cache_subdir"]
+    assert sorted(os.listdir(cdir)) == sorted(want["files"])
+    for name, meta in want["files"].items():
+        raw = open(cdir / name, "rb").read()
+        assert len(raw) == meta["bytes"] and hashlib.sha256(raw).hexdigest() == meta["sha256"], name
+    U, I = int(g["num_users"]), int(g["num_items"])
+    for part, m in (("train", ds.train_data), ("valid", ds.valid_target), ("test", ds.test_target)):
+        ip, ix = g[part + "_indptr"], g[part + "_indices"].astype(np.int64)
+        ref = sp.csr_matrix((np.ones(len(ix)), ix, ip), shape=(U, I))
+        assert (m != ref).nnz == 0, part
+    assert (np.diff(ds.valid_target.indptr) == 1).all() and (np.diff(ds.test_target.indptr) == 1).all()
+
+
 def test_cache_round_trip_on_a_toy_file(tmp_path):
     """runs everywhere (no reference data needed): write, read back, and the file grammar"""
     from recsys_pytorch_amd.data import load_uirt
