@@ -38,6 +38,16 @@ int main(void)
     float res[7 * 6];
     int64_t tp[8] = {0, 2, 4, 6, 8, 10, 12, 14};
     orc_holdout(7, top, K, Ks, 2, tp, indices, res);
+    int32_t held[7] = {0, 3, 22, 1, 9, 4, 4};
+    float res_loo[7 * 4];
+    orc_loo(7, top, K, Ks, 2, held, res_loo);
+    /* the pointwise branch: (user, item, rating) with repeats, both losses, both optimizers */
+    float *y = malloc(sizeof(float) * B);
+    for (int64_t b = 0; b < B; ++b) y[b] = (float)(rand() % 2);
+    orc_pointwise_step_sgd(P, Q, U, I, u, i, y, B, d, 0, 0.05f, gP, gQ, &loss);
+    orc_pointwise_step_sgd(P, Q, U, I, u, i, y, B, d, 1, 0.05f, gP, gQ, &loss);
+    orc_pointwise_step_adam(P, Q, U, I, u, i, y, B, d, 0, 1e-3f, 0.9f, 0.999f, 1e-8f, 2, mP, vP, mQ, vQ, gP, gQ, &loss);
+    free(y);
     /* LightGCN on a tiny symmetric graph: ring of N nodes */
     const int64_t N = U + I;
     int64_t *ap = malloc(sizeof(int64_t) * (N + 1));
