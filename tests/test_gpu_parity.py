@@ -243,7 +243,9 @@ def test_deterministic_step_is_bit_reproducible_and_matches_the_oracle(rsx, orac
     G = torch.zeros_like(Q)
     rsx.bpr_step(P, Q, G, ut, it, jt, 0.5, 1.0 / live.sum(), users_unique=True)
     assert rel_err(P.cpu().numpy(), runs[0][0].cpu().numpy()) < 1e-6    # (the two paths reduce the dot products in different orders)
-    assert rel_err(G.cpu().numpy(), runs[0][1].cpu().numpy()) < 1e-6
+    # (item rows here sum up to ~600 fp32 terms, and the atomic path adds them in whatever order they arrive:
+    #  sqrt(600) * 6e-8 = 1.5e-6 of the row is rounding, not error)
+    assert rel_err(G.cpu().numpy(), runs[0][1].cpu().numpy()) < 5e-6
     with pytest.raises(rsx.RsxError):                                   # needs unique users and its workspace
         rsx.bpr_step(P, Q, G, ut, it, jt, 0.5, 1.0, deterministic=True, ws=ws)
     with pytest.raises(rsx.RsxError):
