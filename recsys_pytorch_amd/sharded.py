@@ -73,6 +73,8 @@ class BPREngine:
         self._trip = None
         self._count = torch.zeros(1, dtype=torch.int64, device=Q.device) if self.sharded else None
         self.optimizer = optimizer
+        self.GP = None              # dense user-gradient buffer: Adam, and the pointwise branch (allocated on first use)
+        self._pw_t = 0              # Adam's step count on the pointwise branch
         if optimizer == "adam":      # the reference's shipped optimizer (models/MF.py:30): dense moments
             self.GP = torch.zeros_like(P_local)
             self.mP, self.vP = torch.zeros_like(P_local), torch.zeros_like(P_local)
@@ -313,7 +315,7 @@ class BPREngine:
         Adam or the SGD sweep over both tables.  One GPU (the pointwise branch is not user-sharded)."""
         if self.sharded:
             raise ValueError("the pointwise branch runs on one GPU")
-        if getattr(self, "GP", None) is None:
+        if self.GP is None:
             self.GP = torch.zeros_like(self.P)
         loss = self._loss
         loss.zero_()
@@ -322,7 +324,7 @@ class BPREngine:
             self.k.pointwise_grad(self.P, self.Q, self.GP, self.G, u, i, y, 1.0 / n, loss_func=loss_func, loss_acc=loss)
         if count_step:
             self.step_count += 1
-        self._pw_t = getattr(self, "_pw_t", 0) + 1
+        self._pw_t += 1
         if self.optimizer == "adam":
             self.k.adam_apply(self.Q, self.mQ, self.vQ, self.G, self.lr, self._pw_t)
             self.k.adam_apply(self.P, self.mP, self.vP, self.GP, self.lr, self._pw_t)
