@@ -6,6 +6,8 @@ from recsys_pytorch_amd import rsx
 from recsys_pytorch_amd.data import synthetic_csr
 U, I, d, K, tiles = 1_000_000, int(os.environ.get("ITEMS", 100_000)), int(os.environ.get("DIM", 128)), 50, 64
 dev = torch.device("cuda")
+if os.environ.get("RSX_SCORE_LANES"):
+    rsx.set_option("score_lanes", int(os.environ["RSX_SCORE_LANES"]))
 torch.manual_seed(0)
 P = torch.randn(U, d, device=dev) * 0.1
 Q = torch.randn(I, d, device=dev) * 0.1
