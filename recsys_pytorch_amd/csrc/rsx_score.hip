@@ -414,6 +414,92 @@ __global__ __launch_bounds__(256) void take_tau_kernel(const float *__restrict__
     if (r < num_rows) { tau[r] = topk_val[(size_t)r * K + K - 1]; cand_cnt[r] = 0; }
 }
 
+// tau of the fused path in ONE pass over the sample scores: the K-th largest value of a row of the [rows x kSampleCols]
+// sample product after the seen items are masked out.  Replaces mask_seen_strided_kernel + topk_rows_kernel (which read the
+// 268 MB of sample scores twice and sort candidates nobody needs in order) + take_tau_kernel: each of the 256 threads keeps
+// its 32 keys of the row in registers, the seen sample columns are a 1 KB bitmap in LDS, and three radix levels
+// (12 + 12 + 8 bits, LDS histogram) fix the K-th key exactly.  Same value as the K-th entry of the sorted top-K.
+constexpr int ST_COLS = 8192;
+constexpr int ST_NPT = ST_COLS / TK_THREADS;     // 32 keys per thread
+__global__ __launch_bounds__(TK_THREADS) void sample_tau_kernel(const float *__restrict__ sample,
+                                                                const int32_t *__restrict__ user_ids, int64_t num_rows,
+                                                                int64_t stride, const int64_t *__restrict__ indptr,
+                                                                const int32_t *__restrict__ indices, int K,
+                                                                float *__restrict__ tau, int32_t *__restrict__ cand_cnt)
+{
+    __shared__ uint32_t hist[TK_BINS];
+    __shared__ uint32_t seen[ST_COLS / 32];
+    __shared__ uint32_t s_wave[TK_THREADS / 64];
+    __shared__ uint32_t s_bin, s_need;
+    const int tid = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    const float *row = sample + (size_t)r * ST_COLS;
+    uint32_t key[ST_NPT];
+#pragma unroll
+    for (int e = 0; e < ST_NPT; ++e) key[e] = f2key(row[e * TK_THREADS + tid]);
+    if (indptr != nullptr) {
+        for (int q = tid; q < ST_COLS / 32; q += TK_THREADS) seen[q] = 0u;
+        __syncthreads();
+        const int32_t u = user_ids[r];
+        const int64_t lo = indptr[u], hi = indptr[u + 1];
+        for (int64_t p = lo + tid; p < hi; p += TK_THREADS) {
+            const int64_t it = indices[p];
+            if (it % stride == 0 && it / stride < ST_COLS) atomicOr(&seen[(it / stride) >> 5], 1u << ((it / stride) & 31));
+        }
+        __syncthreads();
+        const uint32_t kinf = f2key(-INFINITY);
+#pragma unroll
+        for (int e = 0; e < ST_NPT; ++e) {
+            const int col = e * TK_THREADS + tid;
+            if ((seen[col >> 5] >> (col & 31)) & 1u) key[e] = kinf;
+        }
+    }
+    uint32_t prefix = 0, need = (uint32_t)K;
+    int shift = 32;
+    const int level_bits[3] = {12, 12, 8};
+    for (int level = 0; level < 3; ++level) {
+        const int bits = level_bits[level];
+        const int nshift = shift - bits;
+        const uint32_t bmask = (1u << bits) - 1u;
+        for (int b = tid; b < TK_BINS; b += TK_THREADS) hist[b] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < ST_NPT; ++e)
+            if (shift == 32 || (key[e] >> shift) == (prefix >> shift)) atomicAdd(&hist[(key[e] >> nshift) & bmask], 1u);
+        __syncthreads();
+        const int per = TK_BINS / TK_THREADS;
+        uint32_t mine = 0;
+        for (int b = 0; b < per; ++b) mine += hist[tid * per + b];
+        uint32_t suf = mine;
+        {
+            const int lane = tid & 63;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_down(suf, o, 64);
+                if (lane + o < 64) suf += t;
+            }
+            if (lane == 0) s_wave[tid >> 6] = suf;
+            __syncthreads();
+            for (int w = (tid >> 6) + 1; w < TK_THREADS / 64; ++w) suf += s_wave[w];
+        }
+        const uint32_t above = suf - mine;
+        if (above < need && suf >= need) {
+            uint32_t run = above;
+            for (int b = per - 1; b >= 0; --b) {
+                const uint32_t h = hist[tid * per + b];
+                if (run + h >= need) { s_bin = (uint32_t)(tid * per + b); s_need = need - run; break; }
+                run += h;
+            }
+        }
+        __syncthreads();
+        need = s_need;
+        prefix |= s_bin << nshift;
+        shift = nshift;
+        __syncthreads();
+    }
+    if (tid == 0) { tau[r] = key2f(prefix); cand_cnt[r] = 0; }
+}
+
 constexpr int MG_THREADS = 256;
 constexpr int MG_CAP = 4096;    // candidate list capacity per row
 constexpr int MG_BIN_BITS = 10;
@@ -768,13 +854,9 @@ RSX_API int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t 
         hipStream_t ls = lane_st[ti % n_lanes];
         launch_score<false>(P, users, nr, Q, kSampleCols, stride, d, lw.sample, nullptr, nullptr, nullptr, nullptr, 0,
                             nullptr, ls);
-        if (mask_indptr_dev)
-            hipLaunchKernelGGL(mask_seen_strided_kernel, dim3((unsigned)nr), dim3(256), 0, ls, lw.sample, users, nr,
-                               kSampleCols, stride, mask_indptr_dev, mask_indices_dev);
-        hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)nr), dim3(TK_THREADS), 0, ls, lw.sample, kSampleCols, K,
-                           lw.topi, lw.topv);
-        hipLaunchKernelGGL(take_tau_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, ls, lw.topv, nr, K,
-                           lw.tau, lw.ccnt);
+        static_assert(kSampleCols == ST_COLS, "sample_tau_kernel is laid out for the sample size");
+        hipLaunchKernelGGL(sample_tau_kernel, dim3((unsigned)nr), dim3(TK_THREADS), 0, ls, lw.sample, users, nr, stride,
+                           mask_indptr_dev, mask_indices_dev, K, lw.tau, lw.ccnt);
         const int64_t n_it = 2 * ((num_items + BN - 1) / BN), rows_pad = (nr + BM - 1) / BM * BM;
         (void)hipMemsetAsync(lw.slots, 0xFF, (size_t)(n_it * rows_pad) * kSlots * 8, ls);
         launch_score<true>(P, users, nr, Q, num_items, 1, d, nullptr, lw.tau, lw.cval, lw.cidx, lw.ccnt, kSpillCap,
