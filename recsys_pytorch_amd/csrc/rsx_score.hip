@@ -419,7 +419,10 @@ __global__ __launch_bounds__(256) void take_tau_kernel(const float *__restrict__
 // 268 MB of sample scores twice and sort candidates nobody needs in order) + take_tau_kernel: each of the 256 threads keeps
 // its 32 keys of the row in registers, the seen sample columns are a 1 KB bitmap in LDS, and three radix levels
 // (12 + 12 + 8 bits, LDS histogram) fix the K-th key exactly.  Same value as the K-th entry of the sorted top-K.
-constexpr int ST_COLS = 8192;
+#ifndef RSX_SAMPLE_COLS
+#define RSX_SAMPLE_COLS 8192
+#endif
+constexpr int ST_COLS = RSX_SAMPLE_COLS;
 constexpr int ST_NPT = ST_COLS / TK_THREADS;     // 32 keys per thread
 __global__ __launch_bounds__(TK_THREADS) void sample_tau_kernel(const float *__restrict__ sample,
                                                                 const int32_t *__restrict__ user_ids, int64_t num_rows,
@@ -724,7 +727,7 @@ RSX_API int rsx_topk(const float *scores_dev, int64_t num_rows, int64_t num_item
 
 namespace {
 
-constexpr int64_t kSampleCols = 8192;      // sample size of the fused path
+constexpr int64_t kSampleCols = RSX_SAMPLE_COLS;      // sample size of the fused path
 constexpr int64_t kFusedRows = 8192;       // rows per pass of the fused path: one launch of ~50K workgroups
                                            // (a 1024-row pass is 8.15 rounds of 768 resident workgroups:
                                            //  11 % of the time is the ragged last round, plus 7 launches)
