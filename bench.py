@@ -90,7 +90,10 @@ def roofline(kernel, kern_ms, B, I, d, key, two_pass=False):
     return {"bound": "hbm", "kernel": kernel, "achieved": per_s(alg), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": per_s(alg) / HBM_PEAK_GBS, "traffic": hbm, "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms,
             "compulsory_bytes": compulsory, "frac_compulsory": per_s(compulsory) / HBM_PEAK_GBS,
-            "hbm_bytes": hbm, "frac_hbm": per_s(hbm) / HBM_PEAK_GBS if hbm else None, "traffic_key": key}
+            "hbm_bytes": hbm, "frac_hbm": per_s(hbm) / HBM_PEAK_GBS if hbm else None, "traffic_key": key,
+            "note": "achieved / frac are the contract's ALGORITHMIC figure (24 d bytes per triplet / kernel time): where item sums "
+                    "stay on chip it can exceed 1; the physical fractions are frac_hbm (PMC-measured traffic, profiles/traffic.json) "
+                    "and frac_compulsory (every byte the batch cannot avoid moving once)"}
 
 
 SHARDED = False     # a process group is up: N > 1, or RSX_FORCE_SHARDED=1 (the exchange path over a group of one rank)
@@ -391,7 +394,7 @@ def main():
                        "users_per_gpu": U, "items": I, "d": d, "batch_per_gpu": B, "global_batch": head["global_batch"],
                        "positives_per_user": args.degree, "item_popularity": args.popularity, "lr": args.lr,
                        "negatives": f"stratified by item block of {nb}, batch sorted by positive item" if nb else "independent uniform",
-                       "sampler": "on device, one step ahead on a side stream",
+                       "sampler": "on device, two steps ahead on a lowest-priority side stream",
                        "loop": "native (rsx_bpr_trainer_run): no interpreter between the kernels of the timed region",
                        "mean_bpr_loss": head["mean_bpr_loss"],
                        **({"item_replicas_identical": head["item_replicas_identical"]} if SHARDED else {}),
