@@ -380,10 +380,13 @@ int rsx_bpr_trainer_kernel_ms(const rsx_bpr_trainer *t, double *mean_ms, int64_t
  * rsx_topk   : per row of `scores` the K largest, descending; ties by lower index.
  *              topk_val_out nullable.  K <= 1024 and K <= num_items.
  * rsx_score_topk : both, tile by tile through `ws`, without exposing the scores.  For catalogs
- *              of >= 32768 items the dense [rows x items] matrix is never formed: a strided
- *              sample of the catalog gives each row a lower bound tau of its K-th score, the
- *              full product is then computed with an epilogue that keeps only scores >= tau,
- *              and the survivors are masked, sorted and cut to K.  Same result as
+ *              of >= 32768 items the dense [rows x items] matrix is never formed: the item table
+ *              is copied in the order p -> (a p) mod num_items (a coprime to num_items), the first
+ *              8192 rows of the copy -- an equidistributed sample of the catalog -- are scored
+ *              densely and give each row a lower bound tau of its K-th score plus their own K
+ *              candidates, the REST of the copy is scored with an epilogue that keeps only scores
+ *              >= tau, and the survivors are masked, sorted and cut to K (every item is scored
+ *              exactly once).  Same result as
  *              rsx_score + rsx_topk.  This entry point waits for the stream once before it
  *              returns (it reads a counter of rows that must be re-done densely: massive
  *              exact ties).

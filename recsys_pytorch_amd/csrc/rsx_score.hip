@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict
                                                          float *__restrict__ cand_val,
                                                          int32_t *__restrict__ cand_idx,
                                                          int32_t *__restrict__ cand_cnt, int cand_cap,
-                                                         uint2 *__restrict__ slots)
+                                                         uint2 *__restrict__ slots, int64_t item_base)
 {
     __shared__ float As[BK * LDT];
     __shared__ float Bs[BK * LDT];
@@ -162,13 +162,13 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict
                 uint2 *cellp = wbase + (size_t)(site * n_strips) * kSlots;
                 auto emit = [&](int rank, float v, int64_t col) {
                     if (rank < kSlots) {
-                        cellp[rank] = make_uint2(__float_as_uint(v), (unsigned)col);
+                        cellp[rank] = make_uint2(__float_as_uint(v), (unsigned)(col + item_base));
                     } else {                            // rare: more than kSlots survivors in one cell
                         const int64_t row = wave_row + site;
                         const int slot = atomicAdd(cand_cnt + row, 1);
                         if (slot < cand_cap) {
                             cand_val[(size_t)row * cand_cap + slot] = v;
-                            cand_idx[(size_t)row * cand_cap + slot] = (int32_t)col;
+                            cand_idx[(size_t)row * cand_cap + slot] = (int32_t)(col + item_base);
                         }
                     }
                 };
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void take_tau_kernel(const float *__restrict__
 }
 
 // tau of the fused path in ONE pass over the sample scores: the K-th largest value of a row of the [rows x kSampleCols]
-// sample product after the seen items are masked out.  Replaces mask_seen_strided_kernel + topk_rows_kernel (which read the
+// sample product (the first kSampleCols rows of the PERMUTED item table) after the seen items are masked out.  Replaces mask_seen_strided_kernel + topk_rows_kernel (which read the
 // 268 MB of sample scores twice and sort candidates nobody needs in order) + take_tau_kernel: each of the 256 threads keeps
 // its 32 keys of the row in registers, the seen sample columns are a 1 KB bitmap in LDS, and three radix levels
 // (12 + 12 + 8 bits, LDS histogram) fix the K-th key exactly.  Same value as the K-th entry of the sorted top-K.
@@ -426,11 +426,15 @@ constexpr int ST_COLS = RSX_SAMPLE_COLS;
 constexpr int ST_NPT = ST_COLS / TK_THREADS;     // 32 keys per thread
 __global__ __launch_bounds__(TK_THREADS) void sample_tau_kernel(const float *__restrict__ sample,
                                                                 const int32_t *__restrict__ user_ids, int64_t num_rows,
-                                                                int64_t stride, const int64_t *__restrict__ indptr,
+                                                                int64_t perm_inv, int64_t perm_n,
+                                                                const int64_t *__restrict__ indptr,
                                                                 const int32_t *__restrict__ indices, int K,
-                                                                float *__restrict__ tau, int32_t *__restrict__ cand_cnt)
+                                                                float *__restrict__ tau, int32_t *__restrict__ cand_cnt,
+                                                                float *__restrict__ cand_val, int32_t *__restrict__ cand_idx,
+                                                                int cand_cap)
 {
     __shared__ uint32_t hist[TK_BINS];
+    __shared__ uint32_t s_emit;
     __shared__ uint32_t seen[ST_COLS / 32];
     __shared__ uint32_t s_wave[TK_THREADS / 64];
     __shared__ uint32_t s_bin, s_need;
@@ -446,8 +450,8 @@ __global__ __launch_bounds__(TK_THREADS) void sample_tau_kernel(const float *__r
         const int32_t u = user_ids[r];
         const int64_t lo = indptr[u], hi = indptr[u + 1];
         for (int64_t p = lo + tid; p < hi; p += TK_THREADS) {
-            const int64_t it = indices[p];
-            if (it % stride == 0 && it / stride < ST_COLS) atomicOr(&seen[(it / stride) >> 5], 1u << ((it / stride) & 31));
+            const int64_t col = ((int64_t)indices[p] * perm_inv) % perm_n;      // where the permuted table holds this item
+            if (col < ST_COLS) atomicOr(&seen[col >> 5], 1u << (col & 31));
         }
         __syncthreads();
         const uint32_t kinf = f2key(-INFINITY);
@@ -500,7 +504,39 @@ __global__ __launch_bounds__(TK_THREADS) void sample_tau_kernel(const float *__r
         shift = nshift;
         __syncthreads();
     }
-    if (tid == 0) { tau[r] = key2f(prefix); cand_cnt[r] = 0; }
+    // The sample IS part of the catalog (its first ST_COLS items when stride == 1): its own candidates -- every
+    // unseen sample item at or above the K-th key -- go to the row's spill list, and the filtered product then covers
+    // only the REST of the catalog.  More than the list holds (massive exact ties): the count says so and the merge
+    // sends the row to the dense re-do.
+    if (tid == 0) s_emit = 0u;
+    __syncthreads();
+    if (cand_val != nullptr) {
+#pragma unroll
+        for (int e = 0; e < ST_NPT; ++e) {
+            if (key[e] >= prefix) {
+                const uint32_t at = atomicAdd(&s_emit, 1u);
+                if (at < (uint32_t)cand_cap) {
+                    cand_val[(size_t)r * cand_cap + at] = key2f(key[e]);
+                    cand_idx[(size_t)r * cand_cap + at] = (int32_t)(e * TK_THREADS + tid);      // permuted id
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { tau[r] = key2f(prefix); cand_cnt[r] = (int32_t)s_emit; }
+}
+
+// Qp[p] = Q[(a p) mod I]: the item table in the order p -> a p mod I (a coprime to I, a ~ I / kSampleCols), so that the
+// FIRST kSampleCols rows of Qp are an equidistributed sample of the catalog whatever the item ids mean (a contiguous
+// prefix of Q itself would be a biased sample wherever ids correlate with popularity: a loose tau, a flood of survivors)
+__global__ __launch_bounds__(256) void permute_items_kernel(const float4 *__restrict__ Q, float4 *__restrict__ Qp,
+                                                            int64_t num_items, int d4, int64_t perm_a)
+{
+    const int64_t n = num_items * d4;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+        const int64_t p = t / d4, c = t - p * d4;
+        Qp[t] = Q[((p * perm_a) % num_items) * d4 + c];
+    }
 }
 
 constexpr int MG_THREADS = 256;
@@ -514,7 +550,7 @@ __global__ __launch_bounds__(MG_THREADS) void merge_candidates_kernel(
     const int32_t *__restrict__ cand_cnt, int cand_cap, const int32_t *__restrict__ user_ids,
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices, int K,
     int32_t *__restrict__ out_idx, float *__restrict__ out_val, int64_t row_base,
-    int32_t *__restrict__ overflow_rows, int32_t *__restrict__ overflow_count)
+    int32_t *__restrict__ overflow_rows, int32_t *__restrict__ overflow_count, int64_t perm_a, int64_t perm_n)
 {
     __shared__ unsigned long long cand[MG_CAP];
     __shared__ uint32_t s_n, s_total;
@@ -536,7 +572,8 @@ __global__ __launch_bounds__(MG_THREADS) void merge_candidates_kernel(
     }
     int64_t lo = 0, hi = 0;
     if (indptr != nullptr) { const int32_t u = user_ids[row]; lo = indptr[u]; hi = indptr[u + 1]; }
-    auto push = [&](float v, int32_t it) {
+    auto push = [&](float v, int32_t pit) {
+        const int32_t it = (int32_t)(((int64_t)pit * perm_a) % perm_n);      // permuted id -> item id (ties, mask, output)
         int64_t a = lo, z = hi;                 // seen item? (binary search in the sorted CSR row)
         while (a < z) { const int64_t m = (a + z) >> 1; if (indices[m] < it) a = m + 1; else z = m; }
         if (a < hi && indices[a] == it) return;
@@ -636,13 +673,13 @@ constexpr int kMaxLanes = 4;   // g_rsx_score_lanes (rsx_set_option "score_lanes
 template <bool FILTER>
 int launch_score(const float *P, const int32_t *users, int64_t rows, const float *Q, int64_t cols,
                  int64_t item_stride, int d, float *out, const float *tau, float *cand_val,
-                 int32_t *cand_idx, int32_t *cand_cnt, int cand_cap, uint2 *slots, hipStream_t st)
+                 int32_t *cand_idx, int32_t *cand_cnt, int cand_cap, uint2 *slots, hipStream_t st, int64_t item_base = 0)
 {
     dim3 grid((unsigned)((cols + BN - 1) / BN), (unsigned)((rows + BM - 1) / BM));
     switch (d) {
-    case 32: hipLaunchKernelGGL((score_tile_kernel<32, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots); break;
-    case 64: hipLaunchKernelGGL((score_tile_kernel<64, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots); break;
-    default: hipLaunchKernelGGL((score_tile_kernel<128, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots); break;
+    case 32: hipLaunchKernelGGL((score_tile_kernel<32, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, item_base); break;
+    case 64: hipLaunchKernelGGL((score_tile_kernel<64, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, item_base); break;
+    default: hipLaunchKernelGGL((score_tile_kernel<128, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, item_base); break;
     }
     return 0;
 }
@@ -788,7 +825,7 @@ RSX_API int64_t rsx_score_topk_workspace(int64_t num_rows, int64_t num_items)
     const int64_t frows = num_rows < kFusedRows ? num_rows : kFusedRows;
     const int64_t passes = (num_rows + kFusedRows - 1) / kFusedRows;
     const int64_t lanes = passes < kMaxLanes ? passes : kMaxLanes;   // passes in flight (one stream each)
-    const int64_t fused = lanes * carve(nullptr, frows, num_rows, num_items, 512).bytes;
+    const int64_t fused = lanes * carve(nullptr, frows, num_rows, num_items, 512).bytes + a256(num_items * 128 * 4);   // + Qp
     return fused > dense ? fused : dense;   // (K > 512 still takes the dense path)
 }
 
@@ -824,7 +861,6 @@ RSX_API int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t 
     RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64 or 128");
     RSX_CHECK_ARG(K >= 1 && K <= num_items, "K must be in [1, num_items]");
     RSX_CHECK_ARG((mask_indptr_dev == nullptr) == (mask_indices_dev == nullptr), "mask needs both CSR arrays");
-    const int64_t stride = num_items / kSampleCols;          // sample = items 0, stride, 2 stride, ...
     const int64_t tile_rows = num_rows < kFusedRows ? num_rows : kFusedRows;
     const int64_t n_tiles = (num_rows + kFusedRows - 1) / kFusedRows;
     // Several passes in flight, one HIP stream each: the selection kernels of one pass (sample
@@ -835,6 +871,20 @@ RSX_API int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t 
     for (int l = 0; l < n_lanes; ++l)
         lane_ws[l] = carve((char *)ws + (l ? (size_t)l * lane_ws[0].bytes : 0), tile_rows, num_rows, num_items, K);
     FusedWs &w = lane_ws[0];                   // overflow list and dense re-do buffers are lane 0's
+    // the permuted copy of the item table (after the lanes' regions) and its multiplier: the smallest a >= I / sample
+    // coprime to I; a^-1 mod I by the extended Euclidean algorithm
+    float *Qp = (float *)((char *)ws + (size_t)n_lanes * lane_ws[0].bytes);
+    int64_t perm_a = num_items / kSampleCols, perm_inv = 1;
+    for (;; ++perm_a) {
+        int64_t x = perm_a, y = num_items;
+        while (y) { const int64_t t = x % y; x = y; y = t; }
+        if (x == 1) break;
+    }
+    {
+        int64_t r0_ = num_items, r1 = perm_a % num_items, t0 = 0, t1 = 1;
+        while (r1) { const int64_t q = r0_ / r1, r2 = r0_ - q * r1, t2 = t0 - q * t1; r0_ = r1; r1 = r2; t0 = t1; t1 = t2; }
+        perm_inv = ((t0 % num_items) + num_items) % num_items;
+    }
     // side streams and fork/join events belong to the CURRENT device; one caller at a time per device
     // uses them (the lock is held until every launch of this call has been queued)
     LanePool *pool = lane_pool();
@@ -845,7 +895,9 @@ RSX_API int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t 
     hipStream_t lane_st[kMaxLanes] = {st, st, st, st};
     for (int l = 1; l < n_lanes; ++l) lane_st[l] = side_stream[l - 1];
     (void)hipMemsetAsync(w.ovf_cnt, 0, 4, st);
-    if (n_lanes > 1) {
+    hipLaunchKernelGGL(permute_items_kernel, dim3((unsigned)(rsx_num_cus() * 8)), dim3(256), 0, st, (const float4 *)Q,
+                       (float4 *)Qp, num_items, d / 4, perm_a);
+    if (n_lanes > 1) {                          // (the lanes start after the permuted table is complete)
         (void)hipEventRecord(ev_fork, st);
         for (int l = 1; l < n_lanes; ++l) (void)hipStreamWaitEvent(lane_st[l], ev_fork, 0);
     }
@@ -855,20 +907,24 @@ RSX_API int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t 
         const int32_t *users = user_ids_dev + r0;
         FusedWs &lw = lane_ws[ti % n_lanes];
         hipStream_t ls = lane_st[ti % n_lanes];
-        launch_score<false>(P, users, nr, Q, kSampleCols, stride, d, lw.sample, nullptr, nullptr, nullptr, nullptr, 0,
+        // 1. the sample = the FIRST kSampleCols rows of the permuted table, scored densely; tau = the K-th best of its unseen items, and those
+        //    K (or more, on ties) go to the row's candidate list: the sample is not scored a second time
+        launch_score<false>(P, users, nr, Qp, kSampleCols, 1, d, lw.sample, nullptr, nullptr, nullptr, nullptr, 0,
                             nullptr, ls);
         static_assert(kSampleCols == ST_COLS, "sample_tau_kernel is laid out for the sample size");
-        hipLaunchKernelGGL(sample_tau_kernel, dim3((unsigned)nr), dim3(TK_THREADS), 0, ls, lw.sample, users, nr, stride,
-                           mask_indptr_dev, mask_indices_dev, K, lw.tau, lw.ccnt);
-        const int64_t n_it = 2 * ((num_items + BN - 1) / BN), rows_pad = (nr + BM - 1) / BM * BM;
+        hipLaunchKernelGGL(sample_tau_kernel, dim3((unsigned)nr), dim3(TK_THREADS), 0, ls, lw.sample, users, nr, perm_inv, num_items,
+                           mask_indptr_dev, mask_indices_dev, K, lw.tau, lw.ccnt, lw.cval, lw.cidx, kSpillCap);
+        // 2. the rest of the catalog with the FILTER epilogue (item ids offset by the sample)
+        const int64_t rest = num_items - kSampleCols;
+        const int64_t n_it = 2 * ((rest + BN - 1) / BN), rows_pad = (nr + BM - 1) / BM * BM;
         (void)hipMemsetAsync(lw.slots, 0xFF, (size_t)(n_it * rows_pad) * kSlots * 8, ls);
-        launch_score<true>(P, users, nr, Q, num_items, 1, d, nullptr, lw.tau, lw.cval, lw.cidx, lw.ccnt, kSpillCap,
-                           lw.slots, ls);
+        launch_score<true>(P, users, nr, Qp + (size_t)kSampleCols * d, rest, 1, d, nullptr, lw.tau, lw.cval, lw.cidx, lw.ccnt,
+                           kSpillCap, lw.slots, ls, kSampleCols);
         hipLaunchKernelGGL(merge_candidates_kernel, dim3((unsigned)nr), dim3(MG_THREADS), 0, ls, lw.slots,
                            n_it, rows_pad, lw.cval, lw.cidx, lw.ccnt, kSpillCap, users, mask_indptr_dev,
                            mask_indices_dev, K,
                            topk_idx_out + (size_t)r0 * K, topk_val_out ? topk_val_out + (size_t)r0 * K : nullptr,
-                           r0, w.ovf_rows, w.ovf_cnt);
+                           r0, w.ovf_rows, w.ovf_cnt, perm_a, num_items);
         RSX_CHECK_LAUNCH();
     }
     for (int l = 1; l < n_lanes; ++l) {

@@ -423,6 +423,29 @@ def test_fused_score_topk_equals_dense_path(rsx, oracle_mod, d, I, rows, K):
     assert not torch.isinf(val).any()
 
 
+@pytest.mark.parametrize("order", ["ascending", "descending"])
+def test_fused_score_topk_when_scores_follow_the_item_id(rsx, order):
+    """the threshold of the fused path comes from a sample of the catalog: the sample is the first rows of a PERMUTED
+    item table (p -> a p mod I), not a prefix of the ids, so a catalog whose scores rise or fall with the item id (ids
+    sorted by popularity) neither loosens the threshold into a flood of survivors nor changes the result"""
+    torch.manual_seed(5)
+    U, I, d, rows, K = 3000, 50_021, 64, 2000, 20
+    P = torch.rand(U, d, device="cuda") * 0.1 + 0.05                     # positive users: the score follows the item norm
+    trend = torch.linspace(0.1, 2.0, I, device="cuda")
+    if order == "descending":
+        trend = trend.flip(0)
+    Q = (torch.rand(I, d, device="cuda") * 0.02 + 0.1) * trend[:, None]
+    users = torch.randperm(U, device="cuda")[:rows].to(torch.int32)
+    from recsys_pytorch_amd.data import synthetic_csr
+    mask = synthetic_csr(U, I, 30, "cuda", seed=4)
+    idx, val = rsx.score_topk(P, Q, users, K, mask=mask, want_values=True)
+    S = rsx.score(P, Q, users, mask=mask)
+    ref_i, ref_v = rsx.topk(S, K, want_values=True)
+    assert torch.equal(val, ref_v) and torch.equal(idx, ref_i)
+    best = idx[:, 0].float().mean().item() / I                              # the winners sit at the high (low) end of the ids
+    assert (best > 0.95) if order == "ascending" else (best < 0.05)
+
+
 def test_fused_score_topk_on_random_shapes(rsx, oracle_mod):
     """16 random (d, catalog, rows, K, mask density, score scale) problems around the fused path's
     thresholds (32 768 items, 8 192 rows per pass, K up to 512): identical to dense scoring + row top-k
