@@ -401,7 +401,8 @@ def test_topk_ties_and_masked_rows(rsx, oracle_mod):
 
 
 @pytest.mark.parametrize("d,I,rows,K", [(64, 40_001, 300, 50), (128, 65_537, 1500, 10), (32, 33_000, 77, 200),
-                                        (32, 33_000, 17_000, 20)])   # > 8192 rows: passes on two streams
+                                        (32, 33_000, 17_000, 20),    # > 8192 rows: passes on two streams
+                                        (64, 1_000_003, 200, 50)])   # BASELINE configs[3]'s catalog size (a prime)
 def test_fused_score_topk_equals_dense_path(rsx, oracle_mod, d, I, rows, K):
     """catalogs >= 32768 items take the fused path (sample threshold -> filtered MFMA epilogue ->
     merge); it must give exactly what dense scoring + row top-k gives, mask included"""
