@@ -64,3 +64,28 @@ def bpr_sample(indptr, indices, num_items, batch, seed, step, epoch_pos, u_out, 
             if j not in row:
                 break
         j_out[b] = j
+
+
+def pointwise_grad(P, Q, GP, GQ, u, i, y, inv_n, loss_func="ce", loss_acc=None):
+    """same contract as include/rsx.h:rsx_pointwise_grad on host tensors (oracle-backed)"""
+    Pn, Qn = P.numpy(), Q.numpy()
+    gP, gQ = np.zeros_like(Pn), np.zeros_like(Qn)
+    loss = C.c_double(0)
+    n = int(u.numel())
+    oracle.lib().orc_pointwise_grad(Pn, Qn, u.numpy().astype(np.int64), i.numpy().astype(np.int64),
+                                    np.ascontiguousarray(y.numpy(), np.float32), n, Pn.shape[1], int(loss_func == "mse"),
+                                    gP, gQ, C.byref(loss))
+    scale = np.float32(float(inv_n) * n)        # the oracle carries 1/n; rescale to inv_n
+    GP += torch.from_numpy(gP * scale)
+    GQ += torch.from_numpy(gQ * scale)
+    if loss_acc is not None:
+        loss_acc[0] += float(loss.value) * n
+
+
+def adam_apply(W, M, V, G, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):
+    """torch.optim.Adam's single-tensor update (the formulas of oracle/mf_oracle.c:orc_adam_apply), then G = 0"""
+    bc1, bc2 = 1.0 - beta1 ** t, 1.0 - beta2 ** t
+    M += (1.0 - beta1) * (G - M)
+    V.mul_(beta2).addcmul_(G, G, value=1.0 - beta2)
+    W -= (lr / bc1) * (M / (V.sqrt() / bc2 ** 0.5 + eps))
+    G.zero_()

@@ -122,3 +122,50 @@ def test_registry_and_interface_names():
     m = cls(type("D", (), {"num_users": 4, "num_items": 4})(), {"hidden_dim": 8, "pointwise": True, "loss_func": "mse"}, "cpu",
             kernels=cpu_kernels)
     assert m.pointwise and m.loss_func == "mse"
+
+
+def test_pointwise_fit_loop_assembles_the_reference_generators_batches():
+    """MF(hparams['pointwise'] = True).fit on the CPU stand-in kernels: every batch is `batch_size` interactions of a
+    per-epoch permutation PLUS one negative (rating 0, never a positive of that user) for EVERY user
+    (data/generators.py:105-130,79-100), the number of batches is ceil(nnz / batch_size) (:102-103), every
+    interaction is visited once per epoch, and the loss falls"""
+    import types
+    import recsys_pytorch_amd as pkg
+    from recsys_pytorch_amd.sharded import BPREngine
+    g = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "g8_pointwise_generator_matrix.npz"))
+    import scipy.sparse as sp
+    U, I = (int(x) for x in g["shape"])
+    mat = sp.csr_matrix((np.ones(len(g["indices"]), np.float32), g["indices"], g["indptr"]), shape=(U, I))
+    ds = pkg.InteractionData(mat)
+    torch.manual_seed(1)
+    m = pkg.MF(ds, {"hidden_dim": 32, "pointwise": True, "loss_func": "ce", "optimizer": "adam", "lr": 0.01}, "cpu",
+               kernels=cpu_kernels)
+    seen = []
+    orig = BPREngine.pointwise_step
+
+    def spy(self, u, i, y, loss_func="ce", count_step=True):
+        seen.append((u.clone(), i.clone(), y.clone()))
+        return orig(self, u, i, y, loss_func, count_step)
+    BPREngine.pointwise_step = spy
+    try:
+        logged = []
+        logger = types.SimpleNamespace(log_metrics=lambda d, epoch: logged.append(dict(d)))
+        m.fit(ds, types.SimpleNamespace(batch_size=64, num_epochs=3, verbose=0, test_from=1, test_step=1), loggers=[logger])
+    finally:
+        BPREngine.pointwise_step = orig
+    nnz, bs = mat.nnz, 64
+    per_epoch = -(-nnz // bs)
+    assert len(seen) == 3 * per_epoch
+    dense = mat.toarray() > 0
+    for e in range(3):
+        pairs = set()
+        for b, (u, i, y) in enumerate(seen[e * per_epoch:(e + 1) * per_epoch]):
+            n_pos = min(bs, nnz - b * bs)
+            assert len(u) == n_pos + U                                      # + one negative for EVERY user
+            assert (y[:n_pos] == 1).all() and (y[n_pos:] == 0).all()
+            assert dense[u[:n_pos].numpy(), i[:n_pos].numpy()].all()        # interactions
+            assert sorted(u[n_pos:].tolist()) == list(range(U))             # every user once
+            assert not dense[u[n_pos:].numpy(), i[n_pos:].numpy()].any()    # true negatives
+            pairs.update(zip(u[:n_pos].tolist(), i[:n_pos].tolist()))
+        assert len(pairs) == nnz                                            # the whole matrix once per epoch
+    assert logged[-1]["loss"] < logged[0]["loss"]
