@@ -27,6 +27,7 @@ Divergences from the reference, all documented in DESIGN.md:
   * hidden_dim is padded to 32/64/128 columns of zeros internally (they stay zero).
 """
 import numpy as np
+import scipy.sparse as sp
 import torch
 import torch.nn as nn
 
@@ -220,7 +221,7 @@ class MF(BaseModel):
         counts = (indptr[1:] - indptr[:-1])
         users_all = torch.repeat_interleave(torch.arange(self.num_users, device=dev, dtype=torch.int32), counts)
         items_all = indices.to(torch.int32)
-        csr = train_matrix.tocsr()
+        csr = sp.csr_matrix(train_matrix, copy=True)
         csr.sort_indices()                       # the order csr_to_device stores the row in
         ratings_all = torch.as_tensor(np.asarray(csr.data, dtype=np.float32)).to(dev)
         n_data = int(items_all.numel())

@@ -135,10 +135,15 @@ def test_pointwise_fit_loop_assembles_the_reference_generators_batches():
     g = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "g8_pointwise_generator_matrix.npz"))
     import scipy.sparse as sp
     U, I = (int(x) for x in g["shape"])
-    mat = sp.csr_matrix((np.ones(len(g["indices"]), np.float32), g["indices"], g["indptr"]), shape=(U, I))
+    vals = np.random.default_rng(2).integers(1, 6, len(g["indices"])).astype(np.float32)     # explicit ratings 1..5
+    mat = sp.csr_matrix((vals, g["indices"], g["indptr"]), shape=(U, I))
+    mat = mat[:, ::-1].tocsr()                 # a matrix whose rows are NOT stored in ascending item order
+    mat = sp.csr_matrix((mat.data, mat.indices, mat.indptr), shape=(U, I))
+    assert not mat.has_sorted_indices
+    before = (mat.indices.copy(), mat.data.copy())
     ds = pkg.InteractionData(mat)
     torch.manual_seed(1)
-    m = pkg.MF(ds, {"hidden_dim": 32, "pointwise": True, "loss_func": "ce", "optimizer": "adam", "lr": 0.01}, "cpu",
+    m = pkg.MF(ds, {"hidden_dim": 32, "pointwise": True, "loss_func": "mse", "optimizer": "adam", "lr": 0.01}, "cpu",
                kernels=cpu_kernels)
     seen = []
     orig = BPREngine.pointwise_step
@@ -156,14 +161,16 @@ def test_pointwise_fit_loop_assembles_the_reference_generators_batches():
     nnz, bs = mat.nnz, 64
     per_epoch = -(-nnz // bs)
     assert len(seen) == 3 * per_epoch
-    dense = mat.toarray() > 0
+    full = mat.toarray()
+    dense = full > 0
+    assert np.array_equal(mat.indices, before[0]) and np.array_equal(mat.data, before[1])      # the caller's matrix is untouched
     for e in range(3):
         pairs = set()
         for b, (u, i, y) in enumerate(seen[e * per_epoch:(e + 1) * per_epoch]):
             n_pos = min(bs, nnz - b * bs)
             assert len(u) == n_pos + U                                      # + one negative for EVERY user
-            assert (y[:n_pos] == 1).all() and (y[n_pos:] == 0).all()
-            assert dense[u[:n_pos].numpy(), i[:n_pos].numpy()].all()        # interactions
+            assert (y[n_pos:] == 0).all()
+            assert np.array_equal(y[:n_pos].numpy(), np.asarray(full[u[:n_pos].numpy(), i[:n_pos].numpy()]).ravel())   # ITS rating
             assert sorted(u[n_pos:].tolist()) == list(range(U))             # every user once
             assert not dense[u[n_pos:].numpy(), i[n_pos:].numpy()].any()    # true negatives
             pairs.update(zip(u[:n_pos].tolist(), i[:n_pos].tolist()))
