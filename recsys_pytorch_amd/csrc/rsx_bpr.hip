@@ -226,18 +226,19 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
             if (loss_acc != nullptr && k == 0) loss_local += softplus_neg(x);
             // item gradients (shared rows): G[i] += g p ; G[j] -= g p
             if constexpr ((PASS & kPassItems) != 0) {
+                const float gi = RSX_ABL(256) ? g * 1.01f : g;   // (dev build only: a planted 1 % error, tests/test_mutation.py)
                 int32_t hs = -1;
                 if (hot.slot != nullptr) hs = hot.slot[i];
                 if (!RSX_ABL(1)) {
                     if (hs >= 0)       // popular item: one of its private replica rows (a small table: 32-bit offsets)
-                        p.atomic_axpy_at(hot.ghot, row_off<D, uint32_t>(hs * hot.replicas + (int32_t)(wave & (hot.replicas - 1)), k), g);
+                        p.atomic_axpy_at(hot.ghot, row_off<D, uint32_t>(hs * hot.replicas + (int32_t)(wave & (hot.replicas - 1)), k), gi);
                     else
-                        p.atomic_axpy_at(G, i_off, g);
+                        p.atomic_axpy_at(G, i_off, gi);
                 }
-                if (!RSX_ABL(2)) p.atomic_axpy_at(G, j_off, -g);
+                if (!RSX_ABL(2)) p.atomic_axpy_at(G, j_off, -gi);
             }
             // user row: P[u] -= lr * g * (qi - qj)
-            const float s = -lr * g;
+            const float s = -lr * g * (RSX_ABL(128) ? 1.01f : 1.0f);
             if constexpr (MODE == 0) {
                 if constexpr ((PASS & kPassUsers) != 0) {
 #pragma unroll
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
         const float g = -sneg * inv_batch;
         if (loss_acc != nullptr && k == 0) loss_local += softplus_neg(x);
         if constexpr (kItems) {
+            const float gi = RSX_ABL(256) ? g * 1.01f : g;   // (dev build only: a planted 1 % error, tests/test_mutation.py)
             // positive item: extend its run, or flush the run and start a new one
             if (i != run_item) {
                 RSX_RUN_FLUSH(run_item, run)
@@ -372,14 +374,14 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
                 for (int cc = 0; cc < EPL; ++cc) run[cc] = 0.f;
             }
 #pragma unroll
-            for (int cc = 0; cc < EPL; ++cc) run[cc] = fmaf(g, p.v[cc], run[cc]);
+            for (int cc = 0; cc < EPL; ++cc) run[cc] = fmaf(gi, p.v[cc], run[cc]);
             // negative item: the wave's own block goes to its LDS tile, anything else to G.  The tile
             // is wave-private and updated by plain read-modify-write (ds_add_f32 measured ~120 clk per
             // wave instruction); the lane groups of one wavefront may hit the same row, so they take
             // turns -- LDS executes a wavefront's instructions in order.
             const bool neg_local = TILE && (j >= item_lo && j < item_hi);
             if (!RSX_ABL(2)) {
-                if (!neg_local) p.atomic_axpy_at(G, row_off<D, OffT>(j, k), -g);
+                if (!neg_local) p.atomic_axpy_at(G, row_off<D, OffT>(j, k), -gi);
 #pragma unroll
                 for (int tt = 0; TILE && tt < TPW; ++tt) {
                     if (sub == tt && neg_local) {
@@ -387,14 +389,14 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
                         float a[EPL];
                         tile_load<EPL>(cell, a);
 #pragma unroll
-                        for (int cc = 0; cc < EPL; ++cc) a[cc] = fmaf(-g, p.v[cc], a[cc]);
+                        for (int cc = 0; cc < EPL; ++cc) a[cc] = fmaf(-gi, p.v[cc], a[cc]);
                         tile_store<EPL>(cell, a);
                     }
                 }
             }
         }
         if constexpr (kUsers) {      // last: p is dead after its update
-            const float s = -lr * g;
+            const float s = -lr * g * (RSX_ABL(128) ? 1.01f : 1.0f);
 #pragma unroll
             for (int cc = 0; cc < EPL; ++cc) p.v[cc] = fmaf(s, qi.v[cc] - qj.v[cc], p.v[cc]);
             if (!RSX_ABL(4)) p.store_once_at(P, row_off<D, OffT>(u, k));
@@ -477,7 +479,9 @@ __global__ __launch_bounds__(kBlock) void pointwise_grad_kernel(const float *__r
     float loss_local = 0.0f;
     for (int64_t b = wave * TPW + sub; b - sub < n; b += stride) {      // wave-uniform trip count
         if (b >= n) continue;
-        const OffT u_off = row_off<D, OffT>(U_idx[b], k), i_off = row_off<D, OffT>(I_idx[b], k);
+        const int32_t ib = I_idx[b];
+        if (ib < 0) continue;          // no item (a sampler slot of a user without a usable row): skipped like the BPR kernels do
+        const OffT u_off = row_off<D, OffT>(U_idx[b], k), i_off = row_off<D, OffT>(ib, k);
         const float y = Y[b];
         Row<D> p, q;
         p.load_at(P, u_off);

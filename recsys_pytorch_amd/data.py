@@ -115,7 +115,7 @@ def _write_cache(cdir, parts, user_raw, item_raw):
             f.write("".join("%d, %d\n" % (int(old), new) for new, old in enumerate(raw)))
 
 
-def _read_cache(cdir):
+def _read_cache(cdir, protocol="holdout"):
     """data/dataset.py:43-66,209-212: id maps give the table sizes, the three csv files the matrices"""
     sizes = []
     for name in ("user_map", "item_map"):
@@ -129,7 +129,7 @@ def _read_cache(cdir):
         m.sum_duplicates()
         m.data[:] = 1.0                                         # implicit=True: ratings binarised at load
         mats.append(m)
-    return InteractionData(*mats)
+    return InteractionData(*mats, protocol=protocol)
 
 
 def load_uirt(path, separator="\t", min_item_per_user=0, min_user_per_item=0, valid_ratio=0.1,
@@ -166,7 +166,7 @@ def load_uirt(path, separator="\t", min_item_per_user=0, min_user_per_item=0, va
                             _cache_subdir(valid_ratio, test_ratio, split_random, min_item_per_user, min_user_per_item, cache_seed,
                                           protocol, leave_k))
         if all(os.path.exists(os.path.join(cdir, f)) for f in CACHE_FILES):     # dataset.py:183-191
-            return _read_cache(cdir)
+            return _read_cache(cdir, protocol)
     raw = np.loadtxt(path, delimiter=separator, dtype=np.float64, ndmin=2)
     users, items, ratings, ts = raw[:, 0].astype(np.int64), raw[:, 1].astype(np.int64), raw[:, 2], raw[:, 3]
     # filter users, then items (dataset.py:131-146)
@@ -217,4 +217,4 @@ def load_uirt(path, separator="\t", min_item_per_user=0, min_user_per_item=0, va
     if cdir is not None:
         _write_cache(cdir, {n: (users[ix], items[ix], ratings[ix], ts[ix]) for n, ix in
                             (("train", train), ("valid", valid), ("test", test))}, uid, iid)
-    return InteractionData(csr(train), csr(valid), csr(test))
+    return InteractionData(csr(train), csr(valid), csr(test), protocol=protocol)

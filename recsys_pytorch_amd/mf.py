@@ -242,6 +242,12 @@ class MF(BaseModel):
                 eng.epoch_pos = 0
                 nu, _, nj = eng.sample(indptr, indices, self.num_users)
                 eng.step_count += 1              # a fresh draw next batch
+                # a user with an empty (or full) train row has no pairwise sample (j = -1): the reference draws a uniform
+                # negative over ALL items for an empty row (generators.py:87-91: prob is all ones) and trains on it
+                dead = nj < 0
+                if bool(dead.any()):
+                    nj = torch.where(dead, torch.randint(0, self.num_items, nj.shape, device=dev, generator=gen,
+                                                         dtype=torch.int64).to(torch.int32), nj)
                 u = torch.cat([users_all[idx], nu])
                 i = torch.cat([items_all[idx], nj])
                 y = torch.cat([ratings_all[idx], zeros])

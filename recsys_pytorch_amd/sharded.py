@@ -32,8 +32,10 @@ def pick_neg_block(num_items, max_block, wave_slots):
     slots take three rounds for two rounds' worth of work (measured: c = 8 -> 347 us, c = 6 -> 323 us at
     I = 100K on 256 CUs).  Pick the c in [2, max_block] whose last round is fullest; ties go to the
     larger block (fewer wavefronts, fewer partial-run flushes)."""
-    best, best_eff = max(1, min(2, max_block)), -1.0
-    for c in range(2, max(2, max_block) + 1):
+    if max_block < 2:
+        return max(1, int(max_block))
+    best, best_eff = 2, -1.0
+    for c in range(2, max_block + 1):
         waves = -(-num_items // c)
         eff = waves / (-(-waves // wave_slots) * wave_slots)
         if eff >= best_eff - 1e-9:
@@ -99,6 +101,9 @@ class BPREngine:
         self._G_alt = self._Gp_alt = None
         self._pending = []          # exchanges begun and not ended, oldest first: (work, gradient buffer)
         self._begin_step = 0        # exchanges begun by the current native trainer (picks the buffer by parity)
+        # decided ONCE from the backend: gloo (the CPU tests) has no reduce_scatter and takes the same shard out of an
+        # all_reduce; on RCCL a failing collective propagates (never silently another collective than the peers issue)
+        self._has_reduce_scatter = self.sharded and dist.get_backend(group) != "gloo"
         if self.exchange == "scatter_gather":
             self._setup_item_shards()
         self.hot = None
@@ -204,9 +209,9 @@ class BPREngine:
             self._pending.append((dist.all_reduce(G, op=dist.ReduceOp.SUM, group=self.group, async_op=True), G))
             return
         Gp = self._Gp_alt if alt else self._Gp
-        try:        # in place: this rank's shard of G receives the sum over the ranks
+        if self._has_reduce_scatter:    # in place: this rank's shard of G receives the sum over the ranks
             work = dist.reduce_scatter_tensor(Gp[self._mine], Gp, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        except RuntimeError:    # a backend without reduce_scatter (gloo, in the CPU tests): same shard via all_reduce
+        else:                           # gloo (CPU tests): the same shard via all_reduce
             work = dist.all_reduce(Gp, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append((work, Gp))
 

@@ -115,6 +115,10 @@ def test_ml100k_leave_one_out_split_and_cache_equal_the_reference(tmp_path):
         ref = sp.csr_matrix((np.ones(len(ix)), ix, ip), shape=(U, I))
         assert (m != ref).nnz == 0, part
     assert (np.diff(ds.valid_target.indptr) == 1).all() and (np.diff(ds.test_target.indptr) == 1).all()
+    assert ds.protocol == "leave_one_out"                      # what main.py:50 hands to the Evaluator
+    again = load_uirt(str(work / "u.data"), separator="\t", min_item_per_user=10, min_user_per_item=1, split_random=True,
+                      cache_dir="cache", seed=2020, protocol="leave_one_out", leave_k=1)
+    assert again.protocol == "leave_one_out"                   # ... also when served from the cache
 
 
 def test_cache_round_trip_on_a_toy_file(tmp_path):
@@ -132,4 +136,5 @@ def test_cache_round_trip_on_a_toy_file(tmp_path):
     raw, new = open(cdir / "user_map").readline().strip().split(", ")
     assert int(new) == 0 and int(raw) >= 100
     again = load_uirt(p, seed=99, split_random=False, **kw)     # served from the cache: seed irrelevant
+    assert ds.protocol == again.protocol == "holdout"
     assert (again.train_data != ds.train_data).nnz == 0 and (again.test_target != ds.test_target).nnz == 0
