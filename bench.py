@@ -14,14 +14,17 @@ Headline workload = BASELINE.json configs[2] (the d=128 shape the metric is quot
 timed region.  Weak scaling: every rank owns its own 1M-user block (user rows sharded, items replicated).
 
 Prints ONE JSON line (rank 0).
-  roofline      dominant kernel of the headline leg.  `achieved` = ALGORITHMIC bytes (24*d per triplet,
-                SURVEY section 8d) / the kernel's mean duration, HIP events on the launch stream inside the
-                timed region.  The blocked kernel sums item-side gradients on chip, so the algorithmic
-                figure counts row writes that never reach HBM: `frac` can approach or exceed 1.  Next to it
-                therefore `hbm_bytes` (PMC-measured traffic per launch, profiles/traffic.json) with
-                `frac_hbm`, and `compulsory_bytes` (what must cross HBM at least once for this batch:
-                P read + write, every touched Q row read once, every touched G row read + written once)
-                with `frac_compulsory` -- neither can exceed 1.
+  roofline      dominant kernel of the headline leg.  `achieved` / `frac` are PHYSICAL: the HBM bytes one launch moves
+                (`traffic`: rocprofv3 PMC counters, collected per leg by tools/refresh_profiles.sh into
+                profiles/traffic.json -- `traffic_source` names the profile file and the commit it was taken at;
+                the counters cannot be read inside this process) / the kernel's mean duration (HIP events on the
+                launch stream around EVERY step kernel of the timed region) / the 8 TB/s peak.  A leg without a
+                profiled traffic figure prints null and says why.  `compulsory_bytes` / `frac_compulsory`: what
+                the batch cannot avoid moving once (P read + write, every touched Q row read, every touched G row
+                read + written).  The contract's ALGORITHMIC figure (24*d bytes per triplet) is
+                reported as `algorithmic_bytes_per_launch` / `algorithmic_GBs` / `algorithmic_rate_over_peak`:
+                the blocked kernel sums item-side gradients on chip, so those bytes are not all moved and that
+                ratio is NOT a fraction of anything (it exceeds 1 at the headline shape).
   legs          the other section-8d measurements, each with its own roofline: SURVEY's base batch
                 B = 65 536, independent uniform negatives, uniform item popularity, a batch sweep, the
                 configs[1] (d=64) shape, and the configs[3] one-rank slice (1.25M users x 1M items).
@@ -74,26 +77,46 @@ def parse():
 
 
 def traffic_for(key):
-    """PMC-measured HBM bytes per launch of the leg's dominant kernel, if that leg was profiled"""
+    """PMC-measured HBM traffic of the leg's dominant kernel (profiles/traffic.json entry), if that leg was profiled"""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key, {}).get("hbm_bytes_per_launch")
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
     except Exception:       # noqa: BLE001 -- no profile, no traffic figure
         return None
 
 
-def roofline(kernel, kern_ms, B, I, d, key, two_pass=False):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def roofline(kernel, kern_ms, n_timed, B, I, d, key, two_pass=False):
+    """PHYSICAL roofline of one leg's step kernel: achieved = PMC-measured HBM bytes per launch / mean launch duration"""
     alg = (20 if two_pass else 24) * d * B          # per launch (SURVEY section 8d); the item pass writes no P row
     touched = min(2 * B, I)
     compulsory = 8 * d * B + 4 * d * touched + 8 * d * touched
-    hbm = traffic_for(key)
+    t = traffic_for(key)
+    hbm = t.get("hbm_bytes_per_launch") if t else None
     per_s = lambda nbytes: nbytes / (kern_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": kernel, "achieved": per_s(alg), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": per_s(alg) / HBM_PEAK_GBS, "traffic": hbm, "algorithmic_bytes_per_launch": alg, "kernel_ms": kern_ms,
+    return {"bound": "hbm", "kernel": kernel, "kernel_ms": kern_ms, "kernel_launches_timed": n_timed,
+            "achieved": per_s(hbm) if hbm else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": per_s(hbm) / HBM_PEAK_GBS if hbm else None, "traffic": hbm,
+            "traffic_source": ({"file": "profiles/" + str(t.get("profile")), "taken_at_commit": t.get("commit"),
+                                "how": "rocprofv3 --pmc passes over tools/step_prof.py at this leg's shape (tools/refresh_profiles.sh); "
+                                       "read from profiles/traffic.json, NOT measured in this run"} if t else None),
+            **({} if hbm else {"frac_null_reason": f"no PMC profile of this leg in profiles/traffic.json (key {key})"}),
+            "traffic_key": key,
             "compulsory_bytes": compulsory, "frac_compulsory": per_s(compulsory) / HBM_PEAK_GBS,
-            "hbm_bytes": hbm, "frac_hbm": per_s(hbm) / HBM_PEAK_GBS if hbm else None, "traffic_key": key,
-            "note": "achieved / frac are the contract's ALGORITHMIC figure (24 d bytes per triplet / kernel time): where item sums "
-                    "stay on chip it can exceed 1; the physical fractions are frac_hbm (PMC-measured traffic, profiles/traffic.json) "
-                    "and frac_compulsory (every byte the batch cannot avoid moving once)"}
+            "traffic_over_compulsory": hbm / compulsory if hbm else None,
+            "algorithmic_bytes_per_launch": alg, "algorithmic_GBs": per_s(alg),
+            "algorithmic_rate_over_peak": per_s(alg) / HBM_PEAK_GBS,
+            "note": "achieved / frac are physical (HBM bytes the launch moved, PMC).  algorithmic_* is SURVEY section 8d's "
+                    "24 d bytes per triplet over the kernel time: where item sums stay on chip those bytes are not moved and "
+                    "the ratio to the peak is not a fraction (it can exceed 1)"}
 
 
 SHARDED = False     # a process group is up: N > 1, or RSX_FORCE_SHARDED=1 (the exchange path over a group of one rank)
@@ -135,14 +158,14 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     loss.zero_()
     fence(world)
     t0 = time.perf_counter()
-    tr.run(steps, B, gb, time_every=1 if steps < 10 else 5)     # exactly `steps` steps inside the timed region
+    tr.run(steps, B, gb, time_every=1)     # exactly `steps` steps inside the timed region, every step kernel timed
     fence(world)
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if SHARDED:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    kern_ms, _ = tr.kernel_ms()
+    kern_ms, n_timed = tr.kernel_ms()
     tr.close()
     assert torch.isfinite(P).all() and torch.isfinite(Q).all()
     mean_loss = float(loss.double().sum()) / (B * steps)            # this rank's triplets
@@ -161,8 +184,11 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
             "two_pass": bool(eng.overlap_exchange) and not eng.stale_exchange, "exchange": eng.exchange if SHARDED else None,
             "stale_exchange": bool(eng.stale_exchange),
             "item_replicas_identical": replicas_equal, "_Q": Q,
-            "roofline": roofline(kernel, kern_ms, B, I, d, key, two_pass=eng.overlap_exchange),
-            "frac_of_hbm_roofline_end_to_end": gb / world * steps / elapsed * 24 * d / (HBM_PEAK_GBS * 1e9)}
+            "roofline": (rl := roofline(kernel, kern_ms, n_timed, B, I, d, key,
+                                        two_pass=bool(eng.overlap_exchange) and not eng.stale_exchange)),
+            # whole step (kernel + apply + gaps) against the same physical bytes of the step kernel
+            "frac_end_to_end": (rl["traffic"] / (elapsed / steps) / 1e9 / HBM_PEAK_GBS) if rl["traffic"] else None,
+            "algorithmic_end_to_end_over_peak": gb / world * steps / elapsed * 24 * d / (HBM_PEAK_GBS * 1e9)}
 
 
 def lightgcn_leg(U, I, d, indptr, indices, dev, layers=3, batch=65_536):
@@ -198,16 +224,28 @@ def lightgcn_leg(U, I, d, indptr, indices, dev, layers=3, batch=65_536):
     assert torch.isfinite(m._E0).all()
     alg = nnz * (4 * d + 8) + 2 * N * d * 4
     compulsory = nnz * 8 + 2 * N * d * 4      # every embedding row once, the CSR once, the output once
+    key = f"lightgcn_U{U}_I{I}_d{d}_L{layers}"
+    t = traffic_for(key)
+    hbm = t.get("hbm_bytes_per_launch") if t else None
+    per_s = lambda nbytes: nbytes / t_spmm / 1e9
     return {"workload": f"BASELINE configs[4]: LightGCN {U} x {I}, d={d}, {layers} layers, nnz(A_hat)={nnz}",
             "propagation_ms_per_product": t_spmm * 1e3, "train_step_ms": t_step * 1e3, "batch": batch,
             "value": batch / t_step, "unit": "triplets/s",
             "graph_build_host_s": build_s,
-            "roofline": {"bound": "hbm", "kernel": "spmm_csr_kernel", "achieved": alg / t_spmm / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": alg / t_spmm / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg,
-                         "kernel_ms": t_spmm * 1e3, "compulsory_bytes": compulsory,
-                         "frac_compulsory": compulsory / t_spmm / 1e9 / HBM_PEAK_GBS,
-                         "note": "the algorithmic figure counts every neighbour row (a gather of nnz rows); rows that are "
-                                 "re-read hit L2/MALL, so the HBM side only has to move compulsory_bytes"}}
+            "roofline": {"bound": "hbm", "kernel": "spmm_csr_kernel", "kernel_ms": t_spmm * 1e3,
+                         "achieved": per_s(hbm) if hbm else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": per_s(hbm) / HBM_PEAK_GBS if hbm else None, "traffic": hbm,
+                         "traffic_source": ({"file": "profiles/" + str(t.get("profile")), "taken_at_commit": t.get("commit"),
+                                             "how": "rocprofv3 --pmc passes over tools/spmm_prof.py; read from profiles/traffic.json, "
+                                                    "NOT measured in this run"} if t else None),
+                         **({} if hbm else {"frac_null_reason": f"no PMC profile of this leg in profiles/traffic.json (key {key})"}),
+                         "traffic_key": key,
+                         "compulsory_bytes": compulsory, "frac_compulsory": per_s(compulsory) / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": alg, "algorithmic_GBs": per_s(alg),
+                         "algorithmic_rate_over_peak": per_s(alg) / HBM_PEAK_GBS,
+                         "gathered_bytes_served_on_chip": (alg - hbm) if hbm else None,
+                         "note": "the algorithmic figure counts every gathered neighbour row (nnz rows of 4 d bytes); rows that are "
+                                 "re-read are served by L2 / MALL (gathered_bytes_served_on_chip), the HBM side moves `traffic`"}}
 
 
 def cpu_baseline(args, U, I, d, batches):
@@ -256,7 +294,8 @@ def cpu_baseline(args, U, I, d, batches):
     med, n = timed(lambda: oracle.topk(S, K), 3.0, 5)
     legs["top%d_cxx_partial_sort_1_thread" % K] = {"value": 1024 * I / med, "unit": "scores/s", "ms_per_tile": med * 1e3, "tiles": n}
     head = legs[f"sgd_B{batches[0]}"]
-    return {"value": head["value"], "unit": "triplets/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": head["value"], "unit": "triplets/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model(),
+            "host_logical_cpus": os.cpu_count(), "kind": "port",
             "sample": f"{head['steps']} SGD steps of B={batches[0]} (the headline batch) on U={U} I={I} d={d}: torch CPU port of "
                       f"models/MF.py:64-68 (dense grads + full optimizer sweep), median {head['ms_per_step']:.0f} ms/step; "
                       "other legs: same port at the other GPU batches, as-shipped Adam, scoring tile, top-k",
@@ -335,7 +374,8 @@ def main():
                     r = leg(P, Q, indptr, indices, args.lr, b, args.neg_block, args.hot, args.hot_replicas, 100, 10, 1, 0,
                                  args.popularity)
                     sweep.append({**{k: r[k] for k in ("batch_per_gpu", "value", "ms_per_step", "neg_block")},
-                                  "kernel_ms": r["roofline"]["kernel_ms"], "frac": r["roofline"]["frac"]})
+                                  "kernel_ms": r["roofline"]["kernel_ms"], "frac": r["roofline"]["frac"],
+                                  "algorithmic_rate_over_peak": r["roofline"]["algorithmic_rate_over_peak"]})
             legs["batch_sweep"] = sweep
             other = "uniform" if args.popularity == "zipf" else "zipf"
             ip2, ix2 = synthetic_csr(U, I, args.degree, dev, seed=2020, popularity=other)

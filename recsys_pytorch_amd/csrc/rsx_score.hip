@@ -382,41 +382,17 @@ __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float *__re
 }
 
 // ---- fused scoring + Top-K (no dense score matrix) ------------------------------------------
-// 1. score a STRIDED SAMPLE of the catalog (every `stride`-th item) densely, mask, exact top-K:
-//    its K-th value tau[row] is a lower bound of the row's final K-th score;
-// 2. score the whole catalog with the FILTER epilogue: only scores >= tau[row] leave the CU
-//    (expected K * I / n_sample per row);
-// 3. per row: drop seen items among the candidates, bitonic sort, emit K.
+// 1. the item table is copied in the order p -> (a p) mod I; the FIRST kSampleCols rows of the copy -- an equidistributed
+//    sample of the catalog whatever the ids mean -- are scored densely, and sample_tau_kernel takes the exact K-th value
+//    tau[row] of the unseen ones (a lower bound of the row's final K-th score) and emits those K as candidates;
+// 2. the REST of the copy is scored with the FILTER epilogue: only scores >= tau[row] leave the CU (every item is scored
+//    exactly once);
+// 3. per row: map the copy's row numbers back to item ids, drop seen items, bitonic sort, emit K.
 // A row whose candidates overflow the list (massive exact ties) is redone through the dense path.
 
-// sample columns: -inf where the sampled item (col*stride) is in the user's CSR row
-__global__ __launch_bounds__(256) void mask_seen_strided_kernel(float *__restrict__ scores,
-                                                                const int32_t *__restrict__ user_ids,
-                                                                int64_t num_rows, int64_t n_cols, int64_t stride,
-                                                                const int64_t *__restrict__ indptr,
-                                                                const int32_t *__restrict__ indices)
-{
-    const int64_t r = blockIdx.x;
-    if (r >= num_rows) return;
-    const int32_t u = user_ids[r];
-    const int64_t lo = indptr[u], hi = indptr[u + 1];
-    float *row = scores + (size_t)r * n_cols;
-    for (int64_t p = lo + threadIdx.x; p < hi; p += blockDim.x) {
-        const int64_t it = indices[p];
-        if (it % stride == 0 && it / stride < n_cols) row[it / stride] = -INFINITY;
-    }
-}
-
-__global__ __launch_bounds__(256) void take_tau_kernel(const float *__restrict__ topk_val, int64_t num_rows, int K,
-                                                       float *__restrict__ tau, int32_t *__restrict__ cand_cnt)
-{
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r < num_rows) { tau[r] = topk_val[(size_t)r * K + K - 1]; cand_cnt[r] = 0; }
-}
-
 // tau of the fused path in ONE pass over the sample scores: the K-th largest value of a row of the [rows x kSampleCols]
-// sample product (the first kSampleCols rows of the PERMUTED item table) after the seen items are masked out.  Replaces mask_seen_strided_kernel + topk_rows_kernel (which read the
-// 268 MB of sample scores twice and sort candidates nobody needs in order) + take_tau_kernel: each of the 256 threads keeps
+// sample product (the first kSampleCols rows of the PERMUTED item table) after the seen items are masked out.  Instead of a mask pass + a sorted top-K + a gather of its K-th column (which read the
+// 268 MB of sample scores twice and sorted candidates nobody needs in order): each of the 256 threads keeps
 // its 32 keys of the row in registers, the seen sample columns are a 1 KB bitmap in LDS, and three radix levels
 // (12 + 12 + 8 bits, LDS histogram) fix the K-th key exactly.  Same value as the K-th entry of the sorted top-K.
 #ifndef RSX_SAMPLE_COLS

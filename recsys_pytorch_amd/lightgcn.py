@@ -195,8 +195,14 @@ class LightGCN(BaseModel):
         mask = csr_to_device(eval_pos, self.device) if eval_pos is not None else None
         U = self.num_users
         out = []
-        for s in range(0, len(eval_users), test_batch_size):
-            r = self._k.score_topk(self._out[:U], self._out[U:], self._idx(eval_users[s:s + test_batch_size]), K,
-                                   mask=mask, want_values=False)
+        # large catalogs take the fused path, which wants many 8 192-row passes per call (like MF.predict_topk)
+        chunk = max(int(test_batch_size), 65536) if self.num_items >= 32768 else int(test_batch_size)
+        ws = None
+        for s in range(0, len(eval_users), chunk):
+            users = self._idx(eval_users[s:s + chunk])
+            if ws is None and hasattr(self._k, "lib"):
+                need = self._k.lib().rsx_score_topk_workspace(users.numel(), self.num_items)
+                ws = torch.empty(max(need, 4) // 4 + 64, dtype=torch.float32, device=self.device)
+            r = self._k.score_topk(self._out[:U], self._out[U:], users, K, mask=mask, want_values=False, ws=ws)
             out.append(r.cpu().numpy())
         return np.concatenate(out) if out else np.zeros((0, K), np.int32)

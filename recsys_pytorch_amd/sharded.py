@@ -156,9 +156,16 @@ class BPREngine:
         self._cdf = self.k.build_item_cdf(indptr, indices, self.Q.shape[0]) if hasattr(self.k, "build_item_cdf") else None
         self._csr = (indptr, indices, self.neg_block)
 
-    def _neg_key(self, step):
+    def _eff_neg_block(self, batch):
+        """the block size a SAMPLED step of this batch size runs with: blocked negatives engage from two triplets per
+        item on, exactly the rule of the native loop (csrc/rsx_train.hip: effective_neg_block), so that an epoch's
+        short last batch takes the same layout on both paths.  (sample() / step() with an explicit neg_block are the
+        caller's business: the kernels are exact on any triplets.)"""
+        return self.neg_block if (self.neg_block and batch >= 2 * self.Q.shape[0]) else 0
+
+    def _neg_key(self, step, nb=None):
         """per-step key of the negative-block permutation (nonzero); 0 = identity when not sorting"""
-        if not self.neg_block:
+        if not (self.neg_block if nb is None else nb):
             return 0
         z = (self.seed * 0x9E3779B97F4A7C15 + (step + 1) * 0xD1B54A32D192ED03) & (2**64 - 1)
         z ^= z >> 31
@@ -245,10 +252,10 @@ class BPREngine:
         return int(self._count.item())
 
     # -- one step on explicit triplets (local user ids) ---------------------------
-    def _sorts(self, batch):
+    def _sorts(self, batch, nb=None):
         """is a sampled batch of this size ordered by positive item (blocked negatives or not)?"""
-        return bool(self.neg_block) or bool(self.sorted_min_batch and batch >= self.sorted_min_batch
-                                            and hasattr(self.k, "build_item_cdf"))
+        return bool(self.neg_block if nb is None else nb) or bool(self.sorted_min_batch and batch >= self.sorted_min_batch
+                                                                  and hasattr(self.k, "build_item_cdf"))
 
     def step(self, u_local, i, j, global_batch=None, users_unique=False, want_loss=True, neg_block=0,
              neg_key=0, batch_sorted=False):
@@ -340,7 +347,7 @@ class BPREngine:
         return loss
 
     # -- one step on triplets sampled on the device from this rank's CSR rows -----------
-    def _launch_sample(self, indptr, indices, batch, out, step, role="main"):
+    def _launch_sample(self, indptr, indices, batch, out, step, role="main", nb=None):
         """device sampler (include/rsx.h:rsx_bpr_sample) on the CURRENT stream; users unique
         inside the batch.  A batch never straddles two passes over the user permutation: when
         fewer than `batch` users remain in the pass, the pass restarts (tail dropped).
@@ -350,15 +357,16 @@ class BPREngine:
             self.epoch_pos = (self.epoch_pos // U + 1) * U
         u, i, j = out
         kw = {}
-        key = self._neg_key(step)
-        if self._sorts(batch):
+        nb = self.neg_block if nb is None else nb
+        key = self._neg_key(step, nb)
+        if self._sorts(batch, nb):
             need = self.k.bpr_sample_workspace(batch, self.Q.shape[0])
             ws = self._sample_ws.get(role)
             if ws is None or ws.numel() < need:
                 ws = self._sample_ws[role] = torch.empty(need, dtype=torch.uint8, device=self.Q.device)
             self._bind_csr(indptr, indices)
-            kw = {"neg_block": self.neg_block, "neg_key": key, "sort_pos": True, "ws": ws}
-            if self._sig is not None:
+            kw = {"neg_block": nb, "neg_key": key, "sort_pos": True, "ws": ws}
+            if self._sig is not None and nb:
                 kw["user_sig"] = self._sig
             if self._cdf is not None and self.use_item_cdf:
                 kw["item_cdf"] = self._cdf
@@ -379,9 +387,14 @@ class BPREngine:
         return self._trip
 
     def sampled_step(self, indptr, indices, batch, global_batch=None, want_loss=True):
-        u, i, j = self.sample(indptr, indices, batch)
+        batch = min(int(batch), indptr.numel() - 1)
+        nb = self._eff_neg_block(batch)
+        if self._trip is None or self._trip[0].numel() != batch:
+            self._trip = self._triplet_buffers(batch)
+        u, i, j = self._trip
+        key = self.last_neg_key = self._launch_sample(indptr, indices, batch, self._trip, self.step_count, nb=nb)
         return self.step(u, i, j, global_batch=global_batch, users_unique=True, want_loss=want_loss,
-                         neg_block=self.neg_block, neg_key=self.last_neg_key, batch_sorted=self._sorts(batch))
+                         neg_block=nb, neg_key=key, batch_sorted=self._sorts(batch, nb))
 
     def sampled_step_overlapped(self, indptr, indices, batch, global_batch=None, want_loss=True):
         """same result as sampled_step, but the sampler of step t+1 runs on a second HIP stream
@@ -402,13 +415,15 @@ class BPREngine:
             self._cur = 0
             self._sampled_upto = self.step_count          # next step index to sample for
 
+        nb = self._eff_neg_block(batch)
+
         def prefetch(slot):
             buf = self._bufs[slot]
             if buf["free"] is not None:
                 self._side.wait_event(buf["free"])        # the step that read this buffer is done
             buf["pos_before"] = self.epoch_pos
             with torch.cuda.stream(self._side):
-                buf["key"] = self._launch_sample(indptr, indices, batch, buf["t"], self._sampled_upto, role="side")
+                buf["key"] = self._launch_sample(indptr, indices, batch, buf["t"], self._sampled_upto, role="side", nb=nb)
                 buf["ready"] = torch.cuda.Event()
                 buf["ready"].record(self._side)
             self._sampled_upto += 1
@@ -422,7 +437,7 @@ class BPREngine:
         prefetch(cur ^ 1)                                  # sampler of the next step, concurrently
         u, i, j = buf["t"]
         loss = self.step(u, i, j, global_batch=global_batch, users_unique=True, want_loss=want_loss,
-                         neg_block=self.neg_block, neg_key=buf["key"], batch_sorted=self._sorts(batch))
+                         neg_block=nb, neg_key=buf["key"], batch_sorted=self._sorts(batch, nb))
         buf["free"] = torch.cuda.Event()
         buf["free"].record(main)
         self._cur = cur ^ 1
@@ -430,9 +445,10 @@ class BPREngine:
 
     # -- the native batch loop (include/rsx.h: rsx_bpr_trainer_*) ---------------------------------
     def native_trainer(self, indptr, indices, batch, loss_acc=None):
-        """C++ loop over this engine's tables and sampler state: `trainer.run(n)` equals n calls of
-        sampled_step_overlapped (same triplets: same seed, step indices, permutation positions and
-        per-step keys) without returning to Python between kernels.  When sharded, the exchange is
+        """C++ loop over this engine's tables and sampler state: `trainer.run(n, batch)` equals n calls of
+        sampled_step_overlapped(batch) (same triplets: same seed, step indices, permutation positions,
+        per-step keys, and the same layout rule for a short batch: _eff_neg_block) without returning to Python
+        between kernels.  When sharded, the exchange is
         this engine's all-reduce(G) handed in as a pair of callbacks.  SGD only."""
         if self.optimizer != "sgd":
             raise ValueError("the native loop runs the SGD step; optimizer='adam' steps through BPREngine.step")

@@ -42,6 +42,26 @@ def delta_err(a, a0, b, b0=None):
     return float(np.max(np.abs((a - a0) - (b - b0))) / (np.max(np.abs(b - b0)) + 1e-30))
 
 
+# A step size that makes the update RESOLVABLE.  The hot path carries the reference's batch mean (models/MF.py:105): every
+# gradient has a factor 1/B, so at lr = 0.05 and B = 10^4 .. 10^6 one step moves an entry by 1e-8 .. 1e-6 -- at or below
+# the fp32 rounding of the entry itself (3e-8 for |x| in [0.25, 0.5)), and `rel_err(table) < 1e-5` (4.5e-6 absolute) or any
+# absolute slack then passes a kernel that never wrote the table.  With lr = 0.05 * B the factor 1/B cancels: a step moves
+# P rows by 0.05 * sigmoid(-x) * (Q[i] - Q[j]) ~ 1e-3 .. 4e-2 and Q rows by the sum of ~B/I such terms, and the bar
+# `delta_err <= UPDATE_TOL` is a bar on the update itself (1 % wrong -> delta_err 1e-2, a thousand times the bar).
+UPDATE_TOL = 1e-5
+
+
+def resolvable_lr(batch, base=0.05):
+    return float(base) * int(batch)
+
+
+def assert_update(got, start, want, what="table", tol=UPDATE_TOL):
+    """the update (got - start) equals the reference's (want - start) to `tol` of the largest entry of the update"""
+    e = delta_err(got, start, want)
+    assert e <= tol, f"{what}: update error {e:.3e} > {tol:.1e} of the update"
+    return e
+
+
 # fp32 storage bounds what delta_err can resolve: a table entry of magnitude ~0.4 carries ~3e-8 of
 # rounding per step in the reference's own fp32 tables against updates of 1.5e-4 .. 7e-4 of absolute
 # size (G1 fixtures); the C oracle, a different summation order of the same arithmetic, sits at
@@ -65,6 +85,21 @@ def split_pointwise(g):
         n = int(n)
         yield g["u"][off:off + n].astype(np.int64), g["i"][off:off + n].astype(np.int64), g["y"][off:off + n].astype(np.float32)
         off += n
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _planted_error():
+    """tests/test_mutation.py re-runs selected parity tests in a child process against the DEVELOPMENT library
+    (RSX_LIB=librsx_dev.so, -DRSX_ABLATE) with a 1 % error planted in the user-row update (mask 128) or in the item
+    gradients (mask 256), and expects them to FAIL.  Nothing happens unless RSX_ABLATION is set."""
+    mask = int(os.environ.get("RSX_ABLATION", "0"))
+    if mask:
+        import ctypes
+        from recsys_pytorch_amd import rsx
+        fn = rsx.lib().rsx_debug_set_ablation          # only the dev build exports it
+        fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_int]
+        assert fn(mask) == 0
+    yield
 
 
 @pytest.fixture(scope="session")

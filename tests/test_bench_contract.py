@@ -30,8 +30,12 @@ def test_bench_json_contract_small_shape():
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "bpr_step_blocked_kernel"
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r and r["kernel_ms"] > 0
+    # `achieved` / `frac` are PHYSICAL (PMC traffic of this leg / kernel time): this small shape was never profiled, so
+    # they are null with a reason; the full-size legs quote profiles/traffic.json (test_roofline_is_physical below)
+    assert r["frac"] is None and r["achieved"] is None and r["traffic"] is None and "frac_null_reason" in r
+    assert r["kernel_ms"] > 0 and r["kernel_launches_timed"] == 3          # every step kernel of the timed region
     assert 0 < r["frac_compulsory"] <= 1.0 and r["compulsory_bytes"] < r["algorithmic_bytes_per_launch"]
+    assert r["algorithmic_rate_over_peak"] == r["algorithmic_GBs"] / r["peak"]
     assert abs(d["value"] - d["config"]["global_batch"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     legs = d["legs"]
     assert 2 <= legs["base_batch_65536"]["neg_block"] <= 8 and legs["base_batch_65536"]["roofline"]["kernel_ms"] > 0     # 65536 >= 2 * 30000
@@ -40,7 +44,7 @@ def test_bench_json_contract_small_shape():
     assert [s["batch_per_gpu"] for s in legs["batch_sweep"]] == [4096, 16384] and legs["uniform_item_popularity"]["value"] > 0
     assert legs["config1_d64"]["value"] > 0 and "config3_slice_1.25Mx1M" not in legs       # only beside the default shape
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["cpu_model"]
     assert {"sgd_B80000", "sgd_B65536", "adam_B80000", "score_tile_1024xI", "top50_numpy_argpartition",
             "top50_cxx_partial_sort_1_thread"} <= set(c["legs"])
     s = d["scoring"]["roofline"]
@@ -62,3 +66,24 @@ def test_bench_two_ranks_on_one_gpu(two_pass, exchange):
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 240000 and d["config"]["item_replicas_identical"] is True
     assert ("two-pass" in d["config"]["parallelism"]) == (two_pass == "1")
     assert abs(d["value"] - 240000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_roofline_is_physical():
+    """bench.roofline(): `frac` = PMC-measured HBM bytes of the launch / kernel time / peak -- a fraction, never the
+    algorithmic 24 d bytes per triplet (which exceeds the peak where item sums stay on chip); null with a reason for a
+    leg that was not profiled; the source of the traffic figure is named"""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    key = "U1000000_I100000_d128_B1000000_zipf_nb6"
+    assert key in t
+    r = bench.roofline("bpr_step_blocked_kernel", 0.33, 50, 1_000_000, 100_000, 128, key)
+    assert r["traffic"] == t[key]["hbm_bytes_per_launch"]
+    assert abs(r["achieved"] - r["traffic"] / 0.33e-3 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
+    assert 0.3 < r["frac"] < 1.0 and r["traffic_source"]["file"].startswith("profiles/")
+    assert r["algorithmic_rate_over_peak"] > 1.0            # the contract figure: not a fraction, and named accordingly
+    assert 0.9 < r["traffic_over_compulsory"] < 1.5
+    n = bench.roofline("bpr_step_kernel", 0.1, 10, 4321, 100_000, 128, "no_such_leg")
+    assert n["frac"] is None and n["achieved"] is None and "no PMC profile" in n["frac_null_reason"]
+    assert not any(k.startswith("frac") and isinstance(v, float) and v > 1.0 for k, v in {**r, **n}.items())

@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import DELTA_TOL_SMALL_LR, G1_SGD, G1_SGD_BIGLR, GOLDEN, delta_err, golden, rel_err, split_batches
+from conftest import (DELTA_TOL_SMALL_LR, G1_SGD, G1_SGD_BIGLR, GOLDEN, assert_update, delta_err, golden, rel_err, resolvable_lr,
+                      split_batches)
 
 pytestmark = pytest.mark.gpu
 HP = {"hidden_dim": 32, "pointwise": False, "loss_func": "ce"}     # conf/MF.yaml keys
@@ -76,17 +77,18 @@ def test_hidden_dim_padding_d50(oracle_mod):
     import recsys_pytorch_amd as pkg
     rng = np.random.default_rng(2)
     ds = types.SimpleNamespace(num_users=120, num_items=80)
-    m = pkg.MF(ds, dict(HP, hidden_dim=50, lr=0.05), "cuda")
+    lr = resolvable_lr(77)
+    m = pkg.MF(ds, dict(HP, hidden_dim=50, lr=lr), "cuda")
     P0 = (rng.standard_normal((120, 50)) * 0.1).astype(np.float32)
     Q0 = (rng.standard_normal((80, 50)) * 0.1).astype(np.float32)
     m.load_tables(P0, Q0)
-    orc = oracle_mod.MFOracle(P0, Q0, "sgd", 0.05)
+    orc = oracle_mod.MFOracle(P0, Q0, "sgd", lr)
     for _ in range(3):
         u, i, j = rng.integers(0, 120, 77), rng.integers(0, 80, 77), rng.integers(0, 80, 77)
         l = m.train_step(u, i, j)
         assert abs(float(l) - orc.step(u, i, j)) < 1e-5
-    assert rel_err(m.user_embedding.weight.cpu().numpy(), orc.P) < 1e-5
-    assert rel_err(m.item_embedding.weight.cpu().numpy(), orc.Q) < 1e-5
+    assert_update(m.user_embedding.weight.cpu().numpy(), P0, orc.P, "P")
+    assert_update(m.item_embedding.weight.cpu().numpy(), Q0, orc.Q, "Q")
     assert float(m._P[:, 50:].abs().max()) == 0.0 and float(m._Q[:, 50:].abs().max()) == 0.0
     S = m.predict_batch_users(np.arange(120)).cpu().numpy()
     assert rel_err(S, orc.score(np.arange(120))) < 2e-6
@@ -242,14 +244,17 @@ def test_sampled_triplets_replay_through_oracle(oracle_mod):
     torch.manual_seed(3)
     P = torch.randn(U, d, device="cuda") * 0.1
     Q = torch.randn(I, d, device="cuda") * 0.1
-    orc = oracle_mod.MFOracle(P.cpu().numpy(), Q.cpu().numpy(), "sgd", 0.05)
-    eng = BPREngine(P, Q, 0.05)
+    P0, Q0 = P.cpu().numpy(), Q.cpu().numpy()
+    lr = resolvable_lr(B)                       # the update itself is what is compared (conftest.UPDATE_TOL)
+    orc = oracle_mod.MFOracle(P0, Q0, "sgd", lr)
+    eng = BPREngine(P, Q, lr)
     for _ in range(6):
         u, i, j = eng.sample(ip, ix, B)
         lo = orc.step(u.cpu().numpy(), i.cpu().numpy(), j.cpu().numpy())
         acc = eng.step(u, i, j, users_unique=True)
         assert abs(float(acc.sum()) / B - lo) < 1e-5
-    assert rel_err(P.cpu().numpy(), orc.P) < 1e-5 and rel_err(Q.cpu().numpy(), orc.Q) < 1e-5
+    assert_update(P.cpu().numpy(), P0, orc.P, "P")
+    assert_update(Q.cpu().numpy(), Q0, orc.Q, "Q")
 
 
 @pytest.mark.parametrize("replicas", [1, 4, 16])
@@ -261,9 +266,10 @@ def test_hot_item_replicas_do_not_change_the_sums(oracle_mod, replicas):
     P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
     Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
     w = 1.0 / np.arange(1, I + 1); w /= w.sum()
-    orc = oracle_mod.MFOracle(P0, Q0, "sgd", 0.05)
+    lr = resolvable_lr(B)
+    orc = oracle_mod.MFOracle(P0, Q0, "sgd", lr)
     P, Q = torch.from_numpy(P0).cuda(), torch.from_numpy(Q0).cuda()
-    eng = BPREngine(P, Q, 0.05)
+    eng = BPREngine(P, Q, lr)
     eng.set_hot_items(torch.from_numpy(w), num_hot=37, replicas=replicas)
     for unique in (True, False):
         for _ in range(3):
@@ -273,7 +279,8 @@ def test_hot_item_replicas_do_not_change_the_sums(oracle_mod, replicas):
             acc = eng.step(*(torch.from_numpy(a).int().cuda() for a in (u, i, j)), users_unique=unique)
             assert abs(float(acc.sum()) / B - lo) < 1e-5
     assert float(eng.hot.ghot.abs().max()) == 0.0                    # folded and re-zeroed
-    assert rel_err(P.cpu().numpy(), orc.P) < 1e-5 and rel_err(Q.cpu().numpy(), orc.Q) < 1e-5
+    assert_update(P.cpu().numpy(), P0, orc.P, "P")
+    assert_update(Q.cpu().numpy(), Q0, orc.Q, "Q")
 
 
 @pytest.mark.parametrize("cdf", [True, False])
@@ -289,8 +296,10 @@ def test_sorted_blocked_sampled_path_replays_through_oracle(oracle_mod, d, B, I,
     torch.manual_seed(8)
     P = torch.randn(U, d, device="cuda") * 0.1
     Q = torch.randn(I, d, device="cuda") * 0.1
-    orc = oracle_mod.MFOracle(P.cpu().numpy(), Q.cpu().numpy(), "sgd", 0.05)
-    eng = BPREngine(P, Q, 0.05)
+    P0, Q0 = P.cpu().numpy(), Q.cpu().numpy()
+    lr = resolvable_lr(B)
+    orc = oracle_mod.MFOracle(P0, Q0, "sgd", lr)
+    eng = BPREngine(P, Q, lr)
     eng.neg_block = c
     eng.use_item_cdf = cdf          # item-CDF buckets, or the device radix sort
     hist = np.zeros(I)
@@ -317,7 +326,8 @@ def test_sorted_blocked_sampled_path_replays_through_oracle(oracle_mod, d, B, I,
         acc = eng.step(u, i, j, users_unique=True, neg_block=c, neg_key=eng.last_neg_key)
         assert abs(float(acc.sum()) / B - lo) < 1e-5
     assert len(keys) == 3 and 0 not in keys                              # fresh block permutation per step
-    assert rel_err(P.cpu().numpy(), orc.P) < 1e-5 and rel_err(Q.cpu().numpy(), orc.Q) < 1e-5
+    assert_update(P.cpu().numpy(), P0, orc.P, "P")
+    assert_update(Q.cpu().numpy(), Q0, orc.Q, "Q")
     exp = 3 * B / I
     assert abs(hist.mean() - exp) < 1e-9 and hist.std() < 1.5 * np.sqrt(exp) + 1   # ~Poisson spread
     assert hist.min() > 0 or exp < 8
@@ -481,32 +491,55 @@ def test_item_cdf_buckets_piecewise_above_two_million_positions():
         assert i[q] in row and j[q] not in row
 
 
-def _full_size_step_check(U, I, d, B, deg, want_neg_block, hot=True):
-    """one sampled step at a BASELINE shape through properties that hold at any size: every user at
-    most once, (sorted path) batch ordered by positive item, true positives / negatives on a sample,
-    negatives spread evenly over the catalog, column sums of G zero (each triplet adds +g p to i
-    and -g p to j), loss = mean softplus(-x) of the sampled triplets on the pre-step tables, G equal
-    to an fp64 index_add, and the user-row UPDATE equal to the fp64 gather formula
-    P[u] += lr * sigmoid(-x)/B * (Q[i] - Q[j])  (SURVEY section 8 row a6)."""
+def _full_size_step_check(U, I, d, B, deg, want_neg_block, hot=True, force_iid=False, native=False):
+    """one sampled step at a BASELINE shape, verified in fp64 on the device (tests/stepcheck.py) with a step size that
+    makes the update resolvable (lr = 0.05 * B, conftest.resolvable_lr): the user-row update against the gather formula,
+    EVERY row; G against a dense fp64 index_add; Q after the apply; the loss -- each to 1e-5 OF THE UPDATE, no absolute
+    slack.  Plus what holds at any size: every user at most once, (sorted layouts) batch ordered by positive item, true
+    positives / negatives on a sample, negatives spread evenly over the catalog, rows of other users untouched.
+    The step runs with the flags bench.py's native loop passes at this shape (neg_block / RSX_BATCH_SORTED from
+    BPREngine._sorts), or -- native=True -- THROUGH that loop (rsx_bpr_trainer_run + rsx_bpr_trainer_last_batch)."""
+    from conftest import UPDATE_TOL, resolvable_lr
+    from stepcheck import verify_step
     from recsys_pytorch_amd import rsx
     from recsys_pytorch_amd.data import synthetic_csr
     from recsys_pytorch_amd.sharded import BPREngine
-    lr = 0.05
+    lr = resolvable_lr(B)
     ip, ix = synthetic_csr(U, I, deg, "cuda", seed=2020)
     torch.manual_seed(1)
     P = torch.randn(U, d, device="cuda") * 0.1
     Q = torch.randn(I, d, device="cuda") * 0.1
-    P0 = P.clone()
+    P0, Q0 = P.clone(), Q.clone()
     eng = BPREngine(P, Q, lr)
-    nb = eng.set_neg_block(B, 8)
+    nb = 0 if force_iid else eng.set_neg_block(B, 8)
     assert (nb > 0) == (want_neg_block > 0) and nb <= 8, (nb, want_neg_block)   # which step path engages at this shape
+    ordered = eng._sorts(B)                      # blocked kernel (nb > 0), its TILE = false form (ordered, nb == 0) or the plain kernel
     if hot:
         eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 256, 16)
-    u, i, j = eng.sample(ip, ix, B)
+    loss = torch.zeros(rsx.RSX_LOSS_SLOTS, device="cuda")
+    G_before_apply = None
+    if native:
+        tr = eng.native_trainer(ip, ix, B, loss_acc=loss)
+        tr.run(1)
+        torch.cuda.synchronize()
+        u, i, j, nb_ran, key = tr.last_batch()
+        assert nb_ran == nb and (key != 0) == (nb > 0)
+        assert float(eng.G.abs().max()) == 0.0                              # the loop applied and re-zeroed G
+    else:
+        u, i, j = eng.sample(ip, ix, B)
+        rsx.bpr_step(P, Q, eng.G, u, i, j, lr, 1.0 / B, loss_acc=loss, users_unique=True, hot=eng.hot,
+                     neg_block=nb, neg_key=eng.last_neg_key, batch_sorted=ordered and not nb)
+        if hot:
+            rsx.fold_hot_grad(eng.G, eng.hot)
+        G_before_apply = eng.G.clone()
+        assert bool((Q == Q0).all())                                        # the step leaves Q alone
+        rsx.apply_item_grad(Q, eng.G, lr)
+        torch.cuda.synchronize()
+        assert float(eng.G.abs().max()) == 0.0
     ul, il, jl = u.long(), i.long(), j.long()
     assert int(torch.bincount(ul, minlength=U).max()) == 1
     assert int(il.min()) >= 0 and int(jl.min()) >= 0 and int(jl.max()) < I
-    if nb:
+    if ordered:
         assert bool((il[1:] >= il[:-1]).all())
     pick = torch.arange(0, B, 997, device="cuda")
     ipn, ixn = ip.cpu().numpy(), ix.cpu().numpy()
@@ -515,61 +548,56 @@ def _full_size_step_check(U, I, d, B, deg, want_neg_block, hot=True):
         assert ii in row and jj not in row
     neg_hist = torch.bincount(jl, minlength=I).double()
     assert abs(float(neg_hist.mean()) - B / I) < 1e-9 and float(neg_hist.std()) < 1.5 * (B / I) ** 0.5 + 1
-    x = (P[ul].double() * (Q[il].double() - Q[jl].double())).sum(1)
-    want_loss = float(torch.nn.functional.softplus(-x).mean())
-    loss = torch.zeros(rsx.RSX_LOSS_SLOTS, device="cuda")
-    rsx.bpr_step(P, Q, eng.G, u, i, j, lr, 1.0 / B, loss_acc=loss, users_unique=True, hot=eng.hot,
-                 neg_block=nb, neg_key=eng.last_neg_key)
-    if hot:
-        rsx.fold_hot_grad(eng.G, eng.hot)
-    torch.cuda.synchronize()
-    assert abs(float(loss.double().sum()) / B - want_loss) < 1e-5
-    col = eng.G.double().sum(0)
-    assert float(col.abs().max()) < 1e-6 * float(eng.G.double().abs().sum(0).max()) + 1e-9
-    # G against a dense index_add in fp64 on the same triplets
-    c = torch.sigmoid(-x) / B                                            # -dL/dx
-    want = torch.zeros(I, d, dtype=torch.float64, device="cuda")
-    for s0 in range(0, B, 1 << 18):                                      # in slices: fp64 temporaries stay small
-        sl = slice(s0, min(B, s0 + (1 << 18)))
-        g = -c[sl].unsqueeze(1) * P0[ul[sl]].double()
-        want.index_add_(0, il[sl], g); want.index_add_(0, jl[sl], -g)
-    assert float((eng.G.double() - want).abs().max()) < 1e-5 * float(want.abs().max())
-    del want
-    # the user-row update against the fp64 gather formula, every row
-    moved = torch.zeros(U, dtype=torch.bool, device="cuda")
-    moved[ul] = True
-    worst, biggest = 0.0, 0.0
-    for s0 in range(0, B, 1 << 18):
-        sl = slice(s0, min(B, s0 + (1 << 18)))
-        dP_want = lr * c[sl].unsqueeze(1) * (Q[il[sl]].double() - Q[jl[sl]].double())
-        dP_got = P[ul[sl]].double() - P0[ul[sl]].double()
-        worst = max(worst, float((dP_got - dP_want).abs().max()))
-        biggest = max(biggest, float(dP_want.abs().max()))
-    # fp32 rows of magnitude ~0.5 hold an update of ~1e-8..1e-7 only to their own rounding (3e-8)
-    assert worst < 1e-5 * biggest + 4e-8, (worst, biggest)
-    assert bool(torch.isfinite(P).all()) and bool((P[~moved] == P0[~moved]).all())
-    rsx.apply_item_grad(Q, eng.G, lr)
-    assert float(eng.G.abs().max()) == 0.0 and bool(torch.isfinite(Q).all())
+    r = verify_step(P0, Q0, P, Q, u, i, j, lr, 1.0 / B, G=G_before_apply)
+    ctx = {k: (f"{v:.3e}" if isinstance(v, float) else v) for k, v in r.items()}
+    assert abs(float(loss.double().sum()) / B - r["loss"]) < 1e-5, ctx
+    assert r["max_dP"] > 1e-3 and r["max_dQ"] > 1e-3, ctx                   # the updates ARE resolvable at this step size
+    assert r["err_P"] <= UPDATE_TOL and r["err_Q"] <= UPDATE_TOL and r["untouched_rows_equal"], ctx
+    if G_before_apply is not None:
+        assert r["err_G"] <= UPDATE_TOL, ctx
+        col = G_before_apply.double().sum(0)                                # each triplet adds +g p to i and -g p to j
+        assert float(col.abs().max()) < 1e-6 * float(G_before_apply.double().abs().sum(0).max()) + 1e-9
+    assert bool(torch.isfinite(P).all()) and bool(torch.isfinite(Q).all())
 
 
 @pytest.mark.parametrize("d", [64, 128])
 def test_full_size_sampled_step_invariants(d):
     """BASELINE configs[1] (d=64) and configs[2] (d=128): 1M users x 100K items, B = 1M; the bucket
-    sampler + blocked kernel + hot-item replicas engage (neg_block 8)"""
+    sampler + blocked kernel (bpr_step_blocked_kernel<TILE = true>) + hot-item replicas engage (neg_block 8)"""
     _full_size_step_check(1_000_000, 100_000, d, 1_000_000, 20, want_neg_block=8)
 
 
 def test_full_size_config4_one_rank_slice():
     """BASELINE configs[3] as ONE of its 8 ranks sees it: 1.25M users x 1M items, d=128, 10 positives
-    per user, B = 1.25M.  Q and G are 512 MB each, P 640 MB.  Here B < 2 I: fewer than two updates
-    per item row and step, so the on-chip summation is not engaged (neg_block 0) and the step runs
-    through bpr_step_kernel (atomic row updates + hot-item replicas)."""
+    per user, B = 1.25M.  Q and G are 512 MB each, P 640 MB.  Here B < 2 I: fewer than two updates per item row and
+    step, so the negatives are not blocked; the batch is still ordered by positive item (B >= 2^19) and the step is
+    bpr_step_blocked_kernel<TILE = false> -- the kernel bench.py times at this shape."""
     _full_size_step_check(1_250_000, 1_000_000, 128, 1_250_000, 10, want_neg_block=0)
 
 
+def test_full_size_independent_uniform_negatives():
+    """the headline tables with independent uniform negatives (neg_block 0): batch ordered by positive item,
+    bpr_step_blocked_kernel<TILE = false> (bench.py: legs.independent_uniform_negatives)"""
+    _full_size_step_check(1_000_000, 100_000, 128, 1_000_000, 20, want_neg_block=0, force_iid=True)
+
+
 def test_base_batch_65536_on_the_headline_tables():
-    """SURVEY section 8d's base batch on the configs[2] tables: B = 65 536 < I"""
+    """SURVEY section 8d's base batch on the configs[2] tables: B = 65 536 < I, plain bpr_step_kernel"""
     _full_size_step_check(1_000_000, 100_000, 128, 65_536, 20, want_neg_block=0)
+
+
+@pytest.mark.parametrize("shape", ["headline", "iid", "config3_slice", "base_batch"])
+def test_full_size_step_through_the_native_loop(shape):
+    """the same checks on a step driven by rsx_bpr_trainer_run -- the whole of bench.py's timed region: sampler on the
+    trainer's side stream, step kernel, (replica fold in the) apply -- verified from rsx_bpr_trainer_last_batch"""
+    if shape == "headline":
+        _full_size_step_check(1_000_000, 100_000, 128, 1_000_000, 20, want_neg_block=8, native=True)
+    elif shape == "iid":
+        _full_size_step_check(1_000_000, 100_000, 128, 1_000_000, 20, want_neg_block=0, force_iid=True, native=True)
+    elif shape == "config3_slice":
+        _full_size_step_check(1_250_000, 1_000_000, 128, 1_250_000, 10, want_neg_block=0, native=True)
+    else:
+        _full_size_step_check(1_000_000, 100_000, 128, 65_536, 20, want_neg_block=0, native=True)
 
 
 def test_sorted_runs_layout_replays_through_oracle(oracle_mod):
@@ -582,8 +610,10 @@ def test_sorted_runs_layout_replays_through_oracle(oracle_mod):
     torch.manual_seed(8)
     P = torch.randn(U, d, device="cuda") * 0.1
     Q = torch.randn(I, d, device="cuda") * 0.1
-    orc = oracle_mod.MFOracle(P.cpu().numpy(), Q.cpu().numpy(), "sgd", 0.05)
-    eng = BPREngine(P, Q, 0.05)
+    P0, Q0 = P.cpu().numpy(), Q.cpu().numpy()
+    lr = resolvable_lr(B)
+    orc = oracle_mod.MFOracle(P0, Q0, "sgd", lr)
+    eng = BPREngine(P, Q, lr)
     eng.sorted_min_batch = 16384                      # (default: 2 * I; lowered to take this layout at a small size)
     assert eng.set_neg_block(B, 8) == 0 and eng._sorts(B) and not eng._sorts(1000)
     eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 64, 4)
@@ -600,7 +630,8 @@ def test_sorted_runs_layout_replays_through_oracle(oracle_mod):
         lo = orc.step(un, inn, jn)
         acc = eng.step(u, i, j, users_unique=True, batch_sorted=True)
         assert abs(float(acc.sum()) / B - lo) < 1e-5
-    assert rel_err(P.cpu().numpy(), orc.P) < 1e-5 and rel_err(Q.cpu().numpy(), orc.Q) < 1e-5
+    assert_update(P.cpu().numpy(), P0, orc.P, "P")
+    assert_update(Q.cpu().numpy(), Q0, orc.Q, "Q")
     assert jh.max() <= 12                                                     # negatives: independent uniform, not stratified
 
 
@@ -615,7 +646,8 @@ def test_overlapped_sampler_equals_inline_sampler():
         torch.manual_seed(9)
         P = torch.randn(U, d, device="cuda") * 0.1
         Q = torch.randn(I, d, device="cuda") * 0.1
-        eng = BPREngine(P, Q, 0.05)
+        P_init, Q_init = P.clone(), Q.clone()
+        eng = BPREngine(P, Q, resolvable_lr(B))
         eng.set_neg_block(B, 8)
         assert 2 <= eng.neg_block <= 8
         losses = []
@@ -625,8 +657,9 @@ def test_overlapped_sampler_equals_inline_sampler():
         torch.cuda.synchronize()
         out.append((P.clone(), Q.clone(), losses))
     assert np.allclose(out[0][2], out[1][2], rtol=1e-6)              # same triplets; atomics reorder fp32 sums
-    # fp32 atomics reorder sums between runs: compare to rounding, not bitwise
-    assert torch.allclose(out[0][0], out[1][0], rtol=0, atol=1e-6) and torch.allclose(out[0][1], out[1][1], rtol=0, atol=1e-6)
+    # fp32 atomics reorder sums between runs: the seven-step UPDATES agree to 1e-5 of their size, not bitwise
+    assert_update(out[0][0].cpu().numpy(), P_init.cpu().numpy(), out[1][0].cpu().numpy(), "P")
+    assert_update(out[0][1].cpu().numpy(), Q_init.cpu().numpy(), out[1][1].cpu().numpy(), "Q")
 
 
 @pytest.mark.parametrize("U,I,B,hot", [(60_000, 3_000, 20_000, True), (30_000, 40_000, 8_192, False), (70_000, 40_000, 30_000, True)])
@@ -645,7 +678,8 @@ def test_native_trainer_equals_hand_driven_steps(U, I, B, hot):
         torch.manual_seed(9)
         P = torch.randn(U, d, device="cuda") * 0.1
         Q = torch.randn(I, d, device="cuda") * 0.1
-        eng = BPREngine(P, Q, 0.05)
+        P_init, Q_init = P.clone(), Q.clone()
+        eng = BPREngine(P, Q, resolvable_lr(B))
         nb = eng.set_neg_block(B, 8)
         assert (2 <= nb <= 8) if B >= 2 * I else nb == 0
         if (U, I, B) == (70_000, 40_000, 30_000):
@@ -674,8 +708,9 @@ def test_native_trainer_equals_hand_driven_steps(U, I, B, hot):
     (Pa, Qa, la, sa, pa), (Pb, Qb, lb, sb, pb) = outs
     assert (sa, pa) == (sb, pb) and sa == 10
     assert abs(la - lb) < 1e-5 * abs(la)
-    # fp32 atomics reorder sums between runs: compare to rounding, not bitwise
-    assert torch.allclose(Pa, Pb, rtol=0, atol=1e-6) and torch.allclose(Qa, Qb, rtol=0, atol=1e-6)
+    # fp32 atomics reorder sums between runs: the ten-step UPDATES agree to 1e-5 of their size, not bitwise
+    assert_update(Pa.cpu().numpy(), P_init.cpu().numpy(), Pb.cpu().numpy(), "P")
+    assert_update(Qa.cpu().numpy(), Q_init.cpu().numpy(), Qb.cpu().numpy(), "Q")
 
 
 def test_native_trainer_steps_replay_through_the_oracle(oracle_mod):
@@ -688,8 +723,10 @@ def test_native_trainer_steps_replay_through_the_oracle(oracle_mod):
     torch.manual_seed(4)
     P = torch.randn(U, d, device="cuda") * 0.1
     Q = torch.randn(I, d, device="cuda") * 0.1
-    orc = oracle_mod.MFOracle(P.cpu().numpy(), Q.cpu().numpy(), "sgd", 0.05)
-    eng = BPREngine(P, Q, 0.05)
+    P0, Q0 = P.cpu().numpy(), Q.cpu().numpy()
+    lr = resolvable_lr(B)
+    orc = oracle_mod.MFOracle(P0, Q0, "sgd", lr)
+    eng = BPREngine(P, Q, lr)
     assert 2 <= eng.set_neg_block(B, 8) <= 8
     acc = torch.zeros(rsx.RSX_LOSS_SLOTS, device="cuda")
     tr = eng.native_trainer(ip, ix, B, loss_acc=acc)
@@ -710,7 +747,8 @@ def test_native_trainer_steps_replay_through_the_oracle(oracle_mod):
         # two batches fit a pass of 9000 users; the third starts the next pass (tail of 1000 dropped)
         assert tr.state() == [(1, 4000), (2, 8000), (3, 13000), (4, 17000)][t]
     assert len(np.unique(np.concatenate(seen[:2]))) == 2 * B             # one pass: no user twice
-    assert rel_err(P.cpu().numpy(), orc.P) < 1e-5 and rel_err(Q.cpu().numpy(), orc.Q) < 1e-5
+    assert_update(P.cpu().numpy(), P0, orc.P, "P")
+    assert_update(Q.cpu().numpy(), Q0, orc.Q, "Q")
     # seek back to the start: the same batch again (counter-based sampler)
     tr.seek(0, 0)
     tr.run(1)
@@ -718,7 +756,7 @@ def test_native_trainer_steps_replay_through_the_oracle(oracle_mod):
     assert np.array_equal(tr.last_batch()[0].cpu().numpy(), seen[0]) and tr.state()[0] == 1
     tr.close()
     with pytest.raises(rsx.RsxError):
-        rsx.BPRTrainer(P, Q, eng.G, ip, ix, 0.05, batch=U + 1, seed=1, seed_key=1)      # batch > users
+        rsx.BPRTrainer(P, Q, eng.G, ip, ix, lr, batch=U + 1, seed=1, seed_key=1)        # batch > users
 
 
 def test_fit_runs_twice_with_different_csrs(ml100k):
@@ -798,16 +836,18 @@ def test_blocked_kernel_is_exact_on_foreign_triplets(oracle_mod):
     U, I, d, B = 9000, 777, 128, 6000
     P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
     Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
-    orc = oracle_mod.MFOracle(P0, Q0, "sgd", 0.05)
+    lr = resolvable_lr(B)
+    orc = oracle_mod.MFOracle(P0, Q0, "sgd", lr)
     P, Q = torch.from_numpy(P0).cuda(), torch.from_numpy(Q0).cuda()
     G = torch.zeros_like(Q)
     for _ in range(3):
         u, i, j = rng.permutation(U)[:B], rng.integers(0, I, B), rng.integers(0, I, B)
         orc.step(u, i, j)
-        rsx.bpr_step(P, Q, G, *(torch.from_numpy(a).int().cuda() for a in (u, i, j)), 0.05, 1.0 / B,
+        rsx.bpr_step(P, Q, G, *(torch.from_numpy(a).int().cuda() for a in (u, i, j)), lr, 1.0 / B,
                      users_unique=True, neg_block=8)
-        rsx.apply_item_grad(Q, G, 0.05)
-    assert rel_err(P.cpu().numpy(), orc.P) < 1e-5 and rel_err(Q.cpu().numpy(), orc.Q) < 1e-5
+        rsx.apply_item_grad(Q, G, lr)
+    assert_update(P.cpu().numpy(), P0, orc.P, "P")
+    assert_update(Q.cpu().numpy(), Q0, orc.Q, "Q")
 
 
 def test_synthetic_csr_shape_and_popularity():

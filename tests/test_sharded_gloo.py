@@ -14,6 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+from conftest import UPDATE_TOL, assert_update, resolvable_lr  # noqa: E402  (lr = 0.05 * B: the update itself is compared)
+
 
 def _worker(rank, world, port, P0, Q0, batches, lr, out, unique=False, exchange="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -42,7 +44,8 @@ def test_two_ranks_equal_one_process(oracle_mod, exchange):
     """exchange = all_reduce(G) + identical apply, or reduce_scatter(G) -> own item shard applied ->
     all_gather of the updated rows (97 items on 2 ranks: the padded-shard path)"""
     rng = np.random.default_rng(9)
-    U, I, d, B, T, lr = 301, 97, 64, 200, 5, 0.05
+    U, I, d, B, T = 301, 97, 64, 200, 5
+    lr = resolvable_lr(B)
     P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
     Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
     batches = [(rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)) for _ in range(T)]
@@ -61,8 +64,8 @@ def test_two_ranks_equal_one_process(oracle_mod, exchange):
         assert np.allclose(losses, ref_losses, rtol=1e-5, atol=1e-6)
     assert np.array_equal(out[0][3], out[1][3]), "item replicas diverged"
     assert out[0][5] == out[1][5]
-    err = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
-    assert err(P, single.P) < 1e-5 and err(out[0][3], single.Q) < 1e-5
+    assert_update(P, P0, single.P, "P")
+    assert_update(out[0][3], Q0, single.Q, "Q")
 
 
 @pytest.mark.timeout(300)
@@ -71,7 +74,8 @@ def test_two_ranks_with_the_exchange_under_the_user_pass_equal_one_process(oracl
     """batches with unique users take the two-pass step (item pass -> async all-reduce of G ->
     user pass, BPREngine.overlap_exchange): same step as one launch"""
     rng = np.random.default_rng(10)
-    U, I, d, B, T, lr = 301, 97, 64, 200, 4, 0.05
+    U, I, d, B, T = 301, 97, 64, 200, 4
+    lr = resolvable_lr(B)
     P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
     Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
     batches = [(rng.permutation(U)[:B], rng.integers(0, I, B), rng.integers(0, I, B)) for _ in range(T)]
@@ -88,8 +92,8 @@ def test_two_ranks_with_the_exchange_under_the_user_pass_equal_one_process(oracl
         P[lo:hi] = Pr
         assert np.allclose(losses, ref_losses, rtol=1e-5, atol=1e-6)
     assert np.array_equal(out[0][3], out[1][3]), "item replicas diverged"
-    err = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
-    assert err(P, single.P) < 1e-5 and err(out[0][3], single.Q) < 1e-5
+    assert_update(P, P0, single.P, "P")
+    assert_update(out[0][3], Q0, single.Q, "Q")
 
 
 def _gpu_worker(rank, world, port, P0, Q0, batches, lr, out, unique=False, exchange="allreduce"):
@@ -125,7 +129,8 @@ def test_two_ranks_on_hip_kernels_equal_one_process(oracle_mod, exchange):
     """same check with the real HIP kernels: two processes (sharing the box's GPU, gloo for the
     all-reduce) on their own triplets == one process on the concatenated batch"""
     rng = np.random.default_rng(19)
-    U, I, d, B, T, lr = 4001, 1500, 128, 3000, 4, 0.05
+    U, I, d, B, T = 4001, 1500, 128, 3000, 4
+    lr = resolvable_lr(B)
     P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
     Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
     batches = [(rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)) for _ in range(T)]
@@ -140,9 +145,9 @@ def test_two_ranks_on_hip_kernels_equal_one_process(oracle_mod, exchange):
         lo, hi, Pr, Qr, losses = out[r]
         P[lo:hi] = Pr
         assert np.allclose(losses, ref_losses, rtol=1e-5, atol=1e-6)
-    err = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
     assert np.array_equal(out[0][3], out[1][3]), "item replicas diverged"
-    assert err(P, single.P) < 1e-5 and err(out[0][3], single.Q) < 1e-5
+    assert_update(P, P0, single.P, "P")
+    assert_update(out[0][3], Q0, single.Q, "Q")
 
 
 @pytest.mark.gpu
@@ -150,7 +155,8 @@ def test_two_ranks_on_hip_kernels_equal_one_process(oracle_mod, exchange):
 @pytest.mark.parametrize("exchange", ["allreduce", "scatter_gather"])
 def test_two_ranks_on_hip_kernels_with_the_exchange_under_the_user_pass(oracle_mod, exchange):
     rng = np.random.default_rng(29)
-    U, I, d, B, T, lr = 4001, 1501, 128, 3000, 4, 0.05
+    U, I, d, B, T = 4001, 1501, 128, 3000, 4
+    lr = resolvable_lr(B)
     P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
     Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
     batches = [(rng.permutation(U)[:B], (rng.integers(0, I, B) ** 2) // I, rng.integers(0, I, B)) for _ in range(T)]
@@ -165,9 +171,9 @@ def test_two_ranks_on_hip_kernels_with_the_exchange_under_the_user_pass(oracle_m
         lo, hi, Pr, Qr, losses = out[r]
         P[lo:hi] = Pr
         assert np.allclose(losses, ref_losses, rtol=1e-5, atol=1e-6)
-    err = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
     assert np.array_equal(out[0][3], out[1][3]), "item replicas diverged"
-    assert err(P, single.P) < 1e-5 and err(out[0][3], single.Q) < 1e-5
+    assert_update(P, P0, single.P, "P")
+    assert_update(out[0][3], Q0, single.Q, "Q")
 
 
 def _gpu_sampled_worker(rank, world, port, mode, U, I, d, B, steps, out, exchange="allreduce"):
@@ -181,7 +187,8 @@ def _gpu_sampled_worker(rank, world, port, mode, U, I, d, B, steps, out, exchang
     P = torch.randn(U, d, device=dev) * 0.1
     torch.manual_seed(7)
     Q = torch.randn(I, d, device=dev) * 0.1
-    eng = BPREngine(P, Q, 0.05, user_begin=rank * U, seed=11, exchange=exchange)
+    P_init, Q_init = P.cpu().numpy(), Q.cpu().numpy()
+    eng = BPREngine(P, Q, resolvable_lr(world * B), user_begin=rank * U, seed=11, exchange=exchange)
     Q = eng.Q
     eng.set_neg_block(B, 8)
     eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 32, 4)
@@ -197,7 +204,7 @@ def _gpu_sampled_worker(rank, world, port, mode, U, I, d, B, steps, out, exchang
     torch.cuda.synchronize()
     # (the Python-driven engine's epoch_pos already counts the batch it sampled ahead)
     pos = eng.epoch_pos if mode == "native" else eng._bufs[eng._cur]["pos_before"]
-    out[(mode, rank)] = (P.cpu().numpy(), Q.cpu().numpy(), eng.step_count, pos)
+    out[(mode, rank)] = (P.cpu().numpy(), Q.cpu().numpy(), eng.step_count, pos, P_init, Q_init)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -218,10 +225,11 @@ def test_two_ranks_native_loop_with_exchange_callbacks_equals_python_driven(B, I
     for mode in ("python", "native"):
         assert np.array_equal(out[(mode, 0)][1], out[(mode, 1)][1]), f"item replicas diverged ({mode})"
     for r in range(2):
-        Pp, Qp, sp_, pp = out[("python", r)]
-        Pn, Qn, sn, pn = out[("native", r)]
+        Pp, Qp, sp_, pp, P_init, Q_init = out[("python", r)]
+        Pn, Qn, sn, pn = out[("native", r)][:4]
         assert (sp_, pp) == (sn, pn) and sn == steps
-        assert np.abs(Pp - Pn).max() < 1e-6 and np.abs(Qp - Qn).max() < 1e-6
+        assert_update(Pn, P_init, Pp, "P")          # the five-step updates agree to 1e-5 of their size
+        assert_update(Qn, Q_init, Qp, "Q")
 
 
 def _rccl_one_rank_worker(rank, port, U, I, d, B, steps, out):
@@ -233,12 +241,15 @@ def _rccl_one_rank_worker(rank, port, U, I, d, B, steps, out):
     from recsys_pytorch_amd.sharded import BPREngine
     ip, ix = synthetic_csr(U, I, 10, dev, seed=40)
 
+    init = {}
+
     def run(force, exchange, two_pass, mode):
         torch.manual_seed(100)
         P = torch.randn(U, d, device=dev) * 0.1
         torch.manual_seed(7)
         Q = torch.randn(I, d, device=dev) * 0.1
-        eng = BPREngine(P, Q, 0.05, seed=11, exchange=exchange, force_sharded=force)
+        init.setdefault("tables", (P.cpu().numpy(), Q.cpu().numpy()))
+        eng = BPREngine(P, Q, resolvable_lr(B), seed=11, exchange=exchange, force_sharded=force)
         eng.overlap_exchange = bool(two_pass) and force
         eng.set_neg_block(B, 8)
         eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 32, 4)
@@ -253,7 +264,7 @@ def _rccl_one_rank_worker(rank, port, U, I, d, B, steps, out):
         torch.cuda.synchronize()
         return P.cpu().numpy(), eng.Q.cpu().numpy()
 
-    def run_stale(exchange, lr=20.0):
+    def run_stale(exchange, lr=resolvable_lr(B) / 10):
         """native loop with the opt-in one-step-stale exchange, and the same recurrence driven by hand on the same
         triplets: step t's kernel reads the item table WITHOUT the update of step t-1 (applied right after it)"""
         from recsys_pytorch_amd import rsx
@@ -305,6 +316,7 @@ def _rccl_one_rank_worker(rank, port, U, I, d, B, steps, out):
         for two_pass in (False, True):
             for mode in ("native", "python"):
                 res[(exchange, two_pass, mode)] = run(True, exchange, two_pass, mode)
+    res["init"] = init["tables"]
     out.update(res)
     dist.barrier()
     dist.destroy_process_group()
@@ -326,15 +338,17 @@ def test_exchange_over_rccl_with_one_rank_equals_the_unsharded_step(B, I):
     port = 29500 + (os.getpid() + 29 + B) % 2000
     mp.spawn(_rccl_one_rank_worker, args=(port, U, I, d, B, steps, out), nprocs=1, join=True)
     P0, Q0 = out["plain"]
-    assert len(out) == 15
+    P_init, Q_init = out["init"]
+    assert len(out) == 16
     for key, (P, Q) in out.items():
-        if key[0] in ("stale", "stale_ref", "stale_sync"):
+        if key == "init" or key[0] in ("stale", "stale_ref", "stale_sync"):
             continue
-        assert np.abs(P - P0).max() < 1e-6 and np.abs(Q - Q0).max() < 1e-6, key
+        assert_update(P, P_init, P0, f"P {key}")    # the five-step updates agree to 1e-5 of their size
+        assert_update(Q, Q_init, Q0, f"Q {key}")
     # the opt-in one-step-stale exchange: equal to its own recurrence driven by hand, and NOT the synchronous step
     for exchange in ("allreduce", "scatter_gather"):
         (P, Q), (Pr, Qr), (Ps, Qs) = out[("stale", exchange)], out[("stale_ref", exchange)], out[("stale_sync", exchange)]
-        scale = np.abs(Qr - Q0).max()          # lr = 20: the five updates are O(0.1) of the table
+        scale = np.abs(Qr - Q_init).max()      # the five updates are O(0.1) of the table
         assert scale > 1e-2
         assert np.abs(P - Pr).max() < 1e-5 * scale and np.abs(Q - Qr).max() < 1e-5 * scale, exchange
         assert np.abs(Q - Qs).max() > 1e-3 * scale, "the stale recurrence cannot be told from the synchronous step"

@@ -1,34 +1,44 @@
 """tools/install_profiles.py <tag> : copy the summaries tools/refresh_profiles.sh left under gpurun_out/profiles_<tag>/
-into profiles/ and rebuild profiles/traffic.json (PMC-measured HBM bytes per launch of each leg's step kernel)."""
-import csv, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+into profiles/ and rebuild profiles/traffic.json -- the PMC-measured HBM bytes per launch of every bench leg's dominant
+kernel, keyed the way bench.py looks them up, each entry naming the profile file and the commit it was taken at."""
+import csv, glob, json, os, shutil, subprocess, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", f"profiles_{tag}"), os.path.join(root, "profiles")
 for f in os.listdir(src):
     if f.startswith(tag) and (f.endswith(".json") or f.endswith("kernel_stats.csv")):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
-b = json.load(open(os.path.join(dst, f"{tag}_bench_default.json")))
-note = ("rocprofv3 --pmc passes over tools/step_prof.py (tools/refresh_profiles.sh); read side = TCC_EA0_RDREQ x 128 B (all requests of these "
-        "kernels are 128-byte; equals 2 x FETCH_SIZE, the gfx950 correction of MI355X_MICROARCH.md), write side = WRITE_SIZE "
-        "(= TCC_EA0_WRREQ_64B x 64 B + atomics)")
-t = {}
-legs = {"B1M_blocked": (b["roofline"]["traffic_key"], "bpr_step_blocked_kernel<128, 3, unsigned int, true>"),
-        "B65536_plain": (b["legs"]["base_batch_65536"]["roofline"]["traffic_key"], "bpr_step_kernel<128, 0, 3, unsigned int>"),
-        "B1M_iid": (b["legs"]["independent_uniform_negatives"]["roofline"]["traffic_key"], "bpr_step_blocked_kernel<128, 3, unsigned int, false>")}
-if "--pmc-only" in sys.argv:
-    pass
-for leg, (key, kname) in legs.items():
-    d = json.load(open(os.path.join(dst, f"{tag}_pmc_step_{leg}.json")))
-    ks = [k for k in d if k.replace(" ", "") == kname.replace(" ", "")]
-    if not ks:
-        print("no counters for", leg, list(d)); continue
+commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+dirty = bool(subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "recsys_pytorch_amd"], capture_output=True, text=True).stdout.strip())
+note = ("rocprofv3 --pmc passes (tools/refresh_profiles.sh, one pass per counter group); read side = TCC_EA0_RDREQ x 128 B (every "
+        "request of these kernels is 128-byte; equals 2 x FETCH_SIZE, the gfx950 correction of MI355X_MICROARCH.md), write side = "
+        "WRITE_SIZE KB (= TCC_EA0_WRREQ_64B x 64 B + atomics); mean per launch")
+tpath = os.path.join(dst, "traffic.json")
+t = json.load(open(tpath)) if os.path.exists(tpath) and "--fresh" not in sys.argv else {}
+for meta_path in sorted(glob.glob(os.path.join(dst, f"{tag}_pmc_*.meta.json"))):
+    meta = json.load(open(meta_path))
+    prof = os.path.basename(meta_path).replace(".meta.json", ".json")
+    try:
+        d = json.load(open(os.path.join(dst, prof)))
+    except OSError:
+        print("no counters file for", prof); continue
+    want = meta["kernel"].replace(" ", "")
+    ks = [k for k in d if k.replace(" ", "") == want] or [k for k in d if k.replace(" ", "").startswith(want)]
+    if not ks or "TCC_EA0_RDREQ_sum" not in d[ks[0]] or "WRITE_SIZE" not in d[ks[0]]:
+        print("no counters for", prof, meta["kernel"], list(d)); continue
     v = d[ks[0]]
     rd = v["TCC_EA0_RDREQ_sum"] * 128.0
-    t[key] = {"hbm_bytes_per_launch": rd + v["WRITE_SIZE"] * 1024.0, "read_bytes": rd, "write_bytes": v["WRITE_SIZE"] * 1024.0,
-              "FETCH_SIZE_KB": v["FETCH_SIZE"], "WRITE_SIZE_KB": v["WRITE_SIZE"], "ea_atomic_requests": v.get("TCC_EA0_ATOMIC_sum"),
-              "kernel": kname, "profile": f"{tag}_pmc_step_{leg}.json", "kernel_us_under_profiler": v.get("mean_us"), "note": note}
-    print(leg, key, "%.2f GB" % (t[key]["hbm_bytes_per_launch"] / 1e9))
-json.dump(t, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
-print("bench", b["value"], b["ms_per_step"], "kernel_ms", b["roofline"]["kernel_ms"])
-for r in list(csv.DictReader(open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))))[:16]:
-    print(r["Name"].replace("(anonymous namespace)::", "")[:80], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1))
+    t[meta["key"]] = {"hbm_bytes_per_launch": rd + v["WRITE_SIZE"] * 1024.0, "read_bytes": rd, "write_bytes": v["WRITE_SIZE"] * 1024.0,
+                      "FETCH_SIZE_KB": v.get("FETCH_SIZE"), "WRITE_SIZE_KB": v["WRITE_SIZE"], "ea_atomic_requests": v.get("TCC_EA0_ATOMIC_sum"),
+                      "tcc_hit": v.get("TCC_HIT_sum"), "tcc_miss": v.get("TCC_MISS_sum"), "tcc_req": v.get("TCC_REQ_sum"),
+                      "kernel": ks[0], "profile": prof, "commit": commit + ("+uncommitted" if dirty else ""),
+                      "kernel_us_under_profiler": v.get("mean_us"), "command": meta, "note": note}
+    print("%-16s %-46s %.3f GB/launch" % (prof.replace(f"{tag}_pmc_", "").replace(".json", ""), meta["key"], t[meta["key"]]["hbm_bytes_per_launch"] / 1e9))
+json.dump(t, open(tpath, "w"), indent=1)
+try:
+    b = json.load(open(os.path.join(dst, f"{tag}_bench_default.json")))
+    print("bench", b["value"], b["ms_per_step"], "kernel_ms", b["roofline"]["kernel_ms"])
+    for r in list(csv.DictReader(open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))))[:16]:
+        print(r["Name"].replace("(anonymous namespace)::", "")[:80], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1))
+except (OSError, ValueError, KeyError) as e:
+    print("(no bench summary in this refresh:", e, ")")

@@ -12,7 +12,7 @@ import csv, glob
 for f in glob.glob("/tmp/sct/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Name"]
-        if any(s in n for s in ("score_tile", "merge_cand", "topk_rows", "mask_seen", "take_tau", "fill", "Memset", "memset")):
+        if any(s in n for s in ("score_tile", "merge_cand", "topk_rows", "fill", "Memset", "memset")):
             print(f'   {n.split("(")[0][-48:]:48s} calls {r["Calls"]:>4s} avg {float(r["AverageNs"])/1e3:9.1f} us total {float(r["TotalDurationNs"])/1e3:10.1f} us')
 PY
   done

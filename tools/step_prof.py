@@ -1,6 +1,8 @@
 """tools/step_prof.py [B] [neg_block] [steps] : the native loop on the bench workload for a few steps -- the thing
-rocprofv3 wraps in tools/pmc_groups.py (no timing of its own)"""
-import os, sys, torch
+rocprofv3 wraps in tools/pmc_groups.py (no timing of its own).  Shape through the environment: USERS, ITEMS, DIM, DEG, POP.
+With STEP_PROF_META=<file> it also writes which bench leg this is: the traffic key bench.py looks up in
+profiles/traffic.json and the step kernel's full name (tools/install_profiles.py reads it)."""
+import json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from recsys_pytorch_amd import rsx
 from recsys_pytorch_amd.data import synthetic_csr
@@ -9,15 +11,21 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 nbw = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 U, I, d = int(os.environ.get("USERS", 1_000_000)), int(os.environ.get("ITEMS", 100_000)), int(os.environ.get("DIM", 128))
+pop = os.environ.get("POP", "zipf")
 dev = torch.device("cuda")
 torch.manual_seed(2020)
 P = torch.randn(U, d, device=dev) * 0.1
 Q = torch.randn(I, d, device=dev) * 0.1
-ip, ix = synthetic_csr(U, I, int(os.environ.get("DEG", 20)), dev, popularity=os.environ.get("POP", "zipf"))
+ip, ix = synthetic_csr(U, I, int(os.environ.get("DEG", 20)), dev, popularity=pop)
 eng = BPREngine(P, Q, 0.05)
-if nbw:
-    eng.set_neg_block(B, nbw)
+nb = eng.set_neg_block(B, nbw) if nbw else 0
 eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 256, 16)
+if os.environ.get("STEP_PROF_META"):
+    kernel = (f"bpr_step_blocked_kernel<{d}, 3, unsigned int, {'true' if nb else 'false'}>" if (nb or eng._sorts(B))
+              else f"bpr_step_kernel<{d}, 0, 3, unsigned int>")
+    json.dump({"key": f"U{U}_I{I}_d{d}_B{B}_{pop}_nb{nb}", "kernel": kernel, "argv": sys.argv[1:],
+               "env": {k: os.environ[k] for k in ("USERS", "ITEMS", "DIM", "DEG", "POP") if k in os.environ}},
+              open(os.environ["STEP_PROF_META"], "w"))
 loss = torch.zeros(rsx.RSX_LOSS_SLOTS, device=dev)
 tr = eng.native_trainer(ip, ix, B, loss_acc=loss)
 tr.run(steps)
