@@ -287,12 +287,23 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
 // positive item but too small for blocked negatives (B < 2 I: fewer than two updates per item row, so the
 // negative side has nothing to sum): wavefront w owns the positions [w * span, (w + 1) * span), positive runs
 // are summed in registers (Zipf positives at B = 65 536: 65K row updates become ~25K), negatives go to G one by one.
+// ITEM CHUNKS (include/rsx.h; chunks.C > 1, TILE only).  The wavefronts [k * nbc, (k + 1) * nbc) belong to item range k:
+// they take the batch positions [chunk_pos[k], chunk_pos[k + 1]) -- all triplets whose positive lies in the range, and by the
+// sampler's rule their negatives too -- so when they are done the rows [k * Ic, (k + 1) * Ic) of G are complete, and whoever
+// waits on progress[k] == nbc (the native loop's own stream) can exchange / apply that range under the rest of this launch.
+struct ChunkRun {
+    int C;                       // <= 1: off
+    int64_t Ic, nbc;             // rows and negative blocks per range
+    const int64_t *pos;          // [C + 1] first batch position of each range (device, written by the sampler)
+    uint32_t *progress;          // [RSX_PROGRESS_WORDS]
+};
+
 template <int D, int PASS, typename OffT, bool TILE>
 __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_kernel(
     float *__restrict__ P, const float *__restrict__ Q, float *__restrict__ G,
     const int32_t *__restrict__ U_idx, const int32_t *__restrict__ I_idx,
     const int32_t *__restrict__ J_idx, int64_t B, int64_t num_items, int c, int64_t span, uint64_t neg_key, float lr,
-    float inv_batch, float *__restrict__ loss_acc, HotMap hot)
+    float inv_batch, float *__restrict__ loss_acc, HotMap hot, ChunkRun chunks)
 {
     constexpr bool kItems = (PASS & kPassItems) != 0, kUsers = (PASS & kPassUsers) != 0;
     extern __shared__ __attribute__((aligned(16))) float neg_acc[];   // [4 waves][c][D]
@@ -300,16 +311,28 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR;
     const int k = lane % LPR;
-    const int wib = threadIdx.x >> 6;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: everything derived from it lives in SGPRs
     const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wib;
     float *acc = nullptr;
     int64_t b0, b1;
     int32_t item_lo = 0, item_hi = 0;                // the item block of this wavefront's negatives (TILE)
+    int32_t range_lo = 0, range_hi = 0x7fffffff;     // item range every row this wavefront sums into must lie in (chunks)
+    int my_range = 0;
     if constexpr (TILE) {
+        if (chunks.C > 1) {
+            my_range = (int)((uint32_t)wave / (uint32_t)chunks.nbc);
+            if (my_range >= chunks.C) return;
+            const int64_t wic = wave - (int64_t)my_range * chunks.nbc;
+            const int64_t pc = chunks.pos[my_range], nc = chunks.pos[my_range + 1] - pc;
+            b0 = pc + ceil_div64(wic * c * nc, chunks.Ic);
+            b1 = pc + ceil_div64((wic + 1) * c * nc, chunks.Ic);
+            range_lo = (int32_t)(my_range * chunks.Ic);
+            range_hi = (int32_t)(range_lo + chunks.Ic);
+            item_lo = range_lo + (int32_t)(neg_block_of(wic, chunks.nbc, chunk_key(neg_key, my_range)) * c);
+            item_hi = item_lo + c;                   // (padding rows of the range exist in G and stay zero)
+        } else {
         const int64_t nblocks = ceil_div64(num_items, c);
         if (wave >= nblocks) return;
-        acc = neg_acc + (size_t)wib * c * D;
-        for (int e = lane; e < c * D; e += 64) acc[e] = 0.0f;
         // batch positions of this wavefront, and the item block its negatives come from
         const int64_t nom_lo = wave * c;
         const int64_t nom_hi = (nom_lo + c < num_items) ? nom_lo + c : num_items;
@@ -317,6 +340,9 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
         b1 = ceil_div64(nom_hi * B, num_items);
         item_lo = (int32_t)(neg_block_of(wave, nblocks, neg_key) * c);            // num_items < 2^31
         item_hi = (int32_t)(((int64_t)item_lo + c < num_items) ? (int64_t)item_lo + c : num_items);
+        }
+        acc = neg_acc + (size_t)wib * c * D;
+        for (int e = lane; e < c * D; e += 64) acc[e] = 0.0f;
     } else {
         b0 = wave * span;
         if (b0 >= B) return;
@@ -337,6 +363,8 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
     // about the same time (same-line atomics serialise): such rows go to the replicas (HotMap)
 #define RSX_RUN_FLUSH(RI, R)                                                      \
     if (kItems && RI >= 0 && !RSX_ABL(1)) {                                       \
+        if (TILE && (RI < range_lo || RI >= range_hi) && k == 0)                  \
+            atomicAdd(chunks.progress + RSX_PROGRESS_VIOLATIONS, 1u);            \
         int32_t hs = -1;                                                          \
         if (hot.slot != nullptr) hs = hot.slot[RI];                               \
         if (hs >= 0) {                                                            \
@@ -381,7 +409,10 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
             // turns -- LDS executes a wavefront's instructions in order.
             const bool neg_local = TILE && (j >= item_lo && j < item_hi);
             if (!RSX_ABL(2)) {
-                if (!neg_local) p.atomic_axpy_at(G, row_off<D, OffT>(j, k), -gi);
+                if (!neg_local) {
+                    p.atomic_axpy_at(G, row_off<D, OffT>(j, k), -gi);
+                    if (TILE && (j < range_lo || j >= range_hi) && k == 0) atomicAdd(chunks.progress + RSX_PROGRESS_VIOLATIONS, 1u);
+                }
 #pragma unroll
                 for (int tt = 0; TILE && tt < TPW; ++tt) {
                     if (sub == tt && neg_local) {
@@ -455,6 +486,28 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
         const float w = wave_sum(loss_local);
         if (lane == 0) rsx_atomic_add(loss_acc + (wave & 63) * (RSX_LOSS_SLOTS / 64), w);   // one 128-B line per slot
     }
+    if constexpr (TILE && kItems) {
+        if (chunks.C > 1) {      // every sum of this wavefront is in G: count it done for its range
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (lane == 0) __hip_atomic_fetch_add(chunks.progress + my_range, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// the native loop's stream waits here until `target` wavefronts of range k have counted themselves done.  One wavefront,
+// one polling lane, asleep between polls; gives up after ~5 s (progress[RSX_PROGRESS_TIMEOUT] set) so that a bug can never
+// hang the device.
+__global__ __launch_bounds__(64) void wait_progress_kernel(const uint32_t *progress, int k, uint32_t target, uint32_t *flags)
+{
+    if (threadIdx.x == 0) {
+        const uint64_t t0 = wall_clock64();              // 100 MHz
+        for (;;) {
+            if (__hip_atomic_load(progress + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+            if (wall_clock64() - t0 > 500000000ull) { atomicAdd(flags + RSX_PROGRESS_TIMEOUT, 1u); break; }
+            __builtin_amdgcn_s_sleep(32);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 // ---- the pointwise branch of the reference model (models/MF.py:99-102 with hparams['pointwise'] = True) -------------
@@ -684,6 +737,30 @@ __global__ __launch_bounds__(kBlock) void fold_hot_kernel(float *__restrict__ G,
     *dst = g;
 }
 
+// the same for the hot rows inside [row_lo, row_hi) only (one item range of the chunked step)
+template <int D>
+__global__ __launch_bounds__(kBlock) void fold_hot_range_kernel(float *__restrict__ G, float *__restrict__ ghot,
+                                                                const int32_t *__restrict__ hot_items, int n_hot,
+                                                                int replicas, int64_t row_lo, int64_t row_hi)
+{
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int s = t / (D / 4), k = t % (D / 4);
+    if (s >= n_hot) return;
+    const int64_t item = hot_items[s];
+    if (item < row_lo || item >= row_hi) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 *src = reinterpret_cast<float4 *>(ghot + (size_t)s * replicas * D) + k;
+    for (int r = 0; r < replicas; ++r) {
+        const float4 v = src[(size_t)r * (D / 4)];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        src[(size_t)r * (D / 4)] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 *dst = reinterpret_cast<float4 *>(G + (size_t)item * D) + k;
+    float4 g = *dst;
+    g.x += acc.x; g.y += acc.y; g.z += acc.z; g.w += acc.w;
+    *dst = g;
+}
+
 // tables of 4 GB and more need 64-bit row offsets (see ADDRESSING above)
 bool wide_offsets(int64_t num_users, int64_t num_items, int d)
 {
@@ -723,10 +800,11 @@ void dispatch_step(int d, bool wide, float *P, const float *Q, float *G, const i
 template <int PASS, bool TILE>
 void dispatch_blocked(int d, bool wide, unsigned blocks, size_t lds, hipStream_t st, float *P, const float *Q, float *G,
                       const int32_t *u, const int32_t *i, const int32_t *j, int64_t B, int64_t num_items,
-                      int c, int64_t span, uint64_t neg_key, float lr, float inv_batch, float *loss_acc, HotMap hot)
+                      int c, int64_t span, uint64_t neg_key, float lr, float inv_batch, float *loss_acc, HotMap hot,
+                      ChunkRun chunks = ChunkRun{1, 0, 0, nullptr, nullptr})
 {
-#define RSX_LAUNCH(D_) do { if (wide) hipLaunchKernelGGL((bpr_step_blocked_kernel<D_, PASS, uint64_t, TILE>), dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u, i, j, B, num_items, c, span, neg_key, lr, inv_batch, loss_acc, hot); \
-                            else hipLaunchKernelGGL((bpr_step_blocked_kernel<D_, PASS, uint32_t, TILE>), dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u, i, j, B, num_items, c, span, neg_key, lr, inv_batch, loss_acc, hot); } while (0)
+#define RSX_LAUNCH(D_) do { if (wide) hipLaunchKernelGGL((bpr_step_blocked_kernel<D_, PASS, uint64_t, TILE>), dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u, i, j, B, num_items, c, span, neg_key, lr, inv_batch, loss_acc, hot, chunks); \
+                            else hipLaunchKernelGGL((bpr_step_blocked_kernel<D_, PASS, uint32_t, TILE>), dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u, i, j, B, num_items, c, span, neg_key, lr, inv_batch, loss_acc, hot, chunks); } while (0)
     switch (d) {
     case 32: RSX_LAUNCH(32); break;
     case 64: RSX_LAUNCH(64); break;
@@ -963,6 +1041,61 @@ RSX_API int rsx_apply_item_grad(float *Q, float *G, int64_t num_items, int d, fl
     const int64_t blocks = ceil_div64(n4, (int64_t)kBlock * 4);
     hipLaunchKernelGGL(apply_item_grad_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(kBlock), 0,
                        (hipStream_t)stream, (float4 *)Q, (float4 *)G, n4, lr, hot, d / 4);
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+}
+
+RSX_API int rsx_bpr_step_chunked(float *P, const float *Q, float *G, int64_t num_users, int64_t num_items,
+                                 int64_t items_real, int chunks, const int32_t *u_dev, const int32_t *i_dev,
+                                 const int32_t *j_dev, int64_t batch, int d, float lr, float inv_batch, float *loss_acc,
+                                 const int32_t *hot_slot_dev, float *G_hot, int hot_replicas, int neg_block,
+                                 uint64_t neg_key, const int64_t *chunk_pos_dev, uint32_t *progress_dev,
+                                 rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(P && Q && G && chunk_pos_dev && progress_dev, "null pointer");
+    RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64 or 128");
+    RSX_CHECK_ARG(chunks >= 2 && chunks <= RSX_MAX_CHUNKS, "chunks must be in [2, RSX_MAX_CHUNKS]");
+    RSX_CHECK_ARG(neg_block >= 1 && neg_block <= kMaxNegBlock, "the chunked step needs neg_block in [1, 16]");
+    RSX_CHECK_ARG(batch >= 0 && num_users > 0 && items_real > 0, "negative size");
+    const ChunkGeom g = chunk_geom(items_real, chunks, neg_block);
+    RSX_CHECK_ARG(num_items == g.Ic * chunks, "num_items must be chunks * rsx_chunk_rows(items_real, chunks, neg_block)");
+    if (batch == 0) return RSX_OK;
+    RSX_CHECK_ARG(u_dev && i_dev && j_dev, "null index pointer");
+    HotMap hot{nullptr, nullptr, 1};
+    if (hot_slot_dev != nullptr) {
+        RSX_CHECK_ARG(G_hot != nullptr, "hot_slot_dev given without G_hot");
+        RSX_CHECK_ARG(hot_replicas >= 1 && (hot_replicas & (hot_replicas - 1)) == 0, "hot_replicas must be a power of two");
+        hot = HotMap{hot_slot_dev, G_hot, hot_replicas};
+    }
+    const bool wide = wide_offsets(num_users, num_items, d) || batch >= (1ll << 30);
+    const int64_t waves = g.nbc * chunks;
+    const unsigned blocks = (unsigned)ceil_div64(waves, kWavesPerBlock);
+    const size_t lds = (size_t)kWavesPerBlock * neg_block * d * sizeof(float);
+    dispatch_blocked<kPassBoth, true>(d, wide, blocks, lds, (hipStream_t)stream, P, Q, G, u_dev, i_dev, j_dev, batch, num_items,
+                                      neg_block, 0, neg_key, lr, inv_batch, loss_acc, hot,
+                                      ChunkRun{chunks, g.Ic, g.nbc, chunk_pos_dev, progress_dev});
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+}
+
+int rsx_wait_progress(const uint32_t *progress, int k, uint32_t target, hipStream_t st)
+{
+    hipLaunchKernelGGL(wait_progress_kernel, dim3(1), dim3(64), 0, st, progress, k, target, const_cast<uint32_t *>(progress));
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+}
+
+int rsx_fold_hot_grad_range(float *G, float *G_hot, const int32_t *hot_items_dev, int n_hot, int hot_replicas, int d,
+                            int64_t row_lo, int64_t row_hi, hipStream_t st)
+{
+    if (n_hot == 0) return RSX_OK;
+    const int threads = n_hot * (d / 4);
+    const unsigned g = (unsigned)((threads + kBlock - 1) / kBlock);
+    switch (d) {
+    case 32: hipLaunchKernelGGL(fold_hot_range_kernel<32>, dim3(g), dim3(kBlock), 0, st, G, G_hot, hot_items_dev, n_hot, hot_replicas, row_lo, row_hi); break;
+    case 64: hipLaunchKernelGGL(fold_hot_range_kernel<64>, dim3(g), dim3(kBlock), 0, st, G, G_hot, hot_items_dev, n_hot, hot_replicas, row_lo, row_hi); break;
+    default: hipLaunchKernelGGL(fold_hot_range_kernel<128>, dim3(g), dim3(kBlock), 0, st, G, G_hot, hot_items_dev, n_hot, hot_replicas, row_lo, row_hi); break;
+    }
     RSX_CHECK_LAUNCH();
     return RSX_OK;
 }

@@ -106,3 +106,34 @@ __host__ __device__ __forceinline__ int64_t neg_block_of(int64_t w, int64_t nblo
 {
     return neg_key == 0 ? w : (int64_t)feistel_perm((uint32_t)w, (uint32_t)nblocks, half_bits_for(nblocks), neg_key);
 }
+
+// ---- item chunks (include/rsx.h: "item chunks") -------------------------------------------------
+// The relabelled item space holds C ranges of Ic rows (Ic a multiple of the negative block c); range k has
+// real(k) = base + (k < rem) real items at its start, padding rows behind them.  nbc = Ic / c blocks per range.
+struct ChunkGeom {
+    int C, c;
+    int64_t Ic, base, rem, nbc;
+    __host__ __device__ __forceinline__ int64_t real(int k) const { return base + (k < rem ? 1 : 0); }
+};
+__host__ __device__ __forceinline__ ChunkGeom chunk_geom(int64_t items_real, int chunks, int neg_block)
+{
+    ChunkGeom g;
+    g.C = chunks; g.c = neg_block;
+    g.base = items_real / chunks; g.rem = items_real % chunks;
+    const int64_t most = g.base + (g.rem > 0 ? 1 : 0);
+    g.Ic = ceil_div64(most, neg_block) * neg_block;
+    g.nbc = g.Ic / neg_block;
+    return g;
+}
+// per-range key of the negative-block permutation (nonzero)
+__host__ __device__ __forceinline__ uint64_t chunk_key(uint64_t neg_key, int k) { return splitmix64(neg_key ^ (0xA24BAED4963EE407ull * (uint64_t)(k + 1))) | 1ull; }
+
+// rsx_comm.hip: the collectives the native loop issues (in place on device buffers, asynchronous on `st`)
+int rsx_comm_all_reduce(rsx_comm *c, float *buf, int64_t n, hipStream_t st);
+int rsx_comm_reduce_scatter(rsx_comm *c, float *buf, int64_t n_per_rank, hipStream_t st);
+int rsx_comm_all_gather(rsx_comm *c, float *buf, int64_t n_per_rank, hipStream_t st);
+
+// rsx_bpr.hip: pieces of the chunked step the native loop queues on its own stream
+int rsx_wait_progress(const uint32_t *progress, int k, uint32_t target, hipStream_t st);     // returns when progress[k] >= target
+int rsx_fold_hot_grad_range(float *G, float *G_hot, const int32_t *hot_items_dev, int n_hot, int hot_replicas, int d,
+                            int64_t row_lo, int64_t row_hi, hipStream_t st);

@@ -189,7 +189,7 @@ constexpr int kPerThread = kChunk / kChunkThreads;
 constexpr int kBucketMean = 832;          // expected pairs per bucket: 1024 - 6.6 sigma
 constexpr int kSortCap = 2048;            // pairs a bucket may hold and still be sorted in LDS
 constexpr int64_t kPiece = 1ll << 21;     // positions bucketed per pass (bounds LDS bins and workspace)
-constexpr int kMaxBuckets = (int)(kPiece / kBucketMean) + 3;
+constexpr int kMaxBuckets = (int)(kPiece / kBucketMean) + 3 + RSX_MAX_CHUNKS;
 constexpr int kMaxChunks = (int)(kPiece / kChunk);        // 512
 constexpr int kTotalStride = 32;          // bucket totals sit one per 128-B line (same-line atomics serialise)
 constexpr int kRangeCap = 256;            // negative-block ranges a bucket's positions may span and still use the LDS table
@@ -205,10 +205,29 @@ struct __attribute__((packed, aligned(8))) I64Pair { int64_t a, b; };
 
 __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 
+// item chunks (include/rsx.h): C <= 1 is the plain layout.  NBc = buckets per range (the buckets never straddle a range).
+struct ChunkArgs {
+    int C, NBc;
+    ChunkGeom g;
+    int64_t *chunk_pos_out;      // [C + 1]
+};
+
+// negative range of the position `rel` (relative to its range's first position; the range holds nc live positions) inside
+// range ch: block pi_ch(w) of the range, w = floor(floor(rel * Ic / nc) / c); lo = first item id, n = REAL items in the block
+__device__ __forceinline__ void neg_range_chunk(const ChunkGeom &g, int ch, int64_t rel, int64_t nc, uint64_t neg_key,
+                                                int64_t &neg_lo, int64_t &neg_n)
+{
+    const int64_t w = ((rel * g.Ic) / nc) / g.c;
+    const int64_t blk = neg_block_of(w, g.nbc, chunk_key(neg_key, ch));
+    neg_lo = (int64_t)ch * g.Ic + blk * g.c;
+    const int64_t left = g.real(ch) - blk * g.c;
+    neg_n = left <= 0 ? 0 : (left < g.c ? left : g.c);
+}
+
 __global__ __launch_bounds__(kChunkThreads) void bucket_chunk_kernel(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices, const uint32_t *__restrict__ cdf,
     int64_t U, int64_t I, int64_t piece_lo, int64_t n, uint64_t seed, uint64_t step, int64_t epoch_pos, int hb,
-    int nbm, int nblk, uint2 *__restrict__ pairs, uint32_t *__restrict__ table, uint32_t *__restrict__ totals)
+    int nbm, int nblk, uint2 *__restrict__ pairs, uint32_t *__restrict__ table, uint32_t *__restrict__ totals, ChunkArgs ca)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int NB = nbm + 1;
@@ -253,9 +272,19 @@ __global__ __launch_bounds__(kChunkThreads) void bucket_chunk_kernel(
         eb[e] = 0xFFFFFFFFu;
         if (ok[e]) {
             int bk = nbm;                                              // "no positive": own last bucket
-            if ((int64_t)ei[e] < I)
-                bk = (int)mulhi32(c0[e] + mulhi32((uint32_t)splitmix64(0xC2B2AE3D27D4EB4Full ^ eu[e]), c1[e] - c0[e]),
-                                  (uint32_t)nbm);
+            if ((int64_t)ei[e] < I) {
+                // a point of the item's CDF interval picked by a hash of the user (a popular item spreads over buckets)
+                const uint32_t t = c0[e] + mulhi32((uint32_t)splitmix64(0xC2B2AE3D27D4EB4Full ^ eu[e]), c1[e] - c0[e]);
+                if (ca.C > 1) {      // buckets of equal mass INSIDE the item's range: none straddles two ranges
+                    const int ch = (int)(ei[e] / (uint32_t)ca.g.Ic);
+                    const uint32_t lo = cdf[(int64_t)ch * ca.g.Ic], hi = cdf[(int64_t)(ch + 1) * ca.g.Ic];
+                    uint32_t q = hi > lo ? (uint32_t)(((uint64_t)(t - lo) * (uint32_t)ca.NBc) / (hi - lo)) : 0u;
+                    if (q >= (uint32_t)ca.NBc) q = (uint32_t)ca.NBc - 1u;
+                    bk = ch * ca.NBc + (int)q;
+                } else {
+                    bk = (int)mulhi32(t, (uint32_t)nbm);
+                }
+            }
             eb[e] = ((uint32_t)bk << 13) | atomicAdd(&hist[bk], 1u);
         }
     }
@@ -399,12 +428,26 @@ struct GlobalKeys {
 constexpr int kNegGroup = 4;
 static_assert(kMaxChunks == 2 * kBlock, "bucket_sort_kernel reads two chunk-table entries per thread");
 
+// chunked layout (cx.C > 1): the ranges are those of the position's item range (pc = its first position, nc = its
+// live positions), the fall-back candidates are the REAL items of that range -- never the whole catalog: a negative
+// outside the range would reach G after the range was handed on -- and a user who owns the whole range gets no
+// negative (nj = -1) after 192 tries.
+struct NegCtx {
+    int C, ch;
+    ChunkGeom g;
+    int64_t pc, nc;
+    const uint8_t *wn;       // real items per negative range of the bucket's table (chunked layout)
+};
+
 __device__ __forceinline__ void negatives_lockstep(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices, const uint64_t *__restrict__ user_sig,
     int64_t I, int64_t B, uint64_t seed, uint64_t step, int neg_block, uint64_t neg_key, const int64_t *wstart,
     const int32_t *wlo, int m, const bool (&live)[kNegGroup], const int64_t (&p)[kNegGroup],
-    const uint32_t (&u)[kNegGroup], int32_t (&nj)[kNegGroup])
+    const uint32_t (&u)[kNegGroup], int32_t (&nj)[kNegGroup], const NegCtx &cx)
 {
+    const bool chunked = cx.C > 1;
+    const int64_t flo = chunked ? (int64_t)cx.ch * cx.g.Ic : 0, fn = chunked ? cx.g.real(cx.ch) : I;   // fall-back candidates
+    const int give_up = chunked ? 192 : 0x7fffffff;
     int64_t nlo[kNegGroup], nn[kNegGroup], rlo[kNegGroup], rhi[kNegGroup];
     uint32_t s[kNegGroup];
     ulonglong2 rec[kNegGroup];
@@ -425,13 +468,17 @@ __device__ __forceinline__ void negatives_lockstep(
                 int lo = 0, hi = m;
                 while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wstart[mid] <= p[g]) lo = mid; else hi = mid; }
                 nlo[g] = wlo[lo];
-                nn[g] = (nlo[g] + neg_block <= I) ? neg_block : I - nlo[g];
+                nn[g] = chunked ? (int64_t)cx.wn[lo] : ((nlo[g] + neg_block <= I) ? neg_block : I - nlo[g]);
+            } else if (chunked) {
+                neg_range_chunk(cx.g, cx.ch, p[g] - cx.pc, cx.nc, neg_key, nlo[g], nn[g]);
             } else {
                 neg_range(I, p[g], B, neg_block, neg_key, nlo[g], nn[g]);
             }
+            const bool empty = nn[g] == 0;                 // (chunked layout: a block that is all padding)
+            if (empty) { nlo[g] = flo; nn[g] = fn; }
             // a clear signature bit proves the whole item block negative for this user
             // (73 % of the draws at 20 positives per user): no row read at all
-            need[g] = !use_sig || ((rec[g].x >> sig_bit(nlo[g] / neg_block)) & 1ull) != 0ull;
+            need[g] = !use_sig || empty || ((rec[g].x >> sig_bit(nlo[g] / neg_block)) & 1ull) != 0ull;
             if (!need[g]) nj[g] = (int32_t)(nlo[g] + (int64_t)(((uint64_t)xorshift32(s[g]) * (uint64_t)nn[g]) >> 32));
             any |= need[g];
         }
@@ -455,7 +502,8 @@ __device__ __forceinline__ void negatives_lockstep(
 #pragma unroll
             for (int q = 0; q < kRowRegs; ++q) v[q] = q < deg ? row[q] : -1;
             for (int tries = 0;; ++tries) {
-                if (tries == 64) { nlo[g] = 0; nn[g] = I; }     // the user owns (nearly) the whole block
+                if (tries == 64) { nlo[g] = flo; nn[g] = fn; }  // the user owns (nearly) the whole block
+                if (tries == give_up) break;                    // ... and the whole range: no negative (nj stays -1)
                 const int32_t cand = (int32_t)(nlo[g] + (int64_t)(((uint64_t)xorshift32(s[g]) * (uint64_t)nn[g]) >> 32));
                 bool in = false;
 #pragma unroll
@@ -472,8 +520,9 @@ __device__ __forceinline__ void negatives_lockstep(
 #pragma unroll
         for (int g = 0; g < kNegGroup; ++g) {
             a[g] = 0; z[g] = 0; cand[g] = 0;
+            if (need[g] && tries == give_up) need[g] = false;   // owns the whole range: no negative (nj stays -1)
             if (need[g]) {
-                if (tries == 64) { nlo[g] = 0; nn[g] = I; }
+                if (tries == 64) { nlo[g] = flo; nn[g] = fn; }
                 cand[g] = (int32_t)(nlo[g] + (int64_t)(((uint64_t)xorshift32(s[g]) * (uint64_t)nn[g]) >> 32));
                 a[g] = rlo[g]; z[g] = rhi[g];
             }
@@ -509,21 +558,34 @@ __global__ __launch_bounds__(kBlock, 5) void bucket_sort_kernel(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices, const uint64_t *__restrict__ user_sig,
     int64_t I, int64_t B, int64_t piece_lo, uint64_t seed, uint64_t step, int neg_block, uint64_t neg_key, int nbm,
     int nblk, int sort_cap, const uint2 *__restrict__ pairs, const uint32_t *__restrict__ table,
-    const uint32_t *__restrict__ totals, int32_t *u_out, int32_t *i_out, int32_t *__restrict__ j_out)
+    const uint32_t *__restrict__ totals, int32_t *u_out, int32_t *i_out, int32_t *__restrict__ j_out, ChunkArgs ca)
 {
     __shared__ uint64_t keys[kSortCap];
     __shared__ uint32_t cstart[kMaxChunks + 1];    // first bucket-local rank of each chunk's slice
     __shared__ uint16_t csrc[kMaxChunks];          // where that slice starts inside the chunk
     __shared__ uint32_t red[kBlock / 64];
     __shared__ uint32_t wsum[kBlock / 64];
+    __shared__ uint32_t red_cb[kBlock / 64], red_ct[kBlock / 64];
     __shared__ int64_t wstart[kRangeCap];          // first batch position of each negative range met here
     __shared__ int32_t wlo[kRangeCap];             // and the item block it draws from
+    __shared__ uint8_t wn[kRangeCap];              // and (chunked layout) the REAL items in that block
     const int tid = threadIdx.x;
     const int bk = blockIdx.x;
     const int n = (int)totals[(size_t)bk * kTotalStride];
-    if (n == 0) return;
-    // first output position of this bucket = pairs in the buckets before it
-    uint32_t before = 0;
+    const bool chunked = ca.C > 1;
+    if (n == 0 && !chunked) return;
+    // first output position of this bucket = pairs in the buckets before it; chunked layout: also the first position
+    // (cb) and the number of live positions (ct) of the item range this bucket belongs to
+    const int ch = chunked ? (bk < nbm ? bk / ca.NBc : ca.C - 1) : 0;
+    uint32_t before = 0, cb = 0, ct = 0;
+    if (chunked) {
+        const int r0 = ch * ca.NBc, r1 = (bk < nbm) ? r0 + ca.NBc : nbm;
+        for (int q = tid; q < r1; q += kBlock) {
+            const uint32_t v = totals[(size_t)q * kTotalStride];
+            if (q < bk) before += v;
+            if (q < r0) cb += v; else ct += v;
+        }
+    } else
     for (int q = tid; q < bk; q += kBlock) before += totals[(size_t)q * kTotalStride];
     // this bucket's slice of every chunk: (offset in chunk, count) -> exclusive scan of the counts
     constexpr int kEnt = kMaxChunks / kBlock;      // 2 table entries per thread
@@ -535,14 +597,14 @@ __global__ __launch_bounds__(kBlock, 5) void bucket_sort_kernel(
         mine += ent[e] & 0xFFFFu;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
+    for (int off = 32; off > 0; off >>= 1) { before += __shfl_xor(before, off); cb += __shfl_xor(cb, off); ct += __shfl_xor(ct, off); }
     uint32_t incl = mine;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t v = __shfl_up(incl, off);
         if ((tid & 63) >= off) incl += v;
     }
-    if ((tid & 63) == 0) red[tid >> 6] = before;
+    if ((tid & 63) == 0) { red[tid >> 6] = before; red_cb[tid >> 6] = cb; red_ct[tid >> 6] = ct; }
     if ((tid & 63) == 63) wsum[tid >> 6] = incl;
     __syncthreads();
     uint32_t base = incl - mine;
@@ -555,13 +617,36 @@ __global__ __launch_bounds__(kBlock, 5) void bucket_sort_kernel(
     }
     if (tid == kBlock - 1) cstart[kMaxChunks] = base;
     const int64_t p0 = piece_lo + red[0] + red[1] + red[2] + red[3];
+    NegCtx cx{ca.C, ch, ca.g, 0, 0, wn};
+    if (chunked) {
+        cx.pc = (int64_t)red_cb[0] + red_cb[1] + red_cb[2] + red_cb[3];
+        cx.nc = (int64_t)red_ct[0] + red_ct[1] + red_ct[2] + red_ct[3];
+        // the first bucket of a range publishes the range's first position; the "no positive" bucket the number of live ones
+        if (tid == 0 && bk < nbm && bk % ca.NBc == 0) ca.chunk_pos_out[ch] = cx.pc;
+        if (tid == 0 && bk == nbm) ca.chunk_pos_out[ca.C] = p0;
+        if (n == 0) return;
+    }
     const bool in_lds = n <= sort_cap;
     int32_t *ug = u_out + p0, *ig = i_out + p0;
     // negative ranges (rsx.h: neg_block) the positions [p0, p0 + n) fall in: range w starts at
     // position ceil(w*c*B/I) and draws from item block pi(w); 64-bit divisions and the block
     // permutation are paid once per range here instead of once per position
     int m = 0;
-    if (neg_block > 0) {
+    if (chunked && bk < nbm) {
+        const ChunkGeom &g = ca.g;
+        const int64_t w_first = (((p0 - cx.pc) * g.Ic) / cx.nc) / g.c, w_last = (((p0 + n - 1 - cx.pc) * g.Ic) / cx.nc) / g.c;
+        if (w_last - w_first < kRangeCap) {
+            m = (int)(w_last - w_first) + 1;
+            const uint64_t key = chunk_key(neg_key, ch);
+            for (int q = tid; q < m; q += kBlock) {
+                const int64_t blk = neg_block_of(w_first + q, g.nbc, key);
+                wstart[q] = cx.pc + ceil_div64((w_first + q) * g.c * cx.nc, g.Ic);
+                wlo[q] = (int32_t)((int64_t)ch * g.Ic + blk * g.c);
+                const int64_t left = g.real(ch) - blk * g.c;
+                wn[q] = (uint8_t)(left <= 0 ? 0 : (left < g.c ? left : g.c));
+            }
+        }
+    } else if (neg_block > 0) {
         const int64_t w_first = ((p0 * I) / B) / neg_block, w_last = (((p0 + n - 1) * I) / B) / neg_block;
         if (w_last - w_first < kRangeCap) {
             m = (int)(w_last - w_first) + 1;
@@ -602,11 +687,12 @@ __global__ __launch_bounds__(kBlock, 5) void bucket_sort_kernel(
             p[g] = p0 + r;
             live[g] = r < n && (int64_t)item[g] < I;
         }
-        negatives_lockstep(indptr, indices, user_sig, I, B, seed, step, neg_block, neg_key, wstart, wlo, m, live, p, u, nj);
+        negatives_lockstep(indptr, indices, user_sig, I, B, seed, step, neg_block, neg_key, wstart, wlo, m, live, p, u, nj, cx);
 #pragma unroll
         for (int g = 0; g < kNegGroup; ++g) {
             const int r = r0 + g * kBlock + tid;
-            if (r < n) { u_out[p[g]] = (int32_t)u[g]; i_out[p[g]] = live[g] ? (int32_t)item[g] : -1; j_out[p[g]] = nj[g]; }
+            // (a live pair without a negative -- chunked layout, the user owns its whole range -- is skipped by the step)
+            if (r < n) { u_out[p[g]] = (int32_t)u[g]; i_out[p[g]] = (live[g] && nj[g] >= 0) ? (int32_t)item[g] : -1; j_out[p[g]] = nj[g]; }
         }
     }
 }
@@ -698,12 +784,13 @@ int buckets_for(int64_t n) { return (int)((n + kBucketMean - 1) / kBucketMean); 
 int64_t bucket_ws_bytes(int64_t batch)
 {
     const int64_t n = batch < kPiece ? batch : kPiece;
-    const int64_t NB = buckets_for(n) + 1, nblk = (n + kChunk - 1) / kChunk;
+    // (+ RSX_MAX_CHUNKS: the chunked layout rounds the bucket count up to a multiple of the number of ranges)
+    const int64_t NB = buckets_for(n) + 1 + RSX_MAX_CHUNKS, nblk = (n + kChunk - 1) / kChunk;
     return align256(n * 8) + align256(NB * nblk * 4) + align256(NB * 4 * kTotalStride);
 }
-BucketWs bucket_carve(void *ws, int64_t n)
+BucketWs bucket_carve(void *ws, int64_t n, int64_t NB)
 {
-    const int64_t NB = buckets_for(n) + 1, nblk = (n + kChunk - 1) / kChunk;
+    const int64_t nblk = (n + kChunk - 1) / kChunk;
     BucketWs w;
     char *p = (char *)ws;
     w.pairs = (uint2 *)p;      p += align256(n * 8);
@@ -780,7 +867,8 @@ RSX_API int rsx_bpr_sample(const int64_t *indptr_dev, const int32_t *indices_dev
             const int64_t n = (batch - piece_lo < kPiece) ? batch - piece_lo : kPiece;
             const int nbm = buckets_for(n), NB = nbm + 1;
             const int nblk = (int)((n + kChunk - 1) / kChunk);
-            const BucketWs w = bucket_carve(ws, n);
+            const BucketWs w = bucket_carve(ws, n, NB);
+            const ChunkArgs ca{1, 0, ChunkGeom{}, nullptr};
             if (hipMemsetAsync(w.totals, 0, (size_t)NB * 4 * kTotalStride, st) != hipSuccess) {
                 rsx_set_error("rsx_bpr_sample: memset failed");
                 return RSX_E_HIP;
@@ -788,10 +876,10 @@ RSX_API int rsx_bpr_sample(const int64_t *indptr_dev, const int32_t *indices_dev
             const size_t lds = ((size_t)((NB + 3) & ~3)) * 4 + (size_t)kChunk * sizeof(uint2);
             hipLaunchKernelGGL(bucket_chunk_kernel, dim3(nblk), dim3(kChunkThreads), lds, st, indptr_dev, indices_dev,
                                item_cdf_dev, num_users, num_items, piece_lo, n, seed, step, epoch_pos, hb, nbm, nblk,
-                               w.pairs, w.table, w.totals);
+                               w.pairs, w.table, w.totals, ca);
             hipLaunchKernelGGL(bucket_sort_kernel, dim3(NB), dim3(kBlock), 0, st, indptr_dev, indices_dev,
                                user_sig_dev, num_items, batch, piece_lo, seed, step, neg_block, neg_key, nbm, nblk,
-                               lds_sort_cap(), w.pairs, w.table, w.totals, u_out, i_out, j_out);
+                               lds_sort_cap(), w.pairs, w.table, w.totals, u_out, i_out, j_out, ca);
         }
         RSX_CHECK_LAUNCH();
         return RSX_OK;
@@ -814,6 +902,53 @@ RSX_API int rsx_bpr_sample(const int64_t *indptr_dev, const int32_t *indices_dev
     }
     hipLaunchKernelGGL(sample_neg_kernel, dim3(grid_1d(batch)), dim3(kBlock), 0, st, indptr_dev, indices_dev,
                        num_items, batch, seed, step, neg_block, neg_key, keys_out, vals_out, user_sig_dev, u_out, i_out, j_out);
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+}
+
+RSX_API int64_t rsx_chunk_rows(int64_t items_real, int chunks, int neg_block)
+{
+    if (items_real <= 0 || chunks < 1 || chunks > RSX_MAX_CHUNKS || neg_block < 1 || neg_block > kMaxNegBlock) return RSX_E_INVALID;
+    return chunk_geom(items_real, chunks, neg_block).Ic;
+}
+
+RSX_API int rsx_bpr_sample_chunked(const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users,
+                                   int64_t num_items, int64_t items_real, int chunks, int64_t batch, uint64_t seed,
+                                   uint64_t step, int64_t epoch_pos, int neg_block, uint64_t neg_key, void *ws,
+                                   int64_t ws_bytes, const uint64_t *user_sig_dev, const uint32_t *item_cdf_dev,
+                                   int32_t *u_out, int32_t *i_out, int32_t *j_out, int64_t *chunk_pos_out,
+                                   rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(indptr_dev && indices_dev && u_out && i_out && j_out && chunk_pos_out && item_cdf_dev, "null pointer");
+    RSX_CHECK_ARG(chunks >= 2 && chunks <= RSX_MAX_CHUNKS, "chunks must be in [2, RSX_MAX_CHUNKS]");
+    RSX_CHECK_ARG(neg_block >= 1 && neg_block <= kMaxNegBlock, "the chunked layout needs neg_block in [1, 16]");
+    RSX_CHECK_ARG(num_users > 0 && num_users < (1ll << 31) && items_real > 0 && num_items < (1ll << 31), "table sizes must fit int32");
+    const ChunkGeom g = chunk_geom(items_real, chunks, neg_block);
+    RSX_CHECK_ARG(num_items == g.Ic * chunks, "num_items must be chunks * rsx_chunk_rows(items_real, chunks, neg_block)");
+    RSX_CHECK_ARG(batch >= 0 && batch <= kPiece && epoch_pos >= 0, "the chunked layout orders at most 2^21 positions");
+    if (batch == 0) return RSX_OK;
+    const int64_t need = rsx_bpr_sample_workspace(batch, num_items);
+    if (ws == nullptr || ws_bytes < need) {
+        rsx_set_error("rsx_bpr_sample_chunked: needs a workspace of %lld bytes, got %lld", (long long)need, (long long)ws_bytes);
+        return RSX_E_WORKSPACE;
+    }
+    const int hb = (batch == num_users && epoch_pos % num_users == 0) ? -1 : half_bits_for(num_users);
+    hipStream_t st = (hipStream_t)stream;
+    const int NBc = (buckets_for(batch) + chunks - 1) / chunks;
+    const int nbm = NBc * chunks, NB = nbm + 1;
+    const int nblk = (int)((batch + kChunk - 1) / kChunk);
+    const BucketWs w = bucket_carve(ws, batch, NB);
+    if (hipMemsetAsync(w.totals, 0, (size_t)NB * 4 * kTotalStride, st) != hipSuccess) {
+        rsx_set_error("rsx_bpr_sample_chunked: memset failed");
+        return RSX_E_HIP;
+    }
+    const ChunkArgs ca{chunks, NBc, g, chunk_pos_out};
+    const size_t lds = ((size_t)((NB + 3) & ~3)) * 4 + (size_t)kChunk * sizeof(uint2);
+    hipLaunchKernelGGL(bucket_chunk_kernel, dim3(nblk), dim3(kChunkThreads), lds, st, indptr_dev, indices_dev, item_cdf_dev,
+                       num_users, num_items, (int64_t)0, batch, seed, step, epoch_pos, hb, nbm, nblk, w.pairs, w.table, w.totals, ca);
+    hipLaunchKernelGGL(bucket_sort_kernel, dim3(NB), dim3(kBlock), 0, st, indptr_dev, indices_dev, user_sig_dev, num_items,
+                       batch, (int64_t)0, seed, step, neg_block, neg_key, nbm, nblk, lds_sort_cap(), w.pairs, w.table, w.totals,
+                       u_out, i_out, j_out, ca);
     RSX_CHECK_LAUNCH();
     return RSX_OK;
 }
