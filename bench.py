@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--hot", type=int, default=256, help="popular items whose gradient rows are replicated (0 = off)")
     ap.add_argument("--hot-replicas", type=int, default=16)
     ap.add_argument("--neg-block", type=int, default=8, help="item block of the stratified negatives (0 = independent uniform negatives)")
+    ap.add_argument("--chunks", type=int, default=int(os.environ.get("RSX_CHUNKS", "0")),
+                    help="> 1: the step as a pipeline over that many item ranges (include/rsx.h: item chunks): the apply and, "
+                         "with N > 1, the all-reduce of a range travel under the rest of the step kernel")
     ap.add_argument("--no-legs", action="store_true", help="headline only (no section-8d legs)")
     ap.add_argument("--no-lightgcn", action="store_true", help="skip the BASELINE configs[4] leg (LightGCN propagation + step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -129,7 +132,11 @@ def fence(world):
     torch.cuda.synchronize()
 
 
-def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, warmup, world, rank, popularity, two_pass=None):
+COMM = None         # rsx.Comm: the library's own RCCL communicator (N > 1 over the "nccl" backend, unless RSX_NATIVE_RCCL=0)
+
+
+def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, warmup, world, rank, popularity, two_pass=None,
+             chunks=0):
     """one timed region of `steps` native steps; returns the leg record (rank 0 fills the throughput)"""
     from recsys_pytorch_amd import rsx
     from recsys_pytorch_amd.sharded import BPREngine
@@ -140,7 +147,7 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     # N > 1 exchange of the item gradients: all_reduce(G) (default) or RSX_EXCHANGE=scatter_gather
     # (reduce_scatter -> own item shard applied -> all_gather of the updated rows; sharded.py)
     eng = BPREngine(P, Q, lr, user_begin=rank * U, seed=2020, exchange=os.environ.get("RSX_EXCHANGE", "allreduce"),
-                    force_sharded=SHARDED)
+                    force_sharded=SHARDED, comm=COMM)
     Q = eng.Q                                            # (scatter_gather may re-home the item table)
     if two_pass is not None:
         eng.overlap_exchange = bool(two_pass) and SHARDED
@@ -150,6 +157,9 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     nb = eng.set_neg_block(B, want_nb) if want_nb > 0 else 0
     if hot > 0:
         eng.set_hot_items(torch.bincount(indices.long(), minlength=I), hot, hot_replicas)
+    if chunks > 1 and nb and not eng.stale_exchange and (COMM is not None or not SHARDED):
+        eng.set_chunks(chunks)
+        eng.overlap_exchange = False                     # the range pipeline replaces the two-pass step
     # the loss of every batch is accumulated on the device like MF.fit's epoch_loss (models/MF.py:70)
     loss = torch.zeros(rsx.RSX_LOSS_SLOTS, dtype=torch.float32, device=dev)
     tr = eng.native_trainer(indptr, indices, B, loss_acc=loss)
@@ -166,6 +176,8 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     kern_ms, n_timed = tr.kernel_ms()
+    ran_chunks = getattr(tr, "chunks", 0)
+    eng.adopt(tr)                                        # (a chunked run: checks it and copies the item rows back into Q)
     tr.close()
     assert torch.isfinite(P).all() and torch.isfinite(Q).all()
     mean_loss = float(loss.double().sum()) / (B * steps)            # this rank's triplets
@@ -178,8 +190,9 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
         assert replicas_equal, "item replicas diverged"
     # (the walk of the blocked kernel without its negative-side LDS tile when only the positives are ordered)
     kernel = "bpr_step_blocked_kernel" if nb else ("bpr_step_blocked_kernel<TILE=false>" if eng._sorts(B) else "bpr_step_kernel")
-    key = f"U{U}_I{I}_d{d}_B{B}_{popularity}_nb{nb}"
-    return {"batch_per_gpu": B, "global_batch": gb, "value": gb * steps / elapsed, "unit": "triplets/s",
+    key = f"U{U}_I{I}_d{d}_B{B}_{popularity}_nb{nb}" + (f"_c{ran_chunks}" if ran_chunks > 1 else "")
+    return {"batch_per_gpu": B, "chunks": ran_chunks, "exchange_issued_by": ("library (RCCL from librsx)" if COMM is not None else
+                                                                             "torch.distributed callbacks") if SHARDED else None, "global_batch": gb, "value": gb * steps / elapsed, "unit": "triplets/s",
             "ms_per_step": elapsed / steps * 1e3, "steps": steps, "neg_block": nb, "mean_bpr_loss": mean_loss,
             "two_pass": bool(eng.overlap_exchange) and not eng.stale_exchange, "exchange": eng.exchange if SHARDED else None,
             "stale_exchange": bool(eng.stale_exchange),
@@ -327,6 +340,9 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from recsys_pytorch_amd import rsx
+    global COMM
+    if SHARDED and os.environ.get("RSX_DIST_BACKEND", "nccl") == "nccl" and os.environ.get("RSX_NATIVE_RCCL", "1") == "1":
+        COMM = rsx.Comm()        # the exchange is then issued by librsx on the trainer's own stream: no interpreter in the timed region
     from recsys_pytorch_amd.data import synthetic_csr
     rsx.lib()
     if os.environ.get("RSX_SCORE_LANES"):
@@ -348,7 +364,7 @@ def main():
     two_pass = SHARDED and os.environ.get("RSX_TWO_PASS", "1") == "1"
     P, Q, indptr, indices = tables(U, I, d, args.degree, args.popularity)
     head = step_leg(P, Q, indptr, indices, args.lr, B, args.neg_block, args.hot, args.hot_replicas, args.steps, args.warmup,
-                    world, rank, args.popularity, two_pass=two_pass)
+                    world, rank, args.popularity, two_pass=two_pass, chunks=args.chunks)
     Q = head.pop("_Q")
 
     # ---- the other section-8d legs: each its own timed region of the same native loop ------------------------
@@ -436,6 +452,7 @@ def main():
                        "negatives": f"stratified by item block of {nb}, batch sorted by positive item" if nb else "independent uniform",
                        "sampler": "on device, two steps ahead on a lowest-priority side stream",
                        "loop": "native (rsx_bpr_trainer_run): no interpreter between the kernels of the timed region",
+                       "item_chunks": head["chunks"], "exchange_issued_by": head["exchange_issued_by"],
                        "mean_bpr_loss": head["mean_bpr_loss"],
                        **({"item_replicas_identical": head["item_replicas_identical"]} if SHARDED else {}),
                        "hot_items": args.hot, "hot_replicas": args.hot_replicas if args.hot > 0 else 0,

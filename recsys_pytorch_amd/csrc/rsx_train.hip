@@ -19,6 +19,12 @@ struct rsx_bpr_trainer {
     rsx_bpr_trainer_config c;
     int device = 0;
     hipStream_t side = nullptr;
+    // the exchange of a sharded step issued by the library (RCCL, config.comm) and the range-by-range apply of the
+    // chunked step run here: highest priority, so that their few workgroups get the next free wave slots under the step kernel
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_start = nullptr;               // run stream -> aux: the step's counters are reset, the tables are consistent
+    hipEvent_t ev_g = nullptr;                   // run stream -> aux: G (folded) is complete
+    hipEvent_t ev_x[2] = {};                     // aux -> run stream: the exchange (+ apply) of gradient buffer 0 / 1 is done
     // ring of RSX_TRAINER_SLOTS triplet buffers: the one being consumed and the batches sampled ahead.  Two
     // ahead, not one: with one, the step kernel's launch waits on an event the side stream has recorded only
     // microseconds before, and that cross-stream hand-over showed as a 11-12 us hole in front of EVERY step
@@ -38,6 +44,7 @@ struct rsx_bpr_trainer {
     uint64_t slot_key[S] = {};
     int slot_nb[S] = {};
     bool slot_sorted[S] = {};                    // ordered by positive item without blocked negatives
+    bool slot_chunked[S] = {};                   // sampled with the item-range rule (config.chunks > 1)
     int last = -1;                               // slot consumed by the most recent step
     bool flip = false;                           // stale_exchange: the next step accumulates into G_alt
     // live timing of the step kernel (HIP events on the run stream, every `time_every`-th step)
@@ -68,10 +75,17 @@ uint64_t neg_key_for(uint64_t seed, int64_t step)
 // filled with 100 MB of dirty item rows -- and showed as an 11-12 us hole in front of every step kernel.
 constexpr unsigned kOrderOnly = hipEventDisableTiming | hipEventDisableSystemFence;
 
+bool chunked(const rsx_bpr_trainer *t) { return t->c.chunks > 1; }
+
 int effective_neg_block(const rsx_bpr_trainer *t, int64_t batch)
 {
+    // (a chunked trainer lives in a relabelled item space with padding rows, which only the chunked sampler knows to
+    //  avoid: every batch of it, whatever its size, takes the chunked layout)
+    if (chunked(t)) return t->c.neg_block;
     return (t->c.neg_block > 0 && batch >= 2 * t->c.num_items) ? t->c.neg_block : 0;
 }
+
+int64_t *chunk_pos_ptr(const rsx_bpr_trainer *t, int slot) { return t->c.chunk_pos + (size_t)slot * (t->c.chunks + 1); }
 
 #define RSX_TRY(call) do { int rc__ = (call); if (rc__ != RSX_OK) return rc__; } while (0)
 #define RSX_HIP(call)                                                                          \
@@ -94,6 +108,12 @@ int launch_sample(rsx_bpr_trainer *t, int slot, int64_t step_index, int64_t batc
     const bool sorted = nb > 0 || (c.sort_min_batch > 0 && batch >= c.sort_min_batch);
     const uint64_t key = nb ? neg_key_for(c.seed_key, step_index) : 0ull;
     if (t->freed_valid[slot]) RSX_HIP(hipStreamWaitEvent(t->side, t->freed[slot], 0));
+    if (chunked(t))
+        RSX_TRY(rsx_bpr_sample_chunked(c.indptr, c.indices, c.num_users, c.num_items, c.items_real, c.chunks, batch, c.seed,
+                                       (uint64_t)step_index, t->epoch_pos, nb, key, c.sample_ws, c.sample_ws_bytes, c.user_sig,
+                                       c.item_cdf, slot_ptr(t, slot, 0), slot_ptr(t, slot, 1), slot_ptr(t, slot, 2),
+                                       chunk_pos_ptr(t, slot), (rsx_stream_t)t->side));
+    else
     RSX_TRY(rsx_bpr_sample(c.indptr, c.indices, c.num_users, c.num_items, batch, c.seed, (uint64_t)step_index,
                            t->epoch_pos, nb, key, sorted ? RSX_SAMPLE_SORT_POS : 0u, sorted ? c.sample_ws : nullptr,
                            sorted ? c.sample_ws_bytes : 0, nb ? c.user_sig : nullptr, sorted ? c.item_cdf : nullptr,
@@ -104,6 +124,7 @@ int launch_sample(rsx_bpr_trainer *t, int slot, int64_t step_index, int64_t batc
     t->slot_key[slot] = key;
     t->slot_nb[slot] = nb;
     t->slot_sorted[slot] = sorted && nb == 0;
+    t->slot_chunked[slot] = chunked(t);
     return RSX_OK;
 }
 
@@ -124,8 +145,29 @@ RSX_API int rsx_bpr_trainer_create(const rsx_bpr_trainer_config *cfg, rsx_bpr_tr
                   "hot_slot, G_hot and hot_items go together");
     RSX_CHECK_ARG((cfg->exchange_begin == nullptr) == (cfg->exchange_end == nullptr), "exchange_begin and exchange_end go together");
     RSX_CHECK_ARG(cfg->step0 >= 0 && cfg->epoch_pos0 >= 0, "negative start state");
-    RSX_CHECK_ARG(!cfg->stale_exchange || (cfg->exchange_begin != nullptr && cfg->G_alt != nullptr && cfg->G_alt != cfg->G),
-                  "stale_exchange needs the exchange callbacks and a second gradient buffer G_alt");
+    const bool native = cfg->comm != nullptr;
+    RSX_CHECK_ARG(!(native && cfg->exchange_begin != nullptr), "give the exchange callbacks OR a communicator, not both");
+    RSX_CHECK_ARG(!native || cfg->exchange_kind == RSX_EXCHANGE_ALLREDUCE || cfg->exchange_kind == RSX_EXCHANGE_SCATTER_GATHER,
+                  "with comm: exchange_kind must be RSX_EXCHANGE_ALLREDUCE or RSX_EXCHANGE_SCATTER_GATHER");
+    const bool sg = native && cfg->exchange_kind == RSX_EXCHANGE_SCATTER_GATHER;
+    if (sg) {
+        int world = 1;
+        RSX_TRY(rsx_comm_info(cfg->comm, nullptr, &world));
+        RSX_CHECK_ARG(cfg->item_rows_padded >= cfg->num_items && cfg->item_rows_padded % world == 0,
+                      "RSX_EXCHANGE_SCATTER_GATHER: Q and G must hold item_rows_padded = world * shard rows");
+    }
+    RSX_CHECK_ARG(!cfg->stale_exchange || ((cfg->exchange_begin != nullptr || native) && !sg && cfg->G_alt != nullptr && cfg->G_alt != cfg->G),
+                  "stale_exchange needs an exchange (callbacks or an all-reduce communicator) and a second gradient buffer G_alt");
+    if (cfg->chunks > 1) {
+        RSX_CHECK_ARG(cfg->chunks <= RSX_MAX_CHUNKS && cfg->neg_block > 0 && cfg->item_cdf != nullptr && cfg->chunk_pos != nullptr &&
+                      cfg->progress != nullptr && cfg->items_real > 0,
+                      "chunks > 1 needs neg_block, item_cdf, chunk_pos, progress and items_real");
+        RSX_CHECK_ARG(cfg->num_items == cfg->chunks * rsx_chunk_rows(cfg->items_real, cfg->chunks, cfg->neg_block),
+                      "chunks > 1: num_items must be chunks * rsx_chunk_rows(items_real, chunks, neg_block)");
+        RSX_CHECK_ARG(cfg->batch <= (1ll << 21), "chunks > 1: at most 2^21 triplets per step");
+        RSX_CHECK_ARG(cfg->exchange_begin == nullptr && !sg && !cfg->stale_exchange && !cfg->two_pass,
+                      "chunks > 1 replaces two_pass / stale_exchange and needs the all-reduce communicator when sharded");
+    }
     rsx_bpr_trainer *t = new (std::nothrow) rsx_bpr_trainer();
     if (t == nullptr) { rsx_set_error("rsx_bpr_trainer_create: out of memory"); return RSX_E_INVALID; }
     t->c = *cfg;
@@ -139,6 +181,11 @@ RSX_API int rsx_bpr_trainer_create(const rsx_bpr_trainer_config *cfg, rsx_bpr_tr
     const int prio = prio_lo;
     bool ok = hipGetDevice(&t->device) == hipSuccess &&
               hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, prio) == hipSuccess &&
+              hipStreamCreateWithPriority(&t->aux, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+              hipEventCreateWithFlags(&t->ev_start, kOrderOnly) == hipSuccess &&
+              hipEventCreateWithFlags(&t->ev_g, kOrderOnly) == hipSuccess &&
+              hipEventCreateWithFlags(&t->ev_x[0], kOrderOnly) == hipSuccess &&
+              hipEventCreateWithFlags(&t->ev_x[1], kOrderOnly) == hipSuccess &&
               hipEventCreateWithFlags(&t->fork, kOrderOnly) == hipSuccess;
     for (int s = 0; ok && s < rsx_bpr_trainer::S; ++s)
         ok = hipEventCreateWithFlags(&t->ready[s], kOrderOnly) == hipSuccess &&
@@ -156,6 +203,8 @@ RSX_API void rsx_bpr_trainer_destroy(rsx_bpr_trainer *t)
 {
     if (t == nullptr) return;
     if (t->side) { (void)hipStreamSynchronize(t->side); (void)hipStreamDestroy(t->side); }
+    if (t->aux) { (void)hipStreamSynchronize(t->aux); (void)hipStreamDestroy(t->aux); }
+    for (hipEvent_t e : {t->ev_start, t->ev_g, t->ev_x[0], t->ev_x[1]}) if (e) (void)hipEventDestroy(e);
     for (int s = 0; s < rsx_bpr_trainer::S; ++s) {
         if (t->ready[s]) (void)hipEventDestroy(t->ready[s]);
         if (t->freed[s]) (void)hipEventDestroy(t->freed[s]);
@@ -177,7 +226,10 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
     const rsx_bpr_trainer_config &c = t->c;
     hipStream_t st = (hipStream_t)stream;
     const float inv_batch = 1.0f / (float)global_batch;
-    const bool sharded = c.exchange_begin != nullptr;
+    const bool native = c.comm != nullptr;                                     // the library issues the exchange itself (RCCL)
+    const bool sharded = c.exchange_begin != nullptr || native;
+    const bool sg = native && c.exchange_kind == RSX_EXCHANGE_SCATTER_GATHER;
+    const bool applies = sg || (!native && c.exchange_applies);                // the exchange leaves Q updated and G zero
     const bool hot = c.hot_slot != nullptr;
     const bool stale = sharded && c.stale_exchange != 0;
     t->timed = 0;
@@ -206,6 +258,43 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
         }
         return RSX_OK;
     };
+    // the one exchange of a step: the item gradients, summed over the ranks.  begin: `Gbuf` (folded) is complete on the
+    // run stream, start the collective; end: the run stream waits for it.  Either the caller's callbacks (torch.distributed
+    // in this package's CPU tests) or RCCL issued from here on the trainer's own stream.
+    auto exchange_begin = [&](float *Gbuf, int which) -> int {
+        if (!native) {
+            if (c.exchange_begin(c.exchange_ctx) != 0) { rsx_set_error("rsx_bpr_trainer_run: exchange_begin failed"); return RSX_E_INVALID; }
+            return RSX_OK;
+        }
+        RSX_HIP(hipEventRecord(t->ev_g, st));
+        RSX_HIP(hipStreamWaitEvent(t->aux, t->ev_g, 0));
+        if (!sg) {
+            RSX_TRY(rsx_comm_all_reduce(c.comm, Gbuf, c.num_items * c.d, t->aux));
+        } else {
+            // reduce-scatter -> this rank applies ITS shard of item rows -> the other shards of G (partial sums) are
+            // zeroed -> all-gather of the updated Q rows: every row is computed by one rank and copied to the others
+            int rank = 0, world = 1;
+            RSX_TRY(rsx_comm_info(c.comm, &rank, &world));
+            const int64_t shard = c.item_rows_padded / world, n = shard * c.d;
+            RSX_TRY(rsx_comm_reduce_scatter(c.comm, Gbuf, n, t->aux));
+            RSX_TRY(rsx_apply_item_grad(c.Q + (size_t)rank * n, Gbuf + (size_t)rank * n, shard, c.d, c.lr, nullptr, nullptr, 0,
+                                        (rsx_stream_t)t->aux));
+            if (rank > 0) RSX_HIP(hipMemsetAsync(Gbuf, 0, (size_t)rank * n * sizeof(float), t->aux));
+            if (rank + 1 < world)
+                RSX_HIP(hipMemsetAsync(Gbuf + (size_t)(rank + 1) * n, 0, (size_t)(world - rank - 1) * n * sizeof(float), t->aux));
+            RSX_TRY(rsx_comm_all_gather(c.comm, c.Q, n, t->aux));
+        }
+        RSX_HIP(hipEventRecord(t->ev_x[which], t->aux));
+        return RSX_OK;
+    };
+    auto exchange_end = [&](int which) -> int {
+        if (!native) {
+            if (c.exchange_end(c.exchange_ctx) != 0) { rsx_set_error("rsx_bpr_trainer_run: exchange_end failed"); return RSX_E_INVALID; }
+            return RSX_OK;
+        }
+        RSX_HIP(hipStreamWaitEvent(st, t->ev_x[which], 0));
+        return RSX_OK;
+    };
     for (int64_t s = 0; s < n_steps; ++s) {
         const int cur = t->cur;
         RSX_HIP(hipStreamWaitEvent(st, t->ready[cur], 0));
@@ -214,7 +303,8 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
         const int nb = t->slot_nb[cur];
         const uint64_t key = t->slot_key[cur];
         const bool timed = time_every > 0 && (s % time_every) == 0;
-        if (timed) {
+        auto time_begin = [&]() -> int {
+            if (!timed) return RSX_OK;
             if (t->timed == t->t0.size()) {
                 hipEvent_t a, b;
                 RSX_HIP(hipEventCreate(&a));
@@ -222,7 +312,44 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
                 t->t0.push_back(a); t->t1.push_back(b);
             }
             RSX_HIP(hipEventRecord(t->t0[t->timed], st));
-        }
+            return RSX_OK;
+        };
+        auto time_end = [&]() -> int {
+            if (timed) { RSX_HIP(hipEventRecord(t->t1[t->timed], st)); ++t->timed; }
+            return RSX_OK;
+        };
+        if (t->slot_chunked[cur]) {
+            // ---- the step as a pipeline over item ranges (include/rsx.h: "item chunks") --------------------------------
+            // run stream:  counters = 0 -> step kernel (range k's wavefronts count themselves done in progress[k])
+            // aux stream:  for k: wait until range k is done -> [fold its hot rows, all-reduce its rows of G] -> apply them
+            // so the exchange and the apply of range k travel under the wavefronts of the ranges after it.
+            const ChunkGeom g = chunk_geom(c.items_real, c.chunks, c.neg_block);
+            RSX_HIP(hipMemsetAsync(c.progress, 0, RSX_MAX_CHUNKS * sizeof(uint32_t), st));
+            RSX_HIP(hipEventRecord(t->ev_start, st));
+            RSX_HIP(hipStreamWaitEvent(t->aux, t->ev_start, 0));
+            RSX_TRY(time_begin());
+            RSX_TRY(rsx_bpr_step_chunked(c.P, c.Q, c.G, c.num_users, c.num_items, c.items_real, c.chunks, u, i, j, batch, c.d, c.lr,
+                                         inv_batch, c.loss_acc, c.hot_slot, c.G_hot, c.hot_replicas, nb, key, chunk_pos_ptr(t, cur),
+                                         c.progress, stream));
+            RSX_TRY(time_end());
+            if (sharded) RSX_TRY(top_up());                                    // the next batches, beside everything
+            for (int k = 0; k < c.chunks; ++k) {
+                const int64_t lo = (int64_t)k * g.Ic;
+                float *Gk = c.G + (size_t)lo * c.d, *Qk = c.Q + (size_t)lo * c.d;
+                RSX_TRY(rsx_wait_progress(c.progress, k, (uint32_t)g.nbc, t->aux));
+                if (native) {
+                    if (hot) RSX_TRY(rsx_fold_hot_grad_range(c.G, c.G_hot, c.hot_items, c.n_hot, c.hot_replicas, c.d, lo, lo + g.Ic, t->aux));
+                    RSX_TRY(rsx_comm_all_reduce(c.comm, Gk, g.Ic * c.d, t->aux));
+                    RSX_TRY(rsx_apply_item_grad(Qk, Gk, g.Ic, c.d, c.lr, nullptr, nullptr, 0, (rsx_stream_t)t->aux));
+                } else {
+                    RSX_TRY(rsx_apply_item_grad(Qk, Gk, g.Ic, c.d, c.lr, hot ? c.hot_slot + lo : nullptr, c.G_hot, c.hot_replicas,
+                                                (rsx_stream_t)t->aux));
+                }
+            }
+            RSX_HIP(hipEventRecord(t->ev_x[0], t->aux));
+            RSX_HIP(hipStreamWaitEvent(st, t->ev_x[0], 0));
+        } else {
+        RSX_TRY(time_begin());
         const unsigned sorted_flag = t->slot_sorted[cur] ? RSX_BATCH_SORTED : 0u;
         const bool two_pass = sharded && c.two_pass && !stale;
         const unsigned f = RSX_USERS_UNIQUE | sorted_flag | (two_pass ? RSX_ITEMS_ONLY : 0u);
@@ -230,17 +357,17 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
         float *const Gs = (stale && t->flip) ? c.G_alt : c.G;
         if (stale) t->flip = !t->flip;
         float *const Gprev = (Gs == c.G) ? c.G_alt : c.G;
+        const int which = (Gs == c.G) ? 0 : 1;
         RSX_TRY(rsx_bpr_step(c.P, c.Q, Gs, c.num_users, c.num_items, u, i, j, batch, c.d, c.lr, inv_batch, c.loss_acc, f,
                              nullptr, 0, c.hot_slot, c.G_hot, c.hot_replicas, nb, key, stream));
-        if (timed) { RSX_HIP(hipEventRecord(t->t1[t->timed], st)); ++t->timed; }
+        RSX_TRY(time_end());
         if (!sharded) {
             RSX_TRY(rsx_apply_item_grad(c.Q, c.G, c.num_items, c.d, c.lr, c.hot_slot, c.G_hot, c.hot_replicas, stream));
         } else {
-            // the one exchange of the step: the item gradients, summed over the ranks by the caller's
-            // collective (RCCL all-reduce through torch.distributed in this package).  It needs the
+            // the one exchange of the step: the item gradients, summed over the ranks.  It needs the
             // folded G; with two passes it travels under the user pass and the next step's sampler.
             if (hot) RSX_TRY(rsx_fold_hot_grad(Gs, c.G_hot, c.hot_items, c.n_hot, c.hot_replicas, c.d, stream));
-            if (c.exchange_begin(c.exchange_ctx) != 0) { rsx_set_error("rsx_bpr_trainer_run: exchange_begin failed"); return RSX_E_INVALID; }
+            RSX_TRY(exchange_begin(Gs, which));
             RSX_HIP(hipEventRecord(t->fork, st));
             RSX_HIP(hipStreamWaitEvent(t->side, t->fork, 0));
             RSX_TRY(top_up());                                                 // beside the exchange
@@ -248,24 +375,25 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
                 // this step's exchange stays in flight under the NEXT step kernel; what is finished and applied
                 // now is the exchange of the step before (nothing before the first step of a run)
                 if (s > 0) {
-                    if (c.exchange_end(c.exchange_ctx) != 0) { rsx_set_error("rsx_bpr_trainer_run: exchange_end failed"); return RSX_E_INVALID; }
-                    if (!c.exchange_applies)
+                    RSX_TRY(exchange_end(1 - which));
+                    if (!applies)
                         RSX_TRY(rsx_apply_item_grad(c.Q, Gprev, c.num_items, c.d, c.lr, nullptr, nullptr, 0, stream));
                 }
                 if (s + 1 == n_steps) {      // drain: a run leaves nothing unapplied
-                    if (c.exchange_end(c.exchange_ctx) != 0) { rsx_set_error("rsx_bpr_trainer_run: exchange_end failed"); return RSX_E_INVALID; }
-                    if (!c.exchange_applies)
+                    RSX_TRY(exchange_end(which));
+                    if (!applies)
                         RSX_TRY(rsx_apply_item_grad(c.Q, Gs, c.num_items, c.d, c.lr, nullptr, nullptr, 0, stream));
                 }
             } else {
-            if (two_pass)
-                RSX_TRY(rsx_bpr_step(c.P, c.Q, c.G, c.num_users, c.num_items, u, i, j, batch, c.d, c.lr, inv_batch, nullptr,
-                                     RSX_USERS_UNIQUE | RSX_USERS_ONLY | sorted_flag, nullptr, 0, c.hot_slot, c.G_hot, c.hot_replicas, nb,
-                                     key, stream));
-            if (c.exchange_end(c.exchange_ctx) != 0) { rsx_set_error("rsx_bpr_trainer_run: exchange_end failed"); return RSX_E_INVALID; }
-            if (!c.exchange_applies)
-                RSX_TRY(rsx_apply_item_grad(c.Q, c.G, c.num_items, c.d, c.lr, nullptr, nullptr, 0, stream));
+                if (two_pass)
+                    RSX_TRY(rsx_bpr_step(c.P, c.Q, c.G, c.num_users, c.num_items, u, i, j, batch, c.d, c.lr, inv_batch, nullptr,
+                                         RSX_USERS_UNIQUE | RSX_USERS_ONLY | sorted_flag, nullptr, 0, c.hot_slot, c.G_hot, c.hot_replicas, nb,
+                                         key, stream));
+                RSX_TRY(exchange_end(which));
+                if (!applies)
+                    RSX_TRY(rsx_apply_item_grad(c.Q, c.G, c.num_items, c.d, c.lr, nullptr, nullptr, 0, stream));
             }
+        }
         }
         RSX_HIP(hipEventRecord(t->freed[cur], st));
         t->freed_valid[cur] = true;
@@ -273,6 +401,25 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
         t->cur = (cur + 1) % S;
         --t->ahead;
         ++t->step;
+    }
+    return RSX_OK;
+}
+
+RSX_API int rsx_bpr_trainer_check(rsx_bpr_trainer *t, rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(t != nullptr, "null trainer");
+    if (t->c.chunks <= 1 || t->c.progress == nullptr) return RSX_OK;
+    uint32_t h[RSX_PROGRESS_WORDS] = {};
+    RSX_HIP(hipMemcpyAsync(h, t->c.progress, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    RSX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (h[RSX_PROGRESS_TIMEOUT] != 0) {
+        rsx_set_error("rsx_bpr_trainer_check: %u waits on the step kernel's progress timed out (a range was handed on incomplete)", h[RSX_PROGRESS_TIMEOUT]);
+        return RSX_E_INVALID;
+    }
+    if (h[RSX_PROGRESS_VIOLATIONS] != 0) {
+        rsx_set_error("rsx_bpr_trainer_check: %u triplets touched an item row outside their range (their sums reached G after the range was handed on)",
+                      h[RSX_PROGRESS_VIOLATIONS]);
+        return RSX_E_INVALID;
     }
     return RSX_OK;
 }

@@ -24,6 +24,9 @@ Divergences from the reference, all documented in DESIGN.md:
     105-130: batch_size interactions of a per-epoch permutation PLUS one uniformly drawn negative, rating 0, for EVERY
     user of the matrix -- its sample_negatives ignores the batch it is handed), assembled on the device; the gradient
     of a batch is rsx_pointwise_grad, the update the as-shipped Adam or the SGD sweep.
+  * hparams['chunks'] (default 0 = off): > 1 runs the SGD step as a pipeline over that many item ranges when the blocked
+    layout engages (include/rsx.h: "item chunks"; BPREngine.set_chunks): the apply -- and, user-sharded, the exchange --
+    of a range travels under the rest of the step kernel; negatives come from the range of the sampled positive.
   * hidden_dim is padded to 32/64/128 columns of zeros internally (they stay zero).
 """
 import numpy as np
@@ -96,6 +99,7 @@ class MF(BaseModel):
         self.seed = int(_get(hparams, "seed", 2020))
         # item block of the stratified negatives; 0 = independent uniform negatives always
         self.neg_block = int(_get(hparams, "neg_block", 8))
+        self.chunks = int(_get(hparams, "chunks", 0))
         self.device = torch.device(device)
         self._dpad = _pad_dim(self.hidden_dim)
         d = self.hidden_dim
@@ -173,7 +177,8 @@ class MF(BaseModel):
         n_data = self.num_users
         num_batches = int(np.ceil(n_data / batch_size))
         if self.optimizer_name == "sgd":     # on-chip gradient summation when batch >= 2 * items
-            self._engine.set_neg_block(batch_size if self.neg_block > 0 else 0, max(self.neg_block, 1))
+            nb = self._engine.set_neg_block(batch_size if self.neg_block > 0 else 0, max(self.neg_block, 1))
+            self._engine.set_chunks(self.chunks if nb else 0)
         scores = None
         # SGD on the HIP library: the batch loop itself is native (include/rsx.h: rsx_bpr_trainer_run),
         # Python is re-entered once per epoch (or every 50 batches when verbose, for the progress line)

@@ -24,6 +24,13 @@ RSX_BATCH_SORTED = 64
 RSX_SAMPLE_SORT_POS = 1
 RSX_LOSS_SLOTS = 2048
 RSX_TRAINER_SLOTS = 3
+RSX_MAX_CHUNKS = 8
+RSX_PROGRESS_WORDS = 16
+RSX_PROGRESS_VIOLATIONS = 8
+RSX_PROGRESS_TIMEOUT = 9
+RSX_COMM_ID_BYTES = 128
+RSX_EXCHANGE_ALLREDUCE = 1
+RSX_EXCHANGE_SCATTER_GATHER = 2
 SUPPORTED_DIMS = (32, 64, 128)
 
 # symbol -> (restype, argtypes); mirrors include/rsx.h one to one
@@ -61,6 +68,17 @@ SIGNATURES = {
     "rsx_bpr_trainer_seek": (C.c_int, [_P, _I64, _I64, _P]),
     "rsx_bpr_trainer_last_batch": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "rsx_bpr_trainer_kernel_ms": (C.c_int, [_P, _P, _P]),
+    "rsx_bpr_trainer_check": (C.c_int, [_P, _P]),
+    "rsx_chunk_rows": (_I64, [_I64, _I32, _I32]),
+    "rsx_bpr_sample_chunked": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _I64, _U64, _U64, _I64, _I32, _U64, _P, _I64,
+                                         _P, _P, _P, _P, _P, _P, _P]),
+    "rsx_bpr_step_chunked": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I32, _P, _P, _P, _I64, _I32, _F, _F, _P, _P, _P, _I32,
+                                       _I32, _U64, _P, _P, _P]),
+    "rsx_comm_unique_id": (C.c_int, [_P]),
+    "rsx_comm_create": (C.c_int, [_P, _I32, _I32, _P]),
+    "rsx_comm_destroy": (None, [_P]),
+    "rsx_comm_info": (C.c_int, [_P, _P, _P]),
+    "rsx_comm_all_reduce_f32": (C.c_int, [_P, _P, _I64, _P]),
     "rsx_score": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P, _P, _P, _P]),
     "rsx_topk": (C.c_int, [_P, _I64, _I64, _I32, _P, _P, _P]),
     "rsx_score_topk_workspace": (_I64, [_I64, _I64]),
@@ -334,6 +352,75 @@ def bpr_sample(indptr, indices, num_items, batch, seed, step, epoch_pos, u_out, 
         _dev(j_out, torch.int32, "j_out"), _stream()), "rsx_bpr_sample")
 
 
+def chunk_rows(items_real, chunks, neg_block):
+    """rows per item range of the chunked step (include/rsx.h: "item chunks")"""
+    n = lib().rsx_chunk_rows(int(items_real), int(chunks), int(neg_block))
+    if n < 0:
+        raise RsxError("rsx_chunk_rows: invalid shape")
+    return n
+
+
+def bpr_sample_chunked(indptr, indices, num_items, items_real, chunks, batch, seed, step, epoch_pos, u_out, i_out, j_out,
+                       chunk_pos, neg_block, neg_key, ws, item_cdf, user_sig=None):
+    """include/rsx.h:rsx_bpr_sample_chunked (relabelled CSR; chunk_pos: int64 [chunks + 1] device)"""
+    _check(lib().rsx_bpr_sample_chunked(
+        _dev(indptr, torch.int64, "indptr"), _dev(indices, torch.int32, "indices"), indptr.numel() - 1, int(num_items),
+        int(items_real), int(chunks), int(batch), seed & (2**64 - 1), step, epoch_pos, int(neg_block), int(neg_key) & (2**64 - 1),
+        C.c_void_p(ws.data_ptr()), ws.numel() * ws.element_size(),
+        _dev(user_sig, torch.int64, "user_sig") if user_sig is not None else None, _dev(item_cdf, torch.int32, "item_cdf"),
+        _dev(u_out, torch.int32, "u_out"), _dev(i_out, torch.int32, "i_out"), _dev(j_out, torch.int32, "j_out"),
+        _dev(chunk_pos, torch.int64, "chunk_pos"), _stream()), "rsx_bpr_sample_chunked")
+
+
+def bpr_step_chunked(P, Q, G, items_real, chunks, u, i, j, lr, inv_batch, chunk_pos, progress, neg_block, neg_key, loss_acc=None,
+                     hot=None):
+    """include/rsx.h:rsx_bpr_step_chunked; progress: int32 [RSX_PROGRESS_WORDS] device, zero before the call"""
+    _check(lib().rsx_bpr_step_chunked(
+        _dev(P, torch.float32, "P"), _dev(Q, torch.float32, "Q"), _dev(G, torch.float32, "G"), P.shape[0], Q.shape[0],
+        int(items_real), int(chunks), _dev(u, torch.int32, "u"), _dev(i, torch.int32, "i"), _dev(j, torch.int32, "j"), u.numel(),
+        P.shape[1], float(lr), float(inv_batch), _dev(loss_acc, torch.float32, "loss_acc") if loss_acc is not None else None,
+        _dev(hot.slot, torch.int32, "hot slot") if hot is not None else None,
+        _dev(hot.ghot, torch.float32, "ghot") if hot is not None else None, hot.replicas if hot is not None else 0,
+        int(neg_block), int(neg_key) & (2**64 - 1), _dev(chunk_pos, torch.int64, "chunk_pos"),
+        _dev(progress, torch.int32, "progress"), _stream()), "rsx_bpr_step_chunked")
+
+
+class Comm:
+    """RCCL communicator owned by the library (include/rsx.h: rsx_comm_*), one per process, on the current device.
+    The 128-byte unique id travels through torch.distributed (any backend: host-side bootstrap only)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        ident = C.create_string_buffer(RSX_COMM_ID_BYTES)
+        if self.rank == 0:
+            _check(lib().rsx_comm_unique_id(ident), "rsx_comm_unique_id")
+        box = [ident.raw]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        self._h = C.c_void_p()
+        _check(lib().rsx_comm_create(C.create_string_buffer(box[0], RSX_COMM_ID_BYTES), self.rank, self.world, C.byref(self._h)),
+               "rsx_comm_create")
+
+    @property
+    def handle(self):
+        return self._h
+
+    def all_reduce(self, t):
+        """sum over the ranks, in place, on torch's current stream"""
+        _check(lib().rsx_comm_all_reduce_f32(self._h, _dev(t, torch.float32, "buffer"), t.numel(), _stream()), "rsx_comm_all_reduce_f32")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().rsx_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                              # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 
 
@@ -346,7 +433,9 @@ class TrainerConfig(C.Structure):
                 ("hot_items", _P), ("n_hot", C.c_int32), ("hot_replicas", C.c_int32), ("loss_acc", _P),
                 ("exchange_begin", EXCHANGE_FN), ("exchange_end", EXCHANGE_FN), ("exchange_ctx", _P),
                 ("exchange_applies", C.c_int32), ("sort_min_batch", C.c_int32), ("step0", _I64), ("epoch_pos0", _I64),
-                ("G_alt", _P), ("stale_exchange", C.c_int32)]
+                ("G_alt", _P), ("stale_exchange", C.c_int32), ("exchange_kind", C.c_int32), ("comm", _P),
+                ("item_rows_padded", _I64), ("chunks", C.c_int32), ("reserved0", C.c_int32), ("items_real", _I64),
+                ("chunk_pos", _P), ("progress", _P)]
 
 
 class BPRTrainer:
@@ -356,14 +445,22 @@ class BPRTrainer:
 
     def __init__(self, P, Q, G, indptr, indices, lr, batch, seed, seed_key, neg_block=0, hot=None, user_sig=None,
                  item_cdf=None, loss_acc=None, exchange=None, two_pass=False, exchange_applies=False, sort_min_batch=0, step0=0, epoch_pos0=0,
-                 G_alt=None):
+                 G_alt=None, comm=None, exchange_kind=0, item_rows_padded=0, chunks=0, items_real=0, num_items=None):
+        """exchange: (begin, end) callables (the collective stays with the caller) OR comm: an rsx.Comm (the library issues it).
+        chunks > 1: P / Q / G / the CSR live in the caller's relabelled item space of chunks * chunk_rows ids."""
         dev = P.device
         self.batch = int(batch)
+        self.chunks = int(chunks)
+        self.chunk_pos = self.progress = None
+        if self.chunks > 1:
+            self.chunk_pos = torch.zeros(RSX_TRAINER_SLOTS * (self.chunks + 1), dtype=torch.int64, device=dev)
+            self.progress = torch.zeros(RSX_PROGRESS_WORDS, dtype=torch.int32, device=dev)
         self.triplets = torch.empty(RSX_TRAINER_SLOTS * 3 * self.batch, dtype=torch.int32, device=dev)
         self.sample_ws = None
         if neg_block or sort_min_batch:
-            self.sample_ws = torch.empty(bpr_sample_workspace(self.batch, Q.shape[0]), dtype=torch.uint8, device=dev)
-        self._keep = (P, Q, G, indptr, indices, hot, user_sig, item_cdf, loss_acc, G_alt)
+            self.sample_ws = torch.empty(bpr_sample_workspace(self.batch, int(num_items) if num_items is not None else Q.shape[0]),
+                                         dtype=torch.uint8, device=dev)
+        self._keep = (P, Q, G, indptr, indices, hot, user_sig, item_cdf, loss_acc, G_alt, comm)
         ptr = lambda t, dt, name: _dev(t, dt, name) if t is not None else None
         self._cb = (None, None)
         if exchange is not None:                       # (begin, end) callables; exceptions become error codes
@@ -380,7 +477,7 @@ class BPRTrainer:
         self._exc = None
         cfg = TrainerConfig(
             P=_dev(P, torch.float32, "P"), Q=_dev(Q, torch.float32, "Q"), G=_dev(G, torch.float32, "G"),
-            num_users=P.shape[0], num_items=Q.shape[0], d=P.shape[1], lr=float(lr),
+            num_users=P.shape[0], num_items=int(num_items) if num_items is not None else Q.shape[0], d=P.shape[1], lr=float(lr),
             indptr=_dev(indptr, torch.int64, "indptr"), indices=_dev(indices, torch.int32, "indices"),
             batch=self.batch, seed=int(seed) & (2**64 - 1), seed_key=int(seed_key) & (2**64 - 1),
             neg_block=int(neg_block), two_pass=int(bool(two_pass)),
@@ -395,7 +492,10 @@ class BPRTrainer:
             loss_acc=ptr(loss_acc, torch.float32, "loss_acc"),
             exchange_begin=self._cb[0] or EXCHANGE_FN(), exchange_end=self._cb[1] or EXCHANGE_FN(), exchange_ctx=None,
             exchange_applies=int(bool(exchange_applies)), sort_min_batch=int(sort_min_batch), step0=int(step0), epoch_pos0=int(epoch_pos0),
-            G_alt=ptr(G_alt, torch.float32, "G_alt"), stale_exchange=int(G_alt is not None))   # opt-in: one step stale
+            G_alt=ptr(G_alt, torch.float32, "G_alt"), stale_exchange=int(G_alt is not None),   # opt-in: one step stale
+            exchange_kind=int(exchange_kind), comm=comm.handle if comm is not None else None,
+            item_rows_padded=int(item_rows_padded), chunks=self.chunks, reserved0=0, items_real=int(items_real),
+            chunk_pos=ptr(self.chunk_pos, torch.int64, "chunk_pos"), progress=ptr(self.progress, torch.int32, "progress"))
         self._h = C.c_void_p()
         _check(lib().rsx_bpr_trainer_create(C.byref(cfg), C.byref(self._h)), "rsx_bpr_trainer_create")
 
@@ -424,6 +524,17 @@ class BPRTrainer:
         base, es = self.triplets.data_ptr(), 4
         view = lambda p: self.triplets[(p.value - base) // es:(p.value - base) // es + b.value]
         return view(pu), view(pi), view(pj), nb.value, key.value
+
+    def check(self):
+        """after a chunked run: raises if a triplet left its item range or a wait on the step kernel timed out (synchronises)"""
+        _check(lib().rsx_bpr_trainer_check(self._h, _stream()), "rsx_bpr_trainer_check")
+
+    def last_chunk_pos(self):
+        """(chunked) first batch position of every item range in the batch the most recent step consumed"""
+        pu = C.c_void_p()
+        _check(lib().rsx_bpr_trainer_last_batch(self._h, C.byref(pu), None, None, None, None, None), "rsx_bpr_trainer_last_batch")
+        slot = (pu.value - self.triplets.data_ptr()) // 4 // (3 * self.batch)
+        return self.chunk_pos[slot * (self.chunks + 1):(slot + 1) * (self.chunks + 1)]
 
     def kernel_ms(self):
         """mean duration of the timed step kernels of the last run (waits for them)"""

@@ -51,7 +51,7 @@ class BPREngine:
     """
 
     def __init__(self, P_local, Q, lr, kernels=None, group=None, user_begin=0, seed=2020, optimizer="sgd",
-                 exchange="allreduce", force_sharded=False):
+                 exchange="allreduce", force_sharded=False, comm=None):
         if kernels is None:
             from . import rsx as kernels   # the HIP path; raises if librsx.so is missing
         self.k = kernels
@@ -94,6 +94,14 @@ class BPREngine:
             raise ValueError(exchange)
         self.exchange = exchange if (self.sharded and optimizer == "sgd") else "allreduce"
         self._work = None
+        # comm: an rsx.Comm (RCCL communicator owned by the library).  The native loop then issues the exchange ITSELF on its own
+        # stream (include/rsx.h: rsx_bpr_trainer_config.comm) -- no callback into the interpreter inside a run; without it the
+        # exchange is this engine's torch.distributed collective handed in as two callbacks (any backend; the CPU tests' gloo)
+        self.comm = comm if self.sharded else None
+        # > 1: the native loop runs the step as a pipeline over item ranges (include/rsx.h: "item chunks"; set_chunks)
+        self.chunks = 0
+        self._relabel = None
+        self._hot_args = None
         # OPT-IN (native loop only): the exchange of step t travels under the step kernel of step t+1, which
         # then reads an item table WITHOUT step t's update -- one step stale, not the reference's
         # batch-synchronous step (models/MF.py:64-68); include/rsx.h: stale_exchange.  Reported separately.
@@ -175,6 +183,76 @@ class BPREngine:
         """spread the gradients of the `num_hot` most popular items over `replicas` private rows
         (contention relief at the atomic unit, include/rsx.h:rsx_bpr_step hot_slot_dev)"""
         self.hot = self.k.HotItems(item_counts, num_hot, replicas, self.Q.shape[1], self.Q.device) if num_hot > 0 else None
+        self._hot_args = (torch.as_tensor(item_counts), int(num_hot), int(replicas)) if num_hot > 0 else None
+        self._relabel = None
+
+    # -- the step as a pipeline over item ranges (include/rsx.h: "item chunks") ---------------------------------
+    def set_chunks(self, chunks):
+        """chunks > 1 (native loop, SGD, blocked negatives engaged): the item rows are cut into `chunks` ranges and the
+        exchange (when sharded: needs `comm`) and the apply of a range travel under the step kernel's wavefronts of the
+        ranges after it.  The engine then trains on a RELABELLED item space -- a fixed random permutation of the item ids
+        (seeded: the same on every rank), `chunks` ranges of rsx_chunk_rows rows -- held in its own tables; `adopt()` /
+        `sync_items()` copy the item rows back into Q.  What changes for the model: a user's negative is uniform over the
+        items of the range its sampled positive fell in (a random 1/chunks of the catalog) instead of over one item block
+        anywhere."""
+        chunks = int(chunks)
+        if chunks > 1 and (self.optimizer != "sgd" or self.exchange != "allreduce" or (self.sharded and self.comm is None)):
+            raise ValueError("chunks > 1 needs SGD, exchange='allreduce' and, when sharded, the library's own communicator (comm)")
+        if chunks != self.chunks:
+            self._relabel = None
+        self.chunks = chunks if chunks > 1 else 0
+        return self.chunks
+
+    def _build_relabel(self, indptr, indices):
+        """tables of the relabelled item space for THIS CSR and neg_block (cached by the identity of the CSR tensors)"""
+        r = self._relabel
+        if r is not None and r["csr"][0] is indptr and r["csr"][1] is indices and r["nb"] == self.neg_block and r["C"] == self.chunks:
+            return r
+        I, d = self.Q.shape
+        C, nb, dev = self.chunks, self.neg_block, self.Q.device
+        Ic = self.k.chunk_rows(I, C, nb)
+        base, rem = divmod(I, C)
+        gen = torch.Generator().manual_seed(self.seed * 7919 + 13)                 # host generator: identical on every rank
+        perm = torch.randperm(I, generator=gen)                                    # the items in rank order
+        counts = torch.tensor([base + (k < rem) for k in range(C)])
+        starts = torch.cumsum(counts, 0) - counts
+        which = torch.repeat_interleave(torch.arange(C), counts)
+        rank_of_pos = which * Ic + (torch.arange(I) - starts[which])
+        item_rank = torch.empty(I, dtype=torch.int64)
+        item_rank[perm] = rank_of_pos
+        rank_item = torch.full((C * Ic,), -1, dtype=torch.int64)
+        rank_item[rank_of_pos] = perm
+        item_rank, rank_item = item_rank.to(dev), rank_item.to(dev)
+        # the CSR with relabelled columns, rows sorted again
+        U = indptr.numel() - 1
+        rows = torch.repeat_interleave(torch.arange(U, device=dev), indptr[1:] - indptr[:-1])
+        key = rows * (C * Ic) + item_rank[indices.long()]
+        key = torch.sort(key).values
+        indices_m = (key - rows * (C * Ic)).to(torch.int32).contiguous()
+        del rows, key
+        real = rank_item >= 0
+        Qm = torch.zeros(C * Ic, d, dtype=self.Q.dtype, device=dev)
+        hot = None
+        if self._hot_args is not None:
+            cnt, num_hot, replicas = self._hot_args
+            cm = torch.zeros(C * Ic, dtype=cnt.dtype)
+            cm[rank_of_pos] = cnt.cpu()[perm]
+            hot = self.k.HotItems(cm, num_hot, replicas, d, dev)
+        r = {"csr": (indptr, indices), "nb": nb, "C": C, "Ic": Ic, "item_rank": item_rank, "rank_item": rank_item, "real": real,
+             "indices": indices_m, "Q": Qm, "G": torch.zeros_like(Qm), "hot": hot,
+             "sig": self.k.build_signature(indptr, indices_m, nb), "cdf": self.k.build_item_cdf(indptr, indices_m, C * Ic)}
+        self._relabel = r
+        return r
+
+    def _items_to_relabelled(self):
+        r = self._relabel
+        r["Q"][r["real"]] = self.Q[r["rank_item"][r["real"]]]
+
+    def sync_items(self):
+        """copy the item rows of the relabelled table (a chunked native run trains there) back into Q"""
+        r = self._relabel
+        if r is not None and self.chunks:
+            self.Q[r["rank_item"][r["real"]]] = r["Q"][r["real"]]
 
     # -- the exchange of a step's item gradients ------------------------------------------------
     def _setup_item_shards(self):
@@ -453,26 +531,47 @@ class BPREngine:
         if self.optimizer != "sgd":
             raise ValueError("the native loop runs the SGD step; optimizer='adam' steps through BPREngine.step")
         batch = min(int(batch), indptr.numel() - 1)
+        native = self.sharded and self.comm is not None       # the library issues the exchange itself (RCCL)
+        kind = {"allreduce": 1, "scatter_gather": 2}[self.exchange] if native else 0      # RSX_EXCHANGE_*
+        stale = bool(self.stale_exchange) and self.sharded
+        if self.chunks and self.neg_block and batch >= 2 * self.Q.shape[0] and batch <= (1 << 21) and not stale:
+            # the step as a pipeline over item ranges, in the relabelled item space (set_chunks)
+            r = self._build_relabel(indptr, indices)
+            self._items_to_relabelled()
+            return self.k.BPRTrainer(self.P, r["Q"], r["G"], indptr, r["indices"], self.lr, batch,
+                                     seed=self.seed + 7919 * self.user_begin, seed_key=self.seed, neg_block=self.neg_block,
+                                     hot=r["hot"], user_sig=r["sig"], item_cdf=r["cdf"], loss_acc=loss_acc,
+                                     comm=self.comm if native else None, exchange_kind=kind, chunks=self.chunks,
+                                     items_real=self.Q.shape[0], step0=self.step_count, epoch_pos0=self.epoch_pos)
         sort_min = int(self.sorted_min_batch) if (self.sorted_min_batch and not self.neg_block) else 0
         if self.neg_block or sort_min:
             self._bind_csr(indptr, indices)
-        exchange = (self._exchange_begin, self._exchange_end) if self.sharded else None
-        stale = bool(self.stale_exchange) and self.sharded
+        exchange = (self._exchange_begin, self._exchange_end) if (self.sharded and not native) else None
         self._pending.clear()
         self._begin_step = 0                        # the trainer alternates G / G_alt, G first
-        return self.k.BPRTrainer(self.P, self.Q, self.G, indptr, indices, self.lr, batch,
+        sg = self.exchange == "scatter_gather"
+        extra = {}
+        if native:
+            extra = {"comm": self.comm, "exchange_kind": kind, "item_rows_padded": self._Qp.shape[0] if sg else 0,
+                     "num_items": self.Q.shape[0]}
+        return self.k.BPRTrainer(self.P, self._Qp if (native and sg) else self.Q,
+                                 self._Gp if (native and sg) else self.G, indptr, indices, self.lr, batch,
                                  seed=self.seed + 7919 * self.user_begin, seed_key=self.seed, neg_block=self.neg_block,
                                  hot=self.hot, user_sig=self._sig if self.neg_block else None,
                                  item_cdf=self._cdf if ((self.neg_block or sort_min) and self.use_item_cdf) else None,
                                  sort_min_batch=sort_min,
                                  loss_acc=loss_acc, exchange=exchange, two_pass=self.overlap_exchange,
                                  exchange_applies=self.exchange == "scatter_gather",
-                                 step0=self.step_count, epoch_pos0=self.epoch_pos,
+                                 step0=self.step_count, epoch_pos0=self.epoch_pos, **extra,
                                  **({"G_alt": self._stale_buffers()} if stale else {}))
 
     def adopt(self, trainer):
-        """take over the step counter and permutation position a native run has reached"""
+        """take over the step counter and permutation position a native run has reached (and, after a chunked run, the
+        item rows it trained in the relabelled space)"""
         self.step_count, self.epoch_pos = trainer.state()
+        if getattr(trainer, "chunks", 0) > 1:
+            trainer.check()
+            self.sync_items()
 
     # -- replay of GLOBAL-id triplets: each rank keeps the triplets of its own users -----
     def route(self, u_global, i, j):

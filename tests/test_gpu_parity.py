@@ -205,8 +205,8 @@ def test_step_kernels_on_random_shapes(rsx, oracle_mod):
                 rsx.apply_item_grad(Q, G, lr, hot=hot)
             if n_live:
                 assert abs(float(loss.sum()) / n_live - want_loss) < 2e-5 * max(1.0, abs(want_loss)), ctx
-        assert delta_err(P.cpu().numpy(), P0, orc.P) <= REL_TOL, (ctx, delta_err(P.cpu().numpy(), P0, orc.P))
-        assert delta_err(Q.cpu().numpy(), Q0, orc.Q) <= REL_TOL, (ctx, delta_err(Q.cpu().numpy(), Q0, orc.Q))
+        assert_update(P.cpu().numpy(), P0, orc.P, "P, " + ctx)
+        assert_update(Q.cpu().numpy(), Q0, orc.Q, "Q, " + ctx)
         assert float(G.abs().max()) == 0.0 and (hot is None or float(hot.ghot.abs().max()) == 0.0), ctx
 
 

@@ -237,34 +237,41 @@ def _rccl_one_rank_worker(rank, port, U, I, d, B, steps, out):
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)          # "nccl" IS RCCL on ROCm
+    from recsys_pytorch_amd import rsx
     from recsys_pytorch_amd.data import synthetic_csr
     from recsys_pytorch_amd.sharded import BPREngine
     ip, ix = synthetic_csr(U, I, 10, dev, seed=40)
+    lib_comm = rsx.Comm()                  # RCCL communicator owned by librsx (include/rsx.h: rsx_comm_*), one rank
 
     init = {}
 
-    def run(force, exchange, two_pass, mode):
+    def run(force, exchange, two_pass, mode, comm=None, chunks=0):
         torch.manual_seed(100)
         P = torch.randn(U, d, device=dev) * 0.1
         torch.manual_seed(7)
         Q = torch.randn(I, d, device=dev) * 0.1
         init.setdefault("tables", (P.cpu().numpy(), Q.cpu().numpy()))
-        eng = BPREngine(P, Q, resolvable_lr(B), seed=11, exchange=exchange, force_sharded=force)
+        eng = BPREngine(P, Q, resolvable_lr(B), seed=11, exchange=exchange, force_sharded=force, comm=comm)
         eng.overlap_exchange = bool(two_pass) and force
         eng.set_neg_block(B, 8)
         eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 32, 4)
+        if chunks:
+            eng.set_chunks(chunks)
         if mode == "python":
             for _ in range(steps):
                 eng.sampled_step_overlapped(ip, ix, B, global_batch=B, want_loss=False)
         else:
             tr = eng.native_trainer(ip, ix, B)
-            tr.run(steps, B, global_batch=B)
+            assert (tr.chunks > 1) == bool(chunks)
+            tr.run(2, B, global_batch=B)
+            tr.run(steps - 2, B, global_batch=B)
             torch.cuda.synchronize()
+            eng.adopt(tr)                       # (chunked: checks the run and copies the item rows back)
             tr.close()
         torch.cuda.synchronize()
         return P.cpu().numpy(), eng.Q.cpu().numpy()
 
-    def run_stale(exchange, lr=resolvable_lr(B) / 10):
+    def run_stale(exchange, lr=resolvable_lr(B) / 10, comm=None):
         """native loop with the opt-in one-step-stale exchange, and the same recurrence driven by hand on the same
         triplets: step t's kernel reads the item table WITHOUT the update of step t-1 (applied right after it)"""
         from recsys_pytorch_amd import rsx
@@ -274,7 +281,7 @@ def _rccl_one_rank_worker(rank, port, U, I, d, B, steps, out):
             torch.manual_seed(7)
             return P, torch.randn(I, d, device=dev) * 0.1
         P, Q = tables()
-        eng = BPREngine(P, Q, lr, seed=11, exchange=exchange, force_sharded=True)
+        eng = BPREngine(P, Q, lr, seed=11, exchange=exchange, force_sharded=True, comm=comm)
         eng.stale_exchange = True
         eng.set_neg_block(B, 8)
         eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 32, 4)
@@ -316,6 +323,15 @@ def _rccl_one_rank_worker(rank, port, U, I, d, B, steps, out):
         for two_pass in (False, True):
             for mode in ("native", "python"):
                 res[(exchange, two_pass, mode)] = run(True, exchange, two_pass, mode)
+            # the same schedules with the exchange issued BY THE LIBRARY (RCCL from librsx on the trainer's own stream)
+            res[(exchange, two_pass, "native, library RCCL")] = run(True, exchange, two_pass, "native", comm=lib_comm)
+    res[("stale", "library RCCL")], _, _ = run_stale("allreduce", comm=lib_comm)
+    # the step as a pipeline over item ranges: one GPU (apply range by range) and sharded with the library's RCCL (all-reduce
+    # + apply range by range) draw the same triplets and must end at the same tables
+    ck = 4 if B >= 2 * I else 0            # (the ranges need blocked negatives: two triplets per item and step)
+    res[("chunked", "one GPU")] = run(False, "allreduce", False, "native", chunks=ck)
+    res[("chunked", "library RCCL")] = run(True, "allreduce", False, "native", comm=lib_comm, chunks=ck)
+    lib_comm.close()
     res["init"] = init["tables"]
     out.update(res)
     dist.barrier()
@@ -339,15 +355,23 @@ def test_exchange_over_rccl_with_one_rank_equals_the_unsharded_step(B, I):
     mp.spawn(_rccl_one_rank_worker, args=(port, U, I, d, B, steps, out), nprocs=1, join=True)
     P0, Q0 = out["plain"]
     P_init, Q_init = out["init"]
-    assert len(out) == 16
+    assert len(out) == 23
     for key, (P, Q) in out.items():
-        if key == "init" or key[0] in ("stale", "stale_ref", "stale_sync"):
+        if key == "init" or key[0] in ("stale", "stale_ref", "stale_sync", "chunked"):
             continue
         assert_update(P, P_init, P0, f"P {key}")    # the five-step updates agree to 1e-5 of their size
         assert_update(Q, Q_init, Q0, f"Q {key}")
+    (Pc, Qc), (Pr, Qr) = out[("chunked", "one GPU")], out[("chunked", "library RCCL")]
+    assert_update(Pr, P_init, Pc, "P chunked, library RCCL vs one GPU")
+    assert_update(Qr, Q_init, Qc, "Q chunked, library RCCL vs one GPU")
+    if B >= 2 * I:
+        assert np.abs(Qc - Q0).max() > 1e-3 * np.abs(Q0 - Q_init).max()  # (other triplets than the unchunked layout)
     # the opt-in one-step-stale exchange: equal to its own recurrence driven by hand, and NOT the synchronous step
     for exchange in ("allreduce", "scatter_gather"):
         (P, Q), (Pr, Qr), (Ps, Qs) = out[("stale", exchange)], out[("stale_ref", exchange)], out[("stale_sync", exchange)]
+        if exchange == "allreduce":          # the library's own RCCL exchange follows the same recurrence
+            Pl, Ql = out[("stale", "library RCCL")]
+            assert np.abs(Pl - Pr).max() < 1e-5 * np.abs(Qr - Q_init).max() and np.abs(Ql - Qr).max() < 1e-5 * np.abs(Qr - Q_init).max()
         scale = np.abs(Qr - Q_init).max()      # the five updates are O(0.1) of the table
         assert scale > 1e-2
         assert np.abs(P - Pr).max() < 1e-5 * scale and np.abs(Q - Qr).max() < 1e-5 * scale, exchange

@@ -20,11 +20,14 @@ ip, ix = synthetic_csr(U, I, int(os.environ.get("DEG", 20)), dev, popularity=pop
 eng = BPREngine(P, Q, 0.05)
 nb = eng.set_neg_block(B, nbw) if nbw else 0
 eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 256, 16)
+ck = int(os.environ.get("CHUNKS", 0))
+if ck > 1 and nb:
+    eng.set_chunks(ck)
 if os.environ.get("STEP_PROF_META"):
     kernel = (f"bpr_step_blocked_kernel<{d}, 3, unsigned int, {'true' if nb else 'false'}>" if (nb or eng._sorts(B))
               else f"bpr_step_kernel<{d}, 0, 3, unsigned int>")
-    json.dump({"key": f"U{U}_I{I}_d{d}_B{B}_{pop}_nb{nb}", "kernel": kernel, "argv": sys.argv[1:],
-               "env": {k: os.environ[k] for k in ("USERS", "ITEMS", "DIM", "DEG", "POP") if k in os.environ}},
+    json.dump({"key": f"U{U}_I{I}_d{d}_B{B}_{pop}_nb{nb}" + (f"_c{ck}" if (ck > 1 and nb) else ""), "kernel": kernel, "argv": sys.argv[1:],
+               "env": {k: os.environ[k] for k in ("USERS", "ITEMS", "DIM", "DEG", "POP", "CHUNKS") if k in os.environ}},
               open(os.environ["STEP_PROF_META"], "w"))
 loss = torch.zeros(rsx.RSX_LOSS_SLOTS, device=dev)
 tr = eng.native_trainer(ip, ix, B, loss_acc=loss)
