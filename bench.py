@@ -340,6 +340,11 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from recsys_pytorch_amd import rsx
+    if os.environ.get("RSX_EXCHANGE_DELAY_US"):      # DEVELOPMENT library only (RSX_LIB=.../librsx_dev.so): a stand-in for the exchange's
+        import ctypes                                 # time on the wire, for the one-rank schedule comparison (tools/exchange_model.sh)
+        fn = rsx.lib().rsx_debug_set_exchange_delay
+        fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_int]
+        assert fn(int(os.environ["RSX_EXCHANGE_DELAY_US"])) == 0
     global COMM
     if SHARDED and os.environ.get("RSX_DIST_BACKEND", "nccl") == "nccl" and os.environ.get("RSX_NATIVE_RCCL", "1") == "1":
         COMM = rsx.Comm()        # the exchange is then issued by librsx on the trainer's own stream: no interpreter in the timed region
@@ -453,6 +458,7 @@ def main():
                        "sampler": "on device, two steps ahead on a lowest-priority side stream",
                        "loop": "native (rsx_bpr_trainer_run): no interpreter between the kernels of the timed region",
                        "item_chunks": head["chunks"], "exchange_issued_by": head["exchange_issued_by"],
+                       **({"DEBUG_exchange_delay_us": int(os.environ["RSX_EXCHANGE_DELAY_US"])} if os.environ.get("RSX_EXCHANGE_DELAY_US") else {}),
                        "mean_bpr_loss": head["mean_bpr_loss"],
                        **({"item_replicas_identical": head["item_replicas_identical"]} if SHARDED else {}),
                        "hot_items": args.hot, "hot_replicas": args.hot_replicas if args.hot > 0 else 0,

@@ -254,39 +254,42 @@ int rsx_bpr_build_item_cdf(const int64_t *indptr_dev, const int32_t *indices_dev
                            int64_t num_items, uint32_t *cdf_out, void *ws, int64_t ws_bytes,
                            rsx_stream_t stream);
 
-/* ---- item chunks: the step as a pipeline over item ranges -------------------------------------
- * Purpose: the exchange of a sharded step -- and, on one GPU, the apply sweep -- needs the item
- * gradients G COMPLETE.  With `chunks` = C > 1 the item rows are cut into C contiguous ranges of chunk_rows rows
- * and the step is organised so that range k of G is complete when the FIRST (k+1)/C of the step kernel's wavefronts
- * have finished: the all-reduce / apply of range k then travels under the rest of the kernel, one launch, no second
- * pass over the triplets.  What makes a range complete early:
+/* ---- item chunks: the step as independent pipelines over item ranges ------------------------------
+ * Purpose: the exchange of a sharded step needs the item gradients G COMPLETE, and the next step needs
+ * the updated item table, so an exchange cannot slide under the neighbouring step kernels -- unless the step is cut so
+ * that a part of the triplets touches a part of the item rows ONLY.  With `chunks` = C > 1 the item rows are cut into C
+ * contiguous ranges of chunk_rows rows and
  *   - the batch is ordered by positive item (RSX_SAMPLE_SORT_POS), so the positions whose positive lies in range k
  *     are contiguous: [chunk_pos[k], chunk_pos[k+1]);
  *   - the negative of such a position is drawn from an item block of the SAME range (the block permutation is keyed
- *     per step and per range), so every triplet of those positions touches item rows of range k only;
- *   - the step kernel gives range k the wavefronts [k * nbc, (k+1) * nbc), nbc = chunk_rows / neg_block, which the
- *     hardware dispatches in that order, and each wavefront counts itself done in progress[k] when its sums are in G.
- * The caller makes the ranges statistically alike by training on a RELABELLED item space (a fixed random permutation
- * of the item ids, drawn once per fit; recsys_pytorch_amd/sharded.py: BPREngine.set_chunks): the library sees item
- * ids 0 .. C * chunk_rows, of which range k holds real(k) = items_real / C (+1 for k < items_real % C) real items at its
- * start and padding rows (never sampled, gradient always zero) behind them.
+ *     per step and per range), so every triplet of those positions reads and writes item rows of range k only.
+ * Range k of a step is then its own pipeline  step kernel(k) -> [fold hot rows, all-reduce rows of G] -> apply(k)  which
+ * depends on NOTHING of the other ranges' item rows: range k of step t+1 may start as soon as range k of step t has
+ * been exchanged and applied (and every range's kernel of step t is done: the user rows), while the exchanges of the
+ * other ranges of step t are still travelling.  Synchronous semantics -- every row a triplet reads carries ALL updates
+ * of the steps before -- with the exchange under the neighbouring kernels.  The native loop launches each range's
+ * kernel on a stream of its own, in descending priority, so that the ranges finish staggered.
+ * The caller makes the ranges statistically alike by training on a RELABELLED item space (a fixed permutation of the
+ * item ids that balances the ranges' sampling mass, drawn once per fit; recsys_pytorch_amd/sharded.py:
+ * BPREngine.set_chunks): the library sees item ids 0 .. C * chunk_rows, of which range k holds real(k) = items_real / C
+ * (+1 for k < items_real % C) real items at its start and padding rows (never sampled, gradient always zero) behind.
  * Sampling semantics: a user's negative is uniform over the real items of the range its sampled positive fell in --
- * with the random relabelling a random 1/C of the catalog, redrawn with every relabelling.  Sums are exactly those of
- * rsx_bpr_step on the same triplets (tests replay the dumped triplets through the oracle).
- * Contract: triplets that do not honour the range rule are still summed, but would reach G after their range was
- * handed on; the kernel counts them in progress[RSX_PROGRESS_VIOLATIONS] and the native loop reports the run failed.
+ * with the relabelling a fixed pseudo-random 1/C of the catalog per positive item, redrawn with every relabelling.
+ * Sums are exactly those of rsx_bpr_step on the same triplets (tests replay the dumped triplets through the oracle).
+ * Contract: triplets that do not honour the range rule are still summed, but race with the other ranges' pipelines;
+ * the kernel counts them in progress[RSX_PROGRESS_VIOLATIONS] and the native loop reports the run failed.
  *
  * rsx_chunk_rows: rows per range = ceil(items_real / chunks) rounded up to a multiple of neg_block.
  * rsx_bpr_sample_chunked: rsx_bpr_sample(RSX_SAMPLE_SORT_POS, item_cdf) over the relabelled CSR with the range rule;
  *   num_items = chunks * chunk_rows; item_cdf_dev built over those ids (padding rows have no mass); batch <= 2^21;
  *   chunk_pos_out: int64 [chunks + 1] device, first batch position of every range (+ number of live positions).
  *   A user whose row covers its whole range has no negative: i = j = -1 (skipped by the step).
- * rsx_bpr_step_chunked: the blocked step kernel (rsx_bpr_step with neg_block, RSX_USERS_UNIQUE) over those triplets;
- *   progress: uint32 [RSX_PROGRESS_WORDS] device, zero before the launch; progress[k] ends at nbc.               */
+ * rsx_bpr_step_chunked: the blocked step kernel (rsx_bpr_step with neg_block, RSX_USERS_UNIQUE) over the positions of the
+ *   ranges [first_range, first_range + num_ranges); progress: uint32 [RSX_PROGRESS_WORDS] device, zero before the first
+ *   launch of a step; progress[k] ends at nbc = chunk_rows / neg_block (wavefronts done), for the tests.            */
 #define RSX_MAX_CHUNKS 8
 #define RSX_PROGRESS_WORDS 16
 #define RSX_PROGRESS_VIOLATIONS 8     /* triplets outside their range (must stay 0)                       */
-#define RSX_PROGRESS_TIMEOUT 9        /* a wait on progress[k] gave up after 5 s (must stay 0)             */
 int64_t rsx_chunk_rows(int64_t items_real, int chunks, int neg_block);
 
 int rsx_bpr_sample_chunked(const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users,
@@ -301,7 +304,7 @@ int rsx_bpr_step_chunked(float *P, const float *Q, float *G, int64_t num_users, 
                          const int32_t *j_dev, int64_t batch, int d, float lr, float inv_batch, float *loss_acc,
                          const int32_t *hot_slot_dev, float *G_hot, int hot_replicas, int neg_block,
                          uint64_t neg_key, const int64_t *chunk_pos_dev, uint32_t *progress_dev,
-                         rsx_stream_t stream);
+                         int first_range, int num_ranges, rsx_stream_t stream);
 
 /* ---- RCCL from the library --------------------------------------------------------------------
  * One process per GPU, one communicator per process (created on the current device).  RCCL is bound at run time
@@ -366,14 +369,16 @@ int rsx_comm_all_reduce_f32(rsx_comm *c, float *buf_dev, int64_t n, rsx_stream_t
  *                        RSX_EXCHANGE_SCATTER_GATHER: reduce-scatter of G -> the rank applies ITS shard of item rows
  *                        -> all-gather of the updated Q rows (replicas identical by construction); Q and G must then
  *                        hold world * ceil(num_items / world) rows (item_rows_padded), the tail zero.
- *   chunks / items_real / chunk_pos / progress   chunks > 1: the step as a pipeline over item ranges (see "item
- *                        chunks" above): the tables are in the caller's relabelled item space, num_items =
- *                        chunks * rsx_chunk_rows(items_real, chunks, neg_block); chunk_pos int64
+ *   chunks / items_real / chunk_pos / progress   chunks > 1: every step as `chunks` independent pipelines over item
+ *                        ranges (see "item chunks" above): the tables are in the caller's relabelled item space,
+ *                        num_items = chunks * rsx_chunk_rows(items_real, chunks, neg_block); chunk_pos int64
  *                        [RSX_TRAINER_SLOTS][chunks + 1] and progress uint32 [RSX_PROGRESS_WORDS] are device
- *                        scratch.  Range k's all-reduce (when comm is given) and apply run on the trainer's stream as
- *                        soon as its wavefronts are done, under the rest of the step kernel.  Engaged for runs whose
- *                        batch is >= 2 * num_items and <= 2^21 (below: one range); needs neg_block and item_cdf;
- *                        not combined with two_pass / stale_exchange / RSX_EXCHANGE_SCATTER_GATHER.
+ *                        scratch.  Range k's kernel, its all-reduce (when comm is given; all ranges' collectives on ONE
+ *                        trainer-owned stream, in range order on every rank) and its apply form a chain on the trainer's
+ *                        stream for range k; range k of the next step follows its own apply, whatever the other ranges'
+ *                        exchanges are doing.  Every batch of such a trainer (<= 2^21 triplets) takes this form; needs
+ *                        neg_block and item_cdf; not combined with two_pass / stale_exchange / the callbacks /
+ *                        RSX_EXCHANGE_SCATTER_GATHER.
  *   stale_exchange / G_alt   OPT-IN, needs an exchange (callbacks or comm) and a second zeroed [num_items x d] buffer.
  *                        != 0: the exchange of step t's item gradients travels under the step kernel of
  *                        step t+1, which therefore reads an item table that lacks step t's update (ONE STEP
@@ -453,8 +458,8 @@ int rsx_bpr_trainer_seek(rsx_bpr_trainer *t, int64_t step, int64_t epoch_pos, rs
 int rsx_bpr_trainer_last_batch(const rsx_bpr_trainer *t, const int32_t **u, const int32_t **i,
                                const int32_t **j, int64_t *batch, int *neg_block, uint64_t *neg_key);
 int rsx_bpr_trainer_kernel_ms(const rsx_bpr_trainer *t, double *mean_ms, int64_t *count);
-/* after the stream has drained: 0, or RSX_E_INVALID when a chunked run saw triplets outside their range or a wait on
- * the step kernel's progress timed out (text via rsx_last_error); reads progress[] from the device              */
+/* after the stream has drained: 0, or RSX_E_INVALID when a chunked run saw triplets outside their item range (text via
+ * rsx_last_error); reads progress[] from the device                                                              */
 int rsx_bpr_trainer_check(rsx_bpr_trainer *t, rsx_stream_t stream);
 
 /* ---- full-catalog scoring + Top-K ----------------------------------------------

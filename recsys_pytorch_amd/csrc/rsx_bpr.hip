@@ -287,15 +287,17 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
 // positive item but too small for blocked negatives (B < 2 I: fewer than two updates per item row, so the
 // negative side has nothing to sum): wavefront w owns the positions [w * span, (w + 1) * span), positive runs
 // are summed in registers (Zipf positives at B = 65 536: 65K row updates become ~25K), negatives go to G one by one.
-// ITEM CHUNKS (include/rsx.h; chunks.C > 1, TILE only).  The wavefronts [k * nbc, (k + 1) * nbc) belong to item range k:
-// they take the batch positions [chunk_pos[k], chunk_pos[k + 1]) -- all triplets whose positive lies in the range, and by the
-// sampler's rule their negatives too -- so when they are done the rows [k * Ic, (k + 1) * Ic) of G are complete, and whoever
-// waits on progress[k] == nbc (the native loop's own stream) can exchange / apply that range under the rest of this launch.
+// ITEM CHUNKS (include/rsx.h; chunks.C > 1, TILE only).  nbc wavefronts belong to each item range k: they take the batch
+// positions [chunk_pos[k], chunk_pos[k + 1]) -- all triplets whose positive lies in the range, and by the sampler's rule their
+// negatives too -- so they read and write item rows [k * Ic, (k + 1) * Ic) ONLY.  A launch covers the ranges [first, first + count):
+// the native loop launches every range on a stream of its own, which makes a range's gradients, exchange and apply a pipeline
+// independent of the other ranges'.
 struct ChunkRun {
     int C;                       // <= 1: off
+    int first, count;            // the ranges this launch covers
     int64_t Ic, nbc;             // rows and negative blocks per range
     const int64_t *pos;          // [C + 1] first batch position of each range (device, written by the sampler)
-    uint32_t *progress;          // [RSX_PROGRESS_WORDS]
+    uint32_t *progress;          // [RSX_PROGRESS_WORDS]: wavefronts done per range, contract violations
 };
 
 template <int D, int PASS, typename OffT, bool TILE>
@@ -320,9 +322,10 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
     int my_range = 0;
     if constexpr (TILE) {
         if (chunks.C > 1) {
-            my_range = (int)((uint32_t)wave / (uint32_t)chunks.nbc);
-            if (my_range >= chunks.C) return;
-            const int64_t wic = wave - (int64_t)my_range * chunks.nbc;
+            const int local = (int)((uint32_t)wave / (uint32_t)chunks.nbc);
+            if (local >= chunks.count) return;
+            my_range = chunks.first + local;
+            const int64_t wic = wave - (int64_t)local * chunks.nbc;
             const int64_t pc = chunks.pos[my_range], nc = chunks.pos[my_range + 1] - pc;
             b0 = pc + ceil_div64(wic * c * nc, chunks.Ic);
             b1 = pc + ceil_div64((wic + 1) * c * nc, chunks.Ic);
@@ -487,33 +490,10 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
         if (lane == 0) rsx_atomic_add(loss_acc + (wave & 63) * (RSX_LOSS_SLOTS / 64), w);   // one 128-B line per slot
     }
     if constexpr (TILE && kItems) {
-        if (chunks.C > 1) {
-            // Every sum of this wavefront has been handed to memory: count it done for its range.  What the waiter needs
-            // is G, and G is only ever touched by device-scope atomics, which execute at the memory side (DESIGN.md 4.1:
-            // TCC_EA0_ATOMIC = every atomic request) -- so the wavefront waits until all its vector memory operations,
-            // the atomics among them, are acknowledged (vmcnt 0) and then bumps the counter.  A full agent-scope RELEASE
-            // fence here is wrong for the price: it writes back this XCD's whole L2 (the dirty user rows nobody is
-            // waiting for) once per wavefront -- measured: step kernel 318 -> 1058 us.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (chunks.C > 1) {      // bookkeeping the tests read: wavefronts done per range (one relaxed atomic per wavefront)
             if (lane == 0) __hip_atomic_fetch_add(chunks.progress + my_range, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-}
-
-// the native loop's stream waits here until `target` wavefronts of range k have counted themselves done.  One wavefront,
-// one polling lane, asleep between polls; gives up after ~5 s (progress[RSX_PROGRESS_TIMEOUT] set) so that a bug can never
-// hang the device.
-__global__ __launch_bounds__(64) void wait_progress_kernel(const uint32_t *progress, int k, uint32_t target, uint32_t *flags)
-{
-    if (threadIdx.x == 0) {
-        const uint64_t t0 = wall_clock64();              // 100 MHz
-        for (;;) {
-            if (__hip_atomic_load(progress + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
-            if (wall_clock64() - t0 > 500000000ull) { atomicAdd(flags + RSX_PROGRESS_TIMEOUT, 1u); break; }
-            __builtin_amdgcn_s_sleep(32);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 // ---- the pointwise branch of the reference model (models/MF.py:99-102 with hparams['pointwise'] = True) -------------
@@ -807,7 +787,7 @@ template <int PASS, bool TILE>
 void dispatch_blocked(int d, bool wide, unsigned blocks, size_t lds, hipStream_t st, float *P, const float *Q, float *G,
                       const int32_t *u, const int32_t *i, const int32_t *j, int64_t B, int64_t num_items,
                       int c, int64_t span, uint64_t neg_key, float lr, float inv_batch, float *loss_acc, HotMap hot,
-                      ChunkRun chunks = ChunkRun{1, 0, 0, nullptr, nullptr})
+                      ChunkRun chunks = ChunkRun{1, 0, 1, 0, 0, nullptr, nullptr})
 {
 #define RSX_LAUNCH(D_) do { if (wide) hipLaunchKernelGGL((bpr_step_blocked_kernel<D_, PASS, uint64_t, TILE>), dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u, i, j, B, num_items, c, span, neg_key, lr, inv_batch, loss_acc, hot, chunks); \
                             else hipLaunchKernelGGL((bpr_step_blocked_kernel<D_, PASS, uint32_t, TILE>), dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u, i, j, B, num_items, c, span, neg_key, lr, inv_batch, loss_acc, hot, chunks); } while (0)
@@ -1056,9 +1036,10 @@ RSX_API int rsx_bpr_step_chunked(float *P, const float *Q, float *G, int64_t num
                                  const int32_t *j_dev, int64_t batch, int d, float lr, float inv_batch, float *loss_acc,
                                  const int32_t *hot_slot_dev, float *G_hot, int hot_replicas, int neg_block,
                                  uint64_t neg_key, const int64_t *chunk_pos_dev, uint32_t *progress_dev,
-                                 rsx_stream_t stream)
+                                 int first_range, int num_ranges, rsx_stream_t stream)
 {
     RSX_CHECK_ARG(P && Q && G && chunk_pos_dev && progress_dev, "null pointer");
+    RSX_CHECK_ARG(first_range >= 0 && num_ranges >= 1 && first_range + num_ranges <= chunks, "ranges [first, first + count) must lie in [0, chunks)");
     RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64 or 128");
     RSX_CHECK_ARG(chunks >= 2 && chunks <= RSX_MAX_CHUNKS, "chunks must be in [2, RSX_MAX_CHUNKS]");
     RSX_CHECK_ARG(neg_block >= 1 && neg_block <= kMaxNegBlock, "the chunked step needs neg_block in [1, 16]");
@@ -1074,19 +1055,12 @@ RSX_API int rsx_bpr_step_chunked(float *P, const float *Q, float *G, int64_t num
         hot = HotMap{hot_slot_dev, G_hot, hot_replicas};
     }
     const bool wide = wide_offsets(num_users, num_items, d) || batch >= (1ll << 30);
-    const int64_t waves = g.nbc * chunks;
+    const int64_t waves = g.nbc * num_ranges;
     const unsigned blocks = (unsigned)ceil_div64(waves, kWavesPerBlock);
     const size_t lds = (size_t)kWavesPerBlock * neg_block * d * sizeof(float);
     dispatch_blocked<kPassBoth, true>(d, wide, blocks, lds, (hipStream_t)stream, P, Q, G, u_dev, i_dev, j_dev, batch, num_items,
                                       neg_block, 0, neg_key, lr, inv_batch, loss_acc, hot,
-                                      ChunkRun{chunks, g.Ic, g.nbc, chunk_pos_dev, progress_dev});
-    RSX_CHECK_LAUNCH();
-    return RSX_OK;
-}
-
-int rsx_wait_progress(const uint32_t *progress, int k, uint32_t target, hipStream_t st)
-{
-    hipLaunchKernelGGL(wait_progress_kernel, dim3(1), dim3(64), 0, st, progress, k, target, const_cast<uint32_t *>(progress));
+                                      ChunkRun{chunks, first_range, num_ranges, g.Ic, g.nbc, chunk_pos_dev, progress_dev});
     RSX_CHECK_LAUNCH();
     return RSX_OK;
 }

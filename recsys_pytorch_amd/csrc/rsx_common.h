@@ -134,6 +134,5 @@ int rsx_comm_reduce_scatter(rsx_comm *c, float *buf, int64_t n_per_rank, hipStre
 int rsx_comm_all_gather(rsx_comm *c, float *buf, int64_t n_per_rank, hipStream_t st);
 
 // rsx_bpr.hip: pieces of the chunked step the native loop queues on its own stream
-int rsx_wait_progress(const uint32_t *progress, int k, uint32_t target, hipStream_t st);     // returns when progress[k] >= target
 int rsx_fold_hot_grad_range(float *G, float *G_hot, const int32_t *hot_items_dev, int n_hot, int hot_replicas, int d,
                             int64_t row_lo, int64_t row_hi, hipStream_t st);

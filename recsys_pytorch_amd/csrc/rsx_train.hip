@@ -11,6 +11,7 @@
 // rsx_fold_hot_grad, rsx_apply_item_grad): a run of n steps equals n hand-driven steps.
 // The trainer owns only host state (step counter, position in the user permutation, a side
 // stream, events); every device buffer is borrowed from the caller.
+#include <stdlib.h>
 #include <vector>
 
 #include "rsx_common.h"
@@ -25,6 +26,14 @@ struct rsx_bpr_trainer {
     hipEvent_t ev_start = nullptr;               // run stream -> aux: the step's counters are reset, the tables are consistent
     hipEvent_t ev_g = nullptr;                   // run stream -> aux: G (folded) is complete
     hipEvent_t ev_x[2] = {};                     // aux -> run stream: the exchange (+ apply) of gradient buffer 0 / 1 is done
+    // item chunks (config.chunks > 1): one stream per item range, in descending priority.  Range k's chain
+    //   [all kernels of the step before done] -> kernel(k) -> (aux: fold, all-reduce of range k) -> apply(k)
+    // lives on cs[k]; the next step's kernel(k) follows its own apply in stream order.
+    hipStream_t cs[RSX_MAX_CHUNKS] = {};
+    hipEvent_t ev_k[RSX_MAX_CHUNKS][2] = {};     // cs[k] -> everybody: kernel(k) of an even / odd step is done
+    hipEvent_t ev_r[RSX_MAX_CHUNKS] = {};        // aux -> cs[k]: range k's rows of G are reduced over the ranks
+    hipEvent_t ev_a[RSX_MAX_CHUNKS] = {};        // cs[k] -> run stream: apply(k) of the latest step is done
+    bool kernels_in_flight = false;              // the kernels of the step before have been launched in this run
     // ring of RSX_TRAINER_SLOTS triplet buffers: the one being consumed and the batches sampled ahead.  Two
     // ahead, not one: with one, the step kernel's launch waits on an event the side stream has recorded only
     // microseconds before, and that cross-stream hand-over showed as a 11-12 us hole in front of EVERY step
@@ -88,6 +97,30 @@ int effective_neg_block(const rsx_bpr_trainer *t, int64_t batch)
 int64_t *chunk_pos_ptr(const rsx_bpr_trainer *t, int slot) { return t->c.chunk_pos + (size_t)slot * (t->c.chunks + 1); }
 
 #define RSX_TRY(call) do { int rc__ = (call); if (rc__ != RSX_OK) return rc__; } while (0)
+
+// DEVELOPMENT BUILD ONLY (librsx_dev.so, -DRSX_ABLATE): a stand-in for the time an exchange takes on the wire.  On a one-GPU
+// box the collectives of a one-rank communicator are identities; `rsx_debug_set_exchange_delay(us)` makes every FULL
+// exchange of the item gradients hold the trainer's collective stream for `us` microseconds (a range's exchange for
+// us / chunks), with eight idle-spinning workgroups -- the footprint of a collective kernel -- so that the schedules can be
+// compared against an exchange of a given length (tools/exchange_model.py).  The shipped library
+// has no such switch: there the function below is empty.
+#ifdef RSX_ABLATE
+static int g_exchange_delay_us = 0;
+RSX_API int rsx_debug_set_exchange_delay(int us) { g_exchange_delay_us = us < 0 ? 0 : us; return RSX_OK; }
+__global__ __launch_bounds__(256) void exchange_delay_kernel(uint64_t ticks)
+{
+    const uint64_t t0 = wall_clock64();          // 100 MHz
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+static int rsx_debug_exchange_delay(hipStream_t st, int parts)
+{
+    if (g_exchange_delay_us <= 0) return RSX_OK;
+    hipLaunchKernelGGL(exchange_delay_kernel, dim3(8), dim3(256), 0, st, (uint64_t)g_exchange_delay_us * 100ull / (uint64_t)parts);
+    return RSX_OK;
+}
+#else
+static inline int rsx_debug_exchange_delay(hipStream_t, int) { return RSX_OK; }
+#endif
 #define RSX_HIP(call)                                                                          \
     do {                                                                                       \
         hipError_t e__ = (call);                                                               \
@@ -190,6 +223,16 @@ RSX_API int rsx_bpr_trainer_create(const rsx_bpr_trainer_config *cfg, rsx_bpr_tr
     for (int s = 0; ok && s < rsx_bpr_trainer::S; ++s)
         ok = hipEventCreateWithFlags(&t->ready[s], kOrderOnly) == hipSuccess &&
              hipEventCreateWithFlags(&t->freed[s], kOrderOnly) == hipSuccess;
+    for (int k = 0; ok && k < cfg->chunks && cfg->chunks > 1; ++k) {
+        // the ranges finish staggered when the hardware prefers the earlier ones: range 0 most urgent, the last ones least
+        int pk = prio_hi + k;
+        if (pk > prio_lo) pk = prio_lo;
+        ok = hipStreamCreateWithPriority(&t->cs[k], hipStreamNonBlocking, pk) == hipSuccess &&
+             hipEventCreateWithFlags(&t->ev_k[k][0], kOrderOnly) == hipSuccess &&
+             hipEventCreateWithFlags(&t->ev_k[k][1], kOrderOnly) == hipSuccess &&
+             hipEventCreateWithFlags(&t->ev_r[k], kOrderOnly) == hipSuccess &&
+             hipEventCreateWithFlags(&t->ev_a[k], kOrderOnly) == hipSuccess;
+    }
     if (!ok) {
         rsx_set_error("rsx_bpr_trainer_create: could not create the side stream / events");
         rsx_bpr_trainer_destroy(t);
@@ -205,6 +248,10 @@ RSX_API void rsx_bpr_trainer_destroy(rsx_bpr_trainer *t)
     if (t->side) { (void)hipStreamSynchronize(t->side); (void)hipStreamDestroy(t->side); }
     if (t->aux) { (void)hipStreamSynchronize(t->aux); (void)hipStreamDestroy(t->aux); }
     for (hipEvent_t e : {t->ev_start, t->ev_g, t->ev_x[0], t->ev_x[1]}) if (e) (void)hipEventDestroy(e);
+    for (int k = 0; k < RSX_MAX_CHUNKS; ++k) {
+        if (t->cs[k]) { (void)hipStreamSynchronize(t->cs[k]); (void)hipStreamDestroy(t->cs[k]); }
+        for (hipEvent_t e : {t->ev_k[k][0], t->ev_k[k][1], t->ev_r[k], t->ev_a[k]}) if (e) (void)hipEventDestroy(e);
+    }
     for (int s = 0; s < rsx_bpr_trainer::S; ++s) {
         if (t->ready[s]) (void)hipEventDestroy(t->ready[s]);
         if (t->freed[s]) (void)hipEventDestroy(t->freed[s]);
@@ -270,7 +317,7 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
         }
         RSX_HIP(hipEventRecord(t->ev_g, st));
         RSX_HIP(hipStreamWaitEvent(t->aux, t->ev_g, 0));
-        if (!sg) RSX_TRY(rsx_comm_all_reduce(c.comm, Gbuf, c.num_items * c.d, t->aux));
+        if (!sg) { RSX_TRY(rsx_comm_all_reduce(c.comm, Gbuf, c.num_items * c.d, t->aux)); RSX_TRY(rsx_debug_exchange_delay(t->aux, 1)); }
         else RSX_TRY(rsx_comm_reduce_scatter(c.comm, Gbuf, c.item_rows_padded / world_size * c.d, t->aux));
         RSX_HIP(hipEventRecord(t->ev_x[which], t->aux));
         return RSX_OK;
@@ -323,35 +370,66 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
             return RSX_OK;
         };
         if (t->slot_chunked[cur]) {
-            // ---- the step as a pipeline over item ranges (include/rsx.h: "item chunks") --------------------------------
-            // run stream:  counters = 0 -> step kernel (range k's wavefronts count themselves done in progress[k])
-            // aux stream:  for k: wait until range k is done -> [fold its hot rows, all-reduce its rows of G] -> apply them
-            // so the exchange and the apply of range k travel under the wavefronts of the ranges after it.
+            // ---- the step as independent pipelines over item ranges (include/rsx.h: "item chunks") ------------------
+            // cs[k]:  wait(sampler, every kernel of the step before) -> kernel(k) -> wait(all-reduce k) -> apply(k)
+            // aux  :  for k in order: wait(kernel k) -> fold the range's hot rows -> all-reduce the range's rows of G
+            // The run stream only joins: it frees the triplet slot when the kernels are done, and ends the run behind
+            // the last applies.  Range k of the NEXT step follows apply(k) in cs[k]'s own order -- it does not wait for
+            // the other ranges' exchanges, which travel under it.
             const ChunkGeom g = chunk_geom(c.items_real, c.chunks, c.neg_block);
-            RSX_HIP(hipMemsetAsync(c.progress, 0, RSX_MAX_CHUNKS * sizeof(uint32_t), st));
-            RSX_HIP(hipEventRecord(t->ev_start, st));
-            RSX_HIP(hipStreamWaitEvent(t->aux, t->ev_start, 0));
-            RSX_TRY(time_begin());
-            RSX_TRY(rsx_bpr_step_chunked(c.P, c.Q, c.G, c.num_users, c.num_items, c.items_real, c.chunks, u, i, j, batch, c.d, c.lr,
-                                         inv_batch, c.loss_acc, c.hot_slot, c.G_hot, c.hot_replicas, nb, key, chunk_pos_ptr(t, cur),
-                                         c.progress, stream));
-            RSX_TRY(time_end());
-            if (sharded) RSX_TRY(top_up());                                    // the next batches, beside everything
+            const int par = (int)(t->step & 1);
+            if (s == 0) {        // the ranges' streams start behind whatever the run stream holds (a previous run, the caller's work)
+                RSX_HIP(hipMemsetAsync(c.progress, 0, RSX_MAX_CHUNKS * sizeof(uint32_t), st));
+                RSX_HIP(hipEventRecord(t->ev_start, st));
+                for (int k = 0; k < c.chunks; ++k) RSX_HIP(hipStreamWaitEvent(t->cs[k], t->ev_start, 0));
+                t->kernels_in_flight = false;
+            }
+            if (sharded) RSX_TRY(top_up());
             for (int k = 0; k < c.chunks; ++k) {
+                hipStream_t ck = t->cs[k];
+                RSX_HIP(hipStreamWaitEvent(ck, t->ready[cur], 0));
+                if (t->kernels_in_flight)      // user rows: every range's kernel of the step before has written its users
+                    for (int q = 0; q < c.chunks; ++q)
+                        if (q != k) RSX_HIP(hipStreamWaitEvent(ck, t->ev_k[q][1 - par], 0));
+                if (timed && k == 0) {
+                    if (t->timed == t->t0.size()) {
+                        hipEvent_t a, b;
+                        RSX_HIP(hipEventCreate(&a));
+                        RSX_HIP(hipEventCreate(&b));
+                        t->t0.push_back(a); t->t1.push_back(b);
+                    }
+                    RSX_HIP(hipEventRecord(t->t0[t->timed], ck));
+                }
+                RSX_TRY(rsx_bpr_step_chunked(c.P, c.Q, c.G, c.num_users, c.num_items, c.items_real, c.chunks, u, i, j, batch, c.d, c.lr,
+                                             inv_batch, c.loss_acc, c.hot_slot, c.G_hot, c.hot_replicas, nb, key, chunk_pos_ptr(t, cur),
+                                             c.progress, k, 1, (rsx_stream_t)ck));
+                if (timed && k == c.chunks - 1) { RSX_HIP(hipEventRecord(t->t1[t->timed], ck)); ++t->timed; }
+                RSX_HIP(hipEventRecord(t->ev_k[k][par], ck));
+            }
+            for (int k = 0; k < c.chunks; ++k) {
+                hipStream_t ck = t->cs[k];
                 const int64_t lo = (int64_t)k * g.Ic;
                 float *Gk = c.G + (size_t)lo * c.d, *Qk = c.Q + (size_t)lo * c.d;
-                RSX_TRY(rsx_wait_progress(c.progress, k, (uint32_t)g.nbc, t->aux));
                 if (native) {
+                    // one stream for every collective of the communicator, issued in range order on every rank
+                    RSX_HIP(hipStreamWaitEvent(t->aux, t->ev_k[k][par], 0));
                     if (hot) RSX_TRY(rsx_fold_hot_grad_range(c.G, c.G_hot, c.hot_items, c.n_hot, c.hot_replicas, c.d, lo, lo + g.Ic, t->aux));
                     RSX_TRY(rsx_comm_all_reduce(c.comm, Gk, g.Ic * c.d, t->aux));
-                    RSX_TRY(rsx_apply_item_grad(Qk, Gk, g.Ic, c.d, c.lr, nullptr, nullptr, 0, (rsx_stream_t)t->aux));
+                    RSX_TRY(rsx_debug_exchange_delay(t->aux, c.chunks));
+                    RSX_HIP(hipEventRecord(t->ev_r[k], t->aux));
+                    RSX_HIP(hipStreamWaitEvent(ck, t->ev_r[k], 0));
+                    RSX_TRY(rsx_apply_item_grad(Qk, Gk, g.Ic, c.d, c.lr, nullptr, nullptr, 0, (rsx_stream_t)ck));
                 } else {
                     RSX_TRY(rsx_apply_item_grad(Qk, Gk, g.Ic, c.d, c.lr, hot ? c.hot_slot + lo : nullptr, c.G_hot, c.hot_replicas,
-                                                (rsx_stream_t)t->aux));
+                                                (rsx_stream_t)ck));
                 }
+                RSX_HIP(hipEventRecord(t->ev_a[k], ck));
             }
-            RSX_HIP(hipEventRecord(t->ev_x[0], t->aux));
-            RSX_HIP(hipStreamWaitEvent(st, t->ev_x[0], 0));
+            t->kernels_in_flight = true;
+            // the triplet slot is free when every range's kernel is done
+            for (int k = 0; k < c.chunks; ++k) RSX_HIP(hipStreamWaitEvent(st, t->ev_k[k][par], 0));
+            if (s + 1 == n_steps)      // a run ends behind its last applies
+                for (int k = 0; k < c.chunks; ++k) RSX_HIP(hipStreamWaitEvent(st, t->ev_a[k], 0));
         } else {
         RSX_TRY(time_begin());
         const unsigned sorted_flag = t->slot_sorted[cur] ? RSX_BATCH_SORTED : 0u;
@@ -416,12 +494,8 @@ RSX_API int rsx_bpr_trainer_check(rsx_bpr_trainer *t, rsx_stream_t stream)
     uint32_t h[RSX_PROGRESS_WORDS] = {};
     RSX_HIP(hipMemcpyAsync(h, t->c.progress, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
     RSX_HIP(hipStreamSynchronize((hipStream_t)stream));
-    if (h[RSX_PROGRESS_TIMEOUT] != 0) {
-        rsx_set_error("rsx_bpr_trainer_check: %u waits on the step kernel's progress timed out (a range was handed on incomplete)", h[RSX_PROGRESS_TIMEOUT]);
-        return RSX_E_INVALID;
-    }
     if (h[RSX_PROGRESS_VIOLATIONS] != 0) {
-        rsx_set_error("rsx_bpr_trainer_check: %u triplets touched an item row outside their range (their sums reached G after the range was handed on)",
+        rsx_set_error("rsx_bpr_trainer_check: %u triplets touched an item row outside their range (they race with the other ranges' pipelines)",
                       h[RSX_PROGRESS_VIOLATIONS]);
         return RSX_E_INVALID;
     }

@@ -27,7 +27,6 @@ RSX_TRAINER_SLOTS = 3
 RSX_MAX_CHUNKS = 8
 RSX_PROGRESS_WORDS = 16
 RSX_PROGRESS_VIOLATIONS = 8
-RSX_PROGRESS_TIMEOUT = 9
 RSX_COMM_ID_BYTES = 128
 RSX_EXCHANGE_ALLREDUCE = 1
 RSX_EXCHANGE_SCATTER_GATHER = 2
@@ -73,7 +72,7 @@ SIGNATURES = {
     "rsx_bpr_sample_chunked": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _I64, _U64, _U64, _I64, _I32, _U64, _P, _I64,
                                          _P, _P, _P, _P, _P, _P, _P]),
     "rsx_bpr_step_chunked": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I32, _P, _P, _P, _I64, _I32, _F, _F, _P, _P, _P, _I32,
-                                       _I32, _U64, _P, _P, _P]),
+                                       _I32, _U64, _P, _P, _I32, _I32, _P]),
     "rsx_comm_unique_id": (C.c_int, [_P]),
     "rsx_comm_create": (C.c_int, [_P, _I32, _I32, _P]),
     "rsx_comm_destroy": (None, [_P]),
@@ -373,8 +372,9 @@ def bpr_sample_chunked(indptr, indices, num_items, items_real, chunks, batch, se
 
 
 def bpr_step_chunked(P, Q, G, items_real, chunks, u, i, j, lr, inv_batch, chunk_pos, progress, neg_block, neg_key, loss_acc=None,
-                     hot=None):
-    """include/rsx.h:rsx_bpr_step_chunked; progress: int32 [RSX_PROGRESS_WORDS] device, zero before the call"""
+                     hot=None, first_range=0, num_ranges=None):
+    """include/rsx.h:rsx_bpr_step_chunked over the item ranges [first_range, first_range + num_ranges) (default: all);
+    progress: int32 [RSX_PROGRESS_WORDS] device, zero before the first launch of a step"""
     _check(lib().rsx_bpr_step_chunked(
         _dev(P, torch.float32, "P"), _dev(Q, torch.float32, "Q"), _dev(G, torch.float32, "G"), P.shape[0], Q.shape[0],
         int(items_real), int(chunks), _dev(u, torch.int32, "u"), _dev(i, torch.int32, "i"), _dev(j, torch.int32, "j"), u.numel(),
@@ -382,7 +382,8 @@ def bpr_step_chunked(P, Q, G, items_real, chunks, u, i, j, lr, inv_batch, chunk_
         _dev(hot.slot, torch.int32, "hot slot") if hot is not None else None,
         _dev(hot.ghot, torch.float32, "ghot") if hot is not None else None, hot.replicas if hot is not None else 0,
         int(neg_block), int(neg_key) & (2**64 - 1), _dev(chunk_pos, torch.int64, "chunk_pos"),
-        _dev(progress, torch.int32, "progress"), _stream()), "rsx_bpr_step_chunked")
+        _dev(progress, torch.int32, "progress"), int(first_range), int(chunks - first_range if num_ranges is None else num_ranges),
+        _stream()), "rsx_bpr_step_chunked")
 
 
 class Comm:

@@ -212,9 +212,42 @@ class BPREngine:
         C, nb, dev = self.chunks, self.neg_block, self.Q.device
         Ic = self.k.chunk_rows(I, C, nb)
         base, rem = divmod(I, C)
-        gen = torch.Generator().manual_seed(self.seed * 7919 + 13)                 # host generator: identical on every rank
-        perm = torch.randperm(I, generator=gen)                                    # the items in rank order
-        counts = torch.tensor([base + (k < rem) for k in range(C)])
+        # Which item goes to which range.  The ranges should carry the same share of the batch (their kernels then take
+        # the same time and finish staggered by their priorities alone), so the relabelling balances the SAMPLING MASS of
+        # the ranges -- item i is the sampled positive with weight sum over its users of 1 / deg(u), summed over the ranks --
+        # not just their sizes: the few thousand heaviest items are dealt greedily to the currently lightest range
+        # (a popularity-skewed catalog has single items of several percent), the rest at random.  Seeded, and a function of
+        # the global masses only: identical on every rank.
+        import numpy as np
+        U = indptr.numel() - 1
+        deg = (indptr[1:] - indptr[:-1]).double()
+        w = torch.repeat_interleave(1.0 / deg.clamp_min(1.0), indptr[1:] - indptr[:-1])
+        mass = torch.zeros(I, dtype=torch.float64, device=dev).index_add_(0, indices.long(), w)
+        if self.sharded and self.world > 1:
+            m = mass.cpu() if dist.get_backend(self.group) == "gloo" else mass
+            dist.all_reduce(m, group=self.group)
+            mass = m.to(dev)
+        mass = mass.cpu().numpy()
+        rng = np.random.default_rng(self.seed * 7919 + 13)
+        cap = np.array([base + (k < rem) for k in range(C)], dtype=np.int64)      # real items per range
+        order = np.argsort(-mass, kind="stable")
+        heavy = order[:min(I, 4096)]
+        assign = np.full(I, -1, dtype=np.int64)
+        load, cnt = np.zeros(C), np.zeros(C, dtype=np.int64)
+        for it in heavy:
+            k = int(np.argmin(np.where(cnt < cap, load, np.inf)))
+            assign[it] = k; load[k] += mass[it]; cnt[k] += 1
+        rest = order[len(heavy):]
+        seats = np.repeat(np.arange(C), cap - cnt)
+        rng.shuffle(seats)
+        assign[rest] = seats
+        perm_parts = []
+        for k in range(C):
+            members = np.flatnonzero(assign == k)
+            rng.shuffle(members)
+            perm_parts.append(members)
+        perm = torch.from_numpy(np.concatenate(perm_parts))                        # the items in rank order
+        counts = torch.from_numpy(cap)
         starts = torch.cumsum(counts, 0) - counts
         which = torch.repeat_interleave(torch.arange(C), counts)
         rank_of_pos = which * Ic + (torch.arange(I) - starts[which])
@@ -224,7 +257,6 @@ class BPREngine:
         rank_item[rank_of_pos] = perm
         item_rank, rank_item = item_rank.to(dev), rank_item.to(dev)
         # the CSR with relabelled columns, rows sorted again
-        U = indptr.numel() - 1
         rows = torch.repeat_interleave(torch.arange(U, device=dev), indptr[1:] - indptr[:-1])
         key = rows * (C * Ic) + item_rank[indices.long()]
         key = torch.sort(key).values

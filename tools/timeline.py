@@ -6,7 +6,7 @@ for f in files:
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", r.get("Queue_Id", "?"))))
 rows.sort()
-names = {"bpr_step_blocked": "STEP", "bpr_step_kernel": "STEP", "bpr_sample_kernel": "sample", "apply_item": "apply", "sample_ui16": "ui", "sample_neg16": "neg", "rocprim": "sort", "fold_hot": "fold", "bucket_chunk": "chunk", "bucket_sort": "bsort", "fill": "memset"}
+names = {"bpr_step_blocked": "STEP", "bpr_step_kernel": "STEP", "bpr_sample_kernel": "sample", "apply_item": "apply", "sample_ui16": "ui", "sample_neg16": "neg", "rocprim": "sort", "fold_hot": "fold", "bucket_chunk": "chunk", "bucket_sort": "bsort", "fill": "memset", "wait_progress": "wait", "fold_hot_range": "foldr"}
 steps = [i for i, r in enumerate(rows) if "bpr_step_blocked" in r[2] or "bpr_step_kernel" in r[2]]
 if len(steps) > 14:
     lo, hi = steps[10], steps[13]
