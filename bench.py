@@ -70,9 +70,11 @@ def parse():
     ap.add_argument("--hot", type=int, default=256, help="popular items whose gradient rows are replicated (0 = off)")
     ap.add_argument("--hot-replicas", type=int, default=16)
     ap.add_argument("--neg-block", type=int, default=8, help="item block of the stratified negatives (0 = independent uniform negatives)")
-    ap.add_argument("--chunks", type=int, default=int(os.environ.get("RSX_CHUNKS", "0")),
-                    help="> 1: the step as a pipeline over that many item ranges (include/rsx.h: item chunks): the apply and, "
-                         "with N > 1, the all-reduce of a range travel under the rest of the step kernel")
+    ap.add_argument("--chunks", type=int, default=int(os.environ.get("RSX_CHUNKS", "-1")),
+                    help="> 1: every step as that many independent pipelines over item ranges (include/rsx.h: item chunks): the "
+                         "all-reduce + apply of a range travel under the other ranges' kernels of this and the next step.  "
+                         "-1 (default): 3 when N > 1 and the library issues the exchange, 0 (off) on one GPU, where there is "
+                         "nothing to hide and the plain blocked step is faster")
     ap.add_argument("--no-legs", action="store_true", help="headline only (no section-8d legs)")
     ap.add_argument("--no-lightgcn", action="store_true", help="skip the BASELINE configs[4] leg (LightGCN propagation + step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -368,6 +370,8 @@ def main():
     # two passes at every N > 1 (RSX_TWO_PASS=0 for the one-pass schedule)
     two_pass = SHARDED and os.environ.get("RSX_TWO_PASS", "1") == "1"
     P, Q, indptr, indices = tables(U, I, d, args.degree, args.popularity)
+    if args.chunks < 0:
+        args.chunks = 3 if (world > 1 and COMM is not None) else 0
     head = step_leg(P, Q, indptr, indices, args.lr, B, args.neg_block, args.hot, args.hot_replicas, args.steps, args.warmup,
                     world, rank, args.popularity, two_pass=two_pass, chunks=args.chunks)
     Q = head.pop("_Q")

@@ -285,8 +285,8 @@ int rsx_bpr_build_item_cdf(const int64_t *indptr_dev, const int32_t *indices_dev
  *   chunk_pos_out: int64 [chunks + 1] device, first batch position of every range (+ number of live positions).
  *   A user whose row covers its whole range has no negative: i = j = -1 (skipped by the step).
  * rsx_bpr_step_chunked: the blocked step kernel (rsx_bpr_step with neg_block, RSX_USERS_UNIQUE) over the positions of the
- *   ranges [first_range, first_range + num_ranges); progress: uint32 [RSX_PROGRESS_WORDS] device, zero before the first
- *   launch of a step; progress[k] ends at nbc = chunk_rows / neg_block (wavefronts done), for the tests.            */
+ *   ranges [first_range, first_range + num_ranges); progress: uint32 [RSX_PROGRESS_WORDS] device, zeroed by the caller;
+ *   progress[RSX_PROGRESS_VIOLATIONS] counts the triplets that left their range.                                  */
 #define RSX_MAX_CHUNKS 8
 #define RSX_PROGRESS_WORDS 16
 #define RSX_PROGRESS_VIOLATIONS 8     /* triplets outside their range (must stay 0)                       */
@@ -518,6 +518,14 @@ int rsx_spmm_csr(const int32_t *seg_row_dev, const int64_t *seg_begin_dev, const
                  int64_t num_segs, const int64_t *indptr_dev, const int32_t *indices_dev,
                  const float *vals_dev, const float *X, float *Y, float *S_acc, int64_t num_rows, int d,
                  rsx_stream_t stream);
+/* rsx_spmm_csr_sparse_rows: the same product for an X most of whose ROWS are entirely zero; x_row_nonzero_dev (uint8 [N]) is
+ *   zero for such rows (a non-zero row flagged zero would be dropped: the flags are the caller's claim) and they are not
+ *   fetched.  Bit-identical to rsx_spmm_csr.  The first backward product of a LightGCN step: the dense gradient of the
+ *   loss has non-zero rows only for the batch's users and items (models/LightGCN.py:83-87).                        */
+int rsx_spmm_csr_sparse_rows(const int32_t *seg_row_dev, const int64_t *seg_begin_dev, const int32_t *seg_len_dev,
+                             int64_t num_segs, const int64_t *indptr_dev, const int32_t *indices_dev,
+                             const float *vals_dev, const float *X, const uint8_t *x_row_nonzero_dev, float *Y,
+                             float *S_acc, int64_t num_rows, int d, rsx_stream_t stream);
 int rsx_scale(float *X, int64_t n, float alpha, rsx_stream_t stream);
 
 /* ---- holdout metrics (HOST function, host pointers) --------------------------------

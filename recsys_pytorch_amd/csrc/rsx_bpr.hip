@@ -297,7 +297,7 @@ struct ChunkRun {
     int first, count;            // the ranges this launch covers
     int64_t Ic, nbc;             // rows and negative blocks per range
     const int64_t *pos;          // [C + 1] first batch position of each range (device, written by the sampler)
-    uint32_t *progress;          // [RSX_PROGRESS_WORDS]: wavefronts done per range, contract violations
+    uint32_t *progress;          // [RSX_PROGRESS_WORDS]: contract violations (RSX_PROGRESS_VIOLATIONS)
 };
 
 template <int D, int PASS, typename OffT, bool TILE>
@@ -489,11 +489,9 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
         const float w = wave_sum(loss_local);
         if (lane == 0) rsx_atomic_add(loss_acc + (wave & 63) * (RSX_LOSS_SLOTS / 64), w);   // one 128-B line per slot
     }
-    if constexpr (TILE && kItems) {
-        if (chunks.C > 1) {      // bookkeeping the tests read: wavefronts done per range (one relaxed atomic per wavefront)
-            if (lane == 0) __hip_atomic_fetch_add(chunks.progress + my_range, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    // (a per-range "wavefronts done" counter was kept here at first: one atomic per wavefront onto ONE address serialises at the
+    //  memory-side atomic unit -- ~40 same-line operations per microsecond, DESIGN.md 4.1 -- and with 16 667 wavefronts cost the
+    //  chunked kernel 25 us, 300 us with blocks of 3 items: removed)
 }
 
 // ---- the pointwise branch of the reference model (models/MF.py:99-102 with hparams['pointwise'] = True) -------------

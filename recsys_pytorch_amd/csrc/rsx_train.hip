@@ -11,7 +11,6 @@
 // rsx_fold_hot_grad, rsx_apply_item_grad): a run of n steps equals n hand-driven steps.
 // The trainer owns only host state (step counter, position in the user permutation, a side
 // stream, events); every device buffer is borrowed from the caller.
-#include <stdlib.h>
 #include <vector>
 
 #include "rsx_common.h"
@@ -224,9 +223,11 @@ RSX_API int rsx_bpr_trainer_create(const rsx_bpr_trainer_config *cfg, rsx_bpr_tr
         ok = hipEventCreateWithFlags(&t->ready[s], kOrderOnly) == hipSuccess &&
              hipEventCreateWithFlags(&t->freed[s], kOrderOnly) == hipSuccess;
     for (int k = 0; ok && k < cfg->chunks && cfg->chunks > 1; ++k) {
-        // the ranges finish staggered when the hardware prefers the earlier ones: range 0 most urgent, the last ones least
-        int pk = prio_hi + k;
-        if (pk > prio_lo) pk = prio_lo;
+        // range 0 most urgent, the others at the default priority; the LOWEST level stays with the sampler alone.  Measured
+        // (one GPU, no exchange, us per step at C = 2 / 3 / 4): 443 / 467 / 550 with descending priorities, 433 / 474 / 684
+        // all equal, 453 / 471 / 559 two urgent: the choice hardly matters, and one session with two range kernels plus
+        // the sampler on the lowest level ran C = 4 at SECONDS per step (profiles/r03_exp_range_priorities.txt)
+        const int pk = (k == 0) ? prio_hi : (prio_hi + 1 <= prio_lo - 1 ? prio_hi + 1 : prio_hi);
         ok = hipStreamCreateWithPriority(&t->cs[k], hipStreamNonBlocking, pk) == hipSuccess &&
              hipEventCreateWithFlags(&t->ev_k[k][0], kOrderOnly) == hipSuccess &&
              hipEventCreateWithFlags(&t->ev_k[k][1], kOrderOnly) == hipSuccess &&
@@ -416,14 +417,16 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
                     if (hot) RSX_TRY(rsx_fold_hot_grad_range(c.G, c.G_hot, c.hot_items, c.n_hot, c.hot_replicas, c.d, lo, lo + g.Ic, t->aux));
                     RSX_TRY(rsx_comm_all_reduce(c.comm, Gk, g.Ic * c.d, t->aux));
                     RSX_TRY(rsx_debug_exchange_delay(t->aux, c.chunks));
-                    RSX_HIP(hipEventRecord(t->ev_r[k], t->aux));
-                    RSX_HIP(hipStreamWaitEvent(ck, t->ev_r[k], 0));
-                    RSX_TRY(rsx_apply_item_grad(Qk, Gk, g.Ic, c.d, c.lr, nullptr, nullptr, 0, (rsx_stream_t)ck));
+                    RSX_TRY(rsx_apply_item_grad(Qk, Gk, g.Ic, c.d, c.lr, nullptr, nullptr, 0, (rsx_stream_t)t->aux));
                 } else {
+                    RSX_HIP(hipStreamWaitEvent(t->aux, t->ev_k[k][par], 0));
                     RSX_TRY(rsx_apply_item_grad(Qk, Gk, g.Ic, c.d, c.lr, hot ? c.hot_slot + lo : nullptr, c.G_hot, c.hot_replicas,
-                                                (rsx_stream_t)ck));
+                                                (rsx_stream_t)t->aux));
                 }
-                RSX_HIP(hipEventRecord(t->ev_a[k], ck));
+                // (the apply is short and on the critical path of range k's next kernel: it runs on the highest-priority
+                //  stream -- on the range's own, low-priority stream it waited ~250 us behind the next step's other kernels)
+                RSX_HIP(hipEventRecord(t->ev_a[k], t->aux));
+                RSX_HIP(hipStreamWaitEvent(ck, t->ev_a[k], 0));
             }
             t->kernels_in_flight = true;
             // the triplet slot is free when every range's kernel is done

@@ -70,6 +70,7 @@ class LightGCN(BaseModel):
         self.Graph = None
         self._t = 0
         self._fresh = False            # is self._out the propagation of the current E0?
+        self._nz = None                # per-row "non-zero" flags of dL/dOut (first backward product)
 
     # -- tables / graph ------------------------------------------------------------------------
     def load_tables(self, P, Q):
@@ -89,16 +90,20 @@ class LightGCN(BaseModel):
         return torch.as_tensor(t).to(device=self.device, dtype=torch.int32).contiguous()
 
     # -- models/LightGCN.py:174-202 ----------------------------------------------------------------
-    def _propagate(self, src, acc):
-        """acc = mean_{k=0..L} A_hat^k src   (src untouched)"""
+    def _propagate(self, src, acc, src_nonzero=None):
+        """acc = mean_{k=0..L} A_hat^k src   (src untouched).  src_nonzero (uint8 per row, 0 = the row of src is entirely
+        zero) lets the FIRST product skip the fetch of such rows (bit-identical; include/rsx.h: rsx_spmm_csr_sparse_rows)"""
         k = self._k
         if self.Graph is None:
             raise RuntimeError("no graph yet: call fit() or getSparseGraph(train_matrix) first "
                                "(the reference builds it in fit, models/LightGCN.py:70)")
         acc.copy_(src)
         cur, nxt = src, self._ta
-        for _ in range(self.num_layers):
-            k.spmm(self.Graph, cur, nxt, S_acc=acc)
+        for layer in range(self.num_layers):
+            if layer == 0 and src_nonzero is not None and hasattr(k, "lib"):
+                k.spmm(self.Graph, cur, nxt, S_acc=acc, x_nonzero=src_nonzero)
+            else:
+                k.spmm(self.Graph, cur, nxt, S_acc=acc)
             cur, nxt = nxt, (self._tb if nxt is self._ta else self._ta)
         k.scale(acc, 1.0 / (self.num_layers + 1))
 
@@ -122,7 +127,15 @@ class LightGCN(BaseModel):
         acc = torch.zeros(k.RSX_LOSS_SLOTS, dtype=torch.float32, device=self.device)
         k.bpr_grad(self._out[:U], self._out[U:], self._dout[:U], self._dout[U:], u, i, j, 1.0 / max(1, u.numel()),
                    loss_acc=acc)
-        self._propagate(self._dout, self._g)                           # back through the L products
+        # back through the L products; dL/dOut is non-zero only in the rows of the batch's users and items, so the first
+        # product is told which rows to fetch at all (65 536 of 1M users in a batch: 93 % of the rows an item row gathers)
+        if self._nz is None:
+            self._nz = torch.zeros(self._E0.shape[0], dtype=torch.uint8, device=self.device)
+        self._nz.zero_()
+        self._nz[u.long()] = 1
+        self._nz[U + i.long()] = 1
+        self._nz[U + j.long()] = 1
+        self._propagate(self._dout, self._g, src_nonzero=self._nz)
         self._dout.zero_()
         self._t += 1
         k.adam_apply(self._E0, self._m, self._v, self._g, self.lr, self._t)

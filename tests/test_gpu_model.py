@@ -791,9 +791,10 @@ def test_fit_runs_twice_with_different_csrs(ml100k):
 @pytest.mark.timeout(900)
 def test_stratified_sorted_sampler_trains_as_well_as_independent_negatives():
     """the layout the headline number rests on (batch ordered by positive item, negatives stratified by
-    item block, B >= 2 I) against independent uniform negatives on a planted-factor dataset: same
+    item block, B >= 2 I), the same as four item-range pipelines (negatives from the range of the sampled
+    positive, relabelled item space), and independent uniform negatives on a planted-factor dataset: same
     model, same number of steps, two seeds each -- ranking quality (NDCG@10 on held-out positives)
-    must agree within the seed-to-seed noise, and both must be far above an untrained model"""
+    must agree within the seed-to-seed noise, and all must be far above an untrained model"""
     import scipy.sparse as sp
     import recsys_pytorch_amd as pkg
     rng = np.random.default_rng(42)
@@ -812,21 +813,23 @@ def test_stratified_sorted_sampler_trains_as_well_as_independent_negatives():
     ev = pkg.Evaluator(ds.valid_input, ds.valid_target, "holdout", [10])
     cfg = types.SimpleNamespace(batch_size=U, num_epochs=150, verbose=0, test_from=150, test_step=150)   # B = U = 20 I
     res = {}
-    for nb in (8, 0):
+    for arm, nb, chunks in (("blocked", 8, 0), ("iid", 0, 0), ("ranges", 8, 4)):
         for seed in (1, 2):
             torch.manual_seed(seed)
-            m = pkg.MF(ds, dict(HP, hidden_dim=32, lr=0.1 * U, neg_block=nb, seed=seed), "cuda")
+            m = pkg.MF(ds, dict(HP, hidden_dim=32, lr=0.1 * U, neg_block=nb, chunks=chunks, seed=seed), "cuda")
             with torch.no_grad():
                 m._P.mul_(0.1); m._Q.mul_(0.1)
-            if (nb, seed) == (8, 1):
+            if (arm, seed) == ("blocked", 1):
                 untrained = ev.evaluate(m)["NDCG@10"]
             out = m.fit(ds, cfg, evaluator=ev)["scores"]["NDCG@10"]
-            assert (m._engine.neg_block > 0) == (nb > 0)                          # the layout under test really ran
-            res[(nb, seed)] = float(out)
-    a, b = [res[(8, 1)], res[(8, 2)]], [res[(0, 1)], res[(0, 2)]]
-    noise = max(abs(a[0] - a[1]), abs(b[0] - b[1]))
-    assert min(a + b) > max(5 * untrained, 0.05), (res, untrained)              # both learn the planted structure
+            assert (m._engine.neg_block > 0) == (nb > 0) and m._engine.chunks == chunks      # the layout under test really ran
+            res[(arm, seed)] = float(out)
+    a, b, c = ([res[(arm, 1)], res[(arm, 2)]] for arm in ("blocked", "iid", "ranges"))
+    noise = max(abs(a[0] - a[1]), abs(b[0] - b[1]), abs(c[0] - c[1]))
+    assert min(a + b + c) > max(5 * untrained, 0.05), (res, untrained)          # all learn the planted structure
     assert abs(np.mean(a) - np.mean(b)) < max(3 * noise, 0.03 * np.mean(b)), (res, untrained)
+    # ... and so does the range-restricted negative sampling of the item-range pipelines
+    assert abs(np.mean(c) - np.mean(b)) < max(3 * noise, 0.03 * np.mean(b)), (res, untrained)
 
 
 def test_blocked_kernel_is_exact_on_foreign_triplets(oracle_mod):

@@ -107,6 +107,25 @@ def test_hip_spmm_long_rows_vs_oracle(oracle_mod):
         assert rel_err(Y.cpu().numpy(), Yo) < 2e-6
         assert rel_err(S.cpu().numpy(), X + Yo) < 2e-6
         assert float(Y[5].abs().max()) == 0.0
+        # an X most of whose rows are zero, with its row flags: the flagged-off rows are not fetched, the result is BIT-identical
+        # (single-segment rows; split rows add their partial sums atomically, whose order is free: to rounding)
+        Xs = Xd.clone()
+        dead = torch.from_numpy(rng.random(N) < 0.9).cuda()
+        Xs[dead] = 0.0
+        flags = (~dead).to(torch.uint8)
+        Ya, Yb = torch.empty_like(Xd), torch.empty_like(Xd)
+        Sa, Sb = Xs.clone(), Xs.clone()
+        rsx.spmm(G, Xs, Ya, S_acc=Sa)
+        rsx.spmm(G, Xs, Yb, S_acc=Sb, x_nonzero=flags)
+        short = torch.from_numpy(np.diff(A.indptr) <= 128).cuda()
+        assert torch.equal(Ya[short], Yb[short]) and torch.equal(Sa[short], Sb[short])
+        assert float((Ya - Yb).abs().max()) <= 2e-6 * float(Ya.abs().max())
+        # flags that cover only part of the non-zero rows DROP the rest: they are the caller's claim
+        part = flags.clone(); part[::2] = 0
+        rsx.spmm(G, Xs, Yb, x_nonzero=part)
+        Xp = Xs.clone(); Xp[part == 0] = 0.0
+        rsx.spmm(G, Xp, Ya)
+        assert torch.equal(Ya[short], Yb[short])
 
 
 @pytest.mark.gpu
