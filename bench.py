@@ -185,10 +185,15 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     mean_loss = float(loss.double().sum()) / (B * steps)            # this rank's triplets
     assert np.isfinite(mean_loss) and 0.0 < mean_loss < 5.0, mean_loss
     replicas_equal = None
-    if SHARDED:        # every rank applied the same reduced gradient: the item replicas must be identical
-        cs = torch.stack([Q.double().sum(), -Q.double().sum()])
+    if SHARDED:        # every rank applied the same reduced gradient: the item replicas must be identical, ROW BY ROW
+        # (a keyed weighting of every row instead of one sum over the table: two rows swapped or a symmetric error in two
+        #  ranks would cancel in a plain sum)
+        gen = torch.Generator(device=dev).manual_seed(12345)
+        w = torch.rand(Q.shape[1], device=dev, dtype=torch.float64, generator=gen) + 0.5
+        h = (Q.double() * w).sum(1) * torch.arange(1, I + 1, device=dev, dtype=torch.float64)
+        cs = torch.stack([h, -h])
         dist.all_reduce(cs, op=dist.ReduceOp.MAX)
-        replicas_equal = bool(float(cs[0] + cs[1]) == 0.0)          # max(sum) == min(sum)
+        replicas_equal = bool((cs[0] + cs[1] == 0.0).all())        # max over ranks == min over ranks, for every item row
         assert replicas_equal, "item replicas diverged"
     # (the walk of the blocked kernel without its negative-side LDS tile when only the positives are ordered)
     kernel = "bpr_step_blocked_kernel" if nb else ("bpr_step_blocked_kernel<TILE=false>" if eng._sorts(B) else "bpr_step_kernel")

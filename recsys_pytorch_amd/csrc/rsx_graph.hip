@@ -19,6 +19,11 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// what a flagged-off neighbour reads instead of its row: ONE shared all-zero row (always an L1 / L2 hit).  Selecting the ADDRESS
+// keeps every fetch an unconditional dwordx4; selecting the VALUE (`flag ? load : zero`) made the compiler split each fetch into
+// four exec-masked dword loads behind their own branches, which cost what the skipped rows saved (round 3, measured: no gain).
+__device__ __attribute__((aligned(16))) float g_zero_row[128];
+
 // SKIP: `nz` flags the rows of X that are not entirely zero; a flagged-off neighbour row is not fetched (a * 0 adds nothing:
 // the result is bit-identical).  The first backward product of a LightGCN step multiplies A_hat with the dense gradient of the
 // loss, of which only the batch's users' and items' rows are non-zero: with 65 536 of 1M users in the batch, 93 % of the user
@@ -46,13 +51,15 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(
         for (; p + 4 <= len; p += 4) {            // four neighbour rows in flight
             const float a0 = vals[pb + p], a1 = vals[pb + p + 1], a2 = vals[pb + p + 2], a3 = vals[pb + p + 3];
             const int32_t n0 = indices[pb + p], n1 = indices[pb + p + 1], n2 = indices[pb + p + 2], n3 = indices[pb + p + 3];
-            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-            bool f0 = true, f1 = true, f2 = true, f3 = true;
-            if constexpr (SKIP) { f0 = nz[n0] != 0; f1 = nz[n1] != 0; f2 = nz[n2] != 0; f3 = nz[n3] != 0; }
-            const float4 x0 = f0 ? reinterpret_cast<const float4 *>(X + (size_t)n0 * D)[k] : zero;
-            const float4 x1 = f1 ? reinterpret_cast<const float4 *>(X + (size_t)n1 * D)[k] : zero;
-            const float4 x2 = f2 ? reinterpret_cast<const float4 *>(X + (size_t)n2 * D)[k] : zero;
-            const float4 x3 = f3 ? reinterpret_cast<const float4 *>(X + (size_t)n3 * D)[k] : zero;
+            const float *r0 = X + (size_t)n0 * D, *r1 = X + (size_t)n1 * D, *r2 = X + (size_t)n2 * D, *r3 = X + (size_t)n3 * D;
+            if constexpr (SKIP) {
+                const uint8_t f0 = nz[n0], f1 = nz[n1], f2 = nz[n2], f3 = nz[n3];
+                r0 = f0 ? r0 : g_zero_row; r1 = f1 ? r1 : g_zero_row; r2 = f2 ? r2 : g_zero_row; r3 = f3 ? r3 : g_zero_row;
+            }
+            const float4 x0 = reinterpret_cast<const float4 *>(r0)[k];
+            const float4 x1 = reinterpret_cast<const float4 *>(r1)[k];
+            const float4 x2 = reinterpret_cast<const float4 *>(r2)[k];
+            const float4 x3 = reinterpret_cast<const float4 *>(r3)[k];
             acc.x = fmaf(a0, x0.x, acc.x); acc.y = fmaf(a0, x0.y, acc.y); acc.z = fmaf(a0, x0.z, acc.z); acc.w = fmaf(a0, x0.w, acc.w);
             acc.x = fmaf(a1, x1.x, acc.x); acc.y = fmaf(a1, x1.y, acc.y); acc.z = fmaf(a1, x1.z, acc.z); acc.w = fmaf(a1, x1.w, acc.w);
             acc.x = fmaf(a2, x2.x, acc.x); acc.y = fmaf(a2, x2.y, acc.y); acc.z = fmaf(a2, x2.z, acc.z); acc.w = fmaf(a2, x2.w, acc.w);
@@ -61,8 +68,9 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(
         for (; p < len; ++p) {
             const float a = vals[pb + p];
             const int32_t n = indices[pb + p];
-            if constexpr (SKIP) { if (nz[n] == 0) continue; }
-            const float4 x = reinterpret_cast<const float4 *>(X + (size_t)n * D)[k];
+            const float *r = X + (size_t)n * D;
+            if constexpr (SKIP) r = nz[n] ? r : g_zero_row;
+            const float4 x = reinterpret_cast<const float4 *>(r)[k];
             acc.x = fmaf(a, x.x, acc.x); acc.y = fmaf(a, x.y, acc.y); acc.z = fmaf(a, x.z, acc.z); acc.w = fmaf(a, x.w, acc.w);
         }
         const bool whole = (int64_t)len == indptr[row + 1] - indptr[row];

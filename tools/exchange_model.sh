@@ -18,5 +18,4 @@ run "one pass, exchange exposed" RSX_TWO_PASS=0 --
 run "two passes (exchange under users)" RSX_TWO_PASS=1 --
 run "item ranges x2" RSX_TWO_PASS=0 -- --chunks 2
 run "item ranges x3" RSX_TWO_PASS=0 -- --chunks 3
-run "item ranges x4" RSX_TWO_PASS=0 -- --chunks 4
 run "one step stale (not synchronous)" RSX_TWO_PASS=0 RSX_STALE_EXCHANGE=1 --

@@ -27,11 +27,14 @@ for meta_path in sorted(glob.glob(os.path.join(dst, f"{tag}_pmc_*.meta.json"))):
     if not ks or "TCC_EA0_RDREQ_sum" not in d[ks[0]] or "WRITE_SIZE" not in d[ks[0]]:
         print("no counters for", prof, meta["kernel"], list(d)); continue
     v = d[ks[0]]
+    # a chunked step launches the kernel once per item range: the leg's figure is the STEP's (sum over its launches)
+    per_step = int(meta.get("env", {}).get("CHUNKS", 1)) if "_c" in meta["key"].rsplit("_nb", 1)[-1] else 1
+    v = {k_: (x * per_step if isinstance(x, (int, float)) and k_ not in ("launches",) else x) for k_, x in v.items()}
     rd = v["TCC_EA0_RDREQ_sum"] * 128.0
     t[meta["key"]] = {"hbm_bytes_per_launch": rd + v["WRITE_SIZE"] * 1024.0, "read_bytes": rd, "write_bytes": v["WRITE_SIZE"] * 1024.0,
                       "FETCH_SIZE_KB": v.get("FETCH_SIZE"), "WRITE_SIZE_KB": v["WRITE_SIZE"], "ea_atomic_requests": v.get("TCC_EA0_ATOMIC_sum"),
                       "tcc_hit": v.get("TCC_HIT_sum"), "tcc_miss": v.get("TCC_MISS_sum"), "tcc_req": v.get("TCC_REQ_sum"),
-                      "kernel": ks[0], "profile": prof, "commit": commit + ("+uncommitted" if dirty else ""),
+                      "kernel": ks[0], "launches_per_step": per_step, "profile": prof, "commit": commit + ("+uncommitted" if dirty else ""),
                       "kernel_us_under_profiler": v.get("mean_us"), "command": meta, "note": note}
     print("%-16s %-46s %.3f GB/launch" % (prof.replace(f"{tag}_pmc_", "").replace(".json", ""), meta["key"], t[meta["key"]]["hbm_bytes_per_launch"] / 1e9))
 json.dump(t, open(tpath, "w"), indent=1)

@@ -46,6 +46,7 @@ leg config3_slice "$T" "USERS=1250000 ITEMS=1000000 DEG=10" 1250000 8 8
 leg B4096_plain   "$T" - 4096 0 100
 leg B16384_plain  "$T" - 16384 0 100
 leg B262144       "$T" - 262144 8 30
+leg B1M_ranges3   "$T" "CHUNKS=3" 1000000 8 12
 ( export STEP_PROF_META="$out/${tag}_pmc_spmm.meta.json"
   PMC_GROUPS="$T;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" python3 tools/pmc_groups.py "$out/${tag}_pmc_spmm.json" spmm_csr -- python3 tools/spmm_prof.py > /dev/null 2>&1 )
 S="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU_MFMA_MOPS_F32;FETCH_SIZE;WRITE_SIZE"
