@@ -100,6 +100,9 @@ class BPREngine:
         self.comm = comm if self.sharded else None
         # > 1: the native loop runs the step as a pipeline over item ranges (include/rsx.h: "item chunks"; set_chunks)
         self.chunks = 0
+        # EXPERIMENTAL: blocked negatives (and with them the item ranges) also for batches below two triplets per item, where the
+        # on-chip sums have little to sum: the ranges then serve only to hide an exchange as long as the step (configs[3])
+        self.blocked_any_batch = False
         self._relabel = None
         self._hot_args = None
         # OPT-IN (native loop only): the exchange of step t travels under the step kernel of step t+1, which
@@ -138,7 +141,7 @@ class BPREngine:
         updates per step; below that there is nothing to combine.  The block size c <= max_block
         is picked so that the step kernel's ceil(I / c) wavefronts fill the chip's resident
         wavefront slots in whole rounds (`pick_neg_block`)."""
-        nb = pick_neg_block(self.Q.shape[0], int(max_block), self._wave_slots()) if batch >= 2 * self.Q.shape[0] else 0
+        nb = pick_neg_block(self.Q.shape[0], int(max_block), self._wave_slots()) if (batch >= 2 * self.Q.shape[0] or self.blocked_any_batch) else 0
         if nb != self.neg_block:
             self._csr = None        # the user signatures depend on neg_block: rebuild on next use
         self.neg_block = nb
@@ -566,7 +569,7 @@ class BPREngine:
         native = self.sharded and self.comm is not None       # the library issues the exchange itself (RCCL)
         kind = {"allreduce": 1, "scatter_gather": 2}[self.exchange] if native else 0      # RSX_EXCHANGE_*
         stale = bool(self.stale_exchange) and self.sharded
-        if self.chunks and self.neg_block and batch >= 2 * self.Q.shape[0] and batch <= (1 << 21) and not stale:
+        if self.chunks and self.neg_block and (batch >= 2 * self.Q.shape[0] or self.blocked_any_batch) and batch <= (1 << 21) and not stale:
             # the step as a pipeline over item ranges, in the relabelled item space (set_chunks)
             r = self._build_relabel(indptr, indices)
             self._items_to_relabelled()
