@@ -171,3 +171,75 @@ def test_full_size_chunked_step_through_the_native_loop(chunks):
     assert v["err_P"] <= UPDATE_TOL and v["err_Q"] <= UPDATE_TOL and v["untouched_rows_equal"], ctx
     assert float(r["G"].abs().max()) == 0.0
     tr.close()
+
+
+def test_chunked_sampler_on_random_shapes():
+    """30 random CSRs (empty rows, rows owning a whole item range or everything, heavy tails, tiny and ragged sizes, any block
+    size, 2..8 ranges) straight through rsx_bpr_sample_chunked: users unique, live pairs first and ordered by item, first
+    positions of the ranges consistent, positives true, negatives true / real / in the positive's range, a user owning its whole
+    range skipped, twice the same call gives the same bits"""
+    from recsys_pytorch_amd import rsx
+    rng = np.random.default_rng(321)
+    for trial in range(30):
+        C = int(rng.integers(2, 9))
+        c = int(rng.integers(1, 17))
+        I = int(rng.integers(max(2 * C, 8), 3000))
+        U = int(rng.integers(1, 4000))
+        Ic = rsx.chunk_rows(I, C, c)
+        base, rem = divmod(I, C)
+        n_real = np.array([base + (k < rem) for k in range(C)])
+        real_ids = np.concatenate([k * Ic + np.arange(n_real[k]) for k in range(C)])      # the relabelled ids that exist
+        kind = trial % 4
+        if kind == 0:
+            degs = rng.integers(0, min(I, 6), U)
+        elif kind == 1:
+            degs = rng.integers(0, min(I, 120), U)
+        elif kind == 2:
+            degs = rng.integers(1, min(I, 30) + 1, U)
+        else:
+            degs = np.minimum(I - 1, (rng.pareto(1.0, U) * 3).astype(np.int64))
+        rows = [np.sort(rng.choice(real_ids, int(g), replace=False)) for g in degs]
+        owners = rng.random(U) < (0.05 if kind == 2 else 0.0)                          # users owning ALL items of range 0 (+ a few more)
+        for uu in np.flatnonzero(owners):
+            rows[uu] = np.unique(np.concatenate([np.arange(n_real[0]), rows[uu]]))
+        indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+        indices = (np.concatenate(rows) if indptr[-1] else np.zeros(0)).astype(np.int32)
+        ip = torch.from_numpy(indptr).cuda()
+        ix = torch.from_numpy(indices if len(indices) else np.zeros(1, np.int32)).cuda()
+        B = U if trial % 3 == 0 else int(rng.integers(1, U + 1))
+        epoch_pos = 0 if B == U else int(rng.integers(0, U - B + 1))
+        cdf = rsx.build_item_cdf(ip, ix, C * Ic)
+        sig = rsx.build_signature(ip, ix, c) if trial % 2 else None
+        ws = torch.empty(rsx.bpr_sample_workspace(B, C * Ic), dtype=torch.uint8, device="cuda")
+        outs = []
+        for rep in range(2):
+            u, i, j = (torch.full((B,), -7, dtype=torch.int32, device="cuda") for _ in range(3))
+            cp = torch.full((C + 1,), -1, dtype=torch.int64, device="cuda")
+            rsx.bpr_sample_chunked(ip, ix, C * Ic, I, C, B, 11, trial, epoch_pos, u, i, j, cp, c, 2 * trial + 1, ws, cdf, user_sig=sig)
+            torch.cuda.synchronize()
+            outs.append((u.cpu().numpy(), i.cpu().numpy(), j.cpu().numpy(), cp.cpu().numpy()))
+        ctx = f"trial {trial}: U={U} I={I} C={C} c={c} B={B} kind={kind}"
+        (ua, ia, ja, cpa), (ub, ib, jb, cpb) = outs
+        live = ia >= 0
+        n_live = int(live.sum())
+        assert np.array_equal(cpa, cpb) and np.array_equal(ia, ib) and np.array_equal(ja, jb) and np.array_equal(ua[live], ub[live]), ctx
+        assert len(np.unique(ua)) == B and np.all(ja[~live] == -1), ctx
+        if not owners.any():
+            assert live[:n_live].all(), ctx                                               # pairs without a positive come last
+        # cp counts the pairs that HAD a positive; a pair skipped for want of a negative keeps its place (i = -1 inside a range)
+        assert cpa[0] == 0 and np.all(np.diff(cpa) >= 0) and cpa[-1] >= n_live, ctx
+        inside = ia[:cpa[-1]]
+        assert np.all(np.diff(inside[inside >= 0]) >= 0), ctx                             # ordered by item
+        for k in range(C):
+            sl = slice(cpa[k], cpa[k + 1])
+            ok = ia[sl] >= 0
+            assert np.all(ia[sl][ok] // Ic == k) and np.all(ja[sl][ok] // Ic == k), ctx
+            assert np.all(ja[sl][ok] - k * Ic < n_real[k]), ctx                           # real rows, never padding
+        for p in np.flatnonzero(live)[:: max(1, B // 300)]:
+            row = rows[ua[p]]
+            assert ia[p] in row and ja[p] not in row, ctx
+        # a user who owns every item of the range its positive fell in cannot get a negative: skipped, never served from elsewhere
+        for p in np.flatnonzero(~live & (np.arange(B) < cpa[-1])):
+            row = rows[ua[p]]
+            k = int(np.searchsorted(cpa, p, side="right") - 1)
+            assert np.isin(k * Ic + np.arange(n_real[k]), row).all(), ctx
