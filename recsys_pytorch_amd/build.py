@@ -58,6 +58,10 @@ def build(force=False, verbose=False, dev=False):
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib, *objs]
     subprocess.check_call(cmd)
+    # a shared library links with undefined symbols: load it once, so that a kernel whose host stub went missing fails the BUILD
+    # (no GPU needed for dlopen)
+    import ctypes
+    ctypes.CDLL(lib)
     return lib
 
 

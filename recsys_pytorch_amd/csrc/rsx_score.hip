@@ -26,6 +26,19 @@ constexpr int BM = 128, BN = 128, BK = 32;
 #ifndef RSX_SCORE_PREFETCH
 #define RSX_SCORE_PREFETCH 1
 #endif
+// RSX_SCORE_GLDS = 1: the K chunks go from global memory STRAIGHT into LDS (global_load_lds_dwordx4, the LDS-DMA of gfx950)
+// instead of through 32 staging registers and 64 transposing ds_write2 per thread and chunk.  The DMA writes lane-linear
+// (wave-uniform base + lane * 16 B), so the tiles are ROW-major [row][32] without padding, and the bank conflicts of the
+// fragment reads (32 lanes read the same k of 32 consecutive rows: one bank) are broken by an XOR swizzle of the 16-byte slots
+// with (row & 7), applied to the per-lane SOURCE address of the DMA and to the read (the same involution on both sides).
+// Four wavefronts per SIMD then fit (64 accumulators + 64 other registers; 32.5 KB of LDS per workgroup): round 3, same box,
+// 64 x 1024 users x 100K items: 275.1 -> 272.7 us per 1024 users fused, the dense 1024 x 100K product 267 -> 250 us; with three
+// wavefronts the DMA form is SLOWER than register staging (286 us: the chunk's load latency is no longer hidden inside the
+// workgroup), and register staging compiled for four spills 36 registers (297 us).  GLDS = false remains for item tables of 4 GB
+// and more (the DMA's source is a 32-bit offset from the table's base in SGPRs) and as the reference of the A/B.
+#ifndef RSX_SCORE_GLDS
+#define RSX_SCORE_GLDS 1      // 0: never take the LDS-DMA form (development A/B)
+#endif
 // (s_setprio 2 / 3 around the MFMA block, so that a wavefront in its MFMA phase issues ahead of the others' VALU / LDS work:
 //  measured 279.5 -> 283.6 us per 1024 users, same box, round 3 -- dropped)
 constexpr int kSlots = 2;     // private candidate slots per (64-item strip, row) of the filtered product
@@ -35,8 +48,8 @@ constexpr int LDT = BM + 1;   // K-major tile leading dimension (odd -> conflict
 // FILTER = false: out[row, col] = score (column col is item col*item_stride).
 // FILTER = true : nothing is stored densely; every score >= tau[row] is appended to the row's
 //                 candidate list (cand_val / cand_idx, capacity cand_cap, counter cand_cnt).
-template <int D, bool FILTER>
-__global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict__ P,
+template <int D, bool FILTER, bool GLDS>
+__device__ __forceinline__ void score_tile_body(const float *__restrict__ P,
                                                          const int32_t *__restrict__ user_ids,
                                                          int64_t num_rows,
                                                          const float *__restrict__ Q,
@@ -48,9 +61,9 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict
                                                          int32_t *__restrict__ cand_cnt, int cand_cap,
                                                          uint2 *__restrict__ slots, int64_t item_base)
 {
-    __shared__ float As[BK * LDT];
-    __shared__ float Bs[BK * LDT];
-    __shared__ float tau_s[BM];
+    __shared__ __attribute__((aligned(16))) float As[GLDS ? BM * BK : BK * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[GLDS ? BN * BK : BK * LDT];
+    __shared__ __attribute__((aligned(16))) float tau_s[BM];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -67,16 +80,19 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict
     const int srow = tid >> 3;
     const float *a_src[4];
     const float *b_src[4];
+    uint32_t b_off[4];                 // GLDS: byte offsets of the item rows this thread stages (item table below 4 GB: the launcher checks)
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         // rows / items past the edge are clamped to the last valid one: their products are
         // computed and never stored, which keeps every staging load an unconditional dwordx4
         int64_t r = row0 + srow + 32 * n;
         r = (r < num_rows) ? r : num_rows - 1;
-        a_src[n] = P + (size_t)user_ids[r] * D + 4 * kq;
+        const int gq = GLDS ? (kq ^ (srow & 7)) : kq;      // GLDS: LDS slot kq of this row receives the row's k-quad kq ^ (row & 7)
         int64_t it = item0 + srow + 32 * n;
         it = (it < num_items) ? it : num_items - 1;
-        b_src[n] = Q + (size_t)(it * item_stride) * D + 4 * kq;
+        a_src[n] = P + (size_t)user_ids[r] * D + 4 * gq;
+        b_src[n] = Q + (size_t)(it * item_stride) * D + 4 * gq;
+        b_off[n] = (uint32_t)(it * item_stride) * (uint32_t)(D * 4) + (uint32_t)(16 * gq);
     }
     if constexpr (FILTER) {
         if (tid < BM) tau_s[tid] = (row0 + tid < num_rows) ? tau[row0 + tid] : INFINITY;
@@ -90,6 +106,43 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
+    if constexpr (GLDS) {
+    // lane's fragment rows: wr * 64 + l31 (+ 32) of A, wc * 64 + l31 (+ 32) of B; element (row, k) sits at row * 32 + (k ^ x),
+    // x = (row & 7) << 2 = (l31 & 7) << 2 for all four rows; this lane reads k = kk + hi
+    const int xs = (l31 & 7) << 2;
+    const float *ap = As + (wr * 64 + l31) * BK + hi;
+    const float *bp = Bs + (wc * 64 + l31) * BK + hi;
+    for (int k0 = 0; k0 < D; k0 += BK) {
+        // 8 rows x 128 B per wave instruction, rows 32 n + 8 wid .. + 8 of each tile
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            // (item rows: 32-bit byte offsets from the table's base, which stays in SGPRs; user rows: pointers, the user table may be larger)
+            const float *gb = reinterpret_cast<const float *>(reinterpret_cast<const char *>(Q) + (b_off[n] + (uint32_t)k0 * 4u));
+            __builtin_amdgcn_global_load_lds(a_src[n] + k0, As + (32 * n + 8 * wid) * BK, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(gb, Bs + (32 * n + 8 * wid) * BK, 16, 0, 0);
+        }
+        __syncthreads();          // (carries the vmcnt(0) of the DMA: the chunk has landed for every wavefront)
+        float a0 = ap[xs], a1 = ap[32 * BK + xs], b0 = bp[xs], b1 = bp[32 * BK + xs];
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+            if (kk + 2 < BK) {
+                const int o = (kk + 2) ^ xs;
+                na0 = ap[o]; na1 = ap[32 * BK + o];
+                nb0 = bp[o]; nb1 = bp[32 * BK + o];
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        }
+        __syncthreads();          // every wavefront is done reading before the next chunk overwrites the tiles
+    }
+    } else {
     float4 ra[4], rb[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
@@ -154,6 +207,8 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict
         __syncthreads();
     }
 
+    }
+
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     if constexpr (FILTER) {
         // No barrier, no LDS, no global atomic on the common path.  For one accumulator register
@@ -176,16 +231,23 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict
         uint2 *wbase = slots + ((size_t)wave_row * n_strips + strip) * kSlots;
         // (recording the survivors in registers and storing them after the walk was tried: the
         //  fully unrolled walk then needs 126 VGPRs and the whole kernel slows down by 15 %)
+        // lanes whose column exists (the last item tile is ragged), as wave masks: ANDed into the survivor masks below
+        const unsigned long long cm0 = RSX_ABL(4) ? 0ull : __builtin_amdgcn_ballot_w64(col0 < num_items);
+        const unsigned long long cm1 = RSX_ABL(4) ? 0ull : __builtin_amdgcn_ballot_w64(col1 < num_items);
+        // (round 3) the thresholds of four consecutive sites -- rows (r & 3) = 0..3 of one group of eight -- come with ONE
+        // ds_read_b128 instead of four ds_read_b32 each waited for at once, and the survivor masks are taken straight from the
+        // compares (__builtin_amdgcn_ballot_w64; __ballot went through v_cndmask + v_cmp_ne per mask): 8 -> 4 vector
+        // instructions per site on the path where nothing survives, which is nearly every site
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int site = m * 32 + (r & 3) + 8 * (r >> 2);                // compile-time constant
-                const float t = tau_s[wr * 64 + 4 * hi + site];                  // +inf for rows past the edge
+                float4 t4;
+                if ((r & 3) == 0) t4 = *reinterpret_cast<const float4 *>(&tau_s[wr * 64 + 4 * hi + site]);   // sites r .. r + 3
+                const float t = (r & 3) == 0 ? t4.x : (r & 3) == 1 ? t4.y : (r & 3) == 2 ? t4.z : t4.w;      // +inf for rows past the edge
                 const float v0 = acc[m][0][r], v1 = acc[m][1][r];
-                const bool h0 = (col0 < num_items) && (v0 >= t) && !RSX_ABL(4);
-                const bool h1 = (col1 < num_items) && (v1 >= t) && !RSX_ABL(4);
-                const unsigned long long b0 = __ballot(h0), b1 = __ballot(h1);
+                const unsigned long long b0 = __builtin_amdgcn_ballot_w64(v0 >= t) & cm0, b1 = __builtin_amdgcn_ballot_w64(v1 >= t) & cm1;
                 if ((b0 | b1) == 0ull) continue;                                  // wave-uniform
                 const int cnt0 = __popcll(b0 & half);
                 uint2 *cellp = wbase + (size_t)(site * n_strips) * kSlots;
@@ -202,8 +264,8 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict
                     }
                 };
                 if (!RSX_ABL(2)) {
-                    if (h0) emit(__popcll(b0 & below), v0, col0);
-                    if (h1) emit(cnt0 + __popcll(b1 & below), v1, col1);
+                    if ((b0 >> lane) & 1ull) emit(__popcll(b0 & below), v0, col0);
+                    if ((b1 >> lane) & 1ull) emit(cnt0 + __popcll(b1 & below), v1, col1);
                 }
             }
         }
@@ -225,6 +287,20 @@ __global__ __launch_bounds__(256) void score_tile_kernel(const float *__restrict
         }
     }
 }
+
+// the two entry points: register staging (three wavefronts per SIMD) and LDS-DMA (four).  (One template with a launch bound that
+// depends on GLDS left the host stubs of the GLDS = true instantiations undefined at link time: two kernels, one body.)
+#define RSX_SCORE_ARGS const float *__restrict__ P, const int32_t *__restrict__ user_ids, int64_t num_rows, const float *__restrict__ Q, \
+                       int64_t num_items, int64_t item_stride, float *__restrict__ out, const float *__restrict__ tau,               \
+                       float *__restrict__ cand_val, int32_t *__restrict__ cand_idx, int32_t *__restrict__ cand_cnt, int cand_cap,  \
+                       uint2 *__restrict__ slots, int64_t item_base
+#define RSX_SCORE_PASS P, user_ids, num_rows, Q, num_items, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, item_base
+template <int D, bool FILTER>
+__global__ __launch_bounds__(256) void score_tile_kernel(RSX_SCORE_ARGS) { score_tile_body<D, FILTER, false>(RSX_SCORE_PASS); }
+template <int D, bool FILTER>
+__global__ __launch_bounds__(256, 4) void score_tile_glds_kernel(RSX_SCORE_ARGS) { score_tile_body<D, FILTER, true>(RSX_SCORE_PASS); }
+#undef RSX_SCORE_ARGS
+#undef RSX_SCORE_PASS
 
 // scores[r, indices[p]] = -inf for p in the CSR row of user_ids[r]
 __global__ __launch_bounds__(256) void mask_seen_kernel(float *__restrict__ scores,
@@ -681,11 +757,16 @@ int launch_score(const float *P, const int32_t *users, int64_t rows, const float
                  int32_t *cand_idx, int32_t *cand_cnt, int cand_cap, uint2 *slots, hipStream_t st, int64_t item_base = 0)
 {
     dim3 grid((unsigned)((cols + BN - 1) / BN), (unsigned)((rows + BM - 1) / BM));
+    // the LDS-DMA form addresses item rows by 32-bit byte offsets: item tables below 4 GB (every BASELINE catalog: 1M x 128 = 512 MB)
+    const bool glds = RSX_SCORE_GLDS != 0 && cols * item_stride * (int64_t)d * 4 < (1ll << 32);
+#define RSX_SCORE_LAUNCH(D_) do { if (glds) hipLaunchKernelGGL((score_tile_glds_kernel<D_, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, item_base); \
+                                  else hipLaunchKernelGGL((score_tile_kernel<D_, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, item_base); } while (0)
     switch (d) {
-    case 32: hipLaunchKernelGGL((score_tile_kernel<32, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, item_base); break;
-    case 64: hipLaunchKernelGGL((score_tile_kernel<64, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, item_base); break;
-    default: hipLaunchKernelGGL((score_tile_kernel<128, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, item_base); break;
+    case 32: RSX_SCORE_LAUNCH(32); break;
+    case 64: RSX_SCORE_LAUNCH(64); break;
+    default: RSX_SCORE_LAUNCH(128); break;
     }
+#undef RSX_SCORE_LAUNCH
     return 0;
 }
 
