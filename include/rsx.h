@@ -283,7 +283,8 @@ int rsx_bpr_build_item_cdf(const int64_t *indptr_dev, const int32_t *indices_dev
  * rsx_bpr_sample_chunked: rsx_bpr_sample(RSX_SAMPLE_SORT_POS, item_cdf) over the relabelled CSR with the range rule;
  *   num_items = chunks * chunk_rows; item_cdf_dev built over those ids (padding rows have no mass); batch <= 2^21;
  *   chunk_pos_out: int64 [chunks + 1] device, first batch position of every range (+ number of live positions).
- *   A user whose row covers its whole range has no negative: i = j = -1 (skipped by the step).
+ *   A user whose row covers its whole range has no negative there and is skipped (i = j = -1 at its position); one whose
+ *   row covers all but a fraction f of the range is skipped with probability (1 - f)^128 (192 draws, never from elsewhere).
  * rsx_bpr_step_chunked: the blocked step kernel (rsx_bpr_step with neg_block, RSX_USERS_UNIQUE) over the positions of the
  *   ranges [first_range, first_range + num_ranges); progress: uint32 [RSX_PROGRESS_WORDS] device, zeroed by the caller;
  *   progress[RSX_PROGRESS_VIOLATIONS] counts the triplets that left their range.                                  */

@@ -238,8 +238,9 @@ def test_chunked_sampler_on_random_shapes():
         for p in np.flatnonzero(live)[:: max(1, B // 300)]:
             row = rows[ua[p]]
             assert ia[p] in row and ja[p] not in row, ctx
-        # a user who owns every item of the range its positive fell in cannot get a negative: skipped, never served from elsewhere
+        # a user who owns (nearly) every item of the range its positive fell in may end without a negative (192 draws, the last
+        # 128 uniform over the range): skipped for this step, never served from another range
         for p in np.flatnonzero(~live & (np.arange(B) < cpa[-1])):
             row = rows[ua[p]]
             k = int(np.searchsorted(cpa, p, side="right") - 1)
-            assert np.isin(k * Ic + np.arange(n_real[k]), row).all(), ctx
+            assert np.isin(k * Ic + np.arange(n_real[k]), row).mean() > 0.9, ctx
