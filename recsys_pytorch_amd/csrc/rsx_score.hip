@@ -224,16 +224,18 @@ __device__ __forceinline__ void score_tile_body(const float *__restrict__ P,
         // no per-cell count has to be written.  32-bit cell arithmetic, one base per wavefront.
         const int n_strips = (int)gridDim.x * 2;
         const int strip = (int)blockIdx.x * 2 + wc;                              // 64-column strip id
-        const unsigned long long half = hi ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
-        const unsigned long long below = half & ((1ull << lane) - 1ull);
-        const int64_t col0 = item0 + wc * 64 + l31, col1 = col0 + 32;
+        // (round 3: the hit path in 32-bit arithmetic -- with ~29 survivors per wavefront and tile more than half of the 32 sites
+        //  take it, which makes it the largest block of non-MFMA vector instructions of the kernel: ranks from mbcnt instead of
+        //  two 64-bit and + popcount pairs, the slot addressed by a 32-bit byte offset from the array's base in SGPRs)
+        const uint32_t lomask = hi ? 0u : 0xFFFFFFFFu;                            // a high-half lane counts survivors of its own half only
+        const int32_t col0 = (int32_t)item0 + wc * 64 + l31, col1 = col0 + 32;    // (catalogs fit int32)
         const int wave_row = (int)row0 + wr * 64 + 4 * hi;                       // + per-site constant
-        uint2 *wbase = slots + ((size_t)wave_row * n_strips + strip) * kSlots;
+        const uint32_t wave_off = (uint32_t)((wave_row * n_strips + strip) * kSlots) * 8u;    // bytes into `slots` (< 4 GB: rsx_score_topk_workspace)
         // (recording the survivors in registers and storing them after the walk was tried: the
         //  fully unrolled walk then needs 126 VGPRs and the whole kernel slows down by 15 %)
         // lanes whose column exists (the last item tile is ragged), as wave masks: ANDed into the survivor masks below
-        const unsigned long long cm0 = RSX_ABL(4) ? 0ull : __builtin_amdgcn_ballot_w64(col0 < num_items);
-        const unsigned long long cm1 = RSX_ABL(4) ? 0ull : __builtin_amdgcn_ballot_w64(col1 < num_items);
+        const unsigned long long cm0 = RSX_ABL(4) ? 0ull : __builtin_amdgcn_ballot_w64(col0 < (int32_t)num_items);
+        const unsigned long long cm1 = RSX_ABL(4) ? 0ull : __builtin_amdgcn_ballot_w64(col1 < (int32_t)num_items);
         // (round 3) the thresholds of four consecutive sites -- rows (r & 3) = 0..3 of one group of eight -- come with ONE
         // ds_read_b128 instead of four ds_read_b32 each waited for at once, and the survivor masks are taken straight from the
         // compares (__builtin_amdgcn_ballot_w64; __ballot went through v_cndmask + v_cmp_ne per mask): 8 -> 4 vector
@@ -249,23 +251,27 @@ __device__ __forceinline__ void score_tile_body(const float *__restrict__ P,
                 const float v0 = acc[m][0][r], v1 = acc[m][1][r];
                 const unsigned long long b0 = __builtin_amdgcn_ballot_w64(v0 >= t) & cm0, b1 = __builtin_amdgcn_ballot_w64(v1 >= t) & cm1;
                 if ((b0 | b1) == 0ull) continue;                                  // wave-uniform
-                const int cnt0 = __popcll(b0 & half);
-                uint2 *cellp = wbase + (size_t)(site * n_strips) * kSlots;
-                auto emit = [&](int rank, float v, int64_t col) {
-                    if (rank < kSlots) {
-                        cellp[rank] = make_uint2(__float_as_uint(v), (unsigned)(col + item_base));
+                const uint32_t b0lo = (uint32_t)b0, b0hi = (uint32_t)(b0 >> 32), b1lo = (uint32_t)b1, b1hi = (uint32_t)(b1 >> 32);
+                const uint32_t cnt0 = hi ? (uint32_t)__builtin_popcount(b0hi) : (uint32_t)__builtin_popcount(b0lo);
+                const uint32_t site_off = (uint32_t)(site * n_strips * kSlots) * 8u;
+                auto emit = [&](uint32_t rank, float v, int32_t col) {
+                    if (rank < (uint32_t)kSlots) {
+                        uint2 *cell = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(slots) + (wave_off + site_off + rank * 8u));
+                        *cell = make_uint2(__float_as_uint(v), (unsigned)col + (unsigned)item_base);
                     } else {                            // rare: more than kSlots survivors in one cell
                         const int64_t row = wave_row + site;
                         const int slot = atomicAdd(cand_cnt + row, 1);
                         if (slot < cand_cap) {
                             cand_val[(size_t)row * cand_cap + slot] = v;
-                            cand_idx[(size_t)row * cand_cap + slot] = (int32_t)(col + item_base);
+                            cand_idx[(size_t)row * cand_cap + slot] = (int32_t)((unsigned)col + (unsigned)item_base);
                         }
                     }
                 };
                 if (!RSX_ABL(2)) {
-                    if ((b0 >> lane) & 1ull) emit(__popcll(b0 & below), v0, col0);
-                    if ((b1 >> lane) & 1ull) emit(cnt0 + __popcll(b1 & below), v1, col1);
+                    if ((v0 >= t) && col0 < (int32_t)num_items)
+                        emit(__builtin_amdgcn_mbcnt_hi(b0hi, __builtin_amdgcn_mbcnt_lo(b0lo & lomask, 0u)), v0, col0);
+                    if ((v1 >= t) && col1 < (int32_t)num_items)
+                        emit(cnt0 + __builtin_amdgcn_mbcnt_hi(b1hi, __builtin_amdgcn_mbcnt_lo(b1lo & lomask, 0u)), v1, col1);
                 }
             }
         }
@@ -1003,6 +1009,10 @@ RSX_API int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t 
         // 2. the rest of the catalog with the FILTER epilogue (item ids offset by the sample)
         const int64_t rest = num_items - kSampleCols;
         const int64_t n_it = 2 * ((rest + BN - 1) / BN), rows_pad = (nr + BM - 1) / BM * BM;
+        if (n_it * rows_pad * kSlots * 8 >= (1ll << 32)) {      // the filter epilogue addresses its slots with 32-bit byte offsets
+            rsx_set_error("rsx_score_topk: catalogs above ~2 million items are not supported by the fused path (slot array of a pass >= 4 GB)");
+            return RSX_E_INVALID;
+        }
         (void)hipMemsetAsync(lw.slots, 0xFF, (size_t)(n_it * rows_pad) * kSlots * 8, ls);
         launch_score<true>(P, users, nr, Qp + (size_t)kSampleCols * d, rest, 1, d, nullptr, lw.tau, lw.cval, lw.cidx, lw.ccnt,
                            kSpillCap, lw.slots, ls, kSampleCols);
