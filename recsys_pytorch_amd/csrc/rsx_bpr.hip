@@ -196,20 +196,28 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
     float loss_local = 0.0f;
     int64_t b = wave * TPW + sub;
     const int64_t stride = nwaves * TPW;
-    // indices of the first triplet (every lane of the group loads the same word)
-    int32_t u = -1, i = -1, j = -1;
-    if (b < B) { u = U_idx[b]; i = I_idx[b]; j = J_idx[b]; }
+    // SOFTWARE PIPELINE over the trips, as in the blocked kernel below (see the comment there): the rows of the next triplet are
+    // requested at the END of a trip, behind its atomics and stores, and the trip's one wait drains both together.
+    // (u, i, j): the triplet being processed; (un, in, jn): the one whose rows are in flight; (um, im, jm): the one after it.
+    int32_t u = -1, i = -1, j = -1, un = -1, in = -1, jn = -1, um = -1, im = -1, jm = -1;
+    if (b < B) { un = U_idx[b]; in = I_idx[b]; jn = J_idx[b]; }
+    Row<D> p, qi, qj;
+    bool live_n = (b < B) && (in >= 0);
+    auto request_rows = [&]() __attribute__((always_inline)) {
+        if (live_n) {
+            if constexpr (MODE == 0) p.load_once_at(P, row_off<D, OffT>(un, k)); else p.load_at(P, row_off<D, OffT>(un, k));   // unique users: touched once
+            qi.load_at(Q, row_off<D, OffT>(in, k));
+            qj.load_at(Q, row_off<D, OffT>(jn, k));
+        }
+    };
+    request_rows();
+    if (b + stride < B) { um = U_idx[b + stride]; im = I_idx[b + stride]; jm = J_idx[b + stride]; }
     while (b - sub < B) {   // wave-uniform trip count
         const int64_t bn = b + stride;
-        int32_t un = -1, in = -1, jn = -1;
-        if (bn < B) { un = U_idx[bn]; in = I_idx[bn]; jn = J_idx[bn]; }  // prefetch
-        const bool live = (b < B) && (i >= 0);
+        u = un; i = in; j = jn; un = um; in = im; jn = jm;      // (first use of the prefetched indices / the rows: the trip's one wait)
+        const bool live = live_n;
         if (live) {
             const OffT u_off = row_off<D, OffT>(u, k), i_off = row_off<D, OffT>(i, k), j_off = row_off<D, OffT>(j, k);
-            Row<D> p, qi, qj;
-            if constexpr (MODE == 0) p.load_once_at(P, u_off); else p.load_at(P, u_off);   // unique users: touched once
-            qi.load_at(Q, i_off);
-            qj.load_at(Q, j_off);
             float dpos = 0.0f, dneg = 0.0f;
 #pragma unroll
             for (int c = 0; c < EPL; ++c) {
@@ -257,7 +265,12 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
                 }
             }
         }
-        b = bn; u = un; i = in; j = jn;
+        // the next triplet's rows, behind this trip's atomics and stores; then the indices of the one after
+        live_n = (bn < B) && (in >= 0);
+        request_rows();
+        um = im = jm = -1;
+        if (bn + stride < B) { um = U_idx[bn + stride]; im = I_idx[bn + stride]; jm = J_idx[bn + stride]; }
+        b = bn;
     }
     if (loss_acc != nullptr) {
         const float w = wave_sum(loss_local);
@@ -282,6 +295,9 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
 // take the global-atomic path / runs of length one, and the sums are the same.
 #ifndef RSX_BLOCKED_WAVES
 #define RSX_BLOCKED_WAVES 6     // wavefronts per SIMD the blocked kernel is compiled for
+#endif
+#ifndef RSX_STEP_PIPELINE
+#define RSX_STEP_PIPELINE 1     // 0: the round-2 trip loop (development A/B)
 #endif
 // TILE = false is the same walk without the negative-side LDS tile, for batches that are ordered by
 // positive item but too small for blocked negatives (B < 2 I: fewer than two updates per item row, so the
@@ -447,6 +463,43 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
     auto idx = [&](const int32_t *base, int32_t rel) __attribute__((always_inline)) {
         return *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(base) + (pos0 + (OffT)((uint32_t)rel * 4u)));
     };
+#if RSX_STEP_PIPELINE
+    // SOFTWARE PIPELINE over the trips (round 3).  gfx950 has ONE counter (vmcnt) for loads, stores and atomics, and loads
+    // and stores complete out of order with each other: whenever a wavefront waits for ANY load while stores are in flight, the
+    // wait is a full drain (s_waitcnt vmcnt(0)).  The loop used to be  [indices of the next trip] [row gathers] [wait] [compute,
+    // atomics, stores] [copy the prefetched indices: a drain] : two dependent round trips per trip, the gathers of trip t+1 never in
+    // flight together with the stores and atomics of trip t.  Now the row gathers of trip t+1 are ISSUED at the end of trip t,
+    // behind its stores and atomics and into the same registers (all row registers are dead by then), and the one wait of a trip --
+    // at its first use of the rows -- drains both at once.  n* = indices of the trip whose rows are in flight, m* = of the one after.
+    int32_t ua = -1, ia = -1, ja = -1, ub = -1, ib = -1, jb = -1;
+    int32_t una = -1, ina = -1, jna = -1, unb = -1, inb = -1, jnb = -1;
+    int32_t uma = -1, ima = -1, jma = -1, umb = -1, imb = -1, jmb = -1;
+    if (0 < n_pos) { una = idx(U_idx, 0); ina = idx(I_idx, 0); jna = idx(J_idx, 0); }
+    if (1 < n_pos) { unb = idx(U_idx, 1); inb = idx(I_idx, 1); jnb = idx(J_idx, 1); }
+    Row<D> pa, qia, qja, pb, qib, qjb;
+    bool live_a = (0 < n_pos) && (ina >= 0), live_b = (1 < n_pos) && (inb >= 0);
+    if (live_a) { pa.load_once_at(P, row_off<D, OffT>(una, k)); qia.load_at(Q, row_off<D, OffT>(RSX_ABL(32) ? 0 : ina, k)); qja.load_at(Q, row_off<D, OffT>(RSX_ABL(64) ? 1 : jna, k)); }
+    if (live_b) { pb.load_once_at(P, row_off<D, OffT>(unb, k)); qib.load_at(Q, row_off<D, OffT>(RSX_ABL(32) ? 0 : inb, k)); qjb.load_at(Q, row_off<D, OffT>(RSX_ABL(64) ? 1 : jnb, k)); }
+    if (2 < n_pos) { uma = idx(U_idx, 2); ima = idx(I_idx, 2); jma = idx(J_idx, 2); }
+    if (3 < n_pos) { umb = idx(U_idx, 3); imb = idx(I_idx, 3); jmb = idx(J_idx, 3); }
+    for (int32_t t = 0; t < n_trip; t += 2) {       // wave-uniform trip count
+        // (the first use of the prefetched indices / the rows: the trip's one wait)
+        ua = una; ia = ina; ja = jna; ub = unb; ib = inb; jb = jnb;
+        una = uma; ina = ima; jna = jma; unb = umb; inb = imb; jnb = jmb;
+        const bool la = live_a, lb = live_b;
+        process(la, ua, ia, ja, pa, qia, qja);
+        process(lb, ub, ib, jb, pb, qib, qjb);
+        // the next trip's rows, behind this trip's stores and atomics
+        live_a = (t + 2 < n_pos) && (ina >= 0);
+        live_b = (t + 3 < n_pos) && (inb >= 0);
+        if (live_a) { pa.load_once_at(P, row_off<D, OffT>(una, k)); qia.load_at(Q, row_off<D, OffT>(RSX_ABL(32) ? 0 : ina, k)); qja.load_at(Q, row_off<D, OffT>(RSX_ABL(64) ? 1 : jna, k)); }
+        if (live_b) { pb.load_once_at(P, row_off<D, OffT>(unb, k)); qib.load_at(Q, row_off<D, OffT>(RSX_ABL(32) ? 0 : inb, k)); qjb.load_at(Q, row_off<D, OffT>(RSX_ABL(64) ? 1 : jnb, k)); }
+        // ... and the indices of the trip after it
+        uma = ima = jma = umb = imb = jmb = -1;
+        if (t + 4 < n_pos) { uma = idx(U_idx, t + 4); ima = idx(I_idx, t + 4); jma = idx(J_idx, t + 4); }
+        if (t + 5 < n_pos) { umb = idx(U_idx, t + 5); imb = idx(I_idx, t + 5); jmb = idx(J_idx, t + 5); }
+    }
+#else
     int32_t ua = -1, ia = -1, ja = -1, ub = -1, ib = -1, jb = -1;
     if (0 < n_pos) { ua = idx(U_idx, 0); ia = idx(I_idx, 0); ja = idx(J_idx, 0); }
     if (1 < n_pos) { ub = idx(U_idx, 1); ib = idx(I_idx, 1); jb = idx(J_idx, 1); }
@@ -463,6 +516,7 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
         process(live_b, ub, ib, jb, pb, qib, qjb);
         ua = una; ia = ina; ja = jna; ub = unb; ib = inb; jb = jnb;
     }
+#endif
     RSX_RUN_FLUSH(run_item, run)     // last run of this lane group
 #undef RSX_RUN_FLUSH
     // flush the block's rows: one global atomic row per touched item

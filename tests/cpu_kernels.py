@@ -89,3 +89,25 @@ def adam_apply(W, M, V, G, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):
     V.mul_(beta2).addcmul_(G, G, value=1.0 - beta2)
     W -= (lr / bc1) * (M / (V.sqrt() / bc2 ** 0.5 + eps))
     G.zero_()
+
+
+# -- the relabelled item space of the item-range pipelines (BPREngine.set_chunks): only its HOST logic runs on the CPU ----------
+def chunk_rows(items_real, chunks, neg_block):
+    """include/rsx.h:rsx_chunk_rows"""
+    most = -(-items_real // chunks)
+    return -(-most // neg_block) * neg_block
+
+
+def build_signature(indptr, indices, neg_block):
+    return None
+
+
+def build_item_cdf(indptr, indices, num_items):
+    return None
+
+
+class HotItems:
+    def __init__(self, item_counts, num_hot, replicas, d, device):
+        counts = torch.as_tensor(item_counts)
+        self.items = torch.topk(counts, int(min(num_hot, counts.numel()))).indices.to(torch.int32)
+        self.n, self.replicas = int(self.items.numel()), int(replicas)

@@ -96,6 +96,50 @@ def test_two_ranks_with_the_exchange_under_the_user_pass_equal_one_process(oracl
     assert_update(out[0][3], Q0, single.Q, "Q")
 
 
+def _relabel_worker(rank, world, port, U, I, d, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cpu_kernels
+    from recsys_pytorch_amd.sharded import BPREngine
+    rng = np.random.default_rng(100 + rank)                    # every rank its OWN users: different local popularity
+    p = 1.0 / np.arange(1, I + 1) ** (0.8 + 0.3 * rank)
+    p /= p.sum()
+    rows = [np.sort(rng.choice(I, 12, replace=False, p=p)) for _ in range(U)]
+    indptr = torch.arange(U + 1, dtype=torch.int64) * 12
+    indices = torch.from_numpy(np.concatenate(rows).astype(np.int32))
+    eng = BPREngine(torch.zeros(U, d), torch.randn(I, d, generator=torch.Generator().manual_seed(3)), 0.1, kernels=cpu_kernels,
+                    user_begin=rank * U, seed=2020)
+    eng.neg_block, eng.chunks = 6, 4
+    eng.set_hot_items(torch.bincount(indices.long(), minlength=I), 16, 4)
+    r = eng._build_relabel(indptr, indices)
+    local_mass = np.bincount(indices.numpy(), minlength=I) / 12.0
+    out[rank] = (r["rank_item"].numpy().copy(), r["item_rank"].numpy().copy(), int(r["Ic"]), local_mass, r["indices"].numpy().copy(),
+                 indices.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_agree_on_the_relabelled_item_space():
+    """the item-range pipelines train on a relabelled item space that must be THE SAME on every rank (the ranges' rows are
+    all-reduced position by position) although every rank sees other users: the range assignment is a function of the sampling
+    masses summed over the ranks.  Two gloo ranks with different local popularity: identical relabelling, a bijection onto the
+    real rows, range masses balanced on the GLOBAL distribution, the local CSR relabelled consistently"""
+    U, I, d, world = 3000, 1003, 8, 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29500 + (os.getpid() + 41) % 2000
+    mp.spawn(_relabel_worker, args=(world, port, U, I, d, out), nprocs=world, join=True)
+    (ri0, ir0, Ic, m0, im0, ix0), (ri1, ir1, _, m1, im1, ix1) = out[0], out[1]
+    assert np.array_equal(ri0, ri1) and np.array_equal(ir0, ir1)
+    assert np.array_equal(ri0[ir0], np.arange(I)) and (ri0 >= 0).sum() == I
+    mass = m0 + m1
+    share = np.array([mass[ri0[k * Ic:(k + 1) * Ic][ri0[k * Ic:(k + 1) * Ic] >= 0]].sum() for k in range(4)]) / mass.sum()
+    assert np.abs(share - 0.25).max() < 0.01, share
+    for im, ix in ((im0, ix0), (im1, ix1)):                     # each rank's CSR columns: the same items, relabelled, rows re-sorted
+        assert np.array_equal(np.sort(ir0[ix].reshape(U, 12), axis=1), im.reshape(U, 12))
+
+
 def _gpu_worker(rank, world, port, P0, Q0, batches, lr, out, unique=False, exchange="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
