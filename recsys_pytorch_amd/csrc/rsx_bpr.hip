@@ -699,6 +699,9 @@ __global__ __launch_bounds__(kBlock) void pair_score_kernel(const float *__restr
 // Q -= lr*G ; G = 0   (streaming; rows with an all-zero gradient quad are not written).
 // With a HotMap the replicas of a popular row are summed in here (and zeroed), which saves the
 // separate fold launch when no all-reduce sits between the step and the apply.
+// DENSE (the native loop, batches of at least one triplet per item: nearly every row has a gradient): the Q quads are requested
+// TOGETHER with the G quads instead of after them -- one memory latency per thread instead of two.
+template <bool DENSE>
 __global__ __launch_bounds__(kBlock) void apply_item_grad_kernel(float4 *__restrict__ Q,
                                                                  float4 *__restrict__ G, int64_t n4,
                                                                  float lr, HotMap hot, int d4)
@@ -713,7 +716,7 @@ __global__ __launch_bounds__(kBlock) void apply_item_grad_kernel(float4 *__restr
         for (int c = 0; c < kQuads; ++c) {
             const int64_t n = n0 + c * stride;
             g[c] = make_float4(0.f, 0.f, 0.f, 0.f); q[c] = g[c];
-            if (n < n4) g[c] = G[n];
+            if (n < n4) { g[c] = G[n]; if constexpr (DENSE) q[c] = Q[n]; }
         }
         if (hot.slot != nullptr) {
 #pragma unroll
@@ -737,7 +740,7 @@ __global__ __launch_bounds__(kBlock) void apply_item_grad_kernel(float4 *__restr
         for (int c = 0; c < kQuads; ++c) {
             const int64_t n = n0 + c * stride;
             nz[c] = n < n4 && (g[c].x != 0.f || g[c].y != 0.f || g[c].z != 0.f || g[c].w != 0.f);
-            if (nz[c]) q[c] = Q[n];
+            if constexpr (!DENSE) { if (nz[c]) q[c] = Q[n]; }
         }
 #pragma unroll
         for (int c = 0; c < kQuads; ++c) {
@@ -1067,6 +1070,12 @@ RSX_API int rsx_apply_item_grad(float *Q, float *G, int64_t num_items, int d, fl
                                 const int32_t *hot_slot_dev, float *G_hot, int hot_replicas,
                                 rsx_stream_t stream)
 {
+    return rsx_apply_item_grad_ex(Q, G, num_items, d, lr, hot_slot_dev, G_hot, hot_replicas, false, (hipStream_t)stream);
+}
+
+int rsx_apply_item_grad_ex(float *Q, float *G, int64_t num_items, int d, float lr, const int32_t *hot_slot_dev, float *G_hot,
+                           int hot_replicas, bool dense, hipStream_t stream)
+{
     RSX_CHECK_ARG(Q && G, "null table pointer");
     RSX_CHECK_ARG(rsx_dim_ok(d) && num_items > 0, "bad shape");
     HotMap hot{nullptr, nullptr, 1};
@@ -1077,8 +1086,10 @@ RSX_API int rsx_apply_item_grad(float *Q, float *G, int64_t num_items, int d, fl
     const int64_t n4 = num_items * d / 4;
     // one trip of four quads per thread when the table is large (an uneven grid-stride tail costs ~25 %)
     const int64_t blocks = ceil_div64(n4, (int64_t)kBlock * 4);
-    hipLaunchKernelGGL(apply_item_grad_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(kBlock), 0,
-                       (hipStream_t)stream, (float4 *)Q, (float4 *)G, n4, lr, hot, d / 4);
+    if (dense) hipLaunchKernelGGL(apply_item_grad_kernel<true>, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(kBlock), 0, stream,
+                                  (float4 *)Q, (float4 *)G, n4, lr, hot, d / 4);
+    else hipLaunchKernelGGL(apply_item_grad_kernel<false>, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(kBlock), 0, stream,
+                            (float4 *)Q, (float4 *)G, n4, lr, hot, d / 4);
     RSX_CHECK_LAUNCH();
     return RSX_OK;
 }

@@ -133,6 +133,10 @@ int rsx_comm_all_reduce(rsx_comm *c, float *buf, int64_t n, hipStream_t st);
 int rsx_comm_reduce_scatter(rsx_comm *c, float *buf, int64_t n_per_rank, hipStream_t st);
 int rsx_comm_all_gather(rsx_comm *c, float *buf, int64_t n_per_rank, hipStream_t st);
 
+// rsx_bpr.hip: rsx_apply_item_grad with a hint (dense: nearly every row has a gradient; the result is the same either way)
+int rsx_apply_item_grad_ex(float *Q, float *G, int64_t num_items, int d, float lr, const int32_t *hot_slot_dev, float *G_hot,
+                           int hot_replicas, bool dense, hipStream_t stream);
+
 // rsx_bpr.hip: pieces of the chunked step the native loop queues on its own stream
 int rsx_fold_hot_grad_range(float *G, float *G_hot, const int32_t *hot_items_dev, int n_hot, int hot_replicas, int d,
                             int64_t row_lo, int64_t row_hi, hipStream_t st);

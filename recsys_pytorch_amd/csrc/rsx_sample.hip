@@ -184,7 +184,14 @@ __global__ __launch_bounds__(kBlock) void sample_neg_kernel(
 // Buckets are monotone in the item, so the concatenation is ordered by positive item; the order
 // is a pure function of the sampled set (no atomics decide a position).
 constexpr int kChunk = 4096;              // positions per bucket_chunk workgroup (16 per thread)
-constexpr int kChunkThreads = 1024;
+// workgroup of the bucketing pass.  It runs beside the step kernel, whose wavefronts hold 480 of a SIMD's 512 VGPRs: a
+// 1024-thread workgroup needs four wavefronts (4 x 48 VGPRs) on EVERY SIMD of one CU at once, a 512-thread one two (2 x 72).
+// Same box, 300 steps at the headline shape: 340.2 / 350.8 us per step with 1024, 330.6 / 328.8 with 512, 355.3 / 353.1 with
+// 256 (122 VGPRs: sixteen positions per thread) -- profiles/r03_exp_sampler_placement.txt
+#ifndef RSX_CHUNK_THREADS
+#define RSX_CHUNK_THREADS 512
+#endif
+constexpr int kChunkThreads = RSX_CHUNK_THREADS;
 constexpr int kPerThread = kChunk / kChunkThreads;
 constexpr int kBucketMean = 832;          // expected pairs per bucket: 1024 - 6.6 sigma
 constexpr int kSortCap = 2048;            // pairs a bucket may hold and still be sorted in LDS

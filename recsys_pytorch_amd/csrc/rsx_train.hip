@@ -207,7 +207,9 @@ RSX_API int rsx_bpr_trainer_create(const rsx_bpr_trainer_config *cfg, rsx_bpr_tr
     t->epoch_pos = cfg->epoch_pos0;
     // The sampler is the background producer: it has a whole step of slack, so its stream gets the LOWEST
     // priority and its workgroups fill the slots the step kernel leaves free (measured beside the 1M-triplet
-    // step kernel: that kernel 348 -> 326 us, step 386 -> 372 us, same box; highest priority: no gain)
+    // step kernel: that kernel 348 -> 326 us, step 386 -> 372 us, same box; highest priority: no gain; round 3, beside the
+    // pipelined kernel: default priority 349-359 vs 341-354 us per step; CUs of its own -- 16 / 32 / 64 of the 256 by CU mask,
+    // the step on the others -- 757 / 439 / 391 vs 340: profiles/r03_exp_sampler_placement.txt)
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);        // lo = numerically largest = least urgent
     const int prio = prio_lo;
@@ -447,7 +449,7 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
                              nullptr, 0, c.hot_slot, c.G_hot, c.hot_replicas, nb, key, stream));
         RSX_TRY(time_end());
         if (!sharded) {
-            RSX_TRY(rsx_apply_item_grad(c.Q, c.G, c.num_items, c.d, c.lr, c.hot_slot, c.G_hot, c.hot_replicas, stream));
+            RSX_TRY(rsx_apply_item_grad_ex(c.Q, c.G, c.num_items, c.d, c.lr, c.hot_slot, c.G_hot, c.hot_replicas, batch >= c.num_items, st));
         } else {
             // the one exchange of the step: the item gradients, summed over the ranks.  It needs the
             // folded G; with two passes it travels under the user pass and the next step's sampler.
