@@ -158,13 +158,14 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     eng.stale_exchange = SHARDED and os.environ.get("RSX_STALE_EXCHANGE") == "1"
     eng.blocked_any_batch = os.environ.get("RSX_BLOCKED_ANY_BATCH") == "1"      # experiment
     nb = eng.set_neg_block(B, want_nb) if want_nb > 0 else 0
-    if nb and os.environ.get("RSX_NEG_BLOCK_EXACT"):      # experiment: the block size itself, not pick_neg_block's choice
-        nb = eng.neg_block = int(os.environ["RSX_NEG_BLOCK_EXACT"]); eng._csr = None
     if hot > 0:
         eng.set_hot_items(torch.bincount(indices.long(), minlength=I), hot, hot_replicas)
     if chunks > 1 and nb and not eng.stale_exchange and (COMM is not None or not SHARDED):
         eng.set_chunks(chunks)
         eng.overlap_exchange = False                     # the range pipeline replaces the two-pass step
+        nb = eng.neg_block                               # (ranges use blocks of at least 3: sharded.py:pick_neg_block)
+    if nb and os.environ.get("RSX_NEG_BLOCK_EXACT"):      # experiment: the block size itself, not pick_neg_block's choice
+        nb = eng.neg_block = int(os.environ["RSX_NEG_BLOCK_EXACT"]); eng._csr = None; eng._relabel = None
     # the loss of every batch is accumulated on the device like MF.fit's epoch_loss (models/MF.py:70)
     loss = torch.zeros(rsx.RSX_LOSS_SLOTS, dtype=torch.float32, device=dev)
     tr = eng.native_trainer(indptr, indices, B, loss_acc=loss)

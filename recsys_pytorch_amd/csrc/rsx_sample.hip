@@ -185,11 +185,12 @@ __global__ __launch_bounds__(kBlock) void sample_neg_kernel(
 // is a pure function of the sampled set (no atomics decide a position).
 constexpr int kChunk = 4096;              // positions per bucket_chunk workgroup (16 per thread)
 // workgroup of the bucketing pass.  It runs beside the step kernel, whose wavefronts hold 480 of a SIMD's 512 VGPRs: a
-// 1024-thread workgroup needs four wavefronts (4 x 48 VGPRs) on EVERY SIMD of one CU at once, a 512-thread one two (2 x 72).
-// Same box, 300 steps at the headline shape: 340.2 / 350.8 us per step with 1024, 330.6 / 328.8 with 512, 355.3 / 353.1 with
-// 256 (122 VGPRs: sixteen positions per thread) -- profiles/r03_exp_sampler_placement.txt
+// 1024-thread workgroup needs four wavefronts (4 x 48 VGPRs) on EVERY SIMD of one CU at once, a 256-thread one a single one
+// (122 VGPRs: sixteen positions per thread in lockstep).  Same box, 300 steps at the headline shape, us per step: with item
+// blocks of 6 (long step wavefronts) 340 / 331 / 355 at 1024 / 512 / 256 threads; with blocks of 2-3 (short ones, what
+// sharded.py:pick_neg_block now picks there) 345 / 336 / 327 -- profiles/r03_exp_sampler_placement.txt
 #ifndef RSX_CHUNK_THREADS
-#define RSX_CHUNK_THREADS 512
+#define RSX_CHUNK_THREADS 256
 #endif
 constexpr int kChunkThreads = RSX_CHUNK_THREADS;
 constexpr int kPerThread = kChunk / kChunkThreads;
@@ -666,12 +667,26 @@ __global__ __launch_bounds__(kBlock, 5) void bucket_sort_kernel(
     }
     __syncthreads();
     // gather: rank r of the bucket lives in the chunk whose slice covers r
-    for (int r = tid; r < n; r += kBlock) {
-        int lo = 0, hi = kMaxChunks;                               // last chunk with cstart <= r
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cstart[mid] <= (uint32_t)r) lo = mid; else hi = mid; }
-        const uint2 pr = pairs[(size_t)lo * kChunk + csrc[lo] + ((uint32_t)r - cstart[lo])];
-        const uint64_t kv = ((uint64_t)pr.y << 32) | pr.x;
-        if (in_lds) keys[r] = kv; else GlobalKeys{ug, ig}.set(r, kv);
+    // (kGather ranks per thread in lockstep: their pair loads are in flight together -- a bucket of ~832 pairs is one trip)
+    constexpr int kGather = 4;
+    for (int r0 = 0; r0 < n; r0 += kBlock * kGather) {
+        uint32_t src[kGather];
+#pragma unroll
+        for (int e = 0; e < kGather; ++e) {
+            const int r = r0 + e * kBlock + tid;
+            int lo = 0, hi = kMaxChunks;                           // last chunk with cstart <= r
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cstart[mid] <= (uint32_t)r) lo = mid; else hi = mid; }
+            src[e] = (uint32_t)lo * kChunk + csrc[lo] + ((uint32_t)r - cstart[lo]);
+        }
+        uint2 pr[kGather];
+#pragma unroll
+        for (int e = 0; e < kGather; ++e) pr[e] = (r0 + e * kBlock + tid < n) ? pairs[src[e]] : make_uint2(0u, 0u);
+#pragma unroll
+        for (int e = 0; e < kGather; ++e) {
+            const int r = r0 + e * kBlock + tid;
+            const uint64_t kv = ((uint64_t)pr[e].y << 32) | pr[e].x;
+            if (r < n) { if (in_lds) keys[r] = kv; else GlobalKeys{ug, ig}.set(r, kv); }
+        }
     }
     __threadfence_block();
     __syncthreads();

@@ -26,14 +26,27 @@ def user_block(num_users, rank, world):
     return begin, min(begin + per, num_users)
 
 
-def pick_neg_block(num_items, max_block, wave_slots):
-    """item block of the stratified negatives.  The blocked step kernel runs one wavefront per block,
-    each ~100 us long, so its duration is ceil(waves / resident slots) ROUNDS: 12 500 wavefronts on 6 144
-    slots take three rounds for two rounds' worth of work (measured: c = 8 -> 347 us, c = 6 -> 323 us at
-    I = 100K on 256 CUs).  Pick the c in [2, max_block] whose last round is fullest; ties go to the
-    larger block (fewer wavefronts, fewer partial-run flushes)."""
+def pick_neg_block(num_items, max_block, wave_slots, batch=None, min_block=2):
+    """item block c of the stratified negatives.  The blocked step kernel runs one wavefront per block over
+    ~c * batch / num_items positions.
+
+    * many triplets per item (batch / num_items >= 10): the SMALLEST c that still gives a wavefront 20 positions.  Short
+      wavefronts retire often, and the sampler of the next step -- which time-shares the CUs with this kernel, whose
+      wavefronts hold nearly all VGPRs -- finds room continuously instead of at the end of each round.  Measured at
+      I = 100K, B = 2**20 (profiles/r03_exp_sampler_placement.txt): c = 2 -> 341 us per step, 3 -> 345, 6 -> 362.
+    * fewer: a wavefront needs its positions to amortise its start, and the kernel's duration is ceil(waves / resident
+      slots) ROUNDS (12 500 wavefronts on 6 144 slots take three rounds for two rounds' worth of work): the c in
+      [2, max_block] whose last round is fullest; ties go to the larger block.  (B = 262 144 at I = 100K: c = 6 -> 1.54e9
+      triplets/s, 3 -> 1.36e9, 2 -> 1.12e9.)
+
+    min_block: lower bound of the first rule.  The item-range pipelines (set_chunks) use 3: two ranges on one GPU take
+    358 us per step with c = 3, 432-442 with c = 2, 396-409 with c = 6 (same file, block F)."""
     if max_block < 2:
         return max(1, int(max_block))
+    if batch is not None and batch >= 10 * num_items:
+        for c in range(min(min_block, max_block), max_block + 1):
+            if c * batch >= 20 * num_items:
+                return c
     best, best_eff = 2, -1.0
     for c in range(2, max_block + 1):
         waves = -(-num_items // c)
@@ -139,9 +152,9 @@ class BPREngine:
         """enable the on-chip gradient summation (blocked negatives + batch sorted by positive
         item, include/rsx.h: neg_block / RSX_SAMPLE_SORT_POS) when every item row gets >= 2
         updates per step; below that there is nothing to combine.  The block size c <= max_block
-        is picked so that the step kernel's ceil(I / c) wavefronts fill the chip's resident
-        wavefront slots in whole rounds (`pick_neg_block`)."""
-        nb = pick_neg_block(self.Q.shape[0], int(max_block), self._wave_slots()) if (batch >= 2 * self.Q.shape[0] or self.blocked_any_batch) else 0
+        is `pick_neg_block`'s choice for this batch size."""
+        self._nb_args = (int(batch), int(max_block))
+        nb = pick_neg_block(self.Q.shape[0], int(max_block), self._wave_slots(), int(batch), 3 if self.chunks > 1 else 2) if (batch >= 2 * self.Q.shape[0] or self.blocked_any_batch) else 0
         if nb != self.neg_block:
             self._csr = None        # the user signatures depend on neg_block: rebuild on next use
         self.neg_block = nb
@@ -204,6 +217,8 @@ class BPREngine:
         if chunks != self.chunks:
             self._relabel = None
         self.chunks = chunks if chunks > 1 else 0
+        if self.neg_block and getattr(self, "_nb_args", None):      # the block size depends on it (pick_neg_block: min_block)
+            self.set_neg_block(*self._nb_args)
         return self.chunks
 
     def _build_relabel(self, indptr, indices):
