@@ -23,6 +23,7 @@ eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 256, 16)
 ck = int(os.environ.get("CHUNKS", 0))
 if ck > 1 and nb:
     eng.set_chunks(ck)
+    nb = eng.neg_block           # (ranges use blocks of at least 3)
 if os.environ.get("STEP_PROF_META"):
     kernel = (f"bpr_step_blocked_kernel<{d}, 3, unsigned int, {'true' if nb else 'false'}>" if (nb or eng._sorts(B))
               else f"bpr_step_kernel<{d}, 0, 3, unsigned int>")
