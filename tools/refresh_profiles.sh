@@ -7,7 +7,7 @@
 #   <tag>_pmc_step_<leg>.json (+ .meta.json)   tools/pmc_groups.py (one rocprofv3 --pmc pass per counter group, --kernel-trace
 #                                  only) over tools/step_prof.py at the shape of EVERY step leg of bench.py: the HBM traffic
 #                                  bench.py's roofline objects quote (profiles/traffic.json)
-#   <tag>_pmc_spmm.json            the same over tools/spmm_prof.py (LightGCN propagation product)
+#   <tag>_pmc_spmm.json            the same over tools/spmm_prof.py (LightGCN propagation product); _users / _items: its two halves
 #   <tag>_pmc_scoring.json         over tools/score_prof.py for the scoring kernels
 set -u
 tag=${1:-r03}
@@ -49,6 +49,10 @@ leg B262144       "$T" - 262144 8 30
 leg B1M_ranges3   "$T" "CHUNKS=3" 1000000 8 12
 ( export STEP_PROF_META="$out/${tag}_pmc_spmm.meta.json"
   PMC_GROUPS="$T;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" python3 tools/pmc_groups.py "$out/${tag}_pmc_spmm.json" spmm_csr -- python3 tools/spmm_prof.py > /dev/null 2>&1 )
+for half in users items; do
+( export SPMM_HALF=$half
+  PMC_GROUPS="$T;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" python3 tools/pmc_groups.py "$out/${tag}_pmc_spmm_${half}.json" spmm_csr -- python3 tools/spmm_prof.py > /dev/null 2>&1 )
+done
 S="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU_MFMA_MOPS_F32;FETCH_SIZE;WRITE_SIZE"
 PMC_GROUPS="$S" LANES=2 python3 tools/pmc_groups.py "$out/${tag}_pmc_scoring.json" score_,merge_cand,topk_rows,sample_tau,permute_items -- python3 tools/score_prof.py 16 > /dev/null 2>&1
 fi
