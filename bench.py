@@ -356,6 +356,11 @@ def main():
         fn = rsx.lib().rsx_debug_set_exchange_delay
         fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_int]
         assert fn(int(os.environ["RSX_EXCHANGE_DELAY_US"])) == 0
+    if os.environ.get("RSX_SAMPLER_REPLAY") == "1":  # DEVELOPMENT library only: the loop without a sampler beside it (3 batches replayed)
+        import ctypes
+        fn = rsx.lib().rsx_debug_set_sampler_replay
+        fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_int]
+        assert fn(1) == 0
     global COMM
     if SHARDED and os.environ.get("RSX_DIST_BACKEND", "nccl") == "nccl" and os.environ.get("RSX_NATIVE_RCCL", "1") == "1":
         COMM = rsx.Comm()        # the exchange is then issued by librsx on the trainer's own stream: no interpreter in the timed region

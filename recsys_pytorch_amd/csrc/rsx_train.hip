@@ -117,6 +117,11 @@ static int rsx_debug_exchange_delay(hipStream_t st, int parts)
     hipLaunchKernelGGL(exchange_delay_kernel, dim3(8), dim3(256), 0, st, (uint64_t)g_exchange_delay_us * 100ull / (uint64_t)parts);
     return RSX_OK;
 }
+// `rsx_debug_set_sampler_replay(1)`: once every slot of the ring holds a batch, the sampler kernels are no longer launched and
+// the loop steps on the three batches it has (with their own keys) -- the step WITHOUT a sampler beside it, to price what the
+// sampler costs the loop (not training: the same 3 batches again and again).
+static int g_sampler_replay = 0;
+RSX_API int rsx_debug_set_sampler_replay(int on) { g_sampler_replay = on; return RSX_OK; }
 #else
 static inline int rsx_debug_exchange_delay(hipStream_t, int) { return RSX_OK; }
 #endif
@@ -140,6 +145,13 @@ int launch_sample(rsx_bpr_trainer *t, int slot, int64_t step_index, int64_t batc
     const bool sorted = nb > 0 || (c.sort_min_batch > 0 && batch >= c.sort_min_batch);
     const uint64_t key = nb ? neg_key_for(c.seed_key, step_index) : 0ull;
     if (t->freed_valid[slot]) RSX_HIP(hipStreamWaitEvent(t->side, t->freed[slot], 0));
+#ifdef RSX_ABLATE
+    if (g_sampler_replay && step_index >= rsx_bpr_trainer::S && t->slot_batch[slot] == batch) {
+        RSX_HIP(hipEventRecord(t->ready[slot], t->side));
+        t->epoch_pos += batch;
+        return RSX_OK;
+    }
+#endif
     if (chunked(t))
         RSX_TRY(rsx_bpr_sample_chunked(c.indptr, c.indices, c.num_users, c.num_items, c.items_real, c.chunks, batch, c.seed,
                                        (uint64_t)step_index, t->epoch_pos, nb, key, c.sample_ws, c.sample_ws_bytes, c.user_sig,

@@ -60,6 +60,25 @@ def test_eval_holdout_rejects_bad_k():
         rsx.eval_holdout(np.zeros((2, 5), np.int32), [6], np.array([0, 1, 2]), np.array([0, 1], np.int32))
 
 
+def test_pick_neg_block_follows_the_batch_density():
+    """sharded.pick_neg_block: short wavefronts (the smallest block that leaves 20 positions) from 10 triplets per item on, the
+    fullest-last-round rule below, never above max_block, item ranges from 3 up"""
+    from recsys_pytorch_amd.sharded import pick_neg_block
+    slots = 256 * 24
+    assert pick_neg_block(100_000, 8, slots, 1 << 20) == 2            # the headline shape: 10.5 triplets per item
+    assert pick_neg_block(100_000, 8, slots, 1 << 20, 3) == 3         # ... as item ranges
+    assert pick_neg_block(100_000, 8, slots, 1_000_000) == 2
+    assert pick_neg_block(100_000, 8, slots, 262_144) == 6            # 2.6 per item: whole rounds of wavefronts
+    assert pick_neg_block(100_000, 8, slots) == 6                     # no batch given: the round rule
+    assert pick_neg_block(100_000, 4, slots, 1 << 20, 3) == 3
+    assert pick_neg_block(100_000, 2, slots, 1 << 20, 3) == 2         # min_block never exceeds max_block
+    assert pick_neg_block(100_000, 1, slots, 1 << 20) == 1
+    assert pick_neg_block(1_000, 8, slots, 100_000) == 2              # 100 per item: c = 2 gives 200 positions
+    for I, B in ((50_000, 600_000), (7_777, 90_000), (100_000, 3_000_000)):
+        c = pick_neg_block(I, 8, slots, B)
+        assert 2 <= c <= 8 and c * B >= 20 * I and (c == 2 or (c - 1) * B < 20 * I)
+
+
 def test_user_block_partition():
     from recsys_pytorch_amd.sharded import user_block
     for U, W in ((10, 3), (1_000_000, 8), (7, 8), (943, 2)):
