@@ -12,7 +12,7 @@ for cfg in "${@:-16}"; do
     timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmcs_${tag}_$i -- python3 $root/tools/score_prof.py $cfg > /dev/null 2>&1
     python3 $root/tools/prof_summarize.py /tmp/pmcs_${tag}_$i /tmp/pmcs_out_${tag}_$i > /dev/null 2>&1
   done
-  python3 - $tag <<'PY'
+  python3 - $tag $root <<'PY'
 import json, sys, glob
 tag = sys.argv[1]
 out = {}
@@ -24,7 +24,7 @@ for f in sorted(glob.glob(f"/tmp/pmcs_out_{tag}_1_durations.json")):
     for k, v in json.load(open(f)).items():
         if any(s in k for s in ("score_", "merge_cand", "topk_rows")):
             out.setdefault(k.split("(")[0][-60:], {})["mean_us"] = round(v["mean_ns"] / 1e3, 1)
-json.dump(out, open(f"/root/repo/gpurun_out/pmc_score_{tag}.json", "w"), indent=1, sort_keys=True)
+json.dump(out, open(f"{sys.argv[2]}/gpurun_out/pmc_score_{tag}.json", "w"), indent=1, sort_keys=True)
 for k, v in out.items():
     print(tag, k, v)
 PY

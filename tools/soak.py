@@ -1,5 +1,5 @@
 import os, sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from recsys_pytorch_amd import rsx
 from recsys_pytorch_amd.data import synthetic_csr
 from recsys_pytorch_amd.sharded import BPREngine
