@@ -40,7 +40,9 @@ constexpr int BM = 128, BN = 128, BK = 32;
 #define RSX_SCORE_GLDS 1      // 0: never take the LDS-DMA form (development A/B)
 #endif
 // (s_setprio 2 / 3 around the MFMA block, so that a wavefront in its MFMA phase issues ahead of the others' VALU / LDS work:
-//  measured 279.5 -> 283.6 us per 1024 users, same box, round 3 -- dropped)
+//  measured 279.5 -> 283.6 us per 1024 users, same box, round 3 -- dropped.  A FIXED order of precedence among the four wavefronts
+//  that share a SIMD -- s_setprio 3 / 2 / 1 / 0 by HW_ID.wave_id, to keep them from reaching the end of a chunk and waiting for
+//  the next one all together -- changes nothing: 270.0 / 270.2 vs 270.4 / 270.2 us fused, the dense product 250 -> 256 us)
 constexpr int kSlots = 2;     // private candidate slots per (64-item strip, row) of the filtered product
 constexpr int LDT = BM + 1;   // K-major tile leading dimension (odd -> conflict-free transpose)
 
