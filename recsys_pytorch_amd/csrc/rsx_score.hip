@@ -630,6 +630,8 @@ __global__ __launch_bounds__(256) void permute_items_kernel(const float4 *__rest
 
 constexpr int MG_THREADS = 256;
 constexpr int MG_CAP = 4096;    // candidate list capacity per row
+constexpr int MG_SEEN = 512;    // seen items of a user held in LDS for the mask test (longer rows: searched in the CSR)
+constexpr int MG_BATCH = 8;     // cells a thread requests together
 constexpr int MG_BIN_BITS = 10;
 constexpr int MG_BINS = 1 << MG_BIN_BITS;
 
@@ -642,39 +644,61 @@ __global__ __launch_bounds__(MG_THREADS) void merge_candidates_kernel(
     int32_t *__restrict__ overflow_rows, int32_t *__restrict__ overflow_count, int64_t perm_a, int64_t perm_n)
 {
     __shared__ unsigned long long cand[MG_CAP];
-    __shared__ uint32_t s_n, s_total;
+    __shared__ int32_t seen[MG_SEEN];           // the user's seen items (sorted CSR row), when they fit
+    __shared__ uint32_t s_n;
     const int tid = threadIdx.x;
     const int64_t row = blockIdx.x;
-    if (tid == 0) { s_n = 0; s_total = 0; }
-    __syncthreads();
-    // how many candidates does this row have in all item tiles + the spill list?
-    const uint2 *rslots = slots + (size_t)row * n_strips * kSlots;     // this row's cells, contiguous
-    const int64_t n_slots = n_strips * kSlots;
-    uint32_t mine = 0;                          // an unused slot still holds the 0xFF fill: item < 0
-    for (int64_t q = tid; q < n_slots; q += MG_THREADS) mine += ((int32_t)rslots[q].y >= 0) ? 1u : 0u;
-    atomicAdd(&s_total, mine);
-    __syncthreads();
+    if (tid == 0) s_n = 0;
     const int spill = cand_cnt[row];
-    if (spill > cand_cap || s_total + (uint32_t)(spill > 0 ? spill : 0) > (uint32_t)MG_CAP) {   // block-uniform
+    if (spill > cand_cap) {                     // block-uniform: the spill list itself overflowed
         if (tid == 0) overflow_rows[atomicAdd(overflow_count, 1)] = (int32_t)(row_base + row);
         return;
     }
     int64_t lo = 0, hi = 0;
     if (indptr != nullptr) { const int32_t u = user_ids[row]; lo = indptr[u]; hi = indptr[u + 1]; }
+    const int deg = (int)(hi - lo);
+    const bool seen_lds = hi - lo <= (int64_t)MG_SEEN;
+    if (seen_lds)
+        for (int t = tid; t < deg; t += MG_THREADS) seen[t] = indices[lo + t];
+    __syncthreads();
+    // ONE pass over the row's cells (round 3; it used to count first and fetch again): everything that survives the seen-item
+    // test goes to the list, and a list that would not fit sends the row to the dense re-do afterwards.  The cells of a batch are
+    // requested together (MG_BATCH loads in flight per thread instead of one after the other), the seen test is a binary search
+    // in LDS instead of a chain of dependent global loads per survivor.
+    const uint2 *rslots = slots + (size_t)row * n_strips * kSlots;     // this row's cells, contiguous
+    const int64_t n_slots = n_strips * kSlots;  // an unused slot still holds the 0xFF fill: item < 0
     auto push = [&](float v, int32_t pit) {
         const int32_t it = (int32_t)(((int64_t)pit * perm_a) % perm_n);      // permuted id -> item id (ties, mask, output)
-        int64_t a = lo, z = hi;                 // seen item? (binary search in the sorted CSR row)
-        while (a < z) { const int64_t m = (a + z) >> 1; if (indices[m] < it) a = m + 1; else z = m; }
-        if (a < hi && indices[a] == it) return;
-        cand[atomicAdd(&s_n, 1u)] = ((unsigned long long)f2key(v) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)it);
+        if (seen_lds) {
+            int a = 0, z = deg;
+            while (a < z) { const int m = (a + z) >> 1; if (seen[m] < it) a = m + 1; else z = m; }
+            if (a < deg && seen[a] == it) return;
+        } else {
+            int64_t a = lo, z = hi;             // a long row: binary search in the CSR itself
+            while (a < z) { const int64_t m = (a + z) >> 1; if (indices[m] < it) a = m + 1; else z = m; }
+            if (a < hi && indices[a] == it) return;
+        }
+        const uint32_t at = atomicAdd(&s_n, 1u);
+        if (at < (uint32_t)MG_CAP) cand[at] = ((unsigned long long)f2key(v) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)it);
     };
-    for (int64_t q = tid; q < n_slots; q += MG_THREADS) {
-        const uint2 e = rslots[q];
-        if ((int32_t)e.y >= 0) push(__uint_as_float(e.x), (int32_t)e.y);
+    for (int64_t q0 = 0; q0 < n_slots; q0 += MG_THREADS * MG_BATCH) {
+        uint2 e[MG_BATCH];
+#pragma unroll
+        for (int b_ = 0; b_ < MG_BATCH; ++b_) {
+            const int64_t q = q0 + b_ * MG_THREADS + tid;
+            e[b_] = q < n_slots ? rslots[q] : make_uint2(0u, 0xFFFFFFFFu);
+        }
+#pragma unroll
+        for (int b_ = 0; b_ < MG_BATCH; ++b_)
+            if ((int32_t)e[b_].y >= 0) push(__uint_as_float(e[b_].x), (int32_t)e[b_].y);
     }
     for (int t = tid; t < spill; t += MG_THREADS)
         push(cand_val[(size_t)row * cand_cap + t], cand_idx[(size_t)row * cand_cap + t]);
     __syncthreads();
+    if (s_n > (uint32_t)MG_CAP) {               // block-uniform: more unseen survivors than the list holds
+        if (tid == 0) overflow_rows[atomicAdd(overflow_count, 1)] = (int32_t)(row_base + row);
+        return;
+    }
     uint32_t ncand = s_n;
     // Only K of the (typically ~K I / 8192 + K) survivors are wanted: one histogram of the keys,
     // linear between the smallest and largest key, finds the bin of the K-th; everything in or

@@ -484,6 +484,31 @@ def test_fused_score_topk_on_random_shapes(rsx, oracle_mod):
                 assert np.array_equal(idx[:n].cpu().numpy(), oracle_mod.topk(S[:n].cpu().numpy(), K)), ctx
 
 
+def test_fused_score_topk_with_long_seen_rows(rsx, oracle_mod):
+    """the merge kernel holds a user's seen items in LDS up to 512 of them and searches longer rows in the CSR itself: both forms,
+    and users whose best items are mostly seen, against dense scoring + row top-k"""
+    from recsys_pytorch_amd.data import synthetic_csr
+    torch.manual_seed(11)
+    U, I, d, K = 600, 40_009, 64, 50
+    P = torch.randn(U, d, device="cuda") * 0.1
+    Q = torch.randn(I, d, device="cuda") * 0.1
+    users = torch.arange(U, device="cuda", dtype=torch.int32)
+    for deg in (500, 513, 700, 3000):
+        ip, ix = synthetic_csr(U, I, deg, "cuda", seed=deg)
+        # half of the users have SEEN their own best 200 items: the survivors of the threshold are then mostly masked
+        S0 = rsx.score(P, Q, users)
+        best = torch.topk(S0[: U // 2], 200, dim=1).indices.to(torch.int32)
+        rows = [torch.unique(torch.cat([ix[ip[u]:ip[u + 1]], best[u]])) if u < U // 2 else ix[ip[u]:ip[u + 1]] for u in range(U)]
+        ip2 = torch.zeros(U + 1, dtype=torch.int64, device="cuda")
+        ip2[1:] = torch.cumsum(torch.tensor([r.numel() for r in rows], device="cuda"), 0)
+        mask = (ip2, torch.cat(rows).to(torch.int32).contiguous())
+        idx, val = rsx.score_topk(P, Q, users, K, mask=mask, want_values=True)
+        S = rsx.score(P, Q, users, mask=mask)
+        ref_i, ref_v = rsx.topk(S, K, want_values=True)
+        assert torch.equal(val, ref_v) and torch.equal(idx, ref_i), deg
+        assert np.array_equal(idx[:32].cpu().numpy(), oracle_mod.topk(S[:32].cpu().numpy(), K)), deg
+
+
 def test_fused_score_topk_degenerate_ties_take_the_dense_redo(rsx, oracle_mod):
     """all-zero user rows: every score ties at 0 -> candidate lists overflow -> dense re-do;
     mixed with ordinary rows in the same call"""
