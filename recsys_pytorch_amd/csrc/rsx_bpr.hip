@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
 #define RSX_STEP_PIPELINE 1     // 0: the round-2 trip loop (development A/B)
 #endif
 #ifndef RSX_STEP_NP_SMALL
-#define RSX_STEP_NP_SMALL 4     // positions per lane group and trip at d <= 64 (2 = as at d = 128; development A/B)
+#define RSX_STEP_NP_SMALL 2     // positions per lane group and trip at d <= 64 (development A/B: 3 / 4 measured SLOWER, see below)
 #endif
 // TILE = false is the same walk without the negative-side LDS tile, for batches that are ordered by
 // positive item but too small for blocked negatives (B < 2 I: fewer than two updates per item row, so the
@@ -474,8 +474,11 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
     // flight together with the stores and atomics of trip t.  Now the row gathers of trip t+1 are ISSUED at the end of trip t,
     // behind its stores and atomics and into the same registers (all row registers are dead by then), and the one wait of a trip --
     // at its first use of the rows -- drains both at once.  n* = indices of the trip whose rows are in flight, m* = of the one after.
-    // NP positions per lane group and trip: 2 at d = 128 (six row gathers of four registers each in flight per lane), 4 at d <= 64,
-    // where a row is two registers or one -- the same registers buy twice the gathers in flight and half the trips (round 3).
+    // NP positions per lane group and trip: 2 (six row gathers in flight per lane).  At d <= 64 a row is two registers or one, so 4
+    // positions cost the registers 2 cost at d = 128 -- measured (round 3, same box, us per step / kernel, NP = 2 / 3 / 4):
+    // d = 64 blocked 276 / 291 / 287 (226 / 239 / 242), d = 32 236 / 245 / 251, d = 64 independent negatives (TILE = false)
+    // 391 / 380 / 380 (359 / 316 / 320): more gathers in flight do not help where the rows are short -- the bound there is the
+    // number of row accesses and atomics, not their latency -- so NP stays 2 (profiles/r03_exp_sampler_placement.txt, block H).
     constexpr int NP = (D <= 64) ? RSX_STEP_NP_SMALL : 2;
     int32_t uc[NP], ic[NP], jc[NP];          // the trip being processed
     int32_t un[NP], in_[NP], jn[NP];         // the trip whose rows are in flight
