@@ -19,11 +19,15 @@ Q = torch.randn(I, d, device=dev) * 0.1
 ip, ix = synthetic_csr(U, I, int(os.environ.get("DEG", 20)), dev, popularity=pop)
 eng = BPREngine(P, Q, 0.05)
 nb = eng.set_neg_block(B, nbw) if nbw else 0
+if nb and os.environ.get("NEG_EXACT"):        # the block size itself (experiments)
+    nb = eng.neg_block = int(os.environ["NEG_EXACT"]); eng._csr = None
 eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 256, 16)
 ck = int(os.environ.get("CHUNKS", 0))
 if ck > 1 and nb:
     eng.set_chunks(ck)
     nb = eng.neg_block           # (ranges use blocks of at least 3)
+    if os.environ.get("NEG_EXACT"):
+        nb = eng.neg_block = int(os.environ["NEG_EXACT"]); eng._csr = None; eng._relabel = None
 if os.environ.get("STEP_PROF_META"):
     kernel = (f"bpr_step_blocked_kernel<{d}, 3, unsigned int, {'true' if nb else 'false'}>" if (nb or eng._sorts(B))
               else f"bpr_step_kernel<{d}, 0, 3, unsigned int>")
