@@ -299,9 +299,6 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
 #ifndef RSX_STEP_PIPELINE
 #define RSX_STEP_PIPELINE 1     // 0: the round-2 trip loop (development A/B)
 #endif
-#ifndef RSX_STEP_NP_SMALL
-#define RSX_STEP_NP_SMALL 2     // positions per lane group and trip at d <= 64 (development A/B: 3 / 4 measured SLOWER, see below)
-#endif
 // TILE = false is the same walk without the negative-side LDS tile, for batches that are ordered by
 // positive item but too small for blocked negatives (B < 2 I: fewer than two updates per item row, so the
 // negative side has nothing to sum): wavefront w owns the positions [w * span, (w + 1) * span), positive runs
@@ -474,61 +471,37 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
     // flight together with the stores and atomics of trip t.  Now the row gathers of trip t+1 are ISSUED at the end of trip t,
     // behind its stores and atomics and into the same registers (all row registers are dead by then), and the one wait of a trip --
     // at its first use of the rows -- drains both at once.  n* = indices of the trip whose rows are in flight, m* = of the one after.
-    // NP positions per lane group and trip: 2 (six row gathers in flight per lane).  At d <= 64 a row is two registers or one, so 4
-    // positions cost the registers 2 cost at d = 128 -- measured (round 3, same box, us per step / kernel, NP = 2 / 3 / 4):
-    // d = 64 blocked 276 / 291 / 287 (226 / 239 / 242), d = 32 236 / 245 / 251, d = 64 independent negatives (TILE = false)
-    // 391 / 380 / 380 (359 / 316 / 320): more gathers in flight do not help where the rows are short -- the bound there is the
-    // number of row accesses and atomics, not their latency -- so NP stays 2 (profiles/r03_exp_sampler_placement.txt, block H).
-    constexpr int NP = (D <= 64) ? RSX_STEP_NP_SMALL : 2;
-    int32_t uc[NP], ic[NP], jc[NP];          // the trip being processed
-    int32_t un[NP], in_[NP], jn[NP];         // the trip whose rows are in flight
-    int32_t um[NP], im[NP], jm[NP];          // the trip after it (indices only)
-    Row<D> pr[NP], qir[NP], qjr[NP];
-    bool live[NP];
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        uc[q] = ic[q] = jc[q] = un[q] = in_[q] = jn[q] = um[q] = im[q] = jm[q] = -1;
-        if (q < n_pos) { un[q] = idx(U_idx, q); in_[q] = idx(I_idx, q); jn[q] = idx(J_idx, q); }
-    }
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        live[q] = (q < n_pos) && (in_[q] >= 0);
-        if (live[q]) {
-            pr[q].load_once_at(P, row_off<D, OffT>(un[q], k));
-            qir[q].load_at(Q, row_off<D, OffT>(RSX_ABL(32) ? 0 : in_[q], k));
-            qjr[q].load_at(Q, row_off<D, OffT>(RSX_ABL(64) ? 1 : jn[q], k));
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < NP; ++q)
-        if (NP + q < n_pos) { um[q] = idx(U_idx, NP + q); im[q] = idx(I_idx, NP + q); jm[q] = idx(J_idx, NP + q); }
-    for (int32_t t = 0; t < n_trip; t += NP) {      // wave-uniform trip count
+    // (Round 3, measured and NOT kept: this loop written over arrays of NP positions with NP a template constant.  At NP = 2 the
+    //  same registers and no spill, yet 330 -> 392 us per step at the headline and 242 -> 285 at d = 64 on the same box -- the
+    //  compiler schedules the unrolled array form differently; NP = 3 / 4 at d <= 64, where rows are short, were slower still for
+    //  the blocked kernel.  The explicit a / b form below is the measured one: profiles/r03_exp_sampler_placement.txt, block H.)
+    int32_t ua = -1, ia = -1, ja = -1, ub = -1, ib = -1, jb = -1;
+    int32_t una = -1, ina = -1, jna = -1, unb = -1, inb = -1, jnb = -1;
+    int32_t uma = -1, ima = -1, jma = -1, umb = -1, imb = -1, jmb = -1;
+    if (0 < n_pos) { una = idx(U_idx, 0); ina = idx(I_idx, 0); jna = idx(J_idx, 0); }
+    if (1 < n_pos) { unb = idx(U_idx, 1); inb = idx(I_idx, 1); jnb = idx(J_idx, 1); }
+    Row<D> pa, qia, qja, pb, qib, qjb;
+    bool live_a = (0 < n_pos) && (ina >= 0), live_b = (1 < n_pos) && (inb >= 0);
+    if (live_a) { pa.load_once_at(P, row_off<D, OffT>(una, k)); qia.load_at(Q, row_off<D, OffT>(RSX_ABL(32) ? 0 : ina, k)); qja.load_at(Q, row_off<D, OffT>(RSX_ABL(64) ? 1 : jna, k)); }
+    if (live_b) { pb.load_once_at(P, row_off<D, OffT>(unb, k)); qib.load_at(Q, row_off<D, OffT>(RSX_ABL(32) ? 0 : inb, k)); qjb.load_at(Q, row_off<D, OffT>(RSX_ABL(64) ? 1 : jnb, k)); }
+    if (2 < n_pos) { uma = idx(U_idx, 2); ima = idx(I_idx, 2); jma = idx(J_idx, 2); }
+    if (3 < n_pos) { umb = idx(U_idx, 3); imb = idx(I_idx, 3); jmb = idx(J_idx, 3); }
+    for (int32_t t = 0; t < n_trip; t += 2) {       // wave-uniform trip count
         // (the first use of the prefetched indices / the rows: the trip's one wait)
-        bool lc[NP];
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            uc[q] = un[q]; ic[q] = in_[q]; jc[q] = jn[q];
-            un[q] = um[q]; in_[q] = im[q]; jn[q] = jm[q];
-            lc[q] = live[q];
-        }
-#pragma unroll
-        for (int q = 0; q < NP; ++q) process(lc[q], uc[q], ic[q], jc[q], pr[q], qir[q], qjr[q]);
+        ua = una; ia = ina; ja = jna; ub = unb; ib = inb; jb = jnb;
+        una = uma; ina = ima; jna = jma; unb = umb; inb = imb; jnb = jmb;
+        const bool la = live_a, lb = live_b;
+        process(la, ua, ia, ja, pa, qia, qja);
+        process(lb, ub, ib, jb, pb, qib, qjb);
         // the next trip's rows, behind this trip's stores and atomics
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            live[q] = (t + NP + q < n_pos) && (in_[q] >= 0);
-            if (live[q]) {
-                pr[q].load_once_at(P, row_off<D, OffT>(un[q], k));
-                qir[q].load_at(Q, row_off<D, OffT>(RSX_ABL(32) ? 0 : in_[q], k));
-                qjr[q].load_at(Q, row_off<D, OffT>(RSX_ABL(64) ? 1 : jn[q], k));
-            }
-        }
+        live_a = (t + 2 < n_pos) && (ina >= 0);
+        live_b = (t + 3 < n_pos) && (inb >= 0);
+        if (live_a) { pa.load_once_at(P, row_off<D, OffT>(una, k)); qia.load_at(Q, row_off<D, OffT>(RSX_ABL(32) ? 0 : ina, k)); qja.load_at(Q, row_off<D, OffT>(RSX_ABL(64) ? 1 : jna, k)); }
+        if (live_b) { pb.load_once_at(P, row_off<D, OffT>(unb, k)); qib.load_at(Q, row_off<D, OffT>(RSX_ABL(32) ? 0 : inb, k)); qjb.load_at(Q, row_off<D, OffT>(RSX_ABL(64) ? 1 : jnb, k)); }
         // ... and the indices of the trip after it
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            um[q] = im[q] = jm[q] = -1;
-            if (t + 2 * NP + q < n_pos) { um[q] = idx(U_idx, t + 2 * NP + q); im[q] = idx(I_idx, t + 2 * NP + q); jm[q] = idx(J_idx, t + 2 * NP + q); }
-        }
+        uma = ima = jma = umb = imb = jmb = -1;
+        if (t + 4 < n_pos) { uma = idx(U_idx, t + 4); ima = idx(I_idx, t + 4); jma = idx(J_idx, t + 4); }
+        if (t + 5 < n_pos) { umb = idx(U_idx, t + 5); imb = idx(I_idx, t + 5); jmb = idx(J_idx, t + 5); }
     }
 #else
     int32_t ua = -1, ia = -1, ja = -1, ub = -1, ib = -1, jb = -1;
