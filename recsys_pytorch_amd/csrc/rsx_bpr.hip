@@ -375,6 +375,8 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
     float loss_local = 0.0f;
     // running sum of g*P[u] for the current positive item (the sampler orders the batch by it)
     int32_t run_item = -1;
+    int32_t run_hs = -1;         // the run's replica slot (HotMap), fetched with the position's rows: a load at flush time is a
+                                 // wait in the middle of the trip, and on gfx950 that wait drains the trip's atomics and stores too
     float run[EPL];
 #pragma unroll
     for (int cc = 0; cc < EPL; ++cc) run[cc] = 0.f;
@@ -384,8 +386,7 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
     if (kItems && RI >= 0 && !RSX_ABL(1)) {                                       \
         if (TILE && (RI < range_lo || RI >= range_hi) && k == 0)                  \
             atomicAdd(chunks.progress + RSX_PROGRESS_VIOLATIONS, 1u);            \
-        int32_t hs = -1;                                                          \
-        if (hot.slot != nullptr) hs = hot.slot[RI];                               \
+        const int32_t hs = run_hs;                                                \
         if (hs >= 0) {                                                            \
             float *grow = at(hot.ghot, row_off<D, uint32_t>(hs * hot.replicas + (int32_t)(wave & (hot.replicas - 1)), k)); \
             _Pragma("unroll") for (int cc = 0; cc < EPL; ++cc) rsx_atomic_add(grow + 32 * cc, R[cc]); \
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
     }
 
     // one triplet whose three rows are already in registers
-    auto process = [&](bool live, int32_t u, int32_t i, int32_t j, Row<D> &p,
+    auto process = [&](bool live, int32_t u, int32_t i, int32_t j, int32_t hs_i, Row<D> &p,
                        const Row<D> &qi, const Row<D> &qj) __attribute__((always_inline)) {
         if (!live) return;
         float dpos = 0.0f, dneg = 0.0f;
@@ -417,6 +418,7 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
             if (i != run_item) {
                 RSX_RUN_FLUSH(run_item, run)
                 run_item = i;
+                run_hs = hs_i;
 #pragma unroll
                 for (int cc = 0; cc < EPL; ++cc) run[cc] = 0.f;
             }
@@ -481,9 +483,11 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
     if (0 < n_pos) { una = idx(U_idx, 0); ina = idx(I_idx, 0); jna = idx(J_idx, 0); }
     if (1 < n_pos) { unb = idx(U_idx, 1); inb = idx(I_idx, 1); jnb = idx(J_idx, 1); }
     Row<D> pa, qia, qja, pb, qib, qjb;
+    int32_t hsa = -1, hsb = -1;                      // replica slots of the positions' positive items (with the rows)
+    const bool has_hot = kItems && hot.slot != nullptr;
     bool live_a = (0 < n_pos) && (ina >= 0), live_b = (1 < n_pos) && (inb >= 0);
-    if (live_a) { pa.load_once_at(P, row_off<D, OffT>(una, k)); qia.load_at(Q, row_off<D, OffT>(RSX_ABL(32) ? 0 : ina, k)); qja.load_at(Q, row_off<D, OffT>(RSX_ABL(64) ? 1 : jna, k)); }
-    if (live_b) { pb.load_once_at(P, row_off<D, OffT>(unb, k)); qib.load_at(Q, row_off<D, OffT>(RSX_ABL(32) ? 0 : inb, k)); qjb.load_at(Q, row_off<D, OffT>(RSX_ABL(64) ? 1 : jnb, k)); }
+    if (live_a) { pa.load_once_at(P, row_off<D, OffT>(una, k)); qia.load_at(Q, row_off<D, OffT>(RSX_ABL(32) ? 0 : ina, k)); qja.load_at(Q, row_off<D, OffT>(RSX_ABL(64) ? 1 : jna, k)); if (has_hot) hsa = hot.slot[ina]; }
+    if (live_b) { pb.load_once_at(P, row_off<D, OffT>(unb, k)); qib.load_at(Q, row_off<D, OffT>(RSX_ABL(32) ? 0 : inb, k)); qjb.load_at(Q, row_off<D, OffT>(RSX_ABL(64) ? 1 : jnb, k)); if (has_hot) hsb = hot.slot[inb]; }
     if (2 < n_pos) { uma = idx(U_idx, 2); ima = idx(I_idx, 2); jma = idx(J_idx, 2); }
     if (3 < n_pos) { umb = idx(U_idx, 3); imb = idx(I_idx, 3); jmb = idx(J_idx, 3); }
     for (int32_t t = 0; t < n_trip; t += 2) {       // wave-uniform trip count
@@ -491,13 +495,13 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
         ua = una; ia = ina; ja = jna; ub = unb; ib = inb; jb = jnb;
         una = uma; ina = ima; jna = jma; unb = umb; inb = imb; jnb = jmb;
         const bool la = live_a, lb = live_b;
-        process(la, ua, ia, ja, pa, qia, qja);
-        process(lb, ub, ib, jb, pb, qib, qjb);
+        process(la, ua, ia, ja, hsa, pa, qia, qja);
+        process(lb, ub, ib, jb, hsb, pb, qib, qjb);
         // the next trip's rows, behind this trip's stores and atomics
         live_a = (t + 2 < n_pos) && (ina >= 0);
         live_b = (t + 3 < n_pos) && (inb >= 0);
-        if (live_a) { pa.load_once_at(P, row_off<D, OffT>(una, k)); qia.load_at(Q, row_off<D, OffT>(RSX_ABL(32) ? 0 : ina, k)); qja.load_at(Q, row_off<D, OffT>(RSX_ABL(64) ? 1 : jna, k)); }
-        if (live_b) { pb.load_once_at(P, row_off<D, OffT>(unb, k)); qib.load_at(Q, row_off<D, OffT>(RSX_ABL(32) ? 0 : inb, k)); qjb.load_at(Q, row_off<D, OffT>(RSX_ABL(64) ? 1 : jnb, k)); }
+        if (live_a) { pa.load_once_at(P, row_off<D, OffT>(una, k)); qia.load_at(Q, row_off<D, OffT>(RSX_ABL(32) ? 0 : ina, k)); qja.load_at(Q, row_off<D, OffT>(RSX_ABL(64) ? 1 : jna, k)); if (has_hot) hsa = hot.slot[ina]; }
+        if (live_b) { pb.load_once_at(P, row_off<D, OffT>(unb, k)); qib.load_at(Q, row_off<D, OffT>(RSX_ABL(32) ? 0 : inb, k)); qjb.load_at(Q, row_off<D, OffT>(RSX_ABL(64) ? 1 : jnb, k)); if (has_hot) hsb = hot.slot[inb]; }
         // ... and the indices of the trip after it
         uma = ima = jma = umb = imb = jmb = -1;
         if (t + 4 < n_pos) { uma = idx(U_idx, t + 4); ima = idx(I_idx, t + 4); jma = idx(J_idx, t + 4); }
@@ -516,8 +520,10 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
         Row<D> pa, qia, qja, pb, qib, qjb;
         if (live_a) { pa.load_once_at(P, row_off<D, OffT>(ua, k)); qia.load_at(Q, row_off<D, OffT>(RSX_ABL(32) ? 0 : ia, k)); qja.load_at(Q, row_off<D, OffT>(RSX_ABL(64) ? 1 : ja, k)); }
         if (live_b) { pb.load_once_at(P, row_off<D, OffT>(ub, k)); qib.load_at(Q, row_off<D, OffT>(RSX_ABL(32) ? 0 : ib, k)); qjb.load_at(Q, row_off<D, OffT>(RSX_ABL(64) ? 1 : jb, k)); }
-        process(live_a, ua, ia, ja, pa, qia, qja);
-        process(live_b, ub, ib, jb, pb, qib, qjb);
+        int32_t hsa = -1, hsb = -1;
+        if (kItems && hot.slot != nullptr) { if (live_a) hsa = hot.slot[ia]; if (live_b) hsb = hot.slot[ib]; }
+        process(live_a, ua, ia, ja, hsa, pa, qia, qja);
+        process(live_b, ub, ib, jb, hsb, pb, qib, qjb);
         ua = una; ia = ina; ja = jna; ub = unb; ib = inb; jb = jnb;
     }
 #endif

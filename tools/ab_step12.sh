@@ -5,5 +5,5 @@ import json,sys
 d=json.loads(sys.stdin.readline()); r=d['roofline']
 print('%-22s %-12s value %.3e  us/step %.1f  kernel %.1f' % ('$(basename $1)', '$2', d['value'], d['ms_per_step']*1e3, r['kernel_ms']*1e3))"; }
 for round in 1 2 3; do
-for l in recsys_pytorch_amd/librsx.so recsys_pytorch_amd/build/variants/librsx_prenp.so recsys_pytorch_amd/build/variants/librsx_presamp.so; do one $l ""; one $l "--dim 64"; done
+for l in recsys_pytorch_amd/librsx.so recsys_pytorch_amd/build/variants/librsx_nohs.so; do one $l ""; one $l "--dim 64"; one $l "--batch 262144"; one $l "--chunks 2"; done
 done
