@@ -202,12 +202,16 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
     int32_t u = -1, i = -1, j = -1, un = -1, in = -1, jn = -1, um = -1, im = -1, jm = -1;
     if (b < B) { un = U_idx[b]; in = I_idx[b]; jn = J_idx[b]; }
     Row<D> p, qi, qj;
+    int32_t hs = -1;             // replica slot of the positive item (HotMap), requested WITH the rows: fetched after them it is a
+                                 // second dependent round trip in every trip
+    const bool has_hot = (PASS & kPassItems) != 0 && hot.slot != nullptr;
     bool live_n = (b < B) && (in >= 0);
     auto request_rows = [&]() __attribute__((always_inline)) {
         if (live_n) {
             if constexpr (MODE == 0) p.load_once_at(P, row_off<D, OffT>(un, k)); else p.load_at(P, row_off<D, OffT>(un, k));   // unique users: touched once
             qi.load_at(Q, row_off<D, OffT>(in, k));
             qj.load_at(Q, row_off<D, OffT>(jn, k));
+            if (has_hot) hs = hot.slot[in];
         }
     };
     request_rows();
@@ -235,10 +239,8 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
             // item gradients (shared rows): G[i] += g p ; G[j] -= g p
             if constexpr ((PASS & kPassItems) != 0) {
                 const float gi = RSX_ABL(256) ? g * 1.01f : g;   // (dev build only: a planted 1 % error, tests/test_mutation.py)
-                int32_t hs = -1;
-                if (hot.slot != nullptr) hs = hot.slot[i];
                 if (!RSX_ABL(1)) {
-                    if (hs >= 0)       // popular item: one of its private replica rows (a small table: 32-bit offsets)
+                    if (has_hot && hs >= 0)       // popular item: one of its private replica rows (a small table: 32-bit offsets)
                         p.atomic_axpy_at(hot.ghot, row_off<D, uint32_t>(hs * hot.replicas + (int32_t)(wave & (hot.replicas - 1)), k), gi);
                     else
                         p.atomic_axpy_at(G, i_off, gi);
