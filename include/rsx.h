@@ -510,7 +510,8 @@ int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t num_rows
  * is the same product applied to the gradient.
  * rsx_spmm_plan (HOST): cuts rows into segments of <= max_seg non-zeros (item rows of a
  *   popularity-skewed graph have 10^5+ neighbours); call with NULL outputs for the count.
- * rsx_spmm_csr: Y = A X   (Y is overwritten; X [N x d] must not alias Y or S_acc);
+ * rsx_spmm_csr: Y = A X   (Y is overwritten -- every row must own at least one segment, as rsx_spmm_plan's plans do;
+ *   X [N x d] must not alias Y or S_acc);
  *   if S_acc != NULL also S_acc += A X (the running layer sum).
  * rsx_scale: X *= alpha (the 1/(L+1) of the layer mean).                                   */
 int64_t rsx_spmm_plan(const int64_t *indptr_host, int64_t num_rows, int max_seg, int32_t *seg_row_out,

@@ -102,6 +102,24 @@ __global__ __launch_bounds__(kBlock) void scale_kernel(float4 *__restrict__ X, i
     }
 }
 
+// rows cut into several segments are summed with atomics into zeros: only THEIR rows of Y are cleared (a memset of all of Y -- 563 MB at
+// the configs[4] shape -- for a few thousand rows cost 3 % of a product).  The first segment of a split row clears it.
+template <int D>
+__global__ __launch_bounds__(kBlock) void zero_split_rows_kernel(const int32_t *__restrict__ seg_row, const int64_t *__restrict__ seg_begin,
+                                                                 const int32_t *__restrict__ seg_len, int64_t num_segs,
+                                                                 const int64_t *__restrict__ indptr, float *__restrict__ Y)
+{
+    constexpr int LPR = D / 4;
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t s = t / LPR;
+    const int k = (int)(t % LPR);
+    if (s >= num_segs) return;
+    const int32_t row = seg_row[s];
+    const int64_t lo = indptr[row], hi = indptr[row + 1];
+    if (seg_begin[s] == lo && (int64_t)seg_len[s] < hi - lo)
+        reinterpret_cast<float4 *>(Y + (size_t)row * D)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 unsigned grid_for(int64_t threads)
 {
     int64_t blocks = (threads + kBlock - 1) / kBlock;
@@ -136,8 +154,15 @@ static int spmm_launch(const int32_t *seg_row_dev, const int64_t *seg_begin_dev,
                        int64_t num_segs, const int64_t *indptr_dev, const int32_t *indices_dev, const float *vals_dev,
                        const float *X, float *Y, float *S_acc, int64_t num_rows, int d, const uint8_t *nz, hipStream_t st)
 {
-    hipError_t e = hipMemsetAsync(Y, 0, (size_t)num_rows * d * sizeof(float), st);   // split rows add into zeros
-    if (e != hipSuccess) { rsx_set_error("rsx_spmm_csr: %s", hipGetErrorString(e)); return RSX_E_HIP; }
+    {   // split rows add into zeros (whole rows are stored)
+        const int64_t threads = num_segs * (d / 4);
+        const unsigned zb = (unsigned)((threads + kBlock - 1) / kBlock);
+        switch (d) {
+        case 32: hipLaunchKernelGGL(zero_split_rows_kernel<32>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y); break;
+        case 64: hipLaunchKernelGGL(zero_split_rows_kernel<64>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y); break;
+        default: hipLaunchKernelGGL(zero_split_rows_kernel<128>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y); break;
+        }
+    }
     const int gpw = 64 / (d / 4);
     const unsigned g = grid_for((num_segs + gpw - 1) / gpw * 64);
 #define RSX_SPMM(D_) do { if (nz) hipLaunchKernelGGL((spmm_csr_kernel<D_, true>), dim3(g), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, indices_dev, vals_dev, X, Y, S_acc, nz); \

@@ -238,8 +238,14 @@ def adam_apply(W, M, V, G, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):
 class SpmmGraph:
     """device CSR of a (square) sparse matrix + its segment plan (include/rsx.h:rsx_spmm_plan)"""
 
-    def __init__(self, csr, device, max_seg=128):
+    def __init__(self, csr, device, max_seg=None):
         import numpy as np
+        import os
+        if max_seg is None:
+            # rows above max_seg non-zeros are cut and combined with atomics.  Measured at the configs[4] shape (ms per product /
+            # per training step): 64: 4.39 / 29.1, 128: 3.35 / 21.6, 256: 2.88 / 19.3, 512: 2.67 / 17.2, 1024: 2.58 / 16.8,
+            # 2048: 2.60 / 17.0, 4096: 2.66 / 17.7, 16384: 4.8 / 31 (one lane group then walks a segment for milliseconds)
+            max_seg = int(os.environ.get("RSX_SPMM_MAX_SEG", 1024))
         csr = csr.tocsr()
         csr.sort_indices()
         indptr = np.ascontiguousarray(csr.indptr, dtype=np.int64)
@@ -249,6 +255,9 @@ class SpmmGraph:
             raise RsxError("rsx_spmm_plan failed")
         row, beg, ln = np.empty(cnt, np.int32), np.empty(cnt, np.int64), np.empty(cnt, np.int32)
         lib().rsx_spmm_plan(indptr.ctypes.data, n, max_seg, row.ctypes.data, beg.ctypes.data, ln.ctypes.data)
+        # longest segments first (the long item rows of a popularity-skewed graph would otherwise start last and finish alone)
+        order = np.argsort(-ln.astype(np.int64), kind="stable")
+        row, beg, ln = row[order].copy(), beg[order].copy(), ln[order].copy()
         to = lambda a: torch.from_numpy(a).to(device).contiguous()
         self.n, self.num_segs = n, int(cnt)
         self.seg_row, self.seg_begin, self.seg_len = to(row), to(beg), to(ln)

@@ -83,8 +83,10 @@ def test_hip_lightgcn_matches_reference_golden(name):
 
 
 @pytest.mark.gpu
-def test_hip_spmm_long_rows_vs_oracle(oracle_mod):
-    """rows far longer than a segment (split + atomics), empty rows, d = 32/64/128"""
+@pytest.mark.parametrize("max_seg", [None, 128, 7])
+def test_hip_spmm_long_rows_vs_oracle(oracle_mod, max_seg):
+    """rows far longer than a segment (split + atomics into rows the product clears itself), empty rows, d = 32/64/128; the
+    default segment length (1024), the round-2 one and a tiny one"""
     from recsys_pytorch_amd import rsx
     rng = np.random.default_rng(5)
     N = 3000
@@ -94,7 +96,8 @@ def test_hip_spmm_long_rows_vs_oracle(oracle_mod):
     A = A.tocsr()
     A[5, :] = 0
     A.eliminate_zeros()
-    G = rsx.SpmmGraph(A, "cuda")
+    G = rsx.SpmmGraph(A, "cuda", max_seg=max_seg)
+    seg = max_seg or 1024
     for d in (32, 64, 128):
         X = rng.standard_normal((N, d)).astype(np.float32)
         Yo = np.empty_like(X)
@@ -117,7 +120,7 @@ def test_hip_spmm_long_rows_vs_oracle(oracle_mod):
         Sa, Sb = Xs.clone(), Xs.clone()
         rsx.spmm(G, Xs, Ya, S_acc=Sa)
         rsx.spmm(G, Xs, Yb, S_acc=Sb, x_nonzero=flags)
-        short = torch.from_numpy(np.diff(A.indptr) <= 128).cuda()
+        short = torch.from_numpy(np.diff(A.indptr) <= seg).cuda()
         assert torch.equal(Ya[short], Yb[short]) and torch.equal(Sa[short], Sb[short])
         assert float((Ya - Yb).abs().max()) <= 2e-6 * float(Ya.abs().max())
         # flags that cover only part of the non-zero rows DROP the rest: they are the caller's claim
