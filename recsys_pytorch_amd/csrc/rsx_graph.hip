@@ -28,6 +28,9 @@ __device__ __attribute__((aligned(16))) float g_zero_row[128];
 // the result is bit-identical).  The first backward product of a LightGCN step multiplies A_hat with the dense gradient of the
 // loss, of which only the batch's users' and items' rows are non-zero: with 65 536 of 1M users in the batch, 93 % of the user
 // rows an item row would gather are zeros (models/LightGCN.py:83-87 back-propagates through the same dense product).
+#ifndef RSX_SPMM_PIPELINE
+#define RSX_SPMM_PIPELINE 1      // 0: the round-2 loop (development A/B: 2.59 -> 2.53 ms per product at the configs[4] shape)
+#endif
 template <int D, bool SKIP>
 __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(
     const int32_t *__restrict__ seg_row, const int64_t *__restrict__ seg_begin,
@@ -48,6 +51,36 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(
         const int len = seg_len[s];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         int p = 0;
+#if RSX_SPMM_PIPELINE
+        // four neighbour rows in flight, and the NEXT four (value, index) pairs requested before this group's rows are used: one
+        // dependent round trip per group instead of two
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+        if (len >= 4) {
+            a0 = vals[pb]; a1 = vals[pb + 1]; a2 = vals[pb + 2]; a3 = vals[pb + 3];
+            n0 = indices[pb]; n1 = indices[pb + 1]; n2 = indices[pb + 2]; n3 = indices[pb + 3];
+        }
+        for (; p + 4 <= len; p += 4) {
+            const float *r0 = X + (size_t)n0 * D, *r1 = X + (size_t)n1 * D, *r2 = X + (size_t)n2 * D, *r3 = X + (size_t)n3 * D;
+            if constexpr (SKIP) {
+                const uint8_t f0 = nz[n0], f1 = nz[n1], f2 = nz[n2], f3 = nz[n3];
+                r0 = f0 ? r0 : g_zero_row; r1 = f1 ? r1 : g_zero_row; r2 = f2 ? r2 : g_zero_row; r3 = f3 ? r3 : g_zero_row;
+            }
+            const float4 x0 = reinterpret_cast<const float4 *>(r0)[k];
+            const float4 x1 = reinterpret_cast<const float4 *>(r1)[k];
+            const float4 x2 = reinterpret_cast<const float4 *>(r2)[k];
+            const float4 x3 = reinterpret_cast<const float4 *>(r3)[k];
+            const float c0 = a0, c1 = a1, c2 = a2, c3 = a3;
+            if (p + 8 <= len) {
+                a0 = vals[pb + p + 4]; a1 = vals[pb + p + 5]; a2 = vals[pb + p + 6]; a3 = vals[pb + p + 7];
+                n0 = indices[pb + p + 4]; n1 = indices[pb + p + 5]; n2 = indices[pb + p + 6]; n3 = indices[pb + p + 7];
+            }
+            acc.x = fmaf(c0, x0.x, acc.x); acc.y = fmaf(c0, x0.y, acc.y); acc.z = fmaf(c0, x0.z, acc.z); acc.w = fmaf(c0, x0.w, acc.w);
+            acc.x = fmaf(c1, x1.x, acc.x); acc.y = fmaf(c1, x1.y, acc.y); acc.z = fmaf(c1, x1.z, acc.z); acc.w = fmaf(c1, x1.w, acc.w);
+            acc.x = fmaf(c2, x2.x, acc.x); acc.y = fmaf(c2, x2.y, acc.y); acc.z = fmaf(c2, x2.z, acc.z); acc.w = fmaf(c2, x2.w, acc.w);
+            acc.x = fmaf(c3, x3.x, acc.x); acc.y = fmaf(c3, x3.y, acc.y); acc.z = fmaf(c3, x3.z, acc.z); acc.w = fmaf(c3, x3.w, acc.w);
+        }
+#else
         for (; p + 4 <= len; p += 4) {            // four neighbour rows in flight
             const float a0 = vals[pb + p], a1 = vals[pb + p + 1], a2 = vals[pb + p + 2], a3 = vals[pb + p + 3];
             const int32_t n0 = indices[pb + p], n1 = indices[pb + p + 1], n2 = indices[pb + p + 2], n3 = indices[pb + p + 3];
@@ -65,6 +98,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(
             acc.x = fmaf(a2, x2.x, acc.x); acc.y = fmaf(a2, x2.y, acc.y); acc.z = fmaf(a2, x2.z, acc.z); acc.w = fmaf(a2, x2.w, acc.w);
             acc.x = fmaf(a3, x3.x, acc.x); acc.y = fmaf(a3, x3.y, acc.y); acc.z = fmaf(a3, x3.z, acc.z); acc.w = fmaf(a3, x3.w, acc.w);
         }
+#endif
         for (; p < len; ++p) {
             const float a = vals[pb + p];
             const int32_t n = indices[pb + p];
