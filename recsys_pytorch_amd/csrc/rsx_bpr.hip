@@ -299,7 +299,8 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
 #define RSX_BLOCKED_WAVES 6     // wavefronts per SIMD the blocked kernel is compiled for
 #endif
 #ifndef RSX_RUNS_ROUNDS
-#define RSX_RUNS_ROUNDS 1       // TILE = false: rounds of wavefronts the batch is cut into (development A/B)
+#define RSX_RUNS_ROUNDS 2       // TILE = false: rounds of wavefronts the batch is cut into.  Same box, kernel us at 1 / 2 / 4 / 8 rounds:
+                                // independent negatives B = 1M 568 / 523 / 532 / 603, configs[3] slice 826 / 771 / 772 / 815 (round 3)
 #endif
 #ifndef RSX_STEP_PIPELINE
 #define RSX_STEP_PIPELINE 1     // 0: the round-2 trip loop (development A/B)
@@ -944,8 +945,8 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
         return RSX_OK;
     }
     if ((flags & RSX_USERS_UNIQUE) && (flags & RSX_BATCH_SORTED)) {
-        // one round of wavefronts: as many as fit the chip at once (6 per SIMD), each with an even share
-        // of the positions, at least 8 (two trips of two positions per lane group)
+        // RSX_RUNS_ROUNDS rounds of wavefronts (a round = as many as fit the chip at once, 6 per SIMD), each with an even
+        // share of the positions, at least 8 (two trips of two positions per lane group)
         const int64_t slots = (int64_t)rsx_num_cus() * 4 * RSX_BLOCKED_WAVES * RSX_RUNS_ROUNDS;
         int64_t span = 2 * ceil_div64(batch, 2 * slots);
         if (span < 8) span = 8;
