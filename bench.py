@@ -68,7 +68,7 @@ def parse():
                     help="1024-user tiles scored for scores/s (0 = skip); 64 tiles = 6.5e9 scores (SURVEY section 8d)")
     ap.add_argument("--topk", type=int, default=50)
     ap.add_argument("--hot", type=int, default=256, help="popular items whose gradient rows are replicated (0 = off)")
-    ap.add_argument("--hot-replicas", type=int, default=16)
+    ap.add_argument("--hot-replicas", type=int, default=0, help="private rows per popular item (a power of two); 0 = the engine's choice")
     ap.add_argument("--neg-block", type=int, default=8, help="item block of the stratified negatives (0 = independent uniform negatives)")
     ap.add_argument("--chunks", type=int, default=int(os.environ.get("RSX_CHUNKS", "-1")),
                     help="> 1: every step as that many independent pipelines over item ranges (include/rsx.h: item chunks): the "
@@ -159,7 +159,7 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     eng.blocked_any_batch = os.environ.get("RSX_BLOCKED_ANY_BATCH") == "1"      # experiment
     nb = eng.set_neg_block(B, want_nb) if want_nb > 0 else 0
     if hot > 0:
-        eng.set_hot_items(torch.bincount(indices.long(), minlength=I), hot, hot_replicas)
+        eng.set_hot_items(torch.bincount(indices.long(), minlength=I), hot, hot_replicas or None)
     if chunks > 1 and nb and not eng.stale_exchange and (COMM is not None or not SHARDED):
         eng.set_chunks(chunks)
         eng.overlap_exchange = False                     # the range pipeline replaces the two-pass step
@@ -205,6 +205,7 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     return {"batch_per_gpu": B, "chunks": ran_chunks, "exchange_issued_by": ("library (RCCL from librsx)" if COMM is not None else
                                                                              "torch.distributed callbacks") if SHARDED else None, "global_batch": gb, "value": gb * steps / elapsed, "unit": "triplets/s",
             "ms_per_step": elapsed / steps * 1e3, "steps": steps, "neg_block": nb, "mean_bpr_loss": mean_loss,
+            "hot_replicas": eng.hot.replicas if eng.hot is not None else 0,
             "two_pass": bool(eng.overlap_exchange) and not eng.stale_exchange, "exchange": eng.exchange if SHARDED else None,
             "stale_exchange": bool(eng.stale_exchange),
             "item_replicas_identical": replicas_equal, "_Q": Q,
@@ -483,7 +484,7 @@ def main():
                        **({"DEBUG_exchange_delay_us": int(os.environ["RSX_EXCHANGE_DELAY_US"])} if os.environ.get("RSX_EXCHANGE_DELAY_US") else {}),
                        "mean_bpr_loss": head["mean_bpr_loss"],
                        **({"item_replicas_identical": head["item_replicas_identical"]} if SHARDED else {}),
-                       "hot_items": args.hot, "hot_replicas": args.hot_replicas if args.hot > 0 else 0,
+                       "hot_items": args.hot, "hot_replicas": head["hot_replicas"],
                        "parallelism": (f"user-sharded x{world}, items replicated, "
                                        + ("1 all-reduce(G)/step" if head["exchange"] == "allreduce" else
                                           "reduce-scatter(G) + own item shard applied + all-gather(Q rows) per step")

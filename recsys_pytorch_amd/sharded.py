@@ -195,9 +195,14 @@ class BPREngine:
         z ^= z >> 31
         return z | 1
 
-    def set_hot_items(self, item_counts, num_hot=256, replicas=16):
+    def set_hot_items(self, item_counts, num_hot=256, replicas=None):
         """spread the gradients of the `num_hot` most popular items over `replicas` private rows
-        (contention relief at the atomic unit, include/rsx.h:rsx_bpr_step hot_slot_dev)"""
+        (contention relief at the atomic unit, include/rsx.h:rsx_bpr_step hot_slot_dev).  replicas=None: 32 where the blocked
+        kernel runs (set_neg_block came first and engaged), 16 otherwise -- measured, us per step with 16 / 32 / 64 replicas:
+        headline 338 / 329 / 344, d = 64 239 / 236, B = 65 536 (plain kernel) 101 / 105 / 113
+        (profiles/r03_exp_sampler_placement.txt, block J)"""
+        if not replicas:
+            replicas = 32 if self.neg_block else 16
         self.hot = self.k.HotItems(item_counts, num_hot, replicas, self.Q.shape[1], self.Q.device) if num_hot > 0 else None
         self._hot_args = (torch.as_tensor(item_counts), int(num_hot), int(replicas)) if num_hot > 0 else None
         self._relabel = None

@@ -515,7 +515,7 @@ def _full_size_step_check(U, I, d, B, deg, want_neg_block, hot=True, force_iid=F
     assert (nb > 0) == (want_neg_block > 0) and nb <= 8, (nb, want_neg_block)   # which step path engages at this shape
     ordered = eng._sorts(B)                      # blocked kernel (nb > 0), its TILE = false form (ordered, nb == 0) or the plain kernel
     if hot:
-        eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 256, 16)
+        eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 256)
     loss = torch.zeros(rsx.RSX_LOSS_SLOTS, device="cuda")
     G_before_apply = None
     if native:

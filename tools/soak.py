@@ -10,7 +10,7 @@ P = torch.randn(U, d, device=dev) * 0.1
 Q = torch.randn(I, d, device=dev) * 0.1
 ip, ix = synthetic_csr(U, I, 20, dev, popularity="zipf")
 eng = BPREngine(P, Q, 20.0)          # large lr: the 1/B-scaled gradients then move the tables visibly
-eng.set_neg_block(B, 8); eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 256, 16)
+eng.set_neg_block(B, 8); eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 256)
 loss = torch.zeros(rsx.RSX_LOSS_SLOTS, device=dev)
 tr = eng.native_trainer(ip, ix, B, loss_acc=loss)
 t0 = time.perf_counter()

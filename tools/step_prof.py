@@ -21,7 +21,7 @@ eng = BPREngine(P, Q, 0.05)
 nb = eng.set_neg_block(B, nbw) if nbw else 0
 if nb and os.environ.get("NEG_EXACT"):        # the block size itself (experiments)
     nb = eng.neg_block = int(os.environ["NEG_EXACT"]); eng._csr = None
-eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 256, 16)
+eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 256)
 ck = int(os.environ.get("CHUNKS", 0))
 if ck > 1 and nb:
     eng.set_chunks(ck)
