@@ -298,6 +298,9 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
 #ifndef RSX_BLOCKED_WAVES
 #define RSX_BLOCKED_WAVES 6     // wavefronts per SIMD the blocked kernel is compiled for
 #endif
+#ifndef RSX_PLAIN_BLOCKS_PER_CU
+#define RSX_PLAIN_BLOCKS_PER_CU 8   // plain kernel: workgroups per CU the grid is capped at (development A/B)
+#endif
 #ifndef RSX_RUNS_ROUNDS
 #define RSX_RUNS_ROUNDS 2       // TILE = false: rounds of wavefronts the batch is cut into.  Same box, kernel us at 1 / 2 / 4 / 8 rounds:
                                 // independent negatives B = 1M 568 / 523 / 532 / 603, configs[3] slice 826 / 771 / 772 / 815 (round 3)
@@ -832,7 +835,7 @@ void launch_step(float *P, const float *Q, float *G, const int32_t *u, const int
 {
     const int64_t waves = (B + TPW - 1) / TPW;
     int64_t blocks = (waves + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int64_t cap = (int64_t)rsx_num_cus() * 8;   // 8 blocks x 4 waves = 32 waves per CU
+    const int64_t cap = (int64_t)rsx_num_cus() * RSX_PLAIN_BLOCKS_PER_CU;   // 8 blocks x 4 waves = 32 waves per CU
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((bpr_step_kernel<D, MODE, PASS, OffT>), dim3((unsigned)blocks), dim3(kBlock), 0, st, P, Q,
