@@ -28,6 +28,9 @@ __device__ __attribute__((aligned(16))) float g_zero_row[128];
 // the result is bit-identical).  The first backward product of a LightGCN step multiplies A_hat with the dense gradient of the
 // loss, of which only the batch's users' and items' rows are non-zero: with 65 536 of 1M users in the batch, 93 % of the user
 // rows an item row would gather are zeros (models/LightGCN.py:83-87 back-propagates through the same dense product).
+#ifndef RSX_SPMM_BLOCKS_PER_CU
+#define RSX_SPMM_BLOCKS_PER_CU 1024  // grid cap of the product (workgroups of 4 wavefronts per CU): ms per product at 4 / 8 / 16 / 64 / 256 / 1024 per CU: 2.51 / 2.50 / 2.48 / 2.44 / 2.42 / 2.40 -- short workgroups the hardware deals out beat a fixed stride over the segments
+#endif
 #ifndef RSX_SPMM_PIPELINE
 #define RSX_SPMM_PIPELINE 1      // 0: the round-2 loop (development A/B: 2.59 -> 2.53 ms per product at the configs[4] shape)
 #endif
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void zero_split_rows_kernel(const int32_t *
 unsigned grid_for(int64_t threads)
 {
     int64_t blocks = (threads + kBlock - 1) / kBlock;
-    const int64_t cap = (int64_t)rsx_num_cus() * 8;
+    const int64_t cap = (int64_t)rsx_num_cus() * RSX_SPMM_BLOCKS_PER_CU;
     if (blocks > cap) blocks = cap;
     return (unsigned)(blocks < 1 ? 1 : blocks);
 }

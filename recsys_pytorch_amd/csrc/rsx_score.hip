@@ -883,7 +883,10 @@ RSX_API int rsx_topk(const float *scores_dev, int64_t num_rows, int64_t num_item
 namespace {
 
 constexpr int64_t kSampleCols = RSX_SAMPLE_COLS;      // sample size of the fused path
-constexpr int64_t kFusedRows = 8192;       // rows per pass of the fused path: one launch of ~50K workgroups
+#ifndef RSX_FUSED_ROWS
+#define RSX_FUSED_ROWS 8192
+#endif
+constexpr int64_t kFusedRows = RSX_FUSED_ROWS;       // rows per pass of the fused path: one launch of ~50K workgroups (development A/B: 4096 / 16384)
                                            // (a 1024-row pass is 8.15 rounds of 768 resident workgroups:
                                            //  11 % of the time is the ragged last round, plus 7 launches)
 constexpr int64_t kFusedMinItems = 4 * kSampleCols;
