@@ -194,7 +194,10 @@ constexpr int kChunk = 4096;              // positions per bucket_chunk workgrou
 #endif
 constexpr int kChunkThreads = RSX_CHUNK_THREADS;
 constexpr int kPerThread = kChunk / kChunkThreads;
-constexpr int kBucketMean = 832;          // expected pairs per bucket: 1024 - 6.6 sigma
+#ifndef RSX_BUCKET_MEAN
+#define RSX_BUCKET_MEAN 832
+#endif
+constexpr int kBucketMean = RSX_BUCKET_MEAN;          // expected pairs per bucket: 1024 - 6.6 sigma (development A/B: 416 / 1664)
 constexpr int kSortCap = 2048;            // pairs a bucket may hold and still be sorted in LDS
 constexpr int64_t kPiece = 1ll << 21;     // positions bucketed per pass (bounds LDS bins and workspace)
 constexpr int kMaxBuckets = (int)(kPiece / kBucketMean) + 3 + RSX_MAX_CHUNKS;
