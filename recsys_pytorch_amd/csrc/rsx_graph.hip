@@ -146,15 +146,17 @@ __global__ __launch_bounds__(kBlock) void zero_split_rows_kernel(const int32_t *
                                                                  const int32_t *__restrict__ seg_len, int64_t num_segs,
                                                                  const int64_t *__restrict__ indptr, float *__restrict__ Y)
 {
-    constexpr int LPR = D / 4;
-    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int64_t s = t / LPR;
-    const int k = (int)(t % LPR);
+    // one thread per segment decides; the few that start a split row clear it (a thread per quad of every segment -- 35M threads
+    // at the configs[4] shape -- took 99 us, more than the memset it had replaced)
+    const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (s >= num_segs) return;
     const int32_t row = seg_row[s];
     const int64_t lo = indptr[row], hi = indptr[row + 1];
-    if (seg_begin[s] == lo && (int64_t)seg_len[s] < hi - lo)
-        reinterpret_cast<float4 *>(Y + (size_t)row * D)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (seg_begin[s] == lo && (int64_t)seg_len[s] < hi - lo) {
+        float4 *y = reinterpret_cast<float4 *>(Y + (size_t)row * D);
+#pragma unroll 8
+        for (int k = 0; k < D / 4; ++k) y[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 }
 
 unsigned grid_for(int64_t threads)
@@ -192,8 +194,7 @@ static int spmm_launch(const int32_t *seg_row_dev, const int64_t *seg_begin_dev,
                        const float *X, float *Y, float *S_acc, int64_t num_rows, int d, const uint8_t *nz, hipStream_t st)
 {
     {   // split rows add into zeros (whole rows are stored)
-        const int64_t threads = num_segs * (d / 4);
-        const unsigned zb = (unsigned)((threads + kBlock - 1) / kBlock);
+        const unsigned zb = (unsigned)((num_segs + kBlock - 1) / kBlock);
         switch (d) {
         case 32: hipLaunchKernelGGL(zero_split_rows_kernel<32>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y); break;
         case 64: hipLaunchKernelGGL(zero_split_rows_kernel<64>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y); break;
