@@ -240,7 +240,6 @@ class SpmmGraph:
 
     def __init__(self, csr, device, max_seg=None):
         import numpy as np
-        import os
         if max_seg is None:
             # rows above max_seg non-zeros are cut and combined with atomics.  Measured at the configs[4] shape (ms per product /
             # per training step): 64: 4.39 / 29.1, 128: 3.35 / 21.6, 256: 2.88 / 19.3, 512: 2.67 / 17.2, 1024: 2.58 / 16.8,
