@@ -43,6 +43,10 @@ constexpr int BM = 128, BN = 128, BK = 32;
 //  measured 279.5 -> 283.6 us per 1024 users, same box, round 3 -- dropped.  A FIXED order of precedence among the four wavefronts
 //  that share a SIMD -- s_setprio 3 / 2 / 1 / 0 by HW_ID.wave_id, to keep them from reaching the end of a chunk and waiting for
 //  the next one all together -- changes nothing: 270.0 / 270.2 vs 270.4 / 270.2 us fused, the dense product 250 -> 256 us)
+// (Two LDS buffers per tile pair with the next chunk's DMA in flight under this chunk's MFMAs -- s_waitcnt vmcnt(8) + s_barrier by hand,
+//  64 KB of LDS, so TWO workgroups per CU: bit-identical, 256.3 -> 280.5 us per 1024 users.  Four resident wavefronts per SIMD hide
+//  the chunk latency better than a prefetch inside two; with 16-wide chunks (four workgroups again) the 64-byte row pitch costs
+//  2-way LDS bank conflicts on every fragment read.  Round 3, profiles/r03_exp_scoring_variants.txt.)
 constexpr int kSlots = 2;     // private candidate slots per (64-item strip, row) of the filtered product
 constexpr int LDT = BM + 1;   // K-major tile leading dimension (odd -> conflict-free transpose)
 
