@@ -788,6 +788,38 @@ def test_fit_runs_twice_with_different_csrs(ml100k):
         assert dense[un, inn].all() and not dense[un, jn].any()
 
 
+def test_fit_with_and_without_popular_row_replicas_trains_the_same_model():
+    """MF.fit engages the replicas of the most popular items' gradient rows (hparams['hot_items'], default 256): the same
+    triplets, the same sums in another order -- the tables after two epochs agree with a fit without replicas to 1e-5 of the
+    update, on a popularity-skewed matrix, through the blocked kernel (batch >= 2 items) and the plain one"""
+    import scipy.sparse as sp
+    import recsys_pytorch_amd as pkg
+    rng = np.random.default_rng(3)
+    U, I = 6000, 500
+    pop = 1.0 / np.arange(1, I + 1)
+    pop /= pop.sum()
+    rows = np.repeat(np.arange(U), 12)
+    cols = rng.choice(I, size=rows.size, p=pop)
+    mat = sp.csr_matrix((np.ones(rows.size, np.float32), (rows, cols)), shape=(U, I))
+    mat.data[:] = 1.0
+    ds = pkg.InteractionData(mat)
+    for batch in (3000, 400):                               # blocked path (>= 2 * 500) and the plain kernel
+        cfg = types.SimpleNamespace(batch_size=batch, num_epochs=2, verbose=0, test_from=1, test_step=1)
+        tables = []
+        for hot in (0, 64):
+            torch.manual_seed(11)                           # the tables are initialised from torch's generator, like the reference's
+            m = pkg.MF(ds, dict(HP, hidden_dim=32, lr=0.05 * batch, hot_items=hot, seed=7), "cuda")
+            P0, Q0 = m._P.clone(), m._Q.clone()
+            m.fit(ds, cfg)
+            assert (m._engine.hot is not None) == (hot > 0)
+            tables.append((m._P.clone(), m._Q.clone(), P0, Q0))
+        (Pa, Qa, P0, Q0), (Pb, Qb, P0b, Q0b) = tables
+        assert torch.equal(P0, P0b) and torch.equal(Q0, Q0b)            # same initialisation
+        for a, b, z in ((Pa, Pb, P0), (Qa, Qb, Q0)):
+            upd = float((a - z).abs().max())
+            assert upd > 1e-4 and float((a - b).abs().max()) <= 2e-5 * upd, (batch, upd, float((a - b).abs().max()))
+
+
 @pytest.mark.timeout(900)
 def test_stratified_sorted_sampler_trains_as_well_as_independent_negatives():
     """the layout the headline number rests on (batch ordered by positive item, negatives stratified by
