@@ -183,7 +183,10 @@ __global__ __launch_bounds__(kBlock) void sample_neg_kernel(
 //                         final position, write u/i/j
 // Buckets are monotone in the item, so the concatenation is ordered by positive item; the order
 // is a pure function of the sampled set (no atomics decide a position).
-constexpr int kChunk = 4096;              // positions per bucket_chunk workgroup (16 per thread)
+#ifndef RSX_CHUNK_POS
+#define RSX_CHUNK_POS 4096
+#endif
+constexpr int kChunk = RSX_CHUNK_POS;     // positions per bucket_chunk workgroup (development A/B: 2048 / 1024 -- more, shorter workgroups)
 // workgroup of the bucketing pass.  It runs beside the step kernel, whose wavefronts hold 480 of a SIMD's 512 VGPRs: a
 // 1024-thread workgroup needs four wavefronts (4 x 48 VGPRs) on EVERY SIMD of one CU at once, a 256-thread one a single one
 // (122 VGPRs: sixteen positions per thread in lockstep).  Same box, 300 steps at the headline shape, us per step: with item
@@ -449,7 +452,7 @@ struct GlobalKeys {
 // negatives of kNegGroup batch positions per thread, advanced in lockstep (one dependent load
 // level at a time: signature, row bounds, each binary-search probe), same draws as draw_negative()
 constexpr int kNegGroup = 4;
-static_assert(kMaxChunks == 2 * kBlock, "bucket_sort_kernel reads two chunk-table entries per thread");
+static_assert(kMaxChunks % kBlock == 0, "bucket_sort_kernel reads kMaxChunks / kBlock chunk-table entries per thread");
 
 // chunked layout (cx.C > 1): the ranges are those of the position's item range (pc = its first position, nc = its
 // live positions), the fall-back candidates are the REAL items of that range -- never the whole catalog: a negative
