@@ -15,6 +15,18 @@
 
 #include "rsx_common.h"
 
+// The last item range runs on the caller's stream instead of a stream of its own: the run stream only joins in a chunked run, and
+// every HIP stream more is one more client of the runtime's four hardware queues.  Same box, us per step at C = 2 / 3 / 4 ranges:
+// a stream per range 350 / 432 / 525, the last range on the run stream 350 / 425 / 488 (profiles/r03_exp_sampler_placement.txt, block Q).
+#ifndef RSX_RANGE_ON_RUN_STREAM
+#define RSX_RANGE_ON_RUN_STREAM 1
+#endif
+#if RSX_RANGE_ON_RUN_STREAM
+#define RSX_RANGE_STREAM(k) (((k) == c.chunks - 1) ? st : t->cs[k])
+#else
+#define RSX_RANGE_STREAM(k) (t->cs[k])
+#endif
+
 struct rsx_bpr_trainer {
     rsx_bpr_trainer_config c;
     int device = 0;
@@ -242,7 +254,11 @@ RSX_API int rsx_bpr_trainer_create(const rsx_bpr_trainer_config *cfg, rsx_bpr_tr
         // all equal, 453 / 471 / 559 two urgent: the choice hardly matters, and one session with two range kernels plus
         // the sampler on the lowest level ran C = 4 at SECONDS per step (profiles/r03_exp_range_priorities.txt)
         const int pk = (k == 0) ? prio_hi : (prio_hi + 1 <= prio_lo - 1 ? prio_hi + 1 : prio_hi);
-        ok = hipStreamCreateWithPriority(&t->cs[k], hipStreamNonBlocking, pk) == hipSuccess &&
+#if RSX_RANGE_ON_RUN_STREAM
+        if (k == cfg->chunks - 1) t->cs[k] = nullptr; else
+#endif
+        ok = hipStreamCreateWithPriority(&t->cs[k], hipStreamNonBlocking, pk) == hipSuccess;
+        ok = ok &&
              hipEventCreateWithFlags(&t->ev_k[k][0], kOrderOnly) == hipSuccess &&
              hipEventCreateWithFlags(&t->ev_k[k][1], kOrderOnly) == hipSuccess &&
              hipEventCreateWithFlags(&t->ev_r[k], kOrderOnly) == hipSuccess &&
@@ -396,12 +412,12 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
             if (s == 0) {        // the ranges' streams start behind whatever the run stream holds (a previous run, the caller's work)
                 RSX_HIP(hipMemsetAsync(c.progress, 0, RSX_MAX_CHUNKS * sizeof(uint32_t), st));
                 RSX_HIP(hipEventRecord(t->ev_start, st));
-                for (int k = 0; k < c.chunks; ++k) RSX_HIP(hipStreamWaitEvent(t->cs[k], t->ev_start, 0));
+                for (int k = 0; k < c.chunks; ++k) RSX_HIP(hipStreamWaitEvent(RSX_RANGE_STREAM(k), t->ev_start, 0));
                 t->kernels_in_flight = false;
             }
             if (sharded) RSX_TRY(top_up());
             for (int k = 0; k < c.chunks; ++k) {
-                hipStream_t ck = t->cs[k];
+                hipStream_t ck = RSX_RANGE_STREAM(k);
                 RSX_HIP(hipStreamWaitEvent(ck, t->ready[cur], 0));
                 if (t->kernels_in_flight)      // user rows: every range's kernel of the step before has written its users
                     for (int q = 0; q < c.chunks; ++q)
@@ -422,7 +438,7 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
                 RSX_HIP(hipEventRecord(t->ev_k[k][par], ck));
             }
             for (int k = 0; k < c.chunks; ++k) {
-                hipStream_t ck = t->cs[k];
+                hipStream_t ck = RSX_RANGE_STREAM(k);
                 const int64_t lo = (int64_t)k * g.Ic;
                 float *Gk = c.G + (size_t)lo * c.d, *Qk = c.Q + (size_t)lo * c.d;
                 if (native) {
