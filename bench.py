@@ -73,7 +73,7 @@ def parse():
     ap.add_argument("--chunks", type=int, default=int(os.environ.get("RSX_CHUNKS", "-1")),
                     help="> 1: every step as that many independent pipelines over item ranges (include/rsx.h: item chunks): the "
                          "all-reduce + apply of a range travel under the other ranges' kernels of this and the next step.  "
-                         "-1 (default): 3 when N > 1 and the library issues the exchange, 0 (off) on one GPU, where there is "
+                         "-1 (default): 2 when N > 1 and the library issues the exchange, 0 (off) on one GPU, where there is "
                          "nothing to hide and the plain blocked step is faster")
     ap.add_argument("--no-legs", action="store_true", help="headline only (no section-8d legs)")
     ap.add_argument("--no-lightgcn", action="store_true", help="skip the BASELINE configs[4] leg (LightGCN propagation + step)")
@@ -386,7 +386,7 @@ def main():
     two_pass = SHARDED and os.environ.get("RSX_TWO_PASS", "1") == "1"
     P, Q, indptr, indices = tables(U, I, d, args.degree, args.popularity)
     if args.chunks < 0:
-        args.chunks = 3 if (world > 1 and COMM is not None) else 0
+        args.chunks = 2 if (world > 1 and COMM is not None) else 0      # (two ranges beat three at every exchange length)
     head = step_leg(P, Q, indptr, indices, args.lr, B, args.neg_block, args.hot, args.hot_replicas, args.steps, args.warmup,
                     world, rank, args.popularity, two_pass=two_pass, chunks=args.chunks)
     Q = head.pop("_Q")
