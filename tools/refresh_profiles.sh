@@ -47,6 +47,7 @@ leg B4096_plain   "$T" - 4096 0 100
 leg B16384_plain  "$T" - 16384 0 100
 leg B262144       "$T" - 262144 8 30
 leg B1M_ranges3   "$T" "CHUNKS=3" 1000000 8 12
+leg B1M_ranges2   "$T" "CHUNKS=2" 1000000 8 12
 ( export STEP_PROF_META="$out/${tag}_pmc_spmm.meta.json"
   PMC_GROUPS="$T;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" python3 tools/pmc_groups.py "$out/${tag}_pmc_spmm.json" spmm_csr -- python3 tools/spmm_prof.py > /dev/null 2>&1 )
 for half in users items; do
