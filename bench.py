@@ -160,7 +160,7 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     nb = eng.set_neg_block(B, want_nb) if want_nb > 0 else 0
     if hot > 0:
         eng.set_hot_items(torch.bincount(indices.long(), minlength=I), hot, hot_replicas or None)
-    if chunks > 1 and nb and not eng.stale_exchange and (COMM is not None or not SHARDED):
+    if chunks > 1 and nb and not eng.stale_exchange and eng.exchange == "allreduce":
         eng.set_chunks(chunks)
         eng.overlap_exchange = False                     # the range pipeline replaces the two-pass step
         nb = eng.neg_block                               # (ranges use blocks of at least 3: sharded.py:pick_neg_block)
@@ -203,7 +203,7 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     kernel = "bpr_step_blocked_kernel" if nb else ("bpr_step_blocked_kernel<TILE=false>" if eng._sorts(B) else "bpr_step_kernel")
     key = f"U{U}_I{I}_d{d}_B{B}_{popularity}_nb{nb}" + (f"_c{ran_chunks}" if ran_chunks > 1 else "")
     return {"batch_per_gpu": B, "chunks": ran_chunks, "exchange_issued_by": ("library (RCCL from librsx)" if COMM is not None else
-                                                                             "torch.distributed callbacks") if SHARDED else None, "global_batch": gb, "value": gb * steps / elapsed, "unit": "triplets/s",
+                                                                             "torch.distributed callbacks" + (", range by range" if ran_chunks > 1 else "")) if SHARDED else None, "global_batch": gb, "value": gb * steps / elapsed, "unit": "triplets/s",
             "ms_per_step": elapsed / steps * 1e3, "steps": steps, "neg_block": nb, "mean_bpr_loss": mean_loss,
             "hot_replicas": eng.hot.replicas if eng.hot is not None else 0,
             "two_pass": bool(eng.overlap_exchange) and not eng.stale_exchange, "exchange": eng.exchange if SHARDED else None,
@@ -363,8 +363,33 @@ def main():
         fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_int]
         assert fn(1) == 0
     global COMM
+    comm_note = None
     if SHARDED and os.environ.get("RSX_DIST_BACKEND", "nccl") == "nccl" and os.environ.get("RSX_NATIVE_RCCL", "1") == "1":
-        COMM = rsx.Comm()        # the exchange is then issued by librsx on the trainer's own stream: no interpreter in the timed region
+        # the exchange is then issued by librsx on the trainer's own stream: no interpreter in the timed region.  Creating the
+        # communicator is collective: every rank tries, the ranks agree on the outcome, and if ANY rank failed (librccl not
+        # loadable, init error) ALL fall back to the torch.distributed collectives handed in as callbacks -- the same schedule
+        # (item ranges included: include/rsx.h exchange_range), the path the two-rank tests run
+        try:
+            COMM = rsx.Comm()
+            ok = torch.ones(1, device=dev)
+            COMM.all_reduce(ok)                         # one real collective through it, checked
+            torch.cuda.synchronize()
+            good = float(ok.item()) == float(world)
+            err = None if good else f"all-reduce of ones over {world} ranks returned {float(ok.item())}"
+        except Exception as e:       # noqa: BLE001
+            good, err = False, repr(e)
+        flag = torch.tensor([1.0 if good else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) != 1.0:
+            if COMM is not None:
+                try:
+                    COMM.close()
+                except Exception:    # noqa: BLE001
+                    pass
+            COMM = None
+            comm_note = f"library RCCL communicator unavailable on some rank ({err or 'another rank failed'}): exchange through torch.distributed callbacks"
+            if rank == 0:
+                print("bench.py: " + comm_note, file=sys.stderr, flush=True)
     from recsys_pytorch_amd.data import synthetic_csr
     rsx.lib()
     if os.environ.get("RSX_SCORE_LANES"):
@@ -386,7 +411,30 @@ def main():
     two_pass = SHARDED and os.environ.get("RSX_TWO_PASS", "1") == "1"
     P, Q, indptr, indices = tables(U, I, d, args.degree, args.popularity)
     if args.chunks < 0:
-        args.chunks = 2 if (world > 1 and COMM is not None) else 0      # (two ranges beat three at every exchange length)
+        # N > 1: two item ranges (they beat three at every exchange length), with the library's RCCL or -- the
+        # fallback above, and what tests/test_sharded_gloo.py runs with two ranks -- the per-range callbacks
+        args.chunks = 2 if world > 1 else 0
+    # A hang must be impossible to miss: the N > 1 legs run under a watchdog that prints a JSON error line and leaves with a
+    # non-zero status (os._exit: no re-exec, no GPU teardown from a process whose queues are stuck)
+    watchdog = None
+    if world > 1:
+        import threading
+        limit = float(os.environ.get("RSX_WATCHDOG_S", "900"))
+        done = threading.Event()
+
+        def bark():
+            if not done.wait(limit):
+                msg = {"metric": "bpr_triplet_updates_per_sec", "value": None, "unit": "triplets/s", "n_gpus": world,
+                       "error": f"watchdog: rank {rank} did not finish the N > 1 legs within {limit:.0f} s (a collective or a stream "
+                                "wait is stuck)", "config": {"item_chunks": args.chunks,
+                                                             "exchange_issued_by": "library (RCCL from librsx)" if COMM is not None else "torch.distributed callbacks"}}
+                if rank == 0:
+                    print(json.dumps(msg), flush=True)
+                sys.stderr.write(msg["error"] + "\n")
+                sys.stderr.flush()
+                os._exit(3)
+        watchdog = (threading.Thread(target=bark, daemon=True), done)
+        watchdog[0].start()
     head = step_leg(P, Q, indptr, indices, args.lr, B, args.neg_block, args.hot, args.hot_replicas, args.steps, args.warmup,
                     world, rank, args.popularity, two_pass=two_pass, chunks=args.chunks)
     Q = head.pop("_Q")
@@ -465,6 +513,8 @@ def main():
                    "topk_rows": int(top.shape[0])}
     if SHARDED:
         dist.barrier()
+    if watchdog is not None:
+        watchdog[1].set()
 
     if rank == 0:
         nb = head["neg_block"]
@@ -481,6 +531,10 @@ def main():
                        "sampler": "on device, two steps ahead on a lowest-priority side stream",
                        "loop": "native (rsx_bpr_trainer_run): no interpreter between the kernels of the timed region",
                        "item_chunks": head["chunks"], "exchange_issued_by": head["exchange_issued_by"],
+                       **({"exchange_note": comm_note} if comm_note else {}),
+                       **({"negatives_with_item_ranges": "a position's negative is uniform over the real items of the item range its "
+                           f"positive fell in (1/{head['chunks']} of the catalog under a seeded relabelling, redrawn between native "
+                           "runs): NOT the same draw as the N = 1 line's blocks over the whole catalog"} if head["chunks"] > 1 else {}),
                        **({"DEBUG_exchange_delay_us": int(os.environ["RSX_EXCHANGE_DELAY_US"])} if os.environ.get("RSX_EXCHANGE_DELAY_US") else {}),
                        "mean_bpr_loss": head["mean_bpr_loss"],
                        **({"item_replicas_identical": head["item_replicas_identical"]} if SHARDED else {}),

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RSX_ABI_VERSION 4
+#define RSX_ABI_VERSION 5
 
 #define RSX_OK 0
 #define RSX_E_INVALID (-1)   /* bad argument (null pointer, unsupported d, K ...) */
@@ -270,11 +270,12 @@ int rsx_bpr_build_item_cdf(const int64_t *indptr_dev, const int32_t *indices_dev
  * of the steps before -- with the exchange under the neighbouring kernels.  The native loop launches each range's
  * kernel on a stream of its own, in descending priority, so that the ranges finish staggered.
  * The caller makes the ranges statistically alike by training on a RELABELLED item space (a fixed permutation of the
- * item ids that balances the ranges' sampling mass, drawn once per fit; recsys_pytorch_amd/sharded.py:
+ * item ids that balances the ranges' sampling mass, redrawn between native runs every few dozen steps; recsys_pytorch_amd/sharded.py:
  * BPREngine.set_chunks): the library sees item ids 0 .. C * chunk_rows, of which range k holds real(k) = items_real / C
  * (+1 for k < items_real % C) real items at its start and padding rows (never sampled, gradient always zero) behind.
  * Sampling semantics: a user's negative is uniform over the real items of the range its sampled positive fell in --
- * with the relabelling a fixed pseudo-random 1/C of the catalog per positive item, redrawn with every relabelling.
+ * with the relabelling a pseudo-random 1/C of the catalog per positive item, another one after every redraw (over a fit
+ * every item meets every other as a negative).
  * Sums are exactly those of rsx_bpr_step on the same triplets (tests replay the dumped triplets through the oracle).
  * Contract: triplets that do not honour the range rule are still summed, but race with the other ranges' pipelines;
  * the kernel counts them in progress[RSX_PROGRESS_VIOLATIONS] and the native loop reports the run failed.
@@ -286,7 +287,7 @@ int rsx_bpr_build_item_cdf(const int64_t *indptr_dev, const int32_t *indices_dev
  *   A user whose row covers its whole range has no negative there and is skipped (i = j = -1 at its position); one whose
  *   row covers all but a fraction f of the range is skipped with probability (1 - f)^128 (192 draws, never from elsewhere).
  * rsx_bpr_step_chunked: the blocked step kernel (rsx_bpr_step with neg_block, RSX_USERS_UNIQUE) over the positions of the
- *   ranges [first_range, first_range + num_ranges); progress: uint32 [RSX_PROGRESS_WORDS] device, zeroed by the caller;
+ *   ranges [first_range, first_range + num_ranges); progress: uint32 [RSX_PROGRESS_WORDS] device, zeroed by the caller ONCE (at allocation);
  *   progress[RSX_PROGRESS_VIOLATIONS] counts the triplets that left their range.                                  */
 #define RSX_MAX_CHUNKS 8
 #define RSX_PROGRESS_WORDS 16
@@ -378,8 +379,18 @@ int rsx_comm_all_reduce_f32(rsx_comm *c, float *buf_dev, int64_t n, rsx_stream_t
  *                        trainer-owned stream, in range order on every rank) and its apply form a chain on the trainer's
  *                        stream for range k; range k of the next step follows its own apply, whatever the other ranges'
  *                        exchanges are doing.  Every batch of such a trainer (<= 2^21 triplets) takes this form; needs
- *                        neg_block and item_cdf; not combined with two_pass / stale_exchange / the callbacks /
+ *                        neg_block and item_cdf; not combined with two_pass / stale_exchange / exchange_begin, exchange_end /
  *                        RSX_EXCHANGE_SCATTER_GATHER.
+ *   exchange_range       (chunks > 1, no comm) the caller's collective for ONE item range, in place of the library's RCCL
+ *                        all-reduce: exchange_range(ctx, k, G_rows, n, stream) is called while the step is being queued, once per
+ *                        range and step, in range order (the same order on every rank); it must QUEUE on `stream` -- the
+ *                        trainer's collective stream, already ordered behind range k's kernel and the fold of its popular rows
+ *                        -- an in-place all-reduce(sum) over the ranks of the n floats at G_rows (= G + k * chunk_rows * d,
+ *                        padding rows included), so that work queued on `stream` afterwards (the range's apply) sees the
+ *                        reduced rows.  It may block the calling thread (a host-staged collective such as gloo does), never
+ *                        the other streams.  Return 0 on success.  This is how the schedule that rsx_comm runs over RCCL is
+ *                        driven over any other transport (torch.distributed: tests/test_sharded_gloo.py runs it with two
+ *                        ranks).
  *   stale_exchange / G_alt   OPT-IN, needs an exchange (callbacks or comm) and a second zeroed [num_items x d] buffer.
  *                        != 0: the exchange of step t's item gradients travels under the step kernel of
  *                        step t+1, which therefore reads an item table that lacks step t's update (ONE STEP
@@ -391,7 +402,10 @@ int rsx_comm_all_reduce_f32(rsx_comm *c, float *buf_dev, int64_t n, rsx_stream_t
  *                        returns, so nothing is left unapplied between calls.  two_pass is ignored.
  * rsx_bpr_trainer_run(n_steps, batch <= config batch, global_batch = sum of the ranks' batches,
  *   time_every): time_every > 0 brackets the step kernel of every time_every-th step with HIP events
- *   on `stream`; rsx_bpr_trainer_kernel_ms returns their mean once the stream has drained.
+ *   on the stream it is launched on; rsx_bpr_trainer_kernel_ms returns their mean once the stream has drained.  A chunked
+ *   step launches one kernel per item range, each on its own stream: every range's kernel gets its own pair of events and
+ *   the figure per step is the SUM of the ranges' kernel durations (ranges that overlap on the chip are counted twice:
+ *   the figure never flatters the kernel).
  * rsx_bpr_trainer_state: next step index and the permutation position the next batch starts from.
  * rsx_bpr_trainer_seek: set both (drops a batch sampled ahead).
  * rsx_bpr_trainer_last_batch: device pointers of the triplets the most recent step consumed (valid
@@ -399,6 +413,7 @@ int rsx_comm_all_reduce_f32(rsx_comm *c, float *buf_dev, int64_t n, rsx_stream_t
  *   replay exactly what a native step did.                                                   */
 #define RSX_TRAINER_SLOTS 3
 typedef int (*rsx_exchange_fn)(void *ctx);
+typedef int (*rsx_exchange_range_fn)(void *ctx, int range, float *G_rows_dev, int64_t n, rsx_stream_t stream);
 
 typedef struct rsx_bpr_trainer_config {
     float *P;
@@ -443,6 +458,7 @@ typedef struct rsx_bpr_trainer_config {
     int64_t items_real;
     int64_t *chunk_pos;
     uint32_t *progress;
+    rsx_exchange_range_fn exchange_range;   /* chunks > 1 without comm: the caller's all-reduce of one item range  */
 } rsx_bpr_trainer_config;
 
 #define RSX_EXCHANGE_ALLREDUCE 1
@@ -459,8 +475,8 @@ int rsx_bpr_trainer_seek(rsx_bpr_trainer *t, int64_t step, int64_t epoch_pos, rs
 int rsx_bpr_trainer_last_batch(const rsx_bpr_trainer *t, const int32_t **u, const int32_t **i,
                                const int32_t **j, int64_t *batch, int *neg_block, uint64_t *neg_key);
 int rsx_bpr_trainer_kernel_ms(const rsx_bpr_trainer *t, double *mean_ms, int64_t *count);
-/* after the stream has drained: 0, or RSX_E_INVALID when a chunked run saw triplets outside their item range (text via
- * rsx_last_error); reads progress[] from the device                                                              */
+/* waits for `stream`: 0, or RSX_E_INVALID when the chunked steps since the last check saw triplets outside their item range
+ * (text via rsx_last_error); reads progress[RSX_PROGRESS_VIOLATIONS] from the device and resets it                  */
 int rsx_bpr_trainer_check(rsx_bpr_trainer *t, rsx_stream_t stream);
 
 /* ---- full-catalog scoring + Top-K ----------------------------------------------

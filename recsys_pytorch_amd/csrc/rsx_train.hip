@@ -67,9 +67,11 @@ struct rsx_bpr_trainer {
     bool slot_chunked[S] = {};                   // sampled with the item-range rule (config.chunks > 1)
     int last = -1;                               // slot consumed by the most recent step
     bool flip = false;                           // stale_exchange: the next step accumulates into G_alt
-    // live timing of the step kernel (HIP events on the run stream, every `time_every`-th step)
+    // live timing of the step kernel (HIP events on the stream the kernel is launched on, every `time_every`-th step).  A
+    // chunked step has one kernel per item range, each on its own stream: one pair per range (`pairs` counts them, `timed`
+    // the steps), and what is reported per step is the SUM of the ranges' kernel durations
     std::vector<hipEvent_t> t0, t1;
-    size_t timed = 0;
+    size_t timed = 0, pairs = 0;
 };
 
 namespace {
@@ -222,7 +224,10 @@ RSX_API int rsx_bpr_trainer_create(const rsx_bpr_trainer_config *cfg, rsx_bpr_tr
                       "chunks > 1: num_items must be chunks * rsx_chunk_rows(items_real, chunks, neg_block)");
         RSX_CHECK_ARG(cfg->batch <= (1ll << 21), "chunks > 1: at most 2^21 triplets per step");
         RSX_CHECK_ARG(cfg->exchange_begin == nullptr && !sg && !cfg->stale_exchange && !cfg->two_pass,
-                      "chunks > 1 replaces two_pass / stale_exchange and needs the all-reduce communicator when sharded");
+                      "chunks > 1 replaces two_pass / stale_exchange; when sharded it takes the all-reduce communicator or exchange_range");
+        RSX_CHECK_ARG(!(native && cfg->exchange_range != nullptr), "give exchange_range OR a communicator, not both");
+    } else {
+        RSX_CHECK_ARG(cfg->exchange_range == nullptr, "exchange_range is the per-range exchange of a chunked trainer (chunks > 1)");
     }
     rsx_bpr_trainer *t = new (std::nothrow) rsx_bpr_trainer();
     if (t == nullptr) { rsx_set_error("rsx_bpr_trainer_create: out of memory"); return RSX_E_INVALID; }
@@ -305,12 +310,13 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
     hipStream_t st = (hipStream_t)stream;
     const float inv_batch = 1.0f / (float)global_batch;
     const bool native = c.comm != nullptr;                                     // the library issues the exchange itself (RCCL)
-    const bool sharded = c.exchange_begin != nullptr || native;
+    const bool by_range = c.exchange_range != nullptr;                        // chunked: the caller's collective, range by range
+    const bool sharded = c.exchange_begin != nullptr || native || by_range;
     const bool sg = native && c.exchange_kind == RSX_EXCHANGE_SCATTER_GATHER;
     const bool applies = sg || (!native && c.exchange_applies);                // the exchange leaves Q updated and G zero
     const bool hot = c.hot_slot != nullptr;
     const bool stale = sharded && c.stale_exchange != 0;
-    t->timed = 0;
+    t->timed = t->pairs = 0;
     constexpr int S = rsx_bpr_trainer::S;
     if (t->ahead > 0 && t->slot_batch[t->cur] != batch) {
         // batches of another size were sampled ahead (e.g. before an epoch's short last batch): hand their
@@ -385,19 +391,19 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
         const int nb = t->slot_nb[cur];
         const uint64_t key = t->slot_key[cur];
         const bool timed = time_every > 0 && (s % time_every) == 0;
-        auto time_begin = [&]() -> int {
+        auto time_begin = [&](hipStream_t on) -> int {
             if (!timed) return RSX_OK;
-            if (t->timed == t->t0.size()) {
-                hipEvent_t a, b;
-                RSX_HIP(hipEventCreate(&a));
-                RSX_HIP(hipEventCreate(&b));
+            if (t->pairs == t->t0.size()) {
+                hipEvent_t a, b;      // timing events, but order-only like the others: no system-scope release per record
+                RSX_HIP(hipEventCreateWithFlags(&a, hipEventDisableSystemFence));
+                RSX_HIP(hipEventCreateWithFlags(&b, hipEventDisableSystemFence));
                 t->t0.push_back(a); t->t1.push_back(b);
             }
-            RSX_HIP(hipEventRecord(t->t0[t->timed], st));
+            RSX_HIP(hipEventRecord(t->t0[t->pairs], on));
             return RSX_OK;
         };
-        auto time_end = [&]() -> int {
-            if (timed) { RSX_HIP(hipEventRecord(t->t1[t->timed], st)); ++t->timed; }
+        auto time_end = [&](hipStream_t on) -> int {
+            if (timed) { RSX_HIP(hipEventRecord(t->t1[t->pairs], on)); ++t->pairs; }
             return RSX_OK;
         };
         if (t->slot_chunked[cur]) {
@@ -410,7 +416,6 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
             const ChunkGeom g = chunk_geom(c.items_real, c.chunks, c.neg_block);
             const int par = (int)(t->step & 1);
             if (s == 0) {        // the ranges' streams start behind whatever the run stream holds (a previous run, the caller's work)
-                RSX_HIP(hipMemsetAsync(c.progress, 0, RSX_MAX_CHUNKS * sizeof(uint32_t), st));
                 RSX_HIP(hipEventRecord(t->ev_start, st));
                 for (int k = 0; k < c.chunks; ++k) RSX_HIP(hipStreamWaitEvent(RSX_RANGE_STREAM(k), t->ev_start, 0));
                 t->kernels_in_flight = false;
@@ -422,30 +427,27 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
                 if (t->kernels_in_flight)      // user rows: every range's kernel of the step before has written its users
                     for (int q = 0; q < c.chunks; ++q)
                         if (q != k) RSX_HIP(hipStreamWaitEvent(ck, t->ev_k[q][1 - par], 0));
-                if (timed && k == 0) {
-                    if (t->timed == t->t0.size()) {
-                        hipEvent_t a, b;
-                        RSX_HIP(hipEventCreate(&a));
-                        RSX_HIP(hipEventCreate(&b));
-                        t->t0.push_back(a); t->t1.push_back(b);
-                    }
-                    RSX_HIP(hipEventRecord(t->t0[t->timed], ck));
-                }
+                RSX_TRY(time_begin(ck));       // each range's kernel on ITS stream: a pair per range, summed per step
                 RSX_TRY(rsx_bpr_step_chunked(c.P, c.Q, c.G, c.num_users, c.num_items, c.items_real, c.chunks, u, i, j, batch, c.d, c.lr,
                                              inv_batch, c.loss_acc, c.hot_slot, c.G_hot, c.hot_replicas, nb, key, chunk_pos_ptr(t, cur),
                                              c.progress, k, 1, (rsx_stream_t)ck));
-                if (timed && k == c.chunks - 1) { RSX_HIP(hipEventRecord(t->t1[t->timed], ck)); ++t->timed; }
+                RSX_TRY(time_end(ck));
                 RSX_HIP(hipEventRecord(t->ev_k[k][par], ck));
             }
             for (int k = 0; k < c.chunks; ++k) {
                 hipStream_t ck = RSX_RANGE_STREAM(k);
                 const int64_t lo = (int64_t)k * g.Ic;
                 float *Gk = c.G + (size_t)lo * c.d, *Qk = c.Q + (size_t)lo * c.d;
-                if (native) {
-                    // one stream for every collective of the communicator, issued in range order on every rank
+                if (native || by_range) {
+                    // one stream for every collective of the step, issued in range order on every rank: RCCL from here, or the
+                    // caller's collective (exchange_range: it queues the all-reduce of the range's rows on that same stream)
                     RSX_HIP(hipStreamWaitEvent(t->aux, t->ev_k[k][par], 0));
                     if (hot) RSX_TRY(rsx_fold_hot_grad_range(c.G, c.G_hot, c.hot_items, c.n_hot, c.hot_replicas, c.d, lo, lo + g.Ic, t->aux));
-                    RSX_TRY(rsx_comm_all_reduce(c.comm, Gk, g.Ic * c.d, t->aux));
+                    if (native) RSX_TRY(rsx_comm_all_reduce(c.comm, Gk, g.Ic * c.d, t->aux));
+                    else if (c.exchange_range(c.exchange_ctx, k, Gk, g.Ic * c.d, (rsx_stream_t)t->aux) != 0) {
+                        rsx_set_error("rsx_bpr_trainer_run: exchange_range failed (range %d)", k);
+                        return RSX_E_INVALID;
+                    }
                     RSX_TRY(rsx_debug_exchange_delay(t->aux, c.chunks));
                     RSX_TRY(rsx_apply_item_grad(Qk, Gk, g.Ic, c.d, c.lr, nullptr, nullptr, 0, (rsx_stream_t)t->aux));
                 } else {
@@ -461,10 +463,11 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
             t->kernels_in_flight = true;
             // the triplet slot is free when every range's kernel is done
             for (int k = 0; k < c.chunks; ++k) RSX_HIP(hipStreamWaitEvent(st, t->ev_k[k][par], 0));
+            if (timed) ++t->timed;
             if (s + 1 == n_steps)      // a run ends behind its last applies
                 for (int k = 0; k < c.chunks; ++k) RSX_HIP(hipStreamWaitEvent(st, t->ev_a[k], 0));
         } else {
-        RSX_TRY(time_begin());
+        RSX_TRY(time_begin(st));
         const unsigned sorted_flag = t->slot_sorted[cur] ? RSX_BATCH_SORTED : 0u;
         const bool two_pass = sharded && c.two_pass && !stale;
         const unsigned f = RSX_USERS_UNIQUE | sorted_flag | (two_pass ? RSX_ITEMS_ONLY : 0u);
@@ -475,7 +478,8 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
         const int which = (Gs == c.G) ? 0 : 1;
         RSX_TRY(rsx_bpr_step(c.P, c.Q, Gs, c.num_users, c.num_items, u, i, j, batch, c.d, c.lr, inv_batch, c.loss_acc, f,
                              nullptr, 0, c.hot_slot, c.G_hot, c.hot_replicas, nb, key, stream));
-        RSX_TRY(time_end());
+        RSX_TRY(time_end(st));
+        if (timed) ++t->timed;
         if (!sharded) {
             RSX_TRY(rsx_apply_item_grad_ex(c.Q, c.G, c.num_items, c.d, c.lr, c.hot_slot, c.G_hot, c.hot_replicas, batch >= c.num_items, st));
         } else {
@@ -526,6 +530,8 @@ RSX_API int rsx_bpr_trainer_check(rsx_bpr_trainer *t, rsx_stream_t stream)
     if (t->c.chunks <= 1 || t->c.progress == nullptr) return RSX_OK;
     uint32_t h[RSX_PROGRESS_WORDS] = {};
     RSX_HIP(hipMemcpyAsync(h, t->c.progress, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    // (read and reset: a violation fails THIS check, not every later one of the trainer's life)
+    RSX_HIP(hipMemsetAsync(t->c.progress + RSX_PROGRESS_VIOLATIONS, 0, sizeof(uint32_t), (hipStream_t)stream));
     RSX_HIP(hipStreamSynchronize((hipStream_t)stream));
     if (h[RSX_PROGRESS_VIOLATIONS] != 0) {
         rsx_set_error("rsx_bpr_trainer_check: %u triplets touched an item row outside their range (they race with the other ranges' pipelines)",
@@ -575,7 +581,7 @@ RSX_API int rsx_bpr_trainer_kernel_ms(const rsx_bpr_trainer *t, double *mean_ms,
 {
     RSX_CHECK_ARG(t != nullptr && mean_ms != nullptr, "null pointer");
     double sum = 0.0;
-    for (size_t k = 0; k < t->timed; ++k) {
+    for (size_t k = 0; k < t->pairs; ++k) {
         float ms = 0.f;
         RSX_HIP(hipEventSynchronize(t->t1[k]));
         RSX_HIP(hipEventElapsedTime(&ms, t->t0[k], t->t1[k]));

@@ -211,6 +211,9 @@ class MF(BaseModel):
                         print('(%3d / %3d) loss = %.4f' % (b, num_batches, float(chunk_loss) / n))
                     b += n
                 self._engine.adopt(trainer)
+                if self._engine.relabel_due():      # item ranges: the next epochs pair positives with another 1 / C of the catalog
+                    trainer.close()
+                    trainer = self._engine.native_trainer(indptr, indices, batch_size, loss_acc=acc)
             for b in range(num_batches if not native else 0):
                 bsz = min(batch_size, n_data - b * batch_size)
                 step_acc = self._engine.sampled_step(indptr, indices, bsz)

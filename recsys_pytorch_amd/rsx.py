@@ -435,6 +435,7 @@ class Comm:
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+EXCHANGE_RANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p)   # (ctx, range, G rows, n floats, stream)
 
 
 class TrainerConfig(C.Structure):
@@ -448,7 +449,7 @@ class TrainerConfig(C.Structure):
                 ("exchange_applies", C.c_int32), ("sort_min_batch", C.c_int32), ("step0", _I64), ("epoch_pos0", _I64),
                 ("G_alt", _P), ("stale_exchange", C.c_int32), ("exchange_kind", C.c_int32), ("comm", _P),
                 ("item_rows_padded", _I64), ("chunks", C.c_int32), ("reserved0", C.c_int32), ("items_real", _I64),
-                ("chunk_pos", _P), ("progress", _P)]
+                ("chunk_pos", _P), ("progress", _P), ("exchange_range", EXCHANGE_RANGE_FN)]
 
 
 class BPRTrainer:
@@ -458,9 +459,11 @@ class BPRTrainer:
 
     def __init__(self, P, Q, G, indptr, indices, lr, batch, seed, seed_key, neg_block=0, hot=None, user_sig=None,
                  item_cdf=None, loss_acc=None, exchange=None, two_pass=False, exchange_applies=False, sort_min_batch=0, step0=0, epoch_pos0=0,
-                 G_alt=None, comm=None, exchange_kind=0, item_rows_padded=0, chunks=0, items_real=0, num_items=None):
+                 G_alt=None, comm=None, exchange_kind=0, item_rows_padded=0, chunks=0, items_real=0, num_items=None, exchange_range=None):
         """exchange: (begin, end) callables (the collective stays with the caller) OR comm: an rsx.Comm (the library issues it).
-        chunks > 1: P / Q / G / the CSR live in the caller's relabelled item space of chunks * chunk_rows ids."""
+        chunks > 1: P / Q / G / the CSR live in the caller's relabelled item space of chunks * chunk_rows ids; sharded without
+        comm: exchange_range(k, first_row, rows, stream_handle) queues the caller's all-reduce of G[first_row:first_row + rows] on
+        the given HIP stream (include/rsx.h: exchange_range)."""
         dev = P.device
         self.batch = int(batch)
         self.chunks = int(chunks)
@@ -487,6 +490,18 @@ class BPRTrainer:
                         return 1
                 return EXCHANGE_FN(call)
             self._cb = (wrap(exchange[0]), wrap(exchange[1]))
+        self._cb_range = None
+        if exchange_range is not None:
+            row_bytes, base = 4 * P.shape[1], G.data_ptr()
+
+            def call_range(_ctx, k, ptr, n, stream):
+                try:
+                    exchange_range(int(k), (int(ptr) - base) // row_bytes, int(n) // P.shape[1], int(stream or 0))
+                    return 0
+                except Exception as e:                 # noqa: BLE001 -- must not unwind through the C frames
+                    self._exc = e
+                    return 1
+            self._cb_range = EXCHANGE_RANGE_FN(call_range)
         self._exc = None
         cfg = TrainerConfig(
             P=_dev(P, torch.float32, "P"), Q=_dev(Q, torch.float32, "Q"), G=_dev(G, torch.float32, "G"),
@@ -508,7 +523,8 @@ class BPRTrainer:
             G_alt=ptr(G_alt, torch.float32, "G_alt"), stale_exchange=int(G_alt is not None),   # opt-in: one step stale
             exchange_kind=int(exchange_kind), comm=comm.handle if comm is not None else None,
             item_rows_padded=int(item_rows_padded), chunks=self.chunks, reserved0=0, items_real=int(items_real),
-            chunk_pos=ptr(self.chunk_pos, torch.int64, "chunk_pos"), progress=ptr(self.progress, torch.int32, "progress"))
+            chunk_pos=ptr(self.chunk_pos, torch.int64, "chunk_pos"), progress=ptr(self.progress, torch.int32, "progress"),
+            exchange_range=self._cb_range or EXCHANGE_RANGE_FN())
         self._h = C.c_void_p()
         _check(lib().rsx_bpr_trainer_create(C.byref(cfg), C.byref(self._h)), "rsx_bpr_trainer_create")
 

@@ -117,6 +117,13 @@ class BPREngine:
         # on-chip sums have little to sum: the ranges then serve only to hide an exchange as long as the step (configs[3])
         self.blocked_any_batch = False
         self._relabel = None
+        # The range an item sits in decides which negatives its positives are paired with.  One relabelling for a whole fit
+        # would mean that a user whose few positives fall into k < C ranges NEVER meets the other ranges' items as negatives;
+        # so the relabelling is redrawn (seeded with a round counter: identical on every rank) once a trainer has run
+        # `redraw_ranges_every` steps on it -- between native runs (adopt()), never inside one.  0 = keep one relabelling.
+        self.redraw_ranges_every = 64
+        self._relabel_round = 0
+        self._relabel_step0 = 0
         self._hot_args = None
         # OPT-IN (native loop only): the exchange of step t travels under the step kernel of step t+1, which
         # then reads an item table WITHOUT step t's update -- one step stale, not the reference's
@@ -217,8 +224,9 @@ class BPREngine:
         items of the range its sampled positive fell in (a random 1/chunks of the catalog) instead of over one item block
         anywhere."""
         chunks = int(chunks)
-        if chunks > 1 and (self.optimizer != "sgd" or self.exchange != "allreduce" or (self.sharded and self.comm is None)):
-            raise ValueError("chunks > 1 needs SGD, exchange='allreduce' and, when sharded, the library's own communicator (comm)")
+        if chunks > 1 and (self.optimizer != "sgd" or self.exchange != "allreduce"):
+            raise ValueError("chunks > 1 needs SGD and exchange='allreduce' (sharded: the library's communicator `comm`, or without "
+                             "one this engine's torch.distributed all-reduce handed in range by range)")
         if chunks != self.chunks:
             self._relabel = None
         self.chunks = chunks if chunks > 1 else 0
@@ -229,7 +237,8 @@ class BPREngine:
     def _build_relabel(self, indptr, indices):
         """tables of the relabelled item space for THIS CSR and neg_block (cached by the identity of the CSR tensors)"""
         r = self._relabel
-        if r is not None and r["csr"][0] is indptr and r["csr"][1] is indices and r["nb"] == self.neg_block and r["C"] == self.chunks:
+        if (r is not None and r["csr"][0] is indptr and r["csr"][1] is indices and r["nb"] == self.neg_block and r["C"] == self.chunks
+                and r["round"] == self._relabel_round):
             return r
         I, d = self.Q.shape
         C, nb, dev = self.chunks, self.neg_block, self.Q.device
@@ -251,7 +260,7 @@ class BPREngine:
             dist.all_reduce(m, group=self.group)
             mass = m.to(dev)
         mass = mass.cpu().numpy()
-        rng = np.random.default_rng(self.seed * 7919 + 13)
+        rng = np.random.default_rng(self.seed * 7919 + 13 + 104729 * self._relabel_round)
         cap = np.array([base + (k < rem) for k in range(C)], dtype=np.int64)      # real items per range
         order = np.argsort(-mass, kind="stable")
         heavy = order[:min(I, 4096)]
@@ -293,7 +302,7 @@ class BPREngine:
             cm = torch.zeros(C * Ic, dtype=cnt.dtype)
             cm[rank_of_pos] = cnt.cpu()[perm]
             hot = self.k.HotItems(cm, num_hot, replicas, d, dev)
-        r = {"csr": (indptr, indices), "nb": nb, "C": C, "Ic": Ic, "item_rank": item_rank, "rank_item": rank_item, "real": real,
+        r = {"csr": (indptr, indices), "nb": nb, "C": C, "Ic": Ic, "round": self._relabel_round, "item_rank": item_rank, "rank_item": rank_item, "real": real,
              "indices": indices_m, "Q": Qm, "G": torch.zeros_like(Qm), "hot": hot,
              "sig": self.k.build_signature(indptr, indices_m, nb), "cdf": self.k.build_item_cdf(indptr, indices_m, C * Ic)}
         self._relabel = r
@@ -308,6 +317,22 @@ class BPREngine:
         r = self._relabel
         if r is not None and self.chunks:
             self.Q[r["rank_item"][r["real"]]] = r["Q"][r["real"]]
+
+    def relabel_due(self):
+        """a chunked trainer has run its share of steps on the current relabelling: the caller should close it and take a new
+        one from native_trainer(), which then draws the next relabelling (MF.fit does, once per epoch at most)"""
+        return bool(self.chunks and self._relabel is not None and self._relabel["round"] != self._relabel_round)
+
+    def _exchange_range(self, k, first_row, rows, stream):
+        """include/rsx.h: exchange_range -- the all-reduce of ONE item range's gradient rows, queued on the trainer's
+        collective stream (a raw HIP stream handle; 0 for a CPU stand-in): the step of the chunked native loop that the
+        library issues over RCCL itself when it has a communicator, here over torch.distributed (any backend)"""
+        G = self._relabel["G"][first_row:first_row + rows]
+        if G.is_cuda:
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=G.device)):
+                dist.all_reduce(G, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.all_reduce(G, op=dist.ReduceOp.SUM, group=self.group)
 
     # -- the exchange of a step's item gradients ------------------------------------------------
     def _setup_item_shards(self):
@@ -593,11 +618,13 @@ class BPREngine:
             # the step as a pipeline over item ranges, in the relabelled item space (set_chunks)
             r = self._build_relabel(indptr, indices)
             self._items_to_relabelled()
+            self._relabel_step0 = self.step_count
+            by_range = {"exchange_range": self._exchange_range} if (self.sharded and not native) else {}
             return self.k.BPRTrainer(self.P, r["Q"], r["G"], indptr, r["indices"], self.lr, batch,
                                      seed=self.seed + 7919 * self.user_begin, seed_key=self.seed, neg_block=self.neg_block,
                                      hot=r["hot"], user_sig=r["sig"], item_cdf=r["cdf"], loss_acc=loss_acc,
                                      comm=self.comm if native else None, exchange_kind=kind, chunks=self.chunks,
-                                     items_real=self.Q.shape[0], step0=self.step_count, epoch_pos0=self.epoch_pos)
+                                     items_real=self.Q.shape[0], step0=self.step_count, epoch_pos0=self.epoch_pos, **by_range)
         sort_min = int(self.sorted_min_batch) if (self.sorted_min_batch and not self.neg_block) else 0
         if self.neg_block or sort_min:
             self._bind_csr(indptr, indices)
@@ -627,6 +654,9 @@ class BPREngine:
         if getattr(trainer, "chunks", 0) > 1:
             trainer.check()
             self.sync_items()
+            if self.redraw_ranges_every and self.step_count - self._relabel_step0 >= self.redraw_ranges_every \
+                    and self._relabel is not None and self._relabel["round"] == self._relabel_round:
+                self._relabel_round += 1            # the next native_trainer() draws the next relabelling (relabel_due)
 
     # -- replay of GLOBAL-id triplets: each rank keeps the triplets of its own users -----
     def route(self, u_global, i, j):

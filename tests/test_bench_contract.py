@@ -53,19 +53,43 @@ def test_bench_json_contract_small_shape():
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("two_pass,exchange", [("0", "allreduce"), ("1", "allreduce"), ("1", "scatter_gather")])
-def test_bench_two_ranks_on_one_gpu(two_pass, exchange):
+@pytest.mark.parametrize("two_pass,exchange,chunks", [("0", "allreduce", "0"), ("1", "allreduce", "0"), ("1", "scatter_gather", "0"),
+                                                      ("1", "allreduce", None), ("0", "allreduce", "3")])
+def test_bench_two_ranks_on_one_gpu(two_pass, exchange, chunks):
     """the N > 1 code path of bench.py (torch.distributed.run, native loop with the exchange callbacks) with two
-    ranks sharing the box's GPU and gloo moving G: not a performance number, a does-it-run-and-agree check"""
+    ranks sharing the box's GPU and gloo moving G: not a performance number, a does-it-run-and-agree check.  chunks = None:
+    bench.py's own N > 1 DEFAULT -- two item ranges, the exchange range by range (here through the exchange_range callback; on
+    a multi-GPU node through the library's RCCL)"""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29500 + (os.getpid() + 31 + int(two_pass) + 7 * len(exchange)) % 2000), os.path.join(ROOT, "bench.py"), "--gpus", "2",
-           "--steps", "4", "--warmup", "1", "--users", "120000", "--batch", "120000", "--items", "30000", "--score-tiles", "0", "--no-legs"]
+           "--master-port", str(29500 + (os.getpid() + 31 + int(two_pass) + 7 * len(exchange) + 3 * int(chunks or 2)) % 2000), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--steps", "4", "--warmup", "1", "--users", "120000", "--batch", "120000", "--items", "30000", "--score-tiles", "0", "--no-legs",
+           *(["--chunks", chunks] if chunks is not None else [])]
     d = run_bench(cmd, env={"RSX_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "RSX_TWO_PASS": two_pass,
-                                "RSX_EXCHANGE": exchange})
+                                "RSX_EXCHANGE": exchange, "RSX_CHUNKS": "-1"})
     assert ("reduce-scatter" in d["config"]["parallelism"]) == (exchange == "scatter_gather")
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 240000 and d["config"]["item_replicas_identical"] is True
-    assert ("two-pass" in d["config"]["parallelism"]) == (two_pass == "1")
+    want_chunks = int(chunks) if chunks is not None else 2
+    assert d["config"]["item_chunks"] == want_chunks
+    assert ("negatives_with_item_ranges" in d["config"]) == (want_chunks > 1)
+    assert ("range by range" in d["config"]["exchange_issued_by"]) == (want_chunks > 1)
+    assert ("two-pass" in d["config"]["parallelism"]) == (two_pass == "1" and want_chunks == 0)
+    assert d["roofline"]["kernel_launches_timed"] == 4
     assert abs(d["value"] - 240000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_bench_watchdog_turns_a_hang_into_an_error_line_and_a_nonzero_exit():
+    """N > 1: a stuck collective must not look like a slow run.  RSX_WATCHDOG_S = 0: the watchdog fires at once -- rank 0's
+    stdout carries a JSON line with "error" and "value": null, the exit status is not 0"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + (os.getpid() + 97) % 2000), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--steps", "4", "--warmup", "1", "--users", "120000", "--batch", "120000", "--items", "30000", "--score-tiles", "0", "--no-legs"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT,
+                         env={**os.environ, "RSX_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "RSX_WATCHDOG_S": "0"})
+    assert out.returncode != 0
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert lines and all(l["value"] is None and "watchdog" in l["error"] for l in lines)
 
 
 def test_roofline_is_physical():

@@ -140,6 +140,114 @@ def test_two_ranks_agree_on_the_relabelled_item_space():
         assert np.array_equal(np.sort(ir0[ix].reshape(U, 12), axis=1), im.reshape(U, 12))
 
 
+def _ranges_worker(rank, world, port, gpu, U, I, d, B, deg, chunks, steps, one_run, out):
+    """one rank of the chunked native loop with the per-range exchange handed in as a callback (include/rsx.h:
+    exchange_range) over gloo: the CPU stand-in trainer (gpu = False) or the HIP library, both ranks on the box's one GPU"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from recsys_pytorch_amd.sharded import BPREngine
+    dev = torch.device("cuda", 0) if gpu else torch.device("cpu")
+    kernels = None
+    if not gpu:
+        import cpu_kernels as kernels
+    rng = np.random.default_rng(500 + rank)                     # every rank its OWN users, with its own popularity skew
+    p = 1.0 / np.arange(1, I + 1) ** (0.7 + 0.4 * rank)
+    p /= p.sum()
+    rows = [np.sort(rng.choice(I, deg, replace=False, p=p)) for _ in range(U)]
+    indptr = (torch.arange(U + 1, dtype=torch.int64) * deg).to(dev)
+    indices = torch.from_numpy(np.concatenate(rows).astype(np.int32)).to(dev)
+    P = (torch.randn(U, d, generator=torch.Generator().manual_seed(100 + rank)) * 0.1).to(dev)
+    Q = (torch.randn(I, d, generator=torch.Generator().manual_seed(7)) * 0.1).to(dev)
+    P_init, Q_init = P.cpu().numpy().copy(), Q.cpu().numpy().copy()
+    eng = BPREngine(P, Q, resolvable_lr(world * B), kernels=kernels, user_begin=rank * U, seed=11)
+    assert eng.sharded and eng.comm is None
+    if gpu:
+        assert eng.set_neg_block(B, 8) > 0
+        eng.set_hot_items(torch.bincount(indices.long(), minlength=I), 32, 4)
+    else:
+        eng.neg_block = 4
+        eng.set_hot_items(torch.bincount(indices.long(), minlength=I), 8, 2)
+    assert eng.set_chunks(chunks) == chunks
+    acc = torch.zeros(eng.k.RSX_LOSS_SLOTS, dtype=torch.float32, device=dev)
+    tr = eng.native_trainer(indptr, indices, B, loss_acc=acc)
+    assert tr.chunks == chunks
+    r = eng._relabel
+    trips = []
+    if one_run:                                                 # all steps queued by ONE call: the ranges of neighbouring steps interleave
+        tr.run(steps, B, global_batch=world * B)
+    else:
+        for _ in range(steps):                                  # step by step, to dump what every step consumed
+            tr.run(1, B, global_batch=world * B)
+            if gpu:
+                torch.cuda.synchronize()
+            u, i, j = (t.cpu().numpy().astype(np.int64) for t in tr.last_batch()[:3])
+            cp = tr.last_chunk_pos().cpu().numpy()
+            live = i >= 0
+            assert np.array_equal(np.searchsorted(i[live] // r["Ic"], np.arange(chunks + 1)), cp)   # range k = positions [cp[k], cp[k+1])
+            assert np.all(i[live] // r["Ic"] == j[live] // r["Ic"])
+            trips.append((u[live] + rank * U, i[live], j[live]))
+    if gpu:
+        torch.cuda.synchronize()
+    Qm = r["Q"].cpu().numpy().copy()                            # the relabelled replica, padding rows included
+    eng.adopt(tr)                                               # checks the run (no triplet left its range), item rows back to the caller's ids
+    tr.close()
+    out[rank] = (P.cpu().numpy(), eng.Q.cpu().numpy(), Qm, trips, r["rank_item"].cpu().numpy(), float(acc.sum()), P_init, Q_init,
+                 float(r["G"].abs().max()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _check_ranges(oracle_mod, world, port, gpu, U, I, d, B, deg, chunks, steps):
+    """two ranks on the chunked native loop == ONE process (the oracle) on the concatenation of what the ranks sampled"""
+    mgr = mp.Manager()
+    res = {}
+    for one_run in (False, True):
+        out = mgr.dict()
+        mp.spawn(_ranges_worker, args=(world, port + 3 * one_run, gpu, U, I, d, B, deg, chunks, steps, one_run, out), nprocs=world, join=True)
+        res[one_run] = [out[r] for r in range(world)]
+    for arm in res.values():
+        assert np.array_equal(arm[0][2], arm[1][2]), "relabelled item replicas diverged (some range)"
+        assert np.array_equal(arm[0][1], arm[1][1]), "item replicas diverged"
+        assert np.array_equal(arm[0][4], arm[1][4])
+        assert arm[0][8] == 0.0 and arm[1][8] == 0.0              # every range's gradient rows were applied and cleared
+    step_arm = res[False]
+    rank_item, Q_init = step_arm[0][4], step_arm[0][7]
+    P_init = np.concatenate([step_arm[r][6] for r in range(world)])
+    lr = resolvable_lr(world * B)
+    orc = oracle_mod.MFOracle(P_init, Q_init, "sgd", lr)
+    loss_sum = 0.0
+    for t in range(steps):
+        u, i, j = (np.concatenate([step_arm[r][3][t][c] for r in range(world)]) for c in range(3))
+        assert len(u) == world * B                              # (every user of these CSRs has a usable row: 1 / sum_r B_r is exact)
+        loss_sum += orc.step(u, rank_item[i], rank_item[j]) * len(u)          # the triplets in the caller's item ids
+    assert abs(sum(a[5] for a in step_arm) - loss_sum) < 1e-5 * loss_sum
+    P = np.concatenate([a[0] for a in step_arm])
+    assert_update(P, P_init, orc.P, "P (step by step)")
+    assert_update(step_arm[0][1], Q_init, orc.Q, "Q (step by step)")
+    # the same steps queued by one call (same seeds, same triplets): the same tables
+    assert_update(np.concatenate([a[0] for a in res[True]]), P_init, P, "P (one run vs step by step)")
+    assert_update(res[True][0][1], Q_init, step_arm[0][1], "Q (one run vs step by step)")
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("I,chunks", [(203, 2), (150, 3)])
+def test_two_ranks_item_ranges_with_range_callbacks_equal_one_process(oracle_mod, I, chunks):
+    """the N > 1 DEFAULT schedule of bench.py -- every step as pipelines over item ranges, the exchange range by range -- with
+    TWO ranks: the engine's host logic over gloo on the CPU stand-in trainer (tests/cpu_kernels.py)"""
+    _check_ranges(oracle_mod, 2, 29500 + (os.getpid() + 53 + I) % 2000, False, 500, I, 32, 450, 6, chunks, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("I,chunks,d", [(2500, 2, 64), (1999, 3, 128)])
+def test_two_ranks_item_ranges_on_hip_kernels_equal_one_process(oracle_mod, I, chunks, d):
+    """the same through csrc/rsx_train.hip's chunked loop and the HIP kernels, two processes sharing the box's GPU: per-range
+    collectives in the same order on ranks whose range kernels finish at different times, sub-buffers G + lo * d with padding rows
+    summing two ranks' partials, 1 / sum_r B_r, replica identity per range -- step by step against the oracle on the concatenated
+    triplets, and the same steps queued by ONE rsx_bpr_trainer_run"""
+    _check_ranges(oracle_mod, 2, 29500 + (os.getpid() + 59 + I) % 2000, True, 9000, I, d, 6000, 10, chunks, 4)
+
+
 def _gpu_worker(rank, world, port, P0, Q0, batches, lr, out, unique=False, exchange="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
