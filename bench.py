@@ -89,6 +89,29 @@ def traffic_for(key):
         return None
 
 
+KERNEL_SOURCES = {"step": ("rsx_bpr.hip", "rsx_sample.hip", "rsx_train.hip", "rsx_common.h"), "spmm": ("rsx_graph.hip", "rsx_common.h")}
+
+
+def sources_sha(kind):
+    """hash of the kernel sources a profiled traffic figure depends on.  tools/install_profiles.py records it with every
+    profiles/traffic.json entry; a line whose sources hash differently says `stale: true` (the .git directory does not travel
+    to the GPU box: a commit cannot be compared there, file contents can)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES[kind]:
+        h.update(open(os.path.join(ROOT, "recsys_pytorch_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def traffic_source(t, kind, how):
+    if not t:
+        return None
+    sha = t.get("sources_sha")
+    return {"file": "profiles/" + str(t.get("profile")), "taken_at_commit": t.get("commit"), "how": how,
+            # the kernels this figure was measured on vs. the ones in this tree (None: profile older than the hash record)
+            "stale": (sha != sources_sha(kind)) if sha else None}
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -110,9 +133,8 @@ def roofline(kernel, kern_ms, n_timed, B, I, d, key, two_pass=False):
     return {"bound": "hbm", "kernel": kernel, "kernel_ms": kern_ms, "kernel_launches_timed": n_timed,
             "achieved": per_s(hbm) if hbm else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": per_s(hbm) / HBM_PEAK_GBS if hbm else None, "traffic": hbm,
-            "traffic_source": ({"file": "profiles/" + str(t.get("profile")), "taken_at_commit": t.get("commit"),
-                                "how": "rocprofv3 --pmc passes over tools/step_prof.py at this leg's shape (tools/refresh_profiles.sh); "
-                                       "read from profiles/traffic.json, NOT measured in this run"} if t else None),
+            "traffic_source": traffic_source(t, "step", "rocprofv3 --pmc passes over tools/step_prof.py at this leg's shape "
+                                             "(tools/refresh_profiles.sh); read from profiles/traffic.json, NOT measured in this run"),
             **({} if hbm else {"frac_null_reason": f"no PMC profile of this leg in profiles/traffic.json (key {key})"}),
             "traffic_key": key,
             "compulsory_bytes": compulsory, "frac_compulsory": per_s(compulsory) / HBM_PEAK_GBS,
@@ -138,8 +160,9 @@ COMM = None         # rsx.Comm: the library's own RCCL communicator (N > 1 over 
 
 
 def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, warmup, world, rank, popularity, two_pass=None,
-             chunks=0):
-    """one timed region of `steps` native steps; returns the leg record (rank 0 fills the throughput)"""
+             chunks=0, regions=1):
+    """`regions` back-to-back timed regions of `steps` native steps each (the MEDIAN region is the leg's figure); returns the
+    leg record (rank 0 fills the throughput)"""
     from recsys_pytorch_amd import rsx
     from recsys_pytorch_amd.sharded import BPREngine
     U, d = P.shape
@@ -160,7 +183,8 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     nb = eng.set_neg_block(B, want_nb) if want_nb > 0 else 0
     if hot > 0:
         eng.set_hot_items(torch.bincount(indices.long(), minlength=I), hot, hot_replicas or None)
-    if chunks > 1 and nb and not eng.stale_exchange and eng.exchange == "allreduce":
+    if chunks > 1 and want_nb > 0 and not eng.stale_exchange and eng.exchange == "allreduce":
+        # (B >= 2 I: blocked negatives inside the ranges; below: the ranges without blocks -- include/rsx.h "item chunks")
         eng.set_chunks(chunks)
         eng.overlap_exchange = False                     # the range pipeline replaces the two-pass step
         nb = eng.neg_block                               # (ranges use blocks of at least 3: sharded.py:pick_neg_block)
@@ -172,21 +196,25 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     gb = B * world
     tr.run(warmup, B, gb)
     loss.zero_()
-    fence(world)
-    t0 = time.perf_counter()
-    tr.run(steps, B, gb, time_every=1)     # exactly `steps` steps inside the timed region, every step kernel timed
-    fence(world)
-    elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if SHARDED:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-    kern_ms, n_timed = tr.kernel_ms()
+    runs = []
+    for _ in range(max(1, int(regions))):
+        fence(world)
+        t0 = time.perf_counter()
+        tr.run(steps, B, gb, time_every=1)     # exactly `steps` steps inside the timed region, every step kernel timed
+        fence(world)
+        elapsed = time.perf_counter() - t0
+        el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        if SHARDED:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        runs.append((float(el.item()),) + tuple(tr.kernel_ms()))
+    order = sorted(range(len(runs)), key=lambda q: runs[q][0])
+    elapsed, kern_ms, n_timed = runs[order[len(order) // 2]]            # the median region (and ITS kernel timings)
+    region_ms = [r[0] / steps * 1e3 for r in runs]
     ran_chunks = getattr(tr, "chunks", 0)
     eng.adopt(tr)                                        # (a chunked run: checks it and copies the item rows back into Q)
     tr.close()
     assert torch.isfinite(P).all() and torch.isfinite(Q).all()
-    mean_loss = float(loss.double().sum()) / (B * steps)            # this rank's triplets
+    mean_loss = float(loss.double().sum()) / (B * steps * len(runs))            # this rank's triplets
     assert np.isfinite(mean_loss) and 0.0 < mean_loss < 5.0, mean_loss
     replicas_equal = None
     if SHARDED:        # every rank applied the same reduced gradient: the item replicas must be identical, ROW BY ROW
@@ -205,12 +233,16 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     return {"batch_per_gpu": B, "chunks": ran_chunks, "exchange_issued_by": ("library (RCCL from librsx)" if COMM is not None else
                                                                              "torch.distributed callbacks" + (", range by range" if ran_chunks > 1 else "")) if SHARDED else None, "global_batch": gb, "value": gb * steps / elapsed, "unit": "triplets/s",
             "ms_per_step": elapsed / steps * 1e3, "steps": steps, "neg_block": nb, "mean_bpr_loss": mean_loss,
+            "timed_regions": {"count": len(runs), "ms_per_step_each": region_ms, "min": min(region_ms), "max": max(region_ms),
+                              "reported": "median"},
             "hot_replicas": eng.hot.replicas if eng.hot is not None else 0,
             "two_pass": bool(eng.overlap_exchange) and not eng.stale_exchange, "exchange": eng.exchange if SHARDED else None,
             "stale_exchange": bool(eng.stale_exchange),
             "item_replicas_identical": replicas_equal, "_Q": Q,
-            "roofline": (rl := roofline(kernel, kern_ms, n_timed, B, I, d, key,
-                                        two_pass=bool(eng.overlap_exchange) and not eng.stale_exchange)),
+            "roofline": (rl := {**roofline(kernel, kern_ms, n_timed, B, I, d, key,
+                                           two_pass=bool(eng.overlap_exchange) and not eng.stale_exchange),
+                                **({"kernel_ms_is": f"sum of the {ran_chunks} item ranges' kernel durations per step, each timed on its "
+                                                    "own stream (ranges that overlap on the chip count twice)"} if ran_chunks > 1 else {})}),
             # whole step (kernel + apply + gaps) against the same physical bytes of the step kernel
             "frac_end_to_end": (rl["traffic"] / (elapsed / steps) / 1e9 / HBM_PEAK_GBS) if rl["traffic"] else None,
             "algorithmic_end_to_end_over_peak": gb / world * steps / elapsed * 24 * d / (HBM_PEAK_GBS * 1e9)}
@@ -260,9 +292,8 @@ def lightgcn_leg(U, I, d, indptr, indices, dev, layers=3, batch=65_536):
             "roofline": {"bound": "hbm", "kernel": "spmm_csr_kernel", "kernel_ms": t_spmm * 1e3,
                          "achieved": per_s(hbm) if hbm else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": per_s(hbm) / HBM_PEAK_GBS if hbm else None, "traffic": hbm,
-                         "traffic_source": ({"file": "profiles/" + str(t.get("profile")), "taken_at_commit": t.get("commit"),
-                                             "how": "rocprofv3 --pmc passes over tools/spmm_prof.py; read from profiles/traffic.json, "
-                                                    "NOT measured in this run"} if t else None),
+                         "traffic_source": traffic_source(t, "spmm", "rocprofv3 --pmc passes over tools/spmm_prof.py; read from "
+                                                          "profiles/traffic.json, NOT measured in this run"),
                          **({} if hbm else {"frac_null_reason": f"no PMC profile of this leg in profiles/traffic.json (key {key})"}),
                          "traffic_key": key,
                          "compulsory_bytes": compulsory, "frac_compulsory": per_s(compulsory) / HBM_PEAK_GBS,
@@ -392,6 +423,10 @@ def main():
                 print("bench.py: " + comm_note, file=sys.stderr, flush=True)
     from recsys_pytorch_amd.data import synthetic_csr
     rsx.lib()
+    if os.environ.get("RSX_STEP_WAVES"):        # experiment: resident wavefronts per SIMD of the blocked step kernel
+        rsx.set_option("step_waves", int(os.environ["RSX_STEP_WAVES"]))
+    if os.environ.get("RSX_APPLY_STREAM"):      # experiment: the ranges' applies on a stream of their own (include/rsx.h: "apply_stream")
+        rsx.set_option("apply_stream", int(os.environ["RSX_APPLY_STREAM"]))
     if os.environ.get("RSX_SCORE_LANES"):
         rsx.set_option("score_lanes", int(os.environ["RSX_SCORE_LANES"]))
 
@@ -436,7 +471,7 @@ def main():
         watchdog = (threading.Thread(target=bark, daemon=True), done)
         watchdog[0].start()
     head = step_leg(P, Q, indptr, indices, args.lr, B, args.neg_block, args.hot, args.hot_replicas, args.steps, args.warmup,
-                    world, rank, args.popularity, two_pass=two_pass, chunks=args.chunks)
+                    world, rank, args.popularity, two_pass=two_pass, chunks=args.chunks, regions=3)
     Q = head.pop("_Q")
 
     # ---- the other section-8d legs: each its own timed region of the same native loop ------------------------
@@ -476,11 +511,13 @@ def main():
                                                short, 3, 1, 0, args.popularity)
                 del P64, Q64
         # BASELINE configs[3] as each of its ranks sees it: 1.25M users x 1M items per GPU, 10 positives per
-        # user, B = 1.25M per GPU (B < 2 I: the plain step kernel); with N > 1 the 512 MB all-reduce per step
+        # user, B = 1.25M per GPU (B < 2 I: the ordered batch without blocks); with N > 1 the 512 MB exchange per step travels
+        # range by range under the other range's kernels (item ranges without blocks, like the headline's with them)
         if (args.users, args.items, args.dim) == (1_000_000, 100_000, 128):
             P4, Q4, ip4, ix4 = tables(1_250_000, 1_000_000, 128, 10, args.popularity)
             legs["config3_slice_1.25Mx1M"] = leg(P4, Q4, ip4, ix4, args.lr, 1_250_000, args.neg_block, args.hot,
-                                                      args.hot_replicas, 10, 2, world, rank, args.popularity, two_pass=two_pass)
+                                                      args.hot_replicas, 10, 2, world, rank, args.popularity, two_pass=two_pass,
+                                                      chunks=args.chunks)
             del P4, Q4, ip4, ix4
 
     # ---- BASELINE configs[4]: LightGCN on the same interaction graph, d=128, 3 layers -----
@@ -504,7 +541,7 @@ def main():
             dts.append(time.perf_counter() - t1)
         dt = sorted(dts)[2]
         n_scores = 1024 * tiles * I
-        scoring = {"metric": "full_catalog_scores_per_sec", "value": n_scores / dt, "unit": "scores/s",
+        scoring = {"metric": "full_catalog_scores_per_sec", "value": n_scores / dt, "unit": "scores/s", "ms_per_1024_users": dt / tiles * 1e3,
                    "sample": f"{tiles} tiles of 1024 users x {I} items, mask + top-{K} on device; median of 5 calls "
                              f"(min {min(dts)*1e3:.2f} ms, max {max(dts)*1e3:.2f} ms per call)",
                    "roofline": {"bound": "mfma", "achieved": n_scores * 2 * d / dt / 1e12,
@@ -550,6 +587,26 @@ def main():
             "frac_end_to_end": head["frac_end_to_end"],
             "algorithmic_end_to_end_over_peak": head["algorithmic_end_to_end_over_peak"],
         }
+        # every BASELINE config's figure where the driver keeps it (it stores `roofline`, `config` and `cpu_baseline` of this line
+        # and drops the rest): value, ms per step, kernel ms, the PHYSICAL fraction of its roofline, the same end to end
+        sig = lambda x: None if x is None else float(f"{x:.3g}")
+        cfgs = {}
+        for name, key in (("base_batch_65536", "base_batch_65536"), ("config1_d64", "config1_d64"), ("config3_slice", "config3_slice_1.25Mx1M")):
+            if key in legs:
+                g = legs[key]
+                cfgs[name] = {"value": sig(g["value"]), "ms_per_step": sig(g["ms_per_step"]), "kernel_ms": sig(g["roofline"]["kernel_ms"]),
+                              "frac": sig(g["roofline"]["frac"]), "frac_end_to_end": sig(g["frac_end_to_end"])}
+        if "config4_lightgcn" in legs:
+            g = legs["config4_lightgcn"]
+            cfgs["config4_lightgcn"] = {"value": sig(g["value"]), "ms_per_step": sig(g["train_step_ms"]),
+                                        "kernel_ms": sig(g["propagation_ms_per_product"]), "frac": sig(g["roofline"]["frac"]),
+                                        "frac_end_to_end": None}
+        if scoring is not None:
+            cfgs["scoring"] = {"value": sig(scoring["value"]), "ms_per_step": sig(scoring["ms_per_1024_users"]), "kernel_ms": None,
+                               "frac": sig(scoring["roofline"]["frac"]), "frac_end_to_end": sig(scoring["roofline"]["frac"])}
+        if cfgs:
+            out["roofline"] = {**out["roofline"], "configs": cfgs}
+        out["timed_regions"] = head["timed_regions"]
         if legs:
             out["legs"] = legs
         if scoring is not None:

@@ -97,6 +97,14 @@ int rsx_device_info_get(int device, rsx_device_info *out);
  *   "sample_sort_cap" 0..2048 (default 0 = 2048): pairs a bucket of the sorted sampler may hold and
  *                     still be sorted in LDS; tests lower it to exercise the out-of-LDS path.  The
  *                     sampled triplets do not depend on it.
+ *   "step_waves"      0 (default: the library's choice per row width) or 2..8: wavefronts per SIMD the blocked step kernel
+ *                     (rsx_bpr_step with neg_block / RSX_BATCH_SORTED, rsx_bpr_step_chunked) may keep resident; the launch
+ *                     reserves LDS accordingly.  The kernel shares the chip with the NEXT step's sampler (native loop): what it
+ *                     does not occupy the sampler runs in.  The result does not depend on it.
+ *   "apply_stream"    0 (default) / 1: a chunked, sharded trainer (item chunks with comm or exchange_range) runs the applies
+ *                     of its item ranges on a high-priority stream of their own instead of behind the collectives on the
+ *                     collective stream (pays only where an exchange is longer than the whole step).  Read at
+ *                     rsx_bpr_trainer_create.  The result does not depend on it.
  * There is no option that skips work: the development ablation switches of the kernels exist only
  * in the separate dev build (librsx_dev.so, -DRSX_ABLATE), never in librsx.so.                    */
 int rsx_set_option(const char *name, int64_t value);
@@ -186,6 +194,7 @@ int rsx_adam_apply(float *W, float *M, float *V, float *G, int64_t n, float lr, 
  *   loss_kind 1: F.mse_loss                                                                      dl/dx = 2 (x - y)
  * Dense gradients like rsx_bpr_grad: GP[u_b] += dl/dx * inv_n * Q[i_b], GQ[i_b] += dl/dx * inv_n * P[u_b] (tables
  * untouched; both buffers zero between steps); loss_acc (nullable, RSX_LOSS_SLOTS floats) += sum_b l_b, striped.
+ * GP = GQ = NULL (with loss_acc): the loss alone, nothing written but loss_acc (process_one_batch, MF.py:99-102).
  * Then rsx_adam_apply on both tables (the optimizer as shipped, MF.py:30) or rsx_apply_item_grad on both (SGD). */
 int rsx_pointwise_grad(const float *P, const float *Q, float *GP, float *GQ, int64_t num_users, int64_t num_items,
                        const int32_t *u_dev, const int32_t *i_dev, const float *y_dev, int64_t n, int d,
@@ -280,7 +289,13 @@ int rsx_bpr_build_item_cdf(const int64_t *indptr_dev, const int32_t *indices_dev
  * Contract: triplets that do not honour the range rule are still summed, but race with the other ranges' pipelines;
  * the kernel counts them in progress[RSX_PROGRESS_VIOLATIONS] and the native loop reports the run failed.
  *
- * rsx_chunk_rows: rows per range = ceil(items_real / chunks) rounded up to a multiple of neg_block.
+ * WITHOUT BLOCKS (neg_block = 0; batches below two triplets per item, where a block has nothing to sum on chip -- the shape of
+ * BASELINE configs[3], 1.25M triplets on 1M items per GPU): the same ranges and the same pipelines; the negative of a position is
+ * uniform over the REAL items of its positive's range (rejecting the user's own), the step walks the ordered batch like
+ * RSX_BATCH_SORTED (positive runs summed in registers, negatives to G one by one), one launch per range whose wavefronts split
+ * the range's positions evenly.  Everything below accepts neg_block = 0 for this form.
+ *
+ * rsx_chunk_rows: rows per range = ceil(items_real / chunks) rounded up to a multiple of neg_block (of 1 for neg_block = 0).
  * rsx_bpr_sample_chunked: rsx_bpr_sample(RSX_SAMPLE_SORT_POS, item_cdf) over the relabelled CSR with the range rule;
  *   num_items = chunks * chunk_rows; item_cdf_dev built over those ids (padding rows have no mass); batch <= 2^21;
  *   chunk_pos_out: int64 [chunks + 1] device, first batch position of every range (+ number of live positions).
@@ -379,7 +394,7 @@ int rsx_comm_all_reduce_f32(rsx_comm *c, float *buf_dev, int64_t n, rsx_stream_t
  *                        trainer-owned stream, in range order on every rank) and its apply form a chain on the trainer's
  *                        stream for range k; range k of the next step follows its own apply, whatever the other ranges'
  *                        exchanges are doing.  Every batch of such a trainer (<= 2^21 triplets) takes this form; needs
- *                        neg_block and item_cdf; not combined with two_pass / stale_exchange / exchange_begin, exchange_end /
+ *                        item_cdf and the sampler workspace; neg_block = 0 selects the form without blocks; not combined with two_pass / stale_exchange / exchange_begin, exchange_end /
  *                        RSX_EXCHANGE_SCATTER_GATHER.
  *   exchange_range       (chunks > 1, no comm) the caller's collective for ONE item range, in place of the library's RCCL
  *                        all-reduce: exchange_range(ctx, k, G_rows, n, stream) is called while the step is being queued, once per
@@ -545,6 +560,11 @@ int rsx_spmm_csr_sparse_rows(const int32_t *seg_row_dev, const int64_t *seg_begi
                              const float *vals_dev, const float *X, const uint8_t *x_row_nonzero_dev, float *Y,
                              float *S_acc, int64_t num_rows, int d, rsx_stream_t stream);
 int rsx_scale(float *X, int64_t n, float alpha, rsx_stream_t stream);
+/* rsx_spmm_mark_batch_rows: the row flags rsx_spmm_csr_sparse_rows takes, for the gradient of ONE batch of triplets on the
+ *   stacked [users; items] table: flags (uint8 [num_rows]) = 0 everywhere, then 1 at u[b], item_offset + i[b], item_offset + j[b]
+ *   (triplets with i[b] < 0 are skipped, as the step kernels skip them).                                             */
+int rsx_spmm_mark_batch_rows(uint8_t *flags_dev, int64_t num_rows, const int32_t *u_dev, const int32_t *i_dev,
+                             const int32_t *j_dev, int64_t batch, int64_t item_offset, rsx_stream_t stream);
 
 /* ---- holdout metrics (HOST function, host pointers) --------------------------------
  * Replaces evaluation/backend/cython/include/holdout.h:20-103 (evaluate_holdout) and its

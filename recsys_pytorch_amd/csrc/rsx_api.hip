@@ -29,6 +29,8 @@ int rsx_num_cus()
 
 int g_rsx_score_lanes = 2;
 int g_rsx_sort_cap = 0;
+int g_rsx_apply_stream = 0;
+int g_rsx_step_waves = 0;
 
 RSX_API int rsx_set_option(const char *name, int64_t value)
 {
@@ -41,6 +43,16 @@ RSX_API int rsx_set_option(const char *name, int64_t value)
     if (strcmp(name, "sample_sort_cap") == 0) {
         RSX_CHECK_ARG(value >= 0 && value <= 2048, "sample_sort_cap must be in [0, 2048] (0 = default)");
         g_rsx_sort_cap = (int)value;
+        return RSX_OK;
+    }
+    if (strcmp(name, "step_waves") == 0) {
+        RSX_CHECK_ARG(value == 0 || (value >= 2 && value <= 8), "step_waves must be 0 (default) or in [2, 8]");
+        g_rsx_step_waves = (int)value;
+        return RSX_OK;
+    }
+    if (strcmp(name, "apply_stream") == 0) {
+        RSX_CHECK_ARG(value == 0 || value == 1, "apply_stream must be 0 or 1");
+        g_rsx_apply_stream = (int)value;
         return RSX_OK;
     }
     rsx_set_error("rsx_set_option: unknown option '%s'", name);

@@ -135,11 +135,34 @@ __device__ __forceinline__ float wave_sum(float x)
     return x;
 }
 
-// softplus(-x) = -log(sigmoid(x)), stable for any x (the reference's
-// sigmoid().log() underflows for x < -88, MF.py:105; same value elsewhere)
-__device__ __forceinline__ float softplus_neg(float x)
+// sigmoid(-x) (the coefficient of the gradient, MF.py:105 differentiated) and softplus(-x) = -log(sigmoid(x)) (the loss; stable for
+// any x: the reference's sigmoid().log() underflows for x < -88, same value elsewhere) from ONE exponential e = exp(-|x|) in (0, 1]:
+//     sigmoid(-x) = (x >= 0 ? e : 1) / (1 + e)        softplus(-x) = max(-x, 0) + log(1 + e)
+// on the transcendental unit (v_exp_f32, v_rcp_f32, v_log_f32: 1 ulp each) -- a dozen vector instructions per triplet.  Round 4: the
+// C library's log1pf (a double-float routine, ~140 vector instructions) plus an IEEE division were 60 % of the vector instructions
+// of the step kernels' trip, and the kernels had become issue-bound (SQ_ACTIVE_INST_VALU: the vector pipes ~80 % busy at the
+// headline).  Absolute error of the loss <= 1e-7 per triplet (1 + e rounds e away below 6e-8); relative error of the coefficient 2e-7.
+#ifndef RSX_FAST_LOSS
+#define RSX_FAST_LOSS 1         // 0: log1pf and the IEEE division (development A/B)
+#endif
+__device__ __forceinline__ float sigmoid_neg(float x, float &one_plus_e)
 {
-    return fmaxf(-x, 0.0f) + log1pf(__expf(-fabsf(x)));
+#if RSX_FAST_LOSS
+    const float e = __builtin_amdgcn_exp2f(fabsf(x) * -1.4426950408889634f);
+    one_plus_e = 1.0f + e;
+    return (x >= 0.0f ? e : 1.0f) * __builtin_amdgcn_rcpf(one_plus_e);
+#else
+    one_plus_e = 1.0f + __expf(-fabsf(x));
+    return 1.0f / (1.0f + __expf(x));
+#endif
+}
+__device__ __forceinline__ float softplus_neg(float x, float one_plus_e)
+{
+#if RSX_FAST_LOSS
+    return fmaxf(-x, 0.0f) + __builtin_amdgcn_logf(one_plus_e) * 0.6931471805599453f;
+#else
+    return fmaxf(-x, 0.0f) + log1pf(one_plus_e - 1.0f);
+#endif
 }
 
 // EPL contiguous floats of a wave-private LDS tile (one ds_read/ds_write of 4, 8 or 16 bytes)
@@ -222,20 +245,20 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
         const bool live = live_n;
         if (live) {
             const OffT u_off = row_off<D, OffT>(u, k), i_off = row_off<D, OffT>(i, k), j_off = row_off<D, OffT>(j, k);
-            float dpos = 0.0f, dneg = 0.0f;
+            // x = <p, q_i> - <p, q_j> as ONE dot product with the difference row (which the user update needs anyway): one
+            // butterfly instead of two.  (inactive groups skip the butterfly; the partners of every cross-lane step are
+            //  inside the same 32-lane group, which is live or dead as a whole)
+            float dq[EPL], dot = 0.0f;
 #pragma unroll
             for (int c = 0; c < EPL; ++c) {
-                dpos = fmaf(p.v[c], qi.v[c], dpos);
-                dneg = fmaf(p.v[c], qj.v[c], dneg);
+                dq[c] = qi.v[c] - qj.v[c];
+                dot = fmaf(p.v[c], dq[c], dot);
             }
-            // (inactive groups skip the butterfly; the partners of every cross-lane step are
-            //  inside the same 32-lane group, which is live or dead as a whole)
-            dpos = group_sum(dpos);
-            dneg = group_sum(dneg);
-            const float x = dpos - dneg;
-            const float sneg = 1.0f / (1.0f + __expf(x));      // sigmoid(-x)
+            const float x = group_sum(dot);
+            float ope;
+            const float sneg = sigmoid_neg(x, ope);            // sigmoid(-x)
             const float g = -sneg * inv_batch;                 // dL/dx
-            if (loss_acc != nullptr && k == 0) loss_local += softplus_neg(x);
+            if (loss_acc != nullptr && k == 0) loss_local += softplus_neg(x, ope);
             // item gradients (shared rows): G[i] += g p ; G[j] -= g p
             if constexpr ((PASS & kPassItems) != 0) {
                 const float gi = RSX_ABL(256) ? g * 1.01f : g;   // (dev build only: a planted 1 % error, tests/test_mutation.py)
@@ -252,18 +275,18 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
             if constexpr (MODE == 0) {
                 if constexpr ((PASS & kPassUsers) != 0) {
 #pragma unroll
-                    for (int c = 0; c < EPL; ++c) p.v[c] = fmaf(s, qi.v[c] - qj.v[c], p.v[c]);
+                    for (int c = 0; c < EPL; ++c) p.v[c] = fmaf(s, dq[c], p.v[c]);
                     if (!RSX_ABL(4)) p.store_once_at(P, u_off);
                 }
             } else {
-                Row<D> dq;
+                Row<D> dr;
 #pragma unroll
-                for (int c = 0; c < EPL; ++c) dq.v[c] = qi.v[c] - qj.v[c];
+                for (int c = 0; c < EPL; ++c) dr.v[c] = dq[c];
                 if constexpr (MODE == 1) {
                     const int32_t slot = owner[u] - 1;
-                    dq.atomic_axpy(GU + (size_t)slot * D, k, s);
+                    dr.atomic_axpy(GU + (size_t)slot * D, k, s);
                 } else {
-                    dq.atomic_axpy(GU + (size_t)u * D, k, g);
+                    dr.atomic_axpy(GU + (size_t)u * D, k, g);
                 }
             }
         }
@@ -371,6 +394,19 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
         }
         acc = neg_acc + (size_t)wib * c * D;
         for (int e = lane; e < c * D; e += 64) acc[e] = 0.0f;
+    } else if (chunks.C > 1) {
+        // item ranges without blocks (B < 2 I): chunks.nbc wavefronts per range share the range's positions evenly; every item
+        // row they touch -- positive runs and negatives, both through G -- lies in the range by the sampler's rule
+        const int local = (int)((uint32_t)wave / (uint32_t)chunks.nbc);
+        if (local >= chunks.count) return;
+        my_range = chunks.first + local;
+        const int64_t wic = wave - (int64_t)local * chunks.nbc;
+        const int64_t pc = chunks.pos[my_range], nc = chunks.pos[my_range + 1] - pc;
+        b0 = pc + ceil_div64(wic * nc, chunks.nbc);
+        b1 = pc + ceil_div64((wic + 1) * nc, chunks.nbc);
+        if (b0 >= b1) return;
+        range_lo = (int32_t)(my_range * chunks.Ic);
+        range_hi = (int32_t)(range_lo + chunks.Ic);
     } else {
         b0 = wave * span;
         if (b0 >= B) return;
@@ -393,7 +429,7 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
     // about the same time (same-line atomics serialise): such rows go to the replicas (HotMap)
 #define RSX_RUN_FLUSH(RI, R)                                                      \
     if (kItems && RI >= 0 && !RSX_ABL(1)) {                                       \
-        if (TILE && (RI < range_lo || RI >= range_hi) && k == 0)                  \
+        if (chunks.C > 1 && (RI < range_lo || RI >= range_hi) && k == 0)          \
             atomicAdd(chunks.progress + RSX_PROGRESS_VIOLATIONS, 1u);            \
         const int32_t hs = run_hs;                                                \
         if (hs >= 0) {                                                            \
@@ -409,18 +445,18 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
     auto process = [&](bool live, int32_t u, int32_t i, int32_t j, int32_t hs_i, Row<D> &p,
                        const Row<D> &qi, const Row<D> &qj) __attribute__((always_inline)) {
         if (!live) return;
-        float dpos = 0.0f, dneg = 0.0f;
+        // x = <p, q_i> - <p, q_j> as one dot product with the difference row (the user update needs it anyway): one butterfly
+        float dq[EPL], dot = 0.0f;
 #pragma unroll
         for (int cc = 0; cc < EPL; ++cc) {
-            dpos = fmaf(p.v[cc], qi.v[cc], dpos);
-            dneg = fmaf(p.v[cc], qj.v[cc], dneg);
+            dq[cc] = qi.v[cc] - qj.v[cc];
+            dot = fmaf(p.v[cc], dq[cc], dot);
         }
-        dpos = group_sum(dpos);
-        dneg = group_sum(dneg);
-        const float x = dpos - dneg;
-        const float sneg = 1.0f / (1.0f + __expf(x));
+        const float x = group_sum(dot);
+        float ope;
+        const float sneg = sigmoid_neg(x, ope);
         const float g = -sneg * inv_batch;
-        if (loss_acc != nullptr && k == 0) loss_local += softplus_neg(x);
+        if (loss_acc != nullptr && k == 0) loss_local += softplus_neg(x, ope);
         if constexpr (kItems) {
             const float gi = RSX_ABL(256) ? g * 1.01f : g;   // (dev build only: a planted 1 % error, tests/test_mutation.py)
             // positive item: extend its run, or flush the run and start a new one
@@ -441,7 +477,7 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
             if (!RSX_ABL(2)) {
                 if (!neg_local) {
                     p.atomic_axpy_at(G, row_off<D, OffT>(j, k), -gi);
-                    if (TILE && (j < range_lo || j >= range_hi) && k == 0) atomicAdd(chunks.progress + RSX_PROGRESS_VIOLATIONS, 1u);
+                    if (chunks.C > 1 && (j < range_lo || j >= range_hi) && k == 0) atomicAdd(chunks.progress + RSX_PROGRESS_VIOLATIONS, 1u);
                 }
 #pragma unroll
                 for (int tt = 0; TILE && tt < TPW; ++tt) {
@@ -459,7 +495,7 @@ __global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_ke
         if constexpr (kUsers) {      // last: p is dead after its update
             const float s = -lr * g * (RSX_ABL(128) ? 1.01f : 1.0f);
 #pragma unroll
-            for (int cc = 0; cc < EPL; ++cc) p.v[cc] = fmaf(s, qi.v[cc] - qj.v[cc], p.v[cc]);
+            for (int cc = 0; cc < EPL; ++cc) p.v[cc] = fmaf(s, dq[cc], p.v[cc]);
             if (!RSX_ABL(4)) p.store_once_at(P, row_off<D, OffT>(u, k));
         }
     };
@@ -605,11 +641,14 @@ __global__ __launch_bounds__(kBlock) void pointwise_grad_kernel(const float *__r
             g = 2.0f * (x - y) * inv_n;
             if (loss_acc != nullptr && k == 0) loss_local += (x - y) * (x - y);
         } else {
-            g = (1.0f / (1.0f + __expf(-x)) - y) * inv_n;
-            if (loss_acc != nullptr && k == 0) loss_local += fmaxf(x, 0.0f) - x * y + log1pf(__expf(-fabsf(x)));
+            float ope;
+            g = (sigmoid_neg(-x, ope) - y) * inv_n;                                  // sigmoid(x) - y
+            if (loss_acc != nullptr && k == 0) loss_local += softplus_neg(-x, ope) - x * y;   // max(x, 0) - x y + log(1 + exp(-|x|))
         }
-        q.atomic_axpy_at(GP, u_off, g);
-        p.atomic_axpy_at(GQ, i_off, g);
+        if (GP != nullptr) {           // (NULL gradient buffers: the loss alone -- MF.process_one_batch on the pointwise branch)
+            q.atomic_axpy_at(GP, u_off, g);
+            p.atomic_axpy_at(GQ, i_off, g);
+        }
     }
     if (loss_acc != nullptr) {
         const float w = wave_sum(loss_local);
@@ -857,12 +896,36 @@ void dispatch_step(int d, bool wide, float *P, const float *Q, float *G, const i
 #undef RSX_LAUNCH
 }
 
+// Resident wavefronts per SIMD of the blocked kernel, by LDS reservation (a 256-thread workgroup = one wavefront per SIMD; a CU has
+// 160 KB of LDS).  Round 4: with the transcendental-unit loss the kernel needs 64 VGPRs at d = 128 (47 at d = 64) and would run 8
+// wavefronts per SIMD -- its own duration hardly changes between 5 and 8, but the sampler of the next step, which runs in what the
+// step kernel leaves free, is squeezed out and the step's PERIOD grows (same box, headline: 8 resident -> 337-352 us per step
+// against 314-317 at 6; profiles/r04_exp_step_valu.txt).  rsx_set_option("step_waves") overrides.
+#ifndef RSX_STEP_WAVES_D128
+#define RSX_STEP_WAVES_D128 6
+#endif
+#ifndef RSX_STEP_WAVES_D64
+#define RSX_STEP_WAVES_D64 6
+#endif
+static size_t lds_for_residency(size_t need, int d)
+{
+    int waves = g_rsx_step_waves > 0 ? g_rsx_step_waves : (d >= 128 ? RSX_STEP_WAVES_D128 : RSX_STEP_WAVES_D64);
+    if (waves >= 8) return need;
+    // the smallest reservation with which waves + 1 workgroups no longer fit a CU's 160 KB (allocation granule 512 B... 1 KB to be safe)
+    const size_t cu = 160 * 1024;
+    size_t lds = cu / (size_t)(waves + 1) + 1024;
+    lds = (lds + 1023) / 1024 * 1024;
+    if (lds * (size_t)waves > cu) lds = cu / (size_t)waves / 1024 * 1024;
+    return lds > need ? lds : need;
+}
+
 template <int PASS, bool TILE>
 void dispatch_blocked(int d, bool wide, unsigned blocks, size_t lds, hipStream_t st, float *P, const float *Q, float *G,
                       const int32_t *u, const int32_t *i, const int32_t *j, int64_t B, int64_t num_items,
                       int c, int64_t span, uint64_t neg_key, float lr, float inv_batch, float *loss_acc, HotMap hot,
                       ChunkRun chunks = ChunkRun{1, 0, 1, 0, 0, nullptr, nullptr})
 {
+    lds = lds_for_residency(lds, d);
 #define RSX_LAUNCH(D_) do { if (wide) hipLaunchKernelGGL((bpr_step_blocked_kernel<D_, PASS, uint64_t, TILE>), dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u, i, j, B, num_items, c, span, neg_key, lr, inv_batch, loss_acc, hot, chunks); \
                             else hipLaunchKernelGGL((bpr_step_blocked_kernel<D_, PASS, uint32_t, TILE>), dim3(blocks), dim3(kBlock), lds, st, P, Q, G, u, i, j, B, num_items, c, span, neg_key, lr, inv_batch, loss_acc, hot, chunks); } while (0)
     switch (d) {
@@ -1010,7 +1073,7 @@ RSX_API int rsx_pointwise_grad(const float *P, const float *Q, float *GP, float 
                                const int32_t *u_dev, const int32_t *i_dev, const float *y_dev, int64_t n, int d,
                                float inv_n, int loss_kind, float *loss_acc, rsx_stream_t stream)
 {
-    RSX_CHECK_ARG(P && Q && GP && GQ, "null table pointer");
+    RSX_CHECK_ARG(P && Q && ((GP && GQ) || (!GP && !GQ && loss_acc)), "null table pointer (GP and GQ may both be NULL for the loss alone)");
     RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64 or 128");
     RSX_CHECK_ARG(n >= 0 && num_users > 0 && num_items > 0, "negative size");
     RSX_CHECK_ARG(loss_kind == 0 || loss_kind == 1, "loss_kind: 0 = binary cross entropy with logits, 1 = mean squared error");
@@ -1124,9 +1187,9 @@ RSX_API int rsx_bpr_step_chunked(float *P, const float *Q, float *G, int64_t num
     RSX_CHECK_ARG(first_range >= 0 && num_ranges >= 1 && first_range + num_ranges <= chunks, "ranges [first, first + count) must lie in [0, chunks)");
     RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64 or 128");
     RSX_CHECK_ARG(chunks >= 2 && chunks <= RSX_MAX_CHUNKS, "chunks must be in [2, RSX_MAX_CHUNKS]");
-    RSX_CHECK_ARG(neg_block >= 1 && neg_block <= kMaxNegBlock, "the chunked step needs neg_block in [1, 16]");
+    RSX_CHECK_ARG(neg_block >= 0 && neg_block <= kMaxNegBlock, "neg_block must be in [0, 16]");
     RSX_CHECK_ARG(batch >= 0 && num_users > 0 && items_real > 0, "negative size");
-    const ChunkGeom g = chunk_geom(items_real, chunks, neg_block);
+    const ChunkGeom g = chunk_geom(items_real, chunks, neg_block < 1 ? 1 : neg_block);
     RSX_CHECK_ARG(num_items == g.Ic * chunks, "num_items must be chunks * rsx_chunk_rows(items_real, chunks, neg_block)");
     if (batch == 0) return RSX_OK;
     RSX_CHECK_ARG(u_dev && i_dev && j_dev, "null index pointer");
@@ -1137,6 +1200,20 @@ RSX_API int rsx_bpr_step_chunked(float *P, const float *Q, float *G, int64_t num
         hot = HotMap{hot_slot_dev, G_hot, hot_replicas};
     }
     const bool wide = wide_offsets(num_users, num_items, d) || batch >= (1ll << 30);
+    if (neg_block == 0) {
+        // no blocks (batches below two triplets per item): the walk of the ordered batch without the negative-side tile, a
+        // range's share of RSX_RUNS_ROUNDS rounds of wavefronts per range (at least 8 positions per wavefront of an even split)
+        const int64_t slots = (int64_t)rsx_num_cus() * 4 * RSX_BLOCKED_WAVES * RSX_RUNS_ROUNDS;
+        int64_t per_range = ceil_div64(slots, chunks);
+        const int64_t most = ceil_div64(ceil_div64(batch, chunks), 8);
+        if (per_range > most) per_range = most < 1 ? 1 : most;
+        const unsigned blocks = (unsigned)ceil_div64(per_range * num_ranges, kWavesPerBlock);
+        dispatch_blocked<kPassBoth, false>(d, wide, blocks, 0, (hipStream_t)stream, P, Q, G, u_dev, i_dev, j_dev, batch, num_items,
+                                           0, 0, 0, lr, inv_batch, loss_acc, hot,
+                                           ChunkRun{chunks, first_range, num_ranges, g.Ic, per_range, chunk_pos_dev, progress_dev});
+        RSX_CHECK_LAUNCH();
+        return RSX_OK;
+    }
     const int64_t waves = g.nbc * num_ranges;
     const unsigned blocks = (unsigned)ceil_div64(waves, kWavesPerBlock);
     const size_t lds = (size_t)kWavesPerBlock * neg_block * d * sizeof(float);

@@ -52,6 +52,8 @@ static __constant__ int c_rsx_ablate = 0;
 // process-wide options behind rsx_set_option (include/rsx.h)
 extern int g_rsx_score_lanes;   // passes of the fused scoring path in flight (1..4)
 extern int g_rsx_sort_cap;      // LDS sort capacity of the bucket sampler (test hook for the out-of-LDS path)
+extern int g_rsx_step_waves;    // resident wavefronts per SIMD the blocked step kernel is held to (0: the default of rsx_bpr.hip)
+extern int g_rsx_apply_stream;  // chunked + sharded trainer: the ranges' applies on a stream of their own (opt-in)
 
 // rsx_det.hip: the deterministic form of the step (RSX_DETERMINISTIC); arguments validated by rsx_bpr_step
 int rsx_bpr_step_deterministic(float *P, const float *Q, float *G, int64_t num_items, const int32_t *u_dev,

@@ -248,6 +248,37 @@ RSX_API int rsx_spmm_csr_sparse_rows(const int32_t *seg_row_dev, const int64_t *
     return RSX_OK;
 }
 
+__global__ __launch_bounds__(256) void mark_batch_rows_kernel(uint8_t *__restrict__ flags, const int32_t *__restrict__ u,
+                                                              const int32_t *__restrict__ i, const int32_t *__restrict__ j,
+                                                              int64_t B, int64_t item_offset)
+{
+    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (int64_t)gridDim.x * 256) {
+        const int32_t ib = i[b];
+        if (ib < 0) continue;
+        flags[u[b]] = 1;                       // (benign same-value races between triplets that share a row)
+        flags[item_offset + ib] = 1;
+        flags[item_offset + j[b]] = 1;
+    }
+}
+
+RSX_API int rsx_spmm_mark_batch_rows(uint8_t *flags_dev, int64_t num_rows, const int32_t *u_dev, const int32_t *i_dev,
+                                     const int32_t *j_dev, int64_t batch, int64_t item_offset, rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(flags_dev != nullptr && num_rows > 0 && batch >= 0 && item_offset >= 0 && item_offset <= num_rows, "bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(flags_dev, 0, (size_t)num_rows, st) != hipSuccess) {
+        rsx_set_error("rsx_spmm_mark_batch_rows: memset failed");
+        return RSX_E_HIP;
+    }
+    if (batch == 0) return RSX_OK;
+    RSX_CHECK_ARG(u_dev && i_dev && j_dev, "null index pointer");
+    int64_t blocks = (batch + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(mark_batch_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, flags_dev, u_dev, i_dev, j_dev, batch, item_offset);
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+}
+
 RSX_API int rsx_scale(float *X, int64_t n, float alpha, rsx_stream_t stream)
 {
     RSX_CHECK_ARG(X != nullptr && n >= 0 && n % 4 == 0, "n must be a multiple of 4");

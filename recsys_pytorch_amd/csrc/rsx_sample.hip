@@ -224,6 +224,7 @@ struct ChunkArgs {
     int C, NBc;
     ChunkGeom g;
     int64_t *chunk_pos_out;      // [C + 1]
+    bool whole;                  // negatives uniform over the REAL items of the position's range (neg_block = 0: no blocks)
 };
 
 // negative range of the position `rel` (relative to its range's first position; the range holds nc live positions) inside
@@ -463,6 +464,7 @@ struct NegCtx {
     ChunkGeom g;
     int64_t pc, nc;
     const uint8_t *wn;       // real items per negative range of the bucket's table (chunked layout)
+    bool whole;              // chunked layout without blocks: every draw is over the range's real items
 };
 
 __device__ __forceinline__ void negatives_lockstep(
@@ -495,6 +497,8 @@ __device__ __forceinline__ void negatives_lockstep(
                 while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wstart[mid] <= p[g]) lo = mid; else hi = mid; }
                 nlo[g] = wlo[lo];
                 nn[g] = chunked ? (int64_t)cx.wn[lo] : ((nlo[g] + neg_block <= I) ? neg_block : I - nlo[g]);
+            } else if (chunked && cx.whole) {
+                nlo[g] = flo; nn[g] = fn;
             } else if (chunked) {
                 neg_range_chunk(cx.g, cx.ch, p[g] - cx.pc, cx.nc, neg_key, nlo[g], nn[g]);
             } else {
@@ -643,7 +647,7 @@ __global__ __launch_bounds__(kBlock, 5) void bucket_sort_kernel(
     }
     if (tid == kBlock - 1) cstart[kMaxChunks] = base;
     const int64_t p0 = piece_lo + red[0] + red[1] + red[2] + red[3];
-    NegCtx cx{ca.C, ch, ca.g, 0, 0, wn};
+    NegCtx cx{ca.C, ch, ca.g, 0, 0, wn, ca.whole};
     if (chunked) {
         cx.pc = (int64_t)red_cb[0] + red_cb[1] + red_cb[2] + red_cb[3];
         cx.nc = (int64_t)red_ct[0] + red_ct[1] + red_ct[2] + red_ct[3];
@@ -658,7 +662,9 @@ __global__ __launch_bounds__(kBlock, 5) void bucket_sort_kernel(
     // position ceil(w*c*B/I) and draws from item block pi(w); 64-bit divisions and the block
     // permutation are paid once per range here instead of once per position
     int m = 0;
-    if (chunked && bk < nbm) {
+    if (chunked && ca.whole) {
+        // (no blocks: the candidates of every position are the real items of its range)
+    } else if (chunked && bk < nbm) {
         const ChunkGeom &g = ca.g;
         const int64_t w_first = (((p0 - cx.pc) * g.Ic) / cx.nc) / g.c, w_last = (((p0 + n - 1 - cx.pc) * g.Ic) / cx.nc) / g.c;
         if (w_last - w_first < kRangeCap) {
@@ -908,7 +914,7 @@ RSX_API int rsx_bpr_sample(const int64_t *indptr_dev, const int32_t *indices_dev
             const int nbm = buckets_for(n), NB = nbm + 1;
             const int nblk = (int)((n + kChunk - 1) / kChunk);
             const BucketWs w = bucket_carve(ws, n, NB);
-            const ChunkArgs ca{1, 0, ChunkGeom{}, nullptr};
+            const ChunkArgs ca{1, 0, ChunkGeom{}, nullptr, false};
             if (hipMemsetAsync(w.totals, 0, (size_t)NB * 4 * kTotalStride, st) != hipSuccess) {
                 rsx_set_error("rsx_bpr_sample: memset failed");
                 return RSX_E_HIP;
@@ -948,8 +954,8 @@ RSX_API int rsx_bpr_sample(const int64_t *indptr_dev, const int32_t *indices_dev
 
 RSX_API int64_t rsx_chunk_rows(int64_t items_real, int chunks, int neg_block)
 {
-    if (items_real <= 0 || chunks < 1 || chunks > RSX_MAX_CHUNKS || neg_block < 1 || neg_block > kMaxNegBlock) return RSX_E_INVALID;
-    return chunk_geom(items_real, chunks, neg_block).Ic;
+    if (items_real <= 0 || chunks < 1 || chunks > RSX_MAX_CHUNKS || neg_block < 0 || neg_block > kMaxNegBlock) return RSX_E_INVALID;
+    return chunk_geom(items_real, chunks, neg_block < 1 ? 1 : neg_block).Ic;
 }
 
 RSX_API int rsx_bpr_sample_chunked(const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users,
@@ -961,9 +967,12 @@ RSX_API int rsx_bpr_sample_chunked(const int64_t *indptr_dev, const int32_t *ind
 {
     RSX_CHECK_ARG(indptr_dev && indices_dev && u_out && i_out && j_out && chunk_pos_out && item_cdf_dev, "null pointer");
     RSX_CHECK_ARG(chunks >= 2 && chunks <= RSX_MAX_CHUNKS, "chunks must be in [2, RSX_MAX_CHUNKS]");
-    RSX_CHECK_ARG(neg_block >= 1 && neg_block <= kMaxNegBlock, "the chunked layout needs neg_block in [1, 16]");
+    RSX_CHECK_ARG(neg_block >= 0 && neg_block <= kMaxNegBlock, "neg_block must be in [0, 16]");
     RSX_CHECK_ARG(num_users > 0 && num_users < (1ll << 31) && items_real > 0 && num_items < (1ll << 31), "table sizes must fit int32");
-    const ChunkGeom g = chunk_geom(items_real, chunks, neg_block);
+    // neg_block = 0: no item blocks -- the negative of a position is uniform over the real items of its range (batches below two
+    // triplets per item, where the blocked layout has nothing to sum on chip); the ranges are then ceil(items_real / chunks) rows
+    const bool whole = neg_block == 0;
+    const ChunkGeom g = chunk_geom(items_real, chunks, whole ? 1 : neg_block);
     RSX_CHECK_ARG(num_items == g.Ic * chunks, "num_items must be chunks * rsx_chunk_rows(items_real, chunks, neg_block)");
     RSX_CHECK_ARG(batch >= 0 && batch <= kPiece && epoch_pos >= 0, "the chunked layout orders at most 2^21 positions");
     if (batch == 0) return RSX_OK;
@@ -982,7 +991,7 @@ RSX_API int rsx_bpr_sample_chunked(const int64_t *indptr_dev, const int32_t *ind
         rsx_set_error("rsx_bpr_sample_chunked: memset failed");
         return RSX_E_HIP;
     }
-    const ChunkArgs ca{chunks, NBc, g, chunk_pos_out};
+    const ChunkArgs ca{chunks, NBc, g, chunk_pos_out, whole};
     const size_t lds = ((size_t)((NB + 3) & ~3)) * 4 + (size_t)kChunk * sizeof(uint2);
     hipLaunchKernelGGL(bucket_chunk_kernel, dim3(nblk), dim3(kChunkThreads), lds, st, indptr_dev, indices_dev, item_cdf_dev,
                        num_users, num_items, (int64_t)0, batch, seed, step, epoch_pos, hb, nbm, nblk, w.pairs, w.table, w.totals, ca);

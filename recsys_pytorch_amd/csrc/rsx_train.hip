@@ -34,6 +34,12 @@ struct rsx_bpr_trainer {
     // the exchange of a sharded step issued by the library (RCCL, config.comm) and the range-by-range apply of the
     // chunked step run here: highest priority, so that their few workgroups get the next free wave slots under the step kernel
     hipStream_t aux = nullptr;
+    // chunked + sharded, OPT-IN (rsx_set_option "apply_stream" = 1): the ranges' applies leave the collective stream, where
+    // apply(k) holds back the collective of range k + 1 -- at the BASELINE configs[3] shape (1M items: 256 MB per range at two
+    // ranges) an apply is ~150 us.  Measured (profiles/r04_exchange_model_config3.txt, us per step at an exchange of 0.5 / 1.0 /
+    // 1.5 ms): on the collective stream 1154 / 1406 / 1898, on a stream of its own 1392 / 1537 / 1748 -- the fifth HIP stream costs
+    // more than the serialisation until the exchange is longer than the step; off by default
+    hipStream_t apply_st = nullptr;
     hipEvent_t ev_start = nullptr;               // run stream -> aux: the step's counters are reset, the tables are consistent
     hipEvent_t ev_g = nullptr;                   // run stream -> aux: G (folded) is complete
     hipEvent_t ev_x[2] = {};                     // aux -> run stream: the exchange (+ apply) of gradient buffer 0 / 1 is done
@@ -217,9 +223,10 @@ RSX_API int rsx_bpr_trainer_create(const rsx_bpr_trainer_config *cfg, rsx_bpr_tr
     RSX_CHECK_ARG(!cfg->stale_exchange || ((cfg->exchange_begin != nullptr || native) && !sg && cfg->G_alt != nullptr && cfg->G_alt != cfg->G),
                   "stale_exchange needs an exchange (callbacks or an all-reduce communicator) and a second gradient buffer G_alt");
     if (cfg->chunks > 1) {
-        RSX_CHECK_ARG(cfg->chunks <= RSX_MAX_CHUNKS && cfg->neg_block > 0 && cfg->item_cdf != nullptr && cfg->chunk_pos != nullptr &&
-                      cfg->progress != nullptr && cfg->items_real > 0,
-                      "chunks > 1 needs neg_block, item_cdf, chunk_pos, progress and items_real");
+        RSX_CHECK_ARG(cfg->chunks <= RSX_MAX_CHUNKS && cfg->item_cdf != nullptr && cfg->chunk_pos != nullptr &&
+                      cfg->progress != nullptr && cfg->items_real > 0 && cfg->sample_ws != nullptr &&
+                      cfg->sample_ws_bytes >= rsx_bpr_sample_workspace(cfg->batch, cfg->num_items),
+                      "chunks > 1 needs item_cdf, chunk_pos, progress, items_real and the sampler workspace");
         RSX_CHECK_ARG(cfg->num_items == cfg->chunks * rsx_chunk_rows(cfg->items_real, cfg->chunks, cfg->neg_block),
                       "chunks > 1: num_items must be chunks * rsx_chunk_rows(items_real, chunks, neg_block)");
         RSX_CHECK_ARG(cfg->batch <= (1ll << 21), "chunks > 1: at most 2^21 triplets per step");
@@ -253,6 +260,9 @@ RSX_API int rsx_bpr_trainer_create(const rsx_bpr_trainer_config *cfg, rsx_bpr_tr
     for (int s = 0; ok && s < rsx_bpr_trainer::S; ++s)
         ok = hipEventCreateWithFlags(&t->ready[s], kOrderOnly) == hipSuccess &&
              hipEventCreateWithFlags(&t->freed[s], kOrderOnly) == hipSuccess;
+    if (ok && cfg->chunks > 1 && (native || cfg->exchange_range != nullptr)) {
+        if (g_rsx_apply_stream == 1) ok = hipStreamCreateWithPriority(&t->apply_st, hipStreamNonBlocking, prio_hi) == hipSuccess;
+    }
     for (int k = 0; ok && k < cfg->chunks && cfg->chunks > 1; ++k) {
         // range 0 most urgent, the others at the default priority; the LOWEST level stays with the sampler alone.  Measured
         // (one GPU, no exchange, us per step at C = 2 / 3 / 4): 443 / 467 / 550 with descending priorities, 433 / 474 / 684
@@ -283,6 +293,7 @@ RSX_API void rsx_bpr_trainer_destroy(rsx_bpr_trainer *t)
     if (t == nullptr) return;
     if (t->side) { (void)hipStreamSynchronize(t->side); (void)hipStreamDestroy(t->side); }
     if (t->aux) { (void)hipStreamSynchronize(t->aux); (void)hipStreamDestroy(t->aux); }
+    if (t->apply_st) { (void)hipStreamSynchronize(t->apply_st); (void)hipStreamDestroy(t->apply_st); }
     for (hipEvent_t e : {t->ev_start, t->ev_g, t->ev_x[0], t->ev_x[1]}) if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < RSX_MAX_CHUNKS; ++k) {
         if (t->cs[k]) { (void)hipStreamSynchronize(t->cs[k]); (void)hipStreamDestroy(t->cs[k]); }
@@ -413,7 +424,7 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
             // The run stream only joins: it frees the triplet slot when the kernels are done, and ends the run behind
             // the last applies.  Range k of the NEXT step follows apply(k) in cs[k]'s own order -- it does not wait for
             // the other ranges' exchanges, which travel under it.
-            const ChunkGeom g = chunk_geom(c.items_real, c.chunks, c.neg_block);
+            const ChunkGeom g = chunk_geom(c.items_real, c.chunks, c.neg_block < 1 ? 1 : c.neg_block);
             const int par = (int)(t->step & 1);
             if (s == 0) {        // the ranges' streams start behind whatever the run stream holds (a previous run, the caller's work)
                 RSX_HIP(hipEventRecord(t->ev_start, st));
@@ -449,6 +460,14 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
                         return RSX_E_INVALID;
                     }
                     RSX_TRY(rsx_debug_exchange_delay(t->aux, c.chunks));
+                    if (t->apply_st != nullptr) {       // the apply off the collective stream: the next range's collective follows at once
+                        RSX_HIP(hipEventRecord(t->ev_r[k], t->aux));
+                        RSX_HIP(hipStreamWaitEvent(t->apply_st, t->ev_r[k], 0));
+                        RSX_TRY(rsx_apply_item_grad(Qk, Gk, g.Ic, c.d, c.lr, nullptr, nullptr, 0, (rsx_stream_t)t->apply_st));
+                        RSX_HIP(hipEventRecord(t->ev_a[k], t->apply_st));
+                        RSX_HIP(hipStreamWaitEvent(ck, t->ev_a[k], 0));
+                        continue;
+                    }
                     RSX_TRY(rsx_apply_item_grad(Qk, Gk, g.Ic, c.d, c.lr, nullptr, nullptr, 0, (rsx_stream_t)t->aux));
                 } else {
                     RSX_HIP(hipStreamWaitEvent(t->aux, t->ev_k[k][par], 0));

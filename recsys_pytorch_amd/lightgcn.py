@@ -131,10 +131,7 @@ class LightGCN(BaseModel):
         # product is told which rows to fetch at all (65 536 of 1M users in a batch: 93 % of the rows an item row gathers)
         if self._nz is None:
             self._nz = torch.zeros(self._E0.shape[0], dtype=torch.uint8, device=self.device)
-        self._nz.zero_()
-        self._nz[u.long()] = 1
-        self._nz[U + i.long()] = 1
-        self._nz[U + j.long()] = 1
+        k.mark_batch_rows(self._nz, u, i, j, U)
         self._propagate(self._dout, self._g, src_nonzero=self._nz)
         self._dout.zero_()
         self._t += 1

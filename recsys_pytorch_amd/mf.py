@@ -143,11 +143,11 @@ class MF(BaseModel):
     # -- models/MF.py:99-107: the loss of one batch (no update) ---------------------------
     def process_one_batch(self, users, items, ratings):
         if self.pointwise:                       # MF.py:101-102: loss_func(forward(users, items), ratings)
-            x = self.forward(users, items)
-            y = torch.as_tensor(ratings).to(device=self.device, dtype=torch.float32)
-            if self.loss_func == "mse":
-                return ((x - y) ** 2).mean()
-            return (x.clamp_min(0) - x * y + torch.log1p(torch.exp(-x.abs()))).mean()
+            u, i = self._idx(users), self._idx(items)
+            y = torch.as_tensor(ratings).to(device=self.device, dtype=torch.float32).contiguous()
+            acc = torch.zeros(self._k.RSX_LOSS_SLOTS, dtype=torch.float32, device=self.device)
+            self._k.pointwise_grad(self._P, self._Q, None, None, u, i, y, 1.0, loss_func=self.loss_func, loss_acc=acc)
+            return acc.sum() / max(1, u.numel())
         u, i, j = self._idx(users), self._idx(items), self._idx(ratings)
         acc = torch.zeros(self._k.RSX_LOSS_SLOTS, dtype=torch.float32, device=self.device)
         self._k.bpr_step(self._P, self._Q, None, u, i, j, 0.0, 1.0, loss_acc=acc, no_update=True)

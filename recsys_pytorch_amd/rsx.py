@@ -52,6 +52,7 @@ SIGNATURES = {
     "rsx_spmm_csr": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
     "rsx_spmm_csr_sparse_rows": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
     "rsx_scale": (C.c_int, [_P, _I64, _F, _P]),
+    "rsx_spmm_mark_batch_rows": (C.c_int, [_P, _I64, _P, _P, _P, _I64, _I64, _P]),
     "rsx_pair_score": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P]),
     "rsx_eval_holdout": (C.c_int, [_I64, _P, _I32, _P, _I32, _P, _P, _P]),
     "rsx_eval_loo": (C.c_int, [_I64, _P, _I32, _P, _I32, _P, _P]),
@@ -133,7 +134,7 @@ def version():
 
 
 def set_option(name, value):
-    """include/rsx.h:rsx_set_option ("score_lanes", "sample_sort_cap")"""
+    """include/rsx.h:rsx_set_option ("score_lanes", "sample_sort_cap", "apply_stream")"""
     _check(lib().rsx_set_option(name.encode(), int(value)), "rsx_set_option")
 
 
@@ -219,10 +220,10 @@ def bpr_grad(P, Q, GP, GQ, u, i, j, inv_batch, loss_acc=None):
 
 def pointwise_grad(P, Q, GP, GQ, u, i, y, inv_n, loss_func="ce", loss_acc=None):
     """dense gradients of one POINTWISE batch (models/MF.py:99-102, hparams['pointwise']); loss_func "ce"
-    (binary_cross_entropy_with_logits) or "mse"; tables untouched"""
+    (binary_cross_entropy_with_logits) or "mse"; tables untouched.  GP = GQ = None: the loss alone (into loss_acc)"""
     _check(lib().rsx_pointwise_grad(
-        _dev(P, torch.float32, "P"), _dev(Q, torch.float32, "Q"), _dev(GP, torch.float32, "GP"),
-        _dev(GQ, torch.float32, "GQ"), P.shape[0], Q.shape[0], _dev(u, torch.int32, "u"), _dev(i, torch.int32, "i"),
+        _dev(P, torch.float32, "P"), _dev(Q, torch.float32, "Q"), _dev(GP, torch.float32, "GP") if GP is not None else None,
+        _dev(GQ, torch.float32, "GQ") if GQ is not None else None, P.shape[0], Q.shape[0], _dev(u, torch.int32, "u"), _dev(i, torch.int32, "i"),
         _dev(y, torch.float32, "y"), u.numel(), P.shape[1], float(inv_n), int(loss_func == "mse"),
         _dev(loss_acc, torch.float32, "loss_acc") if loss_acc is not None else None, _stream()), "rsx_pointwise_grad")
 
@@ -277,6 +278,13 @@ def spmm(graph, X, Y, S_acc=None, x_nonzero=None):
         _check(lib().rsx_spmm_csr(*common, *tail), "rsx_spmm_csr")
     else:
         _check(lib().rsx_spmm_csr_sparse_rows(*common, _dev(x_nonzero, torch.uint8, "x_nonzero"), *tail), "rsx_spmm_csr_sparse_rows")
+
+
+def mark_batch_rows(flags, u, i, j, item_offset):
+    """include/rsx.h:rsx_spmm_mark_batch_rows -- flags (uint8 [N]) = 1 exactly at the rows a batch's gradient touches"""
+    _check(lib().rsx_spmm_mark_batch_rows(_dev(flags, torch.uint8, "flags"), flags.numel(), _dev(u, torch.int32, "u"),
+                                          _dev(i, torch.int32, "i"), _dev(j, torch.int32, "j"), u.numel(), int(item_offset),
+                                          _stream()), "rsx_spmm_mark_batch_rows")
 
 
 def scale(X, alpha):
@@ -473,7 +481,7 @@ class BPRTrainer:
             self.progress = torch.zeros(RSX_PROGRESS_WORDS, dtype=torch.int32, device=dev)
         self.triplets = torch.empty(RSX_TRAINER_SLOTS * 3 * self.batch, dtype=torch.int32, device=dev)
         self.sample_ws = None
-        if neg_block or sort_min_batch:
+        if neg_block or sort_min_batch or self.chunks > 1:
             self.sample_ws = torch.empty(bpr_sample_workspace(self.batch, int(num_items) if num_items is not None else Q.shape[0]),
                                          dtype=torch.uint8, device=dev)
         self._keep = (P, Q, G, indptr, indices, hot, user_sig, item_cdf, loss_acc, G_alt, comm)

@@ -304,7 +304,8 @@ class BPREngine:
             hot = self.k.HotItems(cm, num_hot, replicas, d, dev)
         r = {"csr": (indptr, indices), "nb": nb, "C": C, "Ic": Ic, "round": self._relabel_round, "item_rank": item_rank, "rank_item": rank_item, "real": real,
              "indices": indices_m, "Q": Qm, "G": torch.zeros_like(Qm), "hot": hot,
-             "sig": self.k.build_signature(indptr, indices_m, nb), "cdf": self.k.build_item_cdf(indptr, indices_m, C * Ic)}
+             "sig": self.k.build_signature(indptr, indices_m, nb) if nb else None,
+             "cdf": self.k.build_item_cdf(indptr, indices_m, C * Ic)}
         self._relabel = r
         return r
 
@@ -614,7 +615,11 @@ class BPREngine:
         native = self.sharded and self.comm is not None       # the library issues the exchange itself (RCCL)
         kind = {"allreduce": 1, "scatter_gather": 2}[self.exchange] if native else 0      # RSX_EXCHANGE_*
         stale = bool(self.stale_exchange) and self.sharded
-        if self.chunks and self.neg_block and (batch >= 2 * self.Q.shape[0] or self.blocked_any_batch) and batch <= (1 << 21) and not stale:
+        blocked = bool(self.neg_block) and (batch >= 2 * self.Q.shape[0] or self.blocked_any_batch)
+        # (below two triplets per item the ranges run WITHOUT blocks -- include/rsx.h "item chunks", neg_block = 0: negatives
+        #  uniform over the real items of the positive's range -- wherever the ordered layout engages at all)
+        unblocked = not self.neg_block and bool(self.sorted_min_batch) and batch >= self.sorted_min_batch
+        if self.chunks and (blocked or unblocked) and batch <= (1 << 21) and not stale:
             # the step as a pipeline over item ranges, in the relabelled item space (set_chunks)
             r = self._build_relabel(indptr, indices)
             self._items_to_relabelled()

@@ -95,6 +95,7 @@ def adam_apply(W, M, V, G, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):
 def chunk_rows(items_real, chunks, neg_block):
     """include/rsx.h:rsx_chunk_rows"""
     most = -(-items_real // chunks)
+    neg_block = max(1, neg_block)
     return -(-most // neg_block) * neg_block
 
 

@@ -49,6 +49,14 @@ def test_bench_json_contract_small_shape():
             "top50_cxx_partial_sort_1_thread"} <= set(c["legs"])
     s = d["scoring"]["roofline"]
     assert s["bound"] == "mfma" and s["peak"] == 157.3
+    # the headline is the MEDIAN of three back-to-back timed regions
+    tr = d["timed_regions"]
+    assert tr["count"] == 3 and tr["min"] <= d["ms_per_step"] <= tr["max"] and sorted(tr["ms_per_step_each"])[1] == d["ms_per_step"]
+    # every config's figure inside the object the driver keeps (`roofline`), compact
+    cf = r["configs"]
+    assert {"base_batch_65536", "config1_d64", "scoring"} <= set(cf) and len(json.dumps(cf)) <= 700
+    for v in cf.values():
+        assert set(v) == {"value", "ms_per_step", "kernel_ms", "frac", "frac_end_to_end"} and v["value"] > 0
 
 
 @pytest.mark.gpu
@@ -107,6 +115,10 @@ def test_roofline_is_physical():
     assert r["traffic"] == t[key]["hbm_bytes_per_launch"]
     assert abs(r["achieved"] - r["traffic"] / 0.33e-3 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
     assert 0.3 < r["frac"] < 1.0 and r["traffic_source"]["file"].startswith("profiles/")
+    # stale: the kernel sources hash differently from the ones the profile was taken on (None: a profile older than the record)
+    assert r["traffic_source"]["stale"] in (None, False, True)
+    if t[key].get("sources_sha"):
+        assert r["traffic_source"]["stale"] == (t[key]["sources_sha"] != bench.sources_sha("step"))
     assert r["algorithmic_rate_over_peak"] > 1.0            # the contract figure: not a fraction, and named accordingly
     assert 0.9 < r["traffic_over_compulsory"] < 1.5
     n = bench.roofline("bpr_step_kernel", 0.1, 10, 4321, 100_000, 128, "no_such_leg")

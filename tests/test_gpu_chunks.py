@@ -11,6 +11,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _engine(U, I, d, B, deg, chunks, lr, seed=3, hot=0, max_block=8, pop="zipf"):
+    """B >= 2 I: the blocked layout (negatives from an item block of the positive's range); below: the ranges WITHOUT blocks
+    (include/rsx.h "item chunks", neg_block = 0: negatives uniform over the real items of the positive's range)"""
     from recsys_pytorch_amd.data import synthetic_csr
     from recsys_pytorch_amd.sharded import BPREngine
     ip, ix = synthetic_csr(U, I, deg, "cuda", seed=seed, popularity=pop)
@@ -19,7 +21,9 @@ def _engine(U, I, d, B, deg, chunks, lr, seed=3, hot=0, max_block=8, pop="zipf")
     Q = torch.randn(I, d, device="cuda") * 0.1
     eng = BPREngine(P, Q, lr)
     nb = eng.set_neg_block(B, max_block)
-    assert nb > 0
+    assert (nb > 0) == (B >= 2 * I)
+    if nb == 0:
+        eng.sorted_min_batch = 1          # (test sizes: the ordered layout engages from min(2 I, 2^19) triplets on by default)
     if hot:
         eng.set_hot_items(torch.bincount(ix.long(), minlength=I), hot, 4)
     eng.set_chunks(chunks)
@@ -27,7 +31,10 @@ def _engine(U, I, d, B, deg, chunks, lr, seed=3, hot=0, max_block=8, pop="zipf")
 
 
 @pytest.mark.parametrize("U,I,d,B,deg,chunks,hot", [(30_000, 5_000, 128, 30_000, 12, 4, 32), (20_000, 3_001, 64, 9_000, 8, 3, 0),
-                                                     (50_000, 7_777, 32, 50_000, 10, 8, 16), (12_000, 1_000, 128, 12_000, 6, 2, 8)])
+                                                     (50_000, 7_777, 32, 50_000, 10, 8, 16), (12_000, 1_000, 128, 12_000, 6, 2, 8),
+                                                     # B < 2 I: the ranges without blocks (the configs[3] shape in small)
+                                                     (30_000, 40_000, 128, 30_000, 12, 2, 32), (20_000, 15_001, 64, 20_000, 8, 4, 0),
+                                                     (25_000, 30_011, 32, 11_000, 10, 3, 16)])
 def test_chunked_native_steps_follow_the_range_rule_and_replay_through_the_oracle(oracle_mod, U, I, d, B, deg, chunks, hot):
     """every native chunked step: users unique, batch ordered by (relabelled) positive item, positions of range k hold
     positives AND negatives of range k only (real items, never padding rows), true positives / negatives; the dumped
@@ -42,7 +49,8 @@ def test_chunked_native_steps_follow_the_range_rule_and_replay_through_the_oracl
     assert tr.chunks == chunks
     r = eng._relabel
     Ic, nb = r["Ic"], eng.neg_block
-    assert Ic % nb == 0 and Ic * chunks == r["Q"].shape[0] >= I
+    assert (nb > 0) == (B >= 2 * I)
+    assert Ic % max(nb, 1) == 0 and Ic * chunks == r["Q"].shape[0] >= I and (nb > 0 or Ic == -(-I // chunks))
     # the relabelling is a bijection onto the real rows, and the relabelled table holds the same item rows
     rank_item = r["rank_item"].cpu().numpy()
     real = rank_item >= 0
@@ -64,7 +72,7 @@ def test_chunked_native_steps_follow_the_range_rule_and_replay_through_the_oracl
         un, inn, jn = u.cpu().numpy(), i.cpu().numpy(), j.cpu().numpy()
         live = inn >= 0
         n_live = int(live.sum())
-        assert nb_ran == nb and key != 0 and len(np.unique(un)) == B
+        assert nb_ran == nb and (key != 0) == (nb > 0) and len(np.unique(un)) == B
         assert live[:n_live].all() and (jn[~live] == -1).all()                       # skipped pairs come last
         assert cp[0] == 0 and cp[-1] == n_live and np.all(np.diff(cp) >= 0)
         assert np.all(np.diff(inn[:n_live]) >= 0)                                    # ordered by (relabelled) positive item
@@ -85,6 +93,10 @@ def test_chunked_native_steps_follow_the_range_rule_and_replay_through_the_oracl
     assert neg_hist[~real].sum() == 0 and neg_hist[real].min() >= 0
     exp = 3 * B / I
     assert abs(neg_hist[real].mean() - exp) < 0.02 * exp + 1e-9
+    if nb == 0:      # no blocks: a position's negative is UNIFORM over the real items of its range -- every item of a range is
+        for k in range(chunks):   # drawn at the same rate (the range's positions / its real items), up to counting noise
+            h = neg_hist[k * Ic:k * Ic + n_real[k]]
+            assert abs(h.std() - np.sqrt(h.mean())) < 0.15 * np.sqrt(h.mean()) + 0.05, (k, h.mean(), h.std())
     eng.adopt(tr)                                                                    # item rows back in the caller's ids
     assert torch.equal(Q[r["rank_item"][r["real"]]], r["Q"][r["real"]]) and not torch.equal(Q, Q_nat0)
     assert float(r["G"].abs().max()) == 0.0
@@ -93,11 +105,13 @@ def test_chunked_native_steps_follow_the_range_rule_and_replay_through_the_oracl
     tr.close()
 
 
-def test_chunked_step_counts_triplets_outside_their_range():
+@pytest.mark.parametrize("nb", [6, 0])
+def test_chunked_step_counts_triplets_outside_their_range(nb):
     """the contract check: the same kernel on triplets that do NOT follow the range rule still sums them, but counts every
-    one that touched a row outside its range (the native loop turns a non-zero count into an error)"""
+    one that touched a row outside its range (the native loop turns a non-zero count into an error); nb = 0: the form without
+    blocks"""
     from recsys_pytorch_amd import rsx
-    U, I, d, B, C, nb = 8000, 1200, 64, 6000, 4, 6
+    U, I, d, B, C = 8000, 1200, 64, 6000, 4
     Ic = rsx.chunk_rows(I, C, nb)
     rng = np.random.default_rng(0)
     P = torch.randn(U, d, device="cuda") * 0.1
@@ -173,6 +187,46 @@ def test_full_size_chunked_step_through_the_native_loop(chunks):
     tr.close()
 
 
+@pytest.mark.parametrize("chunks", [2, 4])
+def test_full_size_config3_slice_as_item_ranges_through_the_native_loop(chunks):
+    """BASELINE configs[3] as one rank sees it (1.25M users x 1M items, d = 128, B = 1.25M < 2 I) through the chunked native
+    loop WITHOUT blocks: the range rule on every triplet, then P rows, Q after the range-by-range apply and the loss verified in
+    fp64 on the device from rsx_bpr_trainer_last_batch on the relabelled tables"""
+    from stepcheck import verify_step
+    from recsys_pytorch_amd import rsx
+    U, I, d, B = 1_250_000, 1_000_000, 128, 1_250_000
+    lr = resolvable_lr(B)
+    eng, P, Q, ip, ix = _engine(U, I, d, B, 10, chunks, lr, seed=2020, hot=256)
+    assert eng.neg_block == 0
+    loss = torch.zeros(rsx.RSX_LOSS_SLOTS, device="cuda")
+    tr = eng.native_trainer(ip, ix, B, loss_acc=loss)
+    assert tr.chunks == chunks
+    r = eng._relabel
+    P0, Qm0 = P.clone(), r["Q"].clone()
+    tr.run(1)
+    torch.cuda.synchronize()
+    tr.check()
+    u, i, j, nb, key = tr.last_batch()
+    assert nb == 0 and int(i.min()) >= 0 and int(torch.bincount(u.long(), minlength=U).max()) == 1
+    cp = tr.last_chunk_pos()
+    Ic = r["Ic"]
+    assert bool(((i.long() // Ic) == (j.long() // Ic)).all()) and int(cp[-1]) == B and bool((i[1:] >= i[:-1]).all())
+    assert bool(r["real"][j.long()].all()) and bool(r["real"][i.long()].all())
+    share = (cp[1:] - cp[:-1]).double() / B
+    assert float((share - 1.0 / chunks).abs().max()) < 0.01, share          # the ranges carry the same share of the batch
+    v = verify_step(P0, Qm0, P, r["Q"], u, i, j, lr, 1.0 / B)
+    ctx = {k: (f"{x:.3e}" if isinstance(x, float) else x) for k, x in v.items()}
+    assert abs(float(loss.double().sum()) / B - v["loss"]) < 1e-5, ctx
+    assert v["max_dP"] > 1e-3 and v["max_dQ"] > 1e-3, ctx
+    assert v["err_P"] <= UPDATE_TOL and v["err_Q"] <= UPDATE_TOL and v["untouched_rows_equal"], ctx
+    assert float(r["G"].abs().max()) == 0.0
+    tr.run(3)                                                                # the ranges of neighbouring steps interleave
+    torch.cuda.synchronize()
+    eng.adopt(tr)                                                            # checks the run
+    assert bool(torch.isfinite(P).all()) and bool(torch.isfinite(eng.Q).all())
+    tr.close()
+
+
 def test_chunked_sampler_on_random_shapes():
     """30 random CSRs (empty rows, rows owning a whole item range or everything, heavy tails, tiny and ragged sizes, any block
     size, 2..8 ranges) straight through rsx_bpr_sample_chunked: users unique, live pairs first and ordered by item, first
@@ -182,7 +236,7 @@ def test_chunked_sampler_on_random_shapes():
     rng = np.random.default_rng(321)
     for trial in range(30):
         C = int(rng.integers(2, 9))
-        c = int(rng.integers(1, 17))
+        c = int(rng.integers(0, 17)) if trial % 5 else 0        # 0: no blocks -- negatives over the real items of the positive's range
         I = int(rng.integers(max(2 * C, 8), 3000))
         U = int(rng.integers(1, 4000))
         Ic = rsx.chunk_rows(I, C, c)
@@ -209,7 +263,7 @@ def test_chunked_sampler_on_random_shapes():
         B = U if trial % 3 == 0 else int(rng.integers(1, U + 1))
         epoch_pos = 0 if B == U else int(rng.integers(0, U - B + 1))
         cdf = rsx.build_item_cdf(ip, ix, C * Ic)
-        sig = rsx.build_signature(ip, ix, c) if trial % 2 else None
+        sig = rsx.build_signature(ip, ix, c) if (trial % 2 and c) else None
         ws = torch.empty(rsx.bpr_sample_workspace(B, C * Ic), dtype=torch.uint8, device="cuda")
         outs = []
         for rep in range(2):

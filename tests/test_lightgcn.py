@@ -219,3 +219,26 @@ def test_hip_lightgcn_full_size_config5_properties():
     # Adam's first step is lr * g / (|g| + eps): at most lr, and close to lr where |g| >> eps = 1e-8
     assert float(step.max()) <= 1e-3 * (1 + 1e-3) and float(step.max()) > 0.5e-3
     assert int((step > 0).any(1).sum()) > B                      # propagation spreads the gradient beyond the batch
+
+
+@pytest.mark.gpu
+def test_mark_batch_rows_flags_exactly_the_rows_of_the_batch():
+    """include/rsx.h:rsx_spmm_mark_batch_rows -- the row flags of the first backward product (LightGCN.train_step): 1 at the
+    batch's users and (offset by U) at its positive and negative items, 0 elsewhere; skipped triplets (i < 0) mark nothing;
+    stale flags of the batch before are cleared"""
+    import torch
+    from recsys_pytorch_amd import rsx
+    U, I, B = 5000, 1200, 700
+    g = torch.Generator().manual_seed(5)
+    flags = torch.ones(U + I, dtype=torch.uint8, device="cuda")             # (stale content)
+    u = torch.randint(0, U, (B,), generator=g).int()
+    i = torch.randint(0, I, (B,), generator=g).int()
+    j = torch.randint(0, I, (B,), generator=g).int()
+    i[::9] = -1; j[::9] = -1
+    rsx.mark_batch_rows(flags, u.cuda(), i.cuda(), j.cuda(), U)
+    want = torch.zeros(U + I, dtype=torch.uint8)
+    live = i >= 0
+    want[u[live].long()] = 1; want[U + i[live].long()] = 1; want[U + j[live].long()] = 1
+    assert torch.equal(flags.cpu(), want)
+    rsx.mark_batch_rows(flags, u[:0].cuda(), i[:0].cuda(), j[:0].cuda(), U)  # an empty batch clears everything
+    assert int(flags.sum()) == 0

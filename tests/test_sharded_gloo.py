@@ -162,7 +162,9 @@ def _ranges_worker(rank, world, port, gpu, U, I, d, B, deg, chunks, steps, one_r
     eng = BPREngine(P, Q, resolvable_lr(world * B), kernels=kernels, user_begin=rank * U, seed=11)
     assert eng.sharded and eng.comm is None
     if gpu:
-        assert eng.set_neg_block(B, 8) > 0
+        assert (eng.set_neg_block(B, 8) > 0) == (B >= 2 * I)
+        if B < 2 * I:
+            eng.sorted_min_batch = 1          # the ranges without blocks (negatives over the real items of the positive's range)
         eng.set_hot_items(torch.bincount(indices.long(), minlength=I), 32, 4)
     else:
         eng.neg_block = 4
@@ -239,12 +241,13 @@ def test_two_ranks_item_ranges_with_range_callbacks_equal_one_process(oracle_mod
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("I,chunks,d", [(2500, 2, 64), (1999, 3, 128)])
+@pytest.mark.parametrize("I,chunks,d", [(2500, 2, 64), (1999, 3, 128), (7001, 2, 128)])
 def test_two_ranks_item_ranges_on_hip_kernels_equal_one_process(oracle_mod, I, chunks, d):
     """the same through csrc/rsx_train.hip's chunked loop and the HIP kernels, two processes sharing the box's GPU: per-range
     collectives in the same order on ranks whose range kernels finish at different times, sub-buffers G + lo * d with padding rows
     summing two ranks' partials, 1 / sum_r B_r, replica identity per range -- step by step against the oracle on the concatenated
-    triplets, and the same steps queued by ONE rsx_bpr_trainer_run"""
+    triplets, and the same steps queued by ONE rsx_bpr_trainer_run.  I = 7001: B < 2 I, the ranges without blocks (the form of
+    BASELINE configs[3])"""
     _check_ranges(oracle_mod, 2, 29500 + (os.getpid() + 59 + I) % 2000, True, 9000, I, d, 6000, 10, chunks, 4)
 
 

@@ -35,7 +35,8 @@ for meta_path in sorted(glob.glob(os.path.join(dst, f"{tag}_pmc_*.meta.json"))):
                       "FETCH_SIZE_KB": v.get("FETCH_SIZE"), "WRITE_SIZE_KB": v["WRITE_SIZE"], "ea_atomic_requests": v.get("TCC_EA0_ATOMIC_sum"),
                       "tcc_hit": v.get("TCC_HIT_sum"), "tcc_miss": v.get("TCC_MISS_sum"), "tcc_req": v.get("TCC_REQ_sum"),
                       "kernel": ks[0], "launches_per_step": per_step, "profile": prof, "commit": commit + ("+uncommitted" if dirty else ""),
-                      "kernel_us_under_profiler": v.get("mean_us"), "command": meta, "note": note}
+                      "kernel_us_under_profiler": v.get("mean_us"), "command": meta, "note": note,
+                      "sources_sha": meta.get("sources_sha")}      # hash of the kernel sources of the run that was profiled (bench.py: stale)
     print("%-16s %-46s %.3f GB/launch" % (prof.replace(f"{tag}_pmc_", "").replace(".json", ""), meta["key"], t[meta["key"]]["hbm_bytes_per_launch"] / 1e9))
 json.dump(t, open(tpath, "w"), indent=1)
 try:

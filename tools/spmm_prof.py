@@ -16,7 +16,8 @@ ds = types.SimpleNamespace(num_users=U, num_items=I, dataname="syn")
 m = pkg.LightGCN(ds, {"emb_dim": d, "num_layers": L, "node_dropout": 0.0, "split": False, "num_folds": 1, "reg": 0, "graph_dir": "g"}, "cuda")
 g = m.getSparseGraph(R)
 if os.environ.get("STEP_PROF_META"):
-    json.dump({"key": f"lightgcn_U{U}_I{I}_d{d}_L{L}" + (f"_{os.environ['SPMM_HALF']}" if os.environ.get("SPMM_HALF") else ""), "kernel": "spmm_csr_kernel", "argv": sys.argv[1:], "env": {}},
+    import bench
+    json.dump({"sources_sha": bench.sources_sha("spmm"), "key": f"lightgcn_U{U}_I{I}_d{d}_L{L}" + (f"_{os.environ['SPMM_HALF']}" if os.environ.get("SPMM_HALF") else ""), "kernel": "spmm_csr_kernel", "argv": sys.argv[1:], "env": {}},
               open(os.environ["STEP_PROF_META"], "w"))
 half = os.environ.get("SPMM_HALF")
 if half:

@@ -23,7 +23,7 @@ if nb and os.environ.get("NEG_EXACT"):        # the block size itself (experimen
     nb = eng.neg_block = int(os.environ["NEG_EXACT"]); eng._csr = None
 eng.set_hot_items(torch.bincount(ix.long(), minlength=I), 256)
 ck = int(os.environ.get("CHUNKS", 0))
-if ck > 1 and nb:
+if ck > 1 and (nb or nbw):      # (B < 2 I: the ranges without blocks)
     eng.set_chunks(ck)
     nb = eng.neg_block           # (ranges use blocks of at least 3)
     if os.environ.get("NEG_EXACT"):
@@ -31,7 +31,9 @@ if ck > 1 and nb:
 if os.environ.get("STEP_PROF_META"):
     kernel = (f"bpr_step_blocked_kernel<{d}, 3, unsigned int, {'true' if nb else 'false'}>" if (nb or eng._sorts(B))
               else f"bpr_step_kernel<{d}, 0, 3, unsigned int>")
-    json.dump({"key": f"U{U}_I{I}_d{d}_B{B}_{pop}_nb{nb}" + (f"_c{ck}" if (ck > 1 and nb) else ""), "kernel": kernel, "argv": sys.argv[1:],
+    import bench                  # (repo root is on sys.path) the hash of the kernel sources THIS run measures: bench.py's stale flag
+    json.dump({"key": f"U{U}_I{I}_d{d}_B{B}_{pop}_nb{nb}" + (f"_c{ck}" if (ck > 1 and (nb or nbw)) else ""), "kernel": kernel, "argv": sys.argv[1:],
+               "sources_sha": bench.sources_sha("step"),
                "env": {k: os.environ[k] for k in ("USERS", "ITEMS", "DIM", "DEG", "POP", "CHUNKS") if k in os.environ}},
               open(os.environ["STEP_PROF_META"], "w"))
 loss = torch.zeros(rsx.RSX_LOSS_SLOTS, device=dev)
