@@ -905,7 +905,7 @@ void dispatch_step(int d, bool wide, float *P, const float *Q, float *G, const i
 #define RSX_STEP_WAVES_D128 6
 #endif
 #ifndef RSX_STEP_WAVES_D64
-#define RSX_STEP_WAVES_D64 6
+#define RSX_STEP_WAVES_D64 7
 #endif
 static size_t lds_for_residency(size_t need, int d)
 {
