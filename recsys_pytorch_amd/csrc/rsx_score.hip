@@ -842,6 +842,11 @@ RSX_API int rsx_debug_set_score_ablation(int mask)     // dev build only (librsx
 {
     return hipMemcpyToSymbol(HIP_SYMBOL(c_rsx_ablate), &mask, sizeof(int)) == hipSuccess ? RSX_OK : RSX_E_HIP;
 }
+// dev build only: a threshold per row of the NEXT rsx_score_topk calls (device array over the call's rows, or NULL) that replaces the
+// sample's tau in the filtered product -- any lower bound of the row's K-th score gives the same result.  It prices what a tighter
+// threshold (e.g. one refreshed inside a pass) could save before building it: tools/exp_tau_bound.py.
+static const float *g_tau_override = nullptr;
+RSX_API int rsx_debug_set_tau_override(const float *tau_dev) { g_tau_override = tau_dev; return RSX_OK; }
 #endif
 
 RSX_API int rsx_score(const float *P, const int32_t *user_ids_dev, int64_t num_rows, const float *Q,
@@ -1039,6 +1044,9 @@ RSX_API int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t 
         static_assert(kSampleCols == ST_COLS, "sample_tau_kernel is laid out for the sample size");
         hipLaunchKernelGGL(sample_tau_kernel, dim3((unsigned)nr), dim3(TK_THREADS), 0, ls, lw.sample, users, nr, perm_inv, num_items,
                            mask_indptr_dev, mask_indices_dev, K, lw.tau, lw.ccnt, lw.cval, lw.cidx, kSpillCap);
+#ifdef RSX_ABLATE
+        if (g_tau_override != nullptr) (void)hipMemcpyAsync(lw.tau, g_tau_override + r0, (size_t)nr * 4, hipMemcpyDeviceToDevice, ls);
+#endif
         // 2. the rest of the catalog with the FILTER epilogue (item ids offset by the sample)
         const int64_t rest = num_items - kSampleCols;
         const int64_t n_it = 2 * ((rest + BN - 1) / BN), rows_pad = (nr + BM - 1) / BM * BM;
