@@ -665,25 +665,18 @@ __global__ __launch_bounds__(MG_THREADS) void merge_candidates_kernel(
     if (seen_lds)
         for (int t = tid; t < deg; t += MG_THREADS) seen[t] = indices[lo + t];
     __syncthreads();
-    // ONE pass over the row's cells (round 3; it used to count first and fetch again): everything that survives the seen-item
-    // test goes to the list, and a list that would not fit sends the row to the dense re-do afterwards.  The cells of a batch are
-    // requested together (MG_BATCH loads in flight per thread instead of one after the other), the seen test is a binary search
-    // in LDS instead of a chain of dependent global loads per survivor.
+    // ONE pass over the row's cells (round 3; it used to count first and fetch again); the cells of a batch are requested together
+    // (MG_BATCH loads in flight per thread instead of one after the other).
+    // Round 4: the survivors go to the list RAW -- (key, id in the permuted table) -- and the three expensive things a survivor used
+    // to pay on arrival (the 64-bit modulo that maps its id back, the search among the user's seen items, its place in the sort) are
+    // paid only by those that can still be among the K best: a histogram of the keys finds the bin of the (K + deg)-th largest --
+    // at most deg of the entries above it are seen items, so at least K unseen ones are -- and everything below that bin is dropped
+    // unexamined (~560 of a row's ~660 survivors at the bench shape).  A list that would not fit sends the row to the dense re-do.
     const uint2 *rslots = slots + (size_t)row * n_strips * kSlots;     // this row's cells, contiguous
     const int64_t n_slots = n_strips * kSlots;  // an unused slot still holds the 0xFF fill: item < 0
-    auto push = [&](float v, int32_t pit) {
-        const int32_t it = (int32_t)(((int64_t)pit * perm_a) % perm_n);      // permuted id -> item id (ties, mask, output)
-        if (seen_lds) {
-            int a = 0, z = deg;
-            while (a < z) { const int m = (a + z) >> 1; if (seen[m] < it) a = m + 1; else z = m; }
-            if (a < deg && seen[a] == it) return;
-        } else {
-            int64_t a = lo, z = hi;             // a long row: binary search in the CSR itself
-            while (a < z) { const int64_t m = (a + z) >> 1; if (indices[m] < it) a = m + 1; else z = m; }
-            if (a < hi && indices[a] == it) return;
-        }
+    auto push_raw = [&](float v, int32_t pit) {
         const uint32_t at = atomicAdd(&s_n, 1u);
-        if (at < (uint32_t)MG_CAP) cand[at] = ((unsigned long long)f2key(v) << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)it);
+        if (at < (uint32_t)MG_CAP) cand[at] = ((unsigned long long)f2key(v) << 32) | (uint32_t)pit;
     };
     for (int64_t q0 = 0; q0 < n_slots; q0 += MG_THREADS * MG_BATCH) {
         uint2 e[MG_BATCH];
@@ -694,31 +687,31 @@ __global__ __launch_bounds__(MG_THREADS) void merge_candidates_kernel(
         }
 #pragma unroll
         for (int b_ = 0; b_ < MG_BATCH; ++b_)
-            if ((int32_t)e[b_].y >= 0) push(__uint_as_float(e[b_].x), (int32_t)e[b_].y);
+            if ((int32_t)e[b_].y >= 0) push_raw(__uint_as_float(e[b_].x), (int32_t)e[b_].y);
     }
     for (int t = tid; t < spill; t += MG_THREADS)
-        push(cand_val[(size_t)row * cand_cap + t], cand_idx[(size_t)row * cand_cap + t]);
+        push_raw(cand_val[(size_t)row * cand_cap + t], cand_idx[(size_t)row * cand_cap + t]);
     __syncthreads();
-    if (s_n > (uint32_t)MG_CAP) {               // block-uniform: more unseen survivors than the list holds
+    if (s_n > (uint32_t)MG_CAP) {               // block-uniform: more survivors than the list holds
         if (tid == 0) overflow_rows[atomicAdd(overflow_count, 1)] = (int32_t)(row_base + row);
         return;
     }
     uint32_t ncand = s_n;
-    // Only K of the (typically ~K I / 8192 + K) survivors are wanted: one histogram of the keys,
-    // linear between the smallest and largest key, finds the bin of the K-th; everything in or
-    // above that bin is compacted to the front (a handful more than K) and only that is sorted.
-    if (ncand > 2u * (uint32_t)K && ncand > 128u) {
+    // entries that can still be among the K best unseen: those in or above the bin of the `need`-th largest key
+    const uint32_t need = (uint32_t)K + (uint32_t)(deg < MG_CAP ? deg : MG_CAP);
+    __shared__ uint32_t s_m;
+    if (ncand > 2u * need && ncand > 128u) {
         __shared__ uint32_t hist[MG_BINS];
-        __shared__ uint32_t s_lo, s_hi, s_bin, s_m, s_wv[MG_THREADS / 64];
+        __shared__ uint32_t s_lo, s_hi, s_bin, s_wv[MG_THREADS / 64];
         if (tid == 0) { s_lo = 0xFFFFFFFFu; s_hi = 0u; s_m = 0u; }
         for (int b_ = tid; b_ < MG_BINS; b_ += MG_THREADS) hist[b_] = 0u;
         __syncthreads();
-        uint32_t lo = 0xFFFFFFFFu, hi_ = 0u;
+        uint32_t lo_k = 0xFFFFFFFFu, hi_k = 0u;
         for (uint32_t t = tid; t < ncand; t += MG_THREADS) {
             const uint32_t k32 = (uint32_t)(cand[t] >> 32);
-            lo = k32 < lo ? k32 : lo; hi_ = k32 > hi_ ? k32 : hi_;
+            lo_k = k32 < lo_k ? k32 : lo_k; hi_k = k32 > hi_k ? k32 : hi_k;
         }
-        atomicMin(&s_lo, lo); atomicMax(&s_hi, hi_);
+        atomicMin(&s_lo, lo_k); atomicMax(&s_hi, hi_k);
         __syncthreads();
         const uint32_t klo = s_lo;
         const uint32_t width = s_hi - klo;                         // largest offset, >= 0
@@ -726,7 +719,7 @@ __global__ __launch_bounds__(MG_THREADS) void merge_candidates_kernel(
         for (uint32_t t = tid; t < ncand; t += MG_THREADS)
             atomicAdd(&hist[((uint32_t)(cand[t] >> 32) - klo) >> shift], 1u);
         __syncthreads();
-        // bin of the K-th largest: suffix counts from the top bin (thread t owns MG_BINS/threads bins)
+        // bin of the need-th largest: suffix counts from the top bin (thread t owns MG_BINS/threads bins)
         constexpr int per = MG_BINS / MG_THREADS;
         uint32_t mine_b = 0;
         for (int q = 0; q < per; ++q) mine_b += hist[tid * per + q];
@@ -740,11 +733,11 @@ __global__ __launch_bounds__(MG_THREADS) void merge_candidates_kernel(
             for (int w_ = (tid >> 6) + 1; w_ < MG_THREADS / 64; ++w_) suf += s_wv[w_];
         }
         const uint32_t above = suf - mine_b;
-        if (above < (uint32_t)K && suf >= (uint32_t)K) {
+        if (above < need && suf >= need) {
             uint32_t run = above;
             for (int q = per - 1; q >= 0; --q) {
                 run += hist[tid * per + q];
-                if (run >= (uint32_t)K) { s_bin = (uint32_t)(tid * per + q); break; }
+                if (run >= need) { s_bin = (uint32_t)(tid * per + q); break; }
             }
         }
         __syncthreads();
@@ -762,6 +755,29 @@ __global__ __launch_bounds__(MG_THREADS) void merge_candidates_kernel(
         __syncthreads();
         ncand = s_m;
     }
+    // the entries that are left: id in the permuted table -> item id, seen items dropped (their entry becomes 0: below every real
+    // key, it sorts last), the rest in the form the sort orders -- key descending, then item id ascending
+    __syncthreads();
+    if (tid == 0) s_m = 0u;
+    __syncthreads();
+    for (uint32_t t = tid; t < ncand; t += MG_THREADS) {
+        const unsigned long long e = cand[t];
+        const int32_t it = (int32_t)(((int64_t)(uint32_t)e * perm_a) % perm_n);
+        bool is_seen = false;
+        if (seen_lds) {
+            int a = 0, z = deg;
+            while (a < z) { const int m = (a + z) >> 1; if (seen[m] < it) a = m + 1; else z = m; }
+            is_seen = a < deg && seen[a] == it;
+        } else {
+            int64_t a = lo, z = hi;             // a long row: binary search in the CSR itself
+            while (a < z) { const int64_t m = (a + z) >> 1; if (indices[m] < it) a = m + 1; else z = m; }
+            is_seen = a < hi && indices[a] == it;
+        }
+        cand[t] = is_seen ? 0ull : ((e & 0xFFFFFFFF00000000ull) | (uint32_t)(0xFFFFFFFFu - (uint32_t)it));
+        if (is_seen) atomicAdd(&s_m, 1u);
+    }
+    __syncthreads();
+    const uint32_t n_valid = ncand - s_m;       // (>= K unless the whole catalog holds fewer unseen items)
     uint32_t n2 = 1;
     while (n2 < ncand) n2 <<= 1;
     for (uint32_t t = ncand + tid; t < n2; t += MG_THREADS) cand[t] = 0ull;
@@ -780,8 +796,8 @@ __global__ __launch_bounds__(MG_THREADS) void merge_candidates_kernel(
     }
     for (int t = tid; t < K; t += MG_THREADS) {
         const unsigned long long e = cand[t];
-        out_idx[(size_t)row * K + t] = (t < (int)ncand) ? (int32_t)(0xFFFFFFFFu - (uint32_t)e) : -1;
-        if (out_val) out_val[(size_t)row * K + t] = (t < (int)ncand) ? key2f((uint32_t)(e >> 32)) : -INFINITY;
+        out_idx[(size_t)row * K + t] = (t < (int)n_valid) ? (int32_t)(0xFFFFFFFFu - (uint32_t)e) : -1;
+        if (out_val) out_val[(size_t)row * K + t] = (t < (int)n_valid) ? key2f((uint32_t)(e >> 32)) : -INFINITY;
     }
 }
 
