@@ -26,7 +26,9 @@ Divergences from the reference, all documented in DESIGN.md:
     of a batch is rsx_pointwise_grad, the update the as-shipped Adam or the SGD sweep.
   * hparams['chunks'] (default 0 = off): > 1 runs the SGD step as a pipeline over that many item ranges when the blocked
     layout engages (include/rsx.h: "item chunks"; BPREngine.set_chunks): the apply -- and, user-sharded, the exchange --
-    of a range travels under the rest of the step kernel; negatives come from the range of the sampled positive.
+    of a range travels under the rest of the step kernel; negatives come from the range of the sampled positive.  Which items
+    share a range is redrawn every hparams['redraw_ranges_every'] steps (default 64; 0 = one relabelling for the whole fit),
+    between epochs: over a fit every item meets every other as a negative.
   * hparams['hot_items'] (default 256; 0 = off; SGD): the gradients of that many most popular items of the train matrix go to
     private replica rows (include/rsx.h: hot_slot_dev) and are folded in the apply -- on a popularity-skewed catalog the atomic
     unit otherwise serialises on a few rows (B = 1M on the Zipf bench graph: 625 vs 340 us per step).  Same sums, another order.
@@ -120,6 +122,7 @@ class MF(BaseModel):
         self.item_embedding.weight.requires_grad_(False)
         self._kernels = kernels
         self._engine = BPREngine(self._P, self._Q, self.lr, kernels=kernels, seed=self.seed, optimizer=opt)
+        self._engine.redraw_ranges_every = int(_get(hparams, "redraw_ranges_every", self._engine.redraw_ranges_every))
         self._k = self._engine.k
 
     # -- tables ---------------------------------------------------------------------

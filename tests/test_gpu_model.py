@@ -864,6 +864,55 @@ def test_stratified_sorted_sampler_trains_as_well_as_independent_negatives():
     assert abs(np.mean(c) - np.mean(b)) < max(3 * noise, 0.03 * np.mean(b)), (res, untrained)
 
 
+@pytest.mark.timeout(900)
+def test_item_ranges_rank_as_well_for_users_with_one_to_three_positives():
+    """the item ranges pair a positive only with negatives of ITS range.  With one relabelling for a whole fit a user whose one
+    to three positives fall into k < C ranges would never meet the other (C - k) / C of the catalog as negatives -- nothing would
+    push those items below the user's positives in the FULL-catalog ranking; the engine therefore redraws the relabelling every
+    `redraw_ranges_every` steps (BPREngine.adopt).  Planted-factor data, every user 1..3 train positives + 2 held out; Recall@20
+    and NDCG@20 over the whole catalog: two ranges with the redraw == independent negatives within the seed noise (and the arm
+    with ONE relabelling for the whole fit is reported beside them)"""
+    import scipy.sparse as sp
+    import recsys_pytorch_amd as pkg
+    rng = np.random.default_rng(7)
+    U, I, k_true = 60_000, 1_500, 12
+    A, Bm = rng.standard_normal((U, k_true)), rng.standard_normal((I, k_true))
+    n_train = rng.integers(1, 4, U)                                             # 1..3 train positives
+    tr_r, tr_c, te_r, te_c = [], [], [], []
+    for lo in range(0, U, 6000):
+        aff = A[lo:lo + 6000] @ Bm.T + rng.gumbel(size=(6000, I)) * 1.0
+        top = np.argpartition(-aff, 5, axis=1)[:, :5]
+        for q, r in enumerate(top):
+            r = rng.permutation(r)
+            n = int(n_train[lo + q])
+            te_r += [lo + q] * 2; te_c += list(r[:2])
+            tr_r += [lo + q] * n; tr_c += list(r[2:2 + n])
+    mk = lambda rr, cc: sp.csr_matrix((np.ones(len(rr)), (rr, cc)), shape=(U, I))
+    train, test = mk(tr_r, tr_c), mk(te_r, te_c)
+    train.sort_indices(); test.sort_indices()
+    ds = pkg.InteractionData(train, test, test)
+    ev = pkg.Evaluator(ds.valid_input, ds.valid_target, "holdout", [20])
+    cfg = types.SimpleNamespace(batch_size=U, num_epochs=240, verbose=0, test_from=240, test_step=240)   # B = U = 40 I
+    res = {}
+    for arm, nb, chunks, redraw in (("iid", 0, 0, 0), ("ranges, redrawn", 8, 2, 30), ("ranges, one relabelling", 8, 2, 0)):
+        for seed in (1, 2):
+            torch.manual_seed(seed)
+            m = pkg.MF(ds, dict(HP, hidden_dim=32, lr=0.1 * U, neg_block=nb, chunks=chunks, seed=seed, redraw_ranges_every=redraw), "cuda")
+            with torch.no_grad():
+                m._P.mul_(0.1); m._Q.mul_(0.1)
+            if (arm, seed) == ("iid", 1):
+                untrained = ev.evaluate(m)
+            sc = m.fit(ds, cfg, evaluator=ev)["scores"]
+            assert m._engine.chunks == chunks and (m._engine._relabel_round > 0) == (redraw > 0)
+            res[(arm, seed)] = (float(sc["Recall@20"]), float(sc["NDCG@20"]))
+    print({k: tuple(round(x, 4) for x in v) for k, v in res.items()}, "untrained", {k: round(float(v), 4) for k, v in untrained.items()})
+    for metric in (0, 1):
+        a, b = ([res[(arm, 1)][metric], res[(arm, 2)][metric]] for arm in ("iid", "ranges, redrawn"))
+        noise = max(abs(a[0] - a[1]), abs(b[0] - b[1]))
+        assert min(a + b) > 3 * float(untrained["Recall@20" if metric == 0 else "NDCG@20"]), (res, untrained)
+        assert abs(np.mean(a) - np.mean(b)) < max(3 * noise, 0.05 * np.mean(a)), (metric, res)
+
+
 def test_blocked_kernel_is_exact_on_foreign_triplets(oracle_mod):
     """neg_block set but the triplets do NOT follow the sampler contract: still exact"""
     from recsys_pytorch_amd import rsx

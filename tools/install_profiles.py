@@ -2,7 +2,7 @@
 into profiles/ and rebuild profiles/traffic.json -- the PMC-measured HBM bytes per launch of every bench leg's dominant
 kernel, keyed the way bench.py looks them up, each entry naming the profile file and the commit it was taken at."""
 import csv, glob, json, os, shutil, subprocess, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", f"profiles_{tag}"), os.path.join(root, "profiles")
 for f in os.listdir(src):

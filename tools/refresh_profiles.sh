@@ -10,7 +10,7 @@
 #   <tag>_pmc_spmm.json            the same over tools/spmm_prof.py (LightGCN propagation product); _users / _items: its two halves
 #   <tag>_pmc_scoring.json         over tools/score_prof.py for the scoring kernels
 set -u
-tag=${1:-r03}
+tag=${1:-r04}
 what=${2:-all}
 root=$(pwd)
 out=$root/gpurun_out/profiles_$tag
@@ -48,6 +48,7 @@ leg B16384_plain  "$T" - 16384 0 100
 leg B262144       "$T" - 262144 8 30
 leg B1M_ranges3   "$T" "CHUNKS=3" 1000000 8 12
 leg B1M_ranges2   "$T" "CHUNKS=2" 1000000 8 12
+leg config3_ranges2 "$T" "USERS=1250000 ITEMS=1000000 DEG=10 CHUNKS=2" 1250000 8 8
 ( export STEP_PROF_META="$out/${tag}_pmc_spmm.meta.json"
   PMC_GROUPS="$T;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" python3 tools/pmc_groups.py "$out/${tag}_pmc_spmm.json" spmm_csr -- python3 tools/spmm_prof.py > /dev/null 2>&1 )
 for half in users items; do
