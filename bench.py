@@ -251,7 +251,7 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
 def lightgcn_leg(U, I, d, indptr, indices, dev, layers=3, batch=65_536):
     """models/LightGCN.py:174-202 (propagation) and :83-87 (one training step: full-graph propagation, BPR gradient on
     the propagated tables, the same products on the gradient, dense Adam) at the BASELINE configs[4] shape.
-    Roofline of the propagation product Y = A_hat X: algorithmic bytes nnz * (4 d + 8) + 2 N d 4 (DESIGN.md 4.6)."""
+    Roofline of the propagation product Y = A_hat X: algorithmic bytes nnz * (4 d + 8) + 2 N d 4 (DESIGN.md 4.5)."""
     import types
     import scipy.sparse as sp
     import recsys_pytorch_amd as pkg
