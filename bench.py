@@ -245,6 +245,10 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
                                                     "own stream (ranges that overlap on the chip count twice)"} if ran_chunks > 1 else {})}),
             # whole step (kernel + apply + gaps) against the same physical bytes of the step kernel
             "frac_end_to_end": (rl["traffic"] / (elapsed / steps) / 1e9 / HBM_PEAK_GBS) if rl["traffic"] else None,
+            # ... and against EVERYTHING the step moves at the fabric side (PMC, same profile): the step kernel, the apply sweep and the
+            # sampler of a later step that runs beside them -- how much of the HBM peak the loop as a whole keeps busy
+            "hbm_utilisation_end_to_end": ((traffic_for(key) or {}).get("step_total_bytes") or 0) / (elapsed / steps) / 1e9 / HBM_PEAK_GBS or None,
+            "step_total_bytes": (traffic_for(key) or {}).get("step_total_bytes"),
             "algorithmic_end_to_end_over_peak": gb / world * steps / elapsed * 24 * d / (HBM_PEAK_GBS * 1e9)}
 
 
@@ -585,6 +589,7 @@ def main():
                                       if SHARDED else "single GPU"},
             "roofline": head["roofline"],
             "frac_end_to_end": head["frac_end_to_end"],
+            "hbm_utilisation_end_to_end": head["hbm_utilisation_end_to_end"], "step_total_bytes": head["step_total_bytes"],
             "algorithmic_end_to_end_over_peak": head["algorithmic_end_to_end_over_peak"],
         }
         # every BASELINE config's figure where the driver keeps it (it stores `roofline`, `config` and `cpu_baseline` of this line

@@ -31,7 +31,15 @@ for meta_path in sorted(glob.glob(os.path.join(dst, f"{tag}_pmc_*.meta.json"))):
     per_step = int(meta.get("env", {}).get("CHUNKS", 1)) if "_c" in meta["key"].rsplit("_nb", 1)[-1] else 1
     v = {k_: (x * per_step if isinstance(x, (int, float)) and k_ not in ("launches",) else x) for k_, x in v.items()}
     rd = v["TCC_EA0_RDREQ_sum"] * 128.0
-    t[meta["key"]] = {"hbm_bytes_per_launch": rd + v["WRITE_SIZE"] * 1024.0, "read_bytes": rd, "write_bytes": v["WRITE_SIZE"] * 1024.0,
+    # everything a STEP moves at the fabric side, not only its dominant kernel: the apply and the sampler's kernels too (each kernel's
+    # bytes per launch x its launches per step; the loop samples two steps ahead, so the sampler has a couple of launches more)
+    steps = int(meta.get("argv", [0, 0, 12])[2]) if len(meta.get("argv", [])) > 2 else 12
+    step_total = 0.0
+    for kname, kv in d.items():
+        if "TCC_EA0_RDREQ_sum" in kv and "WRITE_SIZE" in kv and steps > 0:
+            step_total += (kv["TCC_EA0_RDREQ_sum"] * 128.0 + kv["WRITE_SIZE"] * 1024.0) * max(1, round(kv.get("launches", steps) / steps))
+    t[meta["key"]] = {"step_total_bytes": step_total if not meta["key"].startswith("lightgcn") else None,
+                      "hbm_bytes_per_launch": rd + v["WRITE_SIZE"] * 1024.0, "read_bytes": rd, "write_bytes": v["WRITE_SIZE"] * 1024.0,
                       "FETCH_SIZE_KB": v.get("FETCH_SIZE"), "WRITE_SIZE_KB": v["WRITE_SIZE"], "ea_atomic_requests": v.get("TCC_EA0_ATOMIC_sum"),
                       "tcc_hit": v.get("TCC_HIT_sum"), "tcc_miss": v.get("TCC_MISS_sum"), "tcc_req": v.get("TCC_REQ_sum"),
                       "kernel": ks[0], "launches_per_step": per_step, "profile": prof, "commit": commit + ("+uncommitted" if dirty else ""),
