@@ -530,7 +530,9 @@ def main():
 
     # ---- scoring leg (reported beside the headline; its own timed region) ---------------
     scoring = None
-    if args.score_tiles > 0 and rank == 0:
+    # N > 1: every rank scores ITS users (user rows sharded, items replicated: no collective), all ranks at the same
+    # time; the job's rate is all ranks' scores over the slowest rank's time
+    if args.score_tiles > 0 and (rank == 0 or SHARDED):
         tiles, K = args.score_tiles, args.topk
         users = torch.arange(1024 * tiles, device=dev, dtype=torch.int32) % U
         ws = torch.empty(rsx.lib().rsx_score_topk_workspace(users.numel(), I) // 4 + 64, dtype=torch.float32, device=dev)
@@ -539,18 +541,24 @@ def main():
         torch.cuda.synchronize()
         dts = []
         for _ in range(5):                                      # five whole calls, each its own timed region; the median is reported
+            fence(world)
             t1 = time.perf_counter()
             top = rsx.score_topk(P, Q, users, K, mask=mask, ws=ws)
             torch.cuda.synchronize()
-            dts.append(time.perf_counter() - t1)
+            el = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            if SHARDED:
+                dist.all_reduce(el, op=dist.ReduceOp.MAX)       # the slowest rank's time
+            dts.append(float(el.item()))
         dt = sorted(dts)[2]
-        n_scores = 1024 * tiles * I
-        scoring = {"metric": "full_catalog_scores_per_sec", "value": n_scores / dt, "unit": "scores/s", "ms_per_1024_users": dt / tiles * 1e3,
-                   "sample": f"{tiles} tiles of 1024 users x {I} items, mask + top-{K} on device; median of 5 calls "
-                             f"(min {min(dts)*1e3:.2f} ms, max {max(dts)*1e3:.2f} ms per call)",
+        n_scores = 1024 * tiles * I * world                     # whole job: every rank's tiles
+        scoring = {"metric": "full_catalog_scores_per_sec", "value": n_scores / dt, "unit": "scores/s", "ms_per_1024_users": dt / tiles * 1e3,   # (per rank)
+                   "sample": f"{tiles} tiles of 1024 users x {I} items" + (f" on each of {world} ranks (its own users)" if world > 1 else "")
+                             + f", mask + top-{K} on device; median of 5 calls "
+                             f"(min {min(dts)*1e3:.2f} ms, max {max(dts)*1e3:.2f} ms per call" + (", slowest rank" if world > 1 else "") + ")",
+                   "n_gpus": world,
                    "roofline": {"bound": "mfma", "achieved": n_scores * 2 * d / dt / 1e12,
-                                "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": n_scores * 2 * d / dt / 1e12 / MFMA_F32_PEAK_TFLOPS},
+                                "peak": MFMA_F32_PEAK_TFLOPS * world, "unit": "TFLOP/s",
+                                "frac": n_scores * 2 * d / dt / 1e12 / (MFMA_F32_PEAK_TFLOPS * world)},
                    "topk_rows": int(top.shape[0])}
     if SHARDED:
         dist.barrier()

@@ -70,8 +70,8 @@ def test_bench_two_ranks_on_one_gpu(two_pass, exchange, chunks):
     a multi-GPU node through the library's RCCL)"""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(29500 + (os.getpid() + 31 + int(two_pass) + 7 * len(exchange) + 3 * int(chunks or 2)) % 2000), os.path.join(ROOT, "bench.py"), "--gpus", "2",
-           "--steps", "4", "--warmup", "1", "--users", "120000", "--batch", "120000", "--items", "30000", "--score-tiles", "0", "--no-legs",
-           *(["--chunks", chunks] if chunks is not None else [])]
+           "--steps", "4", "--warmup", "1", "--users", "120000", "--batch", "120000", "--items", "30000",
+           "--score-tiles", "1" if chunks is None else "0", "--no-legs", *(["--chunks", chunks] if chunks is not None else [])]
     d = run_bench(cmd, env={"RSX_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "RSX_TWO_PASS": two_pass,
                                 "RSX_EXCHANGE": exchange, "RSX_CHUNKS": "-1"})
     assert ("reduce-scatter" in d["config"]["parallelism"]) == (exchange == "scatter_gather")
@@ -83,6 +83,9 @@ def test_bench_two_ranks_on_one_gpu(two_pass, exchange, chunks):
     assert ("two-pass" in d["config"]["parallelism"]) == (two_pass == "1" and want_chunks == 0)
     assert d["roofline"]["kernel_launches_timed"] == 4
     assert abs(d["value"] - 240000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    if chunks is None:           # scoring: every rank its own users, the job's rate = all ranks' scores / the slowest rank's time
+        sc = d["scoring"]
+        assert sc["n_gpus"] == 2 and sc["value"] > 0 and sc["roofline"]["peak"] == 2 * 157.3 and 0 < sc["roofline"]["frac"] < 1
 
 
 @pytest.mark.gpu
