@@ -251,6 +251,30 @@ def test_two_ranks_item_ranges_on_hip_kernels_equal_one_process(oracle_mod, I, c
     _check_ranges(oracle_mod, 2, 29500 + (os.getpid() + 59 + I) % 2000, True, 9000, I, d, 6000, 10, chunks, 4)
 
 
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("I,chunks", [(2500, 2), (9001, 3)])
+def test_two_ranks_item_ranges_soak(I, chunks):
+    """sixty steps of the range schedule queued by ONE call on each of two ranks (HIP loop, two processes on the box's GPU, the
+    exchange range by range over gloo): the pipelines of neighbouring steps interleave for a long stretch -- afterwards the item
+    replicas are identical row by row (padding rows included), every gradient row is applied and cleared, no triplet left its
+    range (adopt() checks), everything finite, and the model has learned (the summed loss of the last steps is below ln 2).
+    I = 9001: below two triplets per item, the ranges without blocks"""
+    world, U, d, B, steps = 2, 9000, 64, 6000, 60
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_ranges_worker, args=(world, 29500 + (os.getpid() + 71 + I) % 2000, True, U, I, d, B, 10, chunks, steps, True, out),
+             nprocs=world, join=True)
+    a, b = out[0], out[1]
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[1], b[1]), "item replicas diverged"
+    assert a[8] == 0.0 and b[8] == 0.0
+    for r in (a, b):
+        assert np.isfinite(r[0]).all() and np.isfinite(r[1]).all()
+        assert np.abs(r[0] - r[6]).max() > 1e-3 and np.abs(r[1] - r[7]).max() > 1e-3           # the tables moved
+    mean_loss = (a[5] + b[5]) / (world * B * steps)
+    assert 0.0 < mean_loss < 0.6931, mean_loss
+
+
 def _gpu_worker(rank, world, port, P0, Q0, batches, lr, out, unique=False, exchange="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
