@@ -179,7 +179,6 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     # OPT-IN, never the default: RSX_STALE_EXCHANGE=1 lets a step's exchange travel under the NEXT step kernel (item
     # table one step stale: not the reference's batch-synchronous step; flagged in the JSON line)
     eng.stale_exchange = SHARDED and os.environ.get("RSX_STALE_EXCHANGE") == "1"
-    eng.blocked_any_batch = os.environ.get("RSX_BLOCKED_ANY_BATCH") == "1"      # experiment
     nb = eng.set_neg_block(B, want_nb) if want_nb > 0 else 0
     if hot > 0:
         eng.set_hot_items(torch.bincount(indices.long(), minlength=I), hot, hot_replicas or None)

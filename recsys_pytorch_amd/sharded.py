@@ -113,9 +113,6 @@ class BPREngine:
         self.comm = comm if self.sharded else None
         # > 1: the native loop runs the step as a pipeline over item ranges (include/rsx.h: "item chunks"; set_chunks)
         self.chunks = 0
-        # EXPERIMENTAL: blocked negatives (and with them the item ranges) also for batches below two triplets per item, where the
-        # on-chip sums have little to sum: the ranges then serve only to hide an exchange as long as the step (configs[3])
-        self.blocked_any_batch = False
         self._relabel = None
         # The range an item sits in decides which negatives its positives are paired with.  One relabelling for a whole fit
         # would mean that a user whose few positives fall into k < C ranges NEVER meets the other ranges' items as negatives;
@@ -161,7 +158,7 @@ class BPREngine:
         updates per step; below that there is nothing to combine.  The block size c <= max_block
         is `pick_neg_block`'s choice for this batch size."""
         self._nb_args = (int(batch), int(max_block))
-        nb = pick_neg_block(self.Q.shape[0], int(max_block), self._wave_slots(), int(batch), 3 if self.chunks > 1 else 2) if (batch >= 2 * self.Q.shape[0] or self.blocked_any_batch) else 0
+        nb = pick_neg_block(self.Q.shape[0], int(max_block), self._wave_slots(), int(batch), 3 if self.chunks > 1 else 2) if batch >= 2 * self.Q.shape[0] else 0
         if nb != self.neg_block:
             self._csr = None        # the user signatures depend on neg_block: rebuild on next use
         self.neg_block = nb
@@ -615,7 +612,7 @@ class BPREngine:
         native = self.sharded and self.comm is not None       # the library issues the exchange itself (RCCL)
         kind = {"allreduce": 1, "scatter_gather": 2}[self.exchange] if native else 0      # RSX_EXCHANGE_*
         stale = bool(self.stale_exchange) and self.sharded
-        blocked = bool(self.neg_block) and (batch >= 2 * self.Q.shape[0] or self.blocked_any_batch)
+        blocked = bool(self.neg_block) and batch >= 2 * self.Q.shape[0]
         # (below two triplets per item the ranges run WITHOUT blocks -- include/rsx.h "item chunks", neg_block = 0: negatives
         #  uniform over the real items of the positive's range -- wherever the ordered layout engages at all)
         unblocked = not self.neg_block and bool(self.sorted_min_batch) and batch >= self.sorted_min_batch
