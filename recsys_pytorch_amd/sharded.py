@@ -213,13 +213,15 @@ class BPREngine:
 
     # -- the step as a pipeline over item ranges (include/rsx.h: "item chunks") ---------------------------------
     def set_chunks(self, chunks):
-        """chunks > 1 (native loop, SGD, blocked negatives engaged): the item rows are cut into `chunks` ranges and the
-        exchange (when sharded: needs `comm`) and the apply of a range travel under the step kernel's wavefronts of the
-        ranges after it.  The engine then trains on a RELABELLED item space -- a fixed random permutation of the item ids
-        (seeded: the same on every rank), `chunks` ranges of rsx_chunk_rows rows -- held in its own tables; `adopt()` /
-        `sync_items()` copy the item rows back into Q.  What changes for the model: a user's negative is uniform over the
-        items of the range its sampled positive fell in (a random 1/chunks of the catalog) instead of over one item block
-        anywhere."""
+        """chunks > 1 (native loop, SGD): the item rows are cut into `chunks` ranges and the exchange (when sharded: issued by the
+        library through `comm`, or this engine's torch.distributed all-reduce handed in range by range) and the apply of a range
+        travel under the other ranges' kernels.  With blocked negatives engaged (batch >= 2 items) a position's negative comes
+        from an item block of its positive's range; below that (include/rsx.h "item chunks", neg_block = 0) from all real items of
+        the range.  The engine then trains on a RELABELLED item space -- a seeded permutation of the item ids, the same on every
+        rank, redrawn every `redraw_ranges_every` steps between native runs -- held in its own tables; `adopt()` /
+        `sync_items()` copy the item rows back into Q.  What changes for the model: a user's negative is uniform over the items
+        of the range its sampled positive fell in (1/chunks of the catalog, another one after every redraw) instead of over the
+        whole catalog."""
         chunks = int(chunks)
         if chunks > 1 and (self.optimizer != "sgd" or self.exchange != "allreduce"):
             raise ValueError("chunks > 1 needs SGD and exchange='allreduce' (sharded: the library's communicator `comm`, or without "
