@@ -39,6 +39,14 @@ constexpr int BM = 128, BN = 128, BK = 32;
 #ifndef RSX_SCORE_GLDS
 #define RSX_SCORE_GLDS 1      // 0: never take the LDS-DMA form (development A/B)
 #endif
+// RSX_SCORE_LDS_PAD = 1 (round 4): one dword of LDS padding behind every 8 rows of a GLDS tile.  The XOR swizzle alone leaves the 32
+// lanes of a fragment read on 8 banks, 4 lanes each (SQ_LDS_BANK_CONFLICT 2.8e8 cycles per pass, a quarter of the LDS's time); a DMA
+// instruction writes exactly 8 rows, so its LDS base can carry the pad (the destination is then only dword aligned: the gfx950 DMA
+// takes it), and the four 8-row groups a fragment read spans land on four different bank offsets: conflict-free.  Same box, two rounds:
+// fused 253.6 / 252.8 -> 246.9 / 248.2 us per 1024 users (0.658 -> 0.673 of the MFMA-fp32 peak), identical Top-50 checksum.
+#ifndef RSX_SCORE_LDS_PAD
+#define RSX_SCORE_LDS_PAD 1   // 0: the unpadded tiles (development A/B)
+#endif
 // (s_setprio 2 / 3 around the MFMA block, so that a wavefront in its MFMA phase issues ahead of the others' VALU / LDS work:
 //  measured 279.5 -> 283.6 us per 1024 users, same box, round 3 -- dropped.  A FIXED order of precedence among the four wavefronts
 //  that share a SIMD -- s_setprio 3 / 2 / 1 / 0 by HW_ID.wave_id, to keep them from reaching the end of a chunk and waiting for
@@ -67,8 +75,12 @@ __device__ __forceinline__ void score_tile_body(const float *__restrict__ P,
                                                          int32_t *__restrict__ cand_cnt, int cand_cap,
                                                          uint2 *__restrict__ slots, int64_t item_base)
 {
-    __shared__ __attribute__((aligned(16))) float As[GLDS ? BM * BK : BK * LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[GLDS ? BN * BK : BK * LDT];
+    // (GLDS + RSX_SCORE_LDS_PAD: one dword of padding behind every 8 rows -- the 8 rows one DMA instruction of a wavefront writes.  With
+    //  the XOR swizzle alone the 32 lanes of a fragment read fall on 8 banks, 4 lanes each; the pad moves the four 8-row groups of
+    //  those lanes to four different bank offsets: conflict-free.)
+    constexpr int PADA = (GLDS && RSX_SCORE_LDS_PAD) ? BM / 8 : 0;
+    __shared__ __attribute__((aligned(16))) float As[GLDS ? BM * BK + PADA : BK * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[GLDS ? BN * BK + PADA : BK * LDT];
     __shared__ __attribute__((aligned(16))) float tau_s[BM];
 
     const int tid = threadIdx.x;
@@ -116,27 +128,28 @@ __device__ __forceinline__ void score_tile_body(const float *__restrict__ P,
     // lane's fragment rows: wr * 64 + l31 (+ 32) of A, wc * 64 + l31 (+ 32) of B; element (row, k) sits at row * 32 + (k ^ x),
     // x = (row & 7) << 2 = (l31 & 7) << 2 for all four rows; this lane reads k = kk + hi
     const int xs = (l31 & 7) << 2;
-    const float *ap = As + (wr * 64 + l31) * BK + hi;
-    const float *bp = Bs + (wc * 64 + l31) * BK + hi;
+    constexpr int P8 = RSX_SCORE_LDS_PAD ? 1 : 0;      // dwords of padding per 8-row group
+    const float *ap = As + (wr * 64 + l31) * BK + ((wr * 64 + l31) >> 3) * P8 + hi;
+    const float *bp = Bs + (wc * 64 + l31) * BK + ((wc * 64 + l31) >> 3) * P8 + hi;
     for (int k0 = 0; k0 < D; k0 += BK) {
         // 8 rows x 128 B per wave instruction, rows 32 n + 8 wid .. + 8 of each tile
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             // (item rows: 32-bit byte offsets from the table's base, which stays in SGPRs; user rows: pointers, the user table may be larger)
             const float *gb = reinterpret_cast<const float *>(reinterpret_cast<const char *>(Q) + (b_off[n] + (uint32_t)k0 * 4u));
-            __builtin_amdgcn_global_load_lds(a_src[n] + k0, As + (32 * n + 8 * wid) * BK, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(gb, Bs + (32 * n + 8 * wid) * BK, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(a_src[n] + k0, As + (32 * n + 8 * wid) * BK + (4 * n + wid) * P8, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(gb, Bs + (32 * n + 8 * wid) * BK + (4 * n + wid) * P8, 16, 0, 0);
         }
         __syncthreads();          // (carries the vmcnt(0) of the DMA: the chunk has landed for every wavefront)
-        float a0 = ap[xs], a1 = ap[32 * BK + xs], b0 = bp[xs], b1 = bp[32 * BK + xs];
+        float a0 = ap[xs], a1 = ap[32 * BK + 4 * P8 + xs], b0 = bp[xs], b1 = bp[32 * BK + 4 * P8 + xs];
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
             if (kk + 2 < BK) {
                 const int o = (kk + 2) ^ xs;
-                na0 = ap[o]; na1 = ap[32 * BK + o];
-                nb0 = bp[o]; nb1 = bp[32 * BK + o];
+                na0 = ap[o]; na1 = ap[32 * BK + 4 * P8 + o];
+                nb0 = bp[o]; nb1 = bp[32 * BK + 4 * P8 + o];
             }
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
