@@ -39,7 +39,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(
     const int32_t *__restrict__ seg_row, const int64_t *__restrict__ seg_begin,
     const int32_t *__restrict__ seg_len, int64_t num_segs, const int64_t *__restrict__ indptr,
     const int32_t *__restrict__ indices, const float *__restrict__ vals, const float *__restrict__ X,
-    float *__restrict__ Y, float *__restrict__ S, const uint8_t *__restrict__ nz)
+    float *__restrict__ Y, float *__restrict__ S, const uint8_t *__restrict__ nz, const uint8_t *__restrict__ want)
 {
     constexpr int LPR = D / 4;
     constexpr int GPW = 64 / LPR;                 // lane groups (segments) per wavefront
@@ -50,6 +50,9 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(
     const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
     for (int64_t s = wave * GPW + sub; s < num_segs; s += nwaves * GPW) {
         const int32_t row = seg_row[s];
+        // `want` (nullable): only the flagged rows of Y are computed -- the LAST forward product of a LightGCN training step, whose
+        // result is read at the batch's users and items only (models/LightGCN.py:117-123 indexes the propagated tables by the batch)
+        if (want != nullptr && want[row] == 0) continue;
         const int64_t pb = seg_begin[s];
         const int len = seg_len[s];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -191,7 +194,8 @@ RSX_API int64_t rsx_spmm_plan(const int64_t *indptr_host, int64_t num_rows, int 
 
 static int spmm_launch(const int32_t *seg_row_dev, const int64_t *seg_begin_dev, const int32_t *seg_len_dev,
                        int64_t num_segs, const int64_t *indptr_dev, const int32_t *indices_dev, const float *vals_dev,
-                       const float *X, float *Y, float *S_acc, int64_t num_rows, int d, const uint8_t *nz, hipStream_t st)
+                       const float *X, float *Y, float *S_acc, int64_t num_rows, int d, const uint8_t *nz, const uint8_t *want,
+                       hipStream_t st)
 {
     {   // split rows add into zeros (whole rows are stored)
         const unsigned zb = (unsigned)((num_segs + kBlock - 1) / kBlock);
@@ -203,8 +207,8 @@ static int spmm_launch(const int32_t *seg_row_dev, const int64_t *seg_begin_dev,
     }
     const int gpw = 64 / (d / 4);
     const unsigned g = grid_for((num_segs + gpw - 1) / gpw * 64);
-#define RSX_SPMM(D_) do { if (nz) hipLaunchKernelGGL((spmm_csr_kernel<D_, true>), dim3(g), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, indices_dev, vals_dev, X, Y, S_acc, nz); \
-                           else hipLaunchKernelGGL((spmm_csr_kernel<D_, false>), dim3(g), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, indices_dev, vals_dev, X, Y, S_acc, nz); } while (0)
+#define RSX_SPMM(D_) do { if (nz) hipLaunchKernelGGL((spmm_csr_kernel<D_, true>), dim3(g), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, indices_dev, vals_dev, X, Y, S_acc, nz, want); \
+                           else hipLaunchKernelGGL((spmm_csr_kernel<D_, false>), dim3(g), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, indices_dev, vals_dev, X, Y, S_acc, nz, want); } while (0)
     switch (d) {
     case 32: RSX_SPMM(32); break;
     case 64: RSX_SPMM(64); break;
@@ -225,7 +229,7 @@ RSX_API int rsx_spmm_csr(const int32_t *seg_row_dev, const int64_t *seg_begin_de
     RSX_CHECK_ARG(X != Y && X != S_acc, "X must not alias an output");
     if (num_rows == 0) return RSX_OK;
     int rc = spmm_launch(seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, indices_dev, vals_dev, X, Y, S_acc, num_rows, d,
-                         nullptr, (hipStream_t)stream);
+                         nullptr, nullptr, (hipStream_t)stream);
     if (rc != RSX_OK) return rc;
     RSX_CHECK_LAUNCH();
     return RSX_OK;
@@ -242,7 +246,24 @@ RSX_API int rsx_spmm_csr_sparse_rows(const int32_t *seg_row_dev, const int64_t *
     RSX_CHECK_ARG(X != Y && X != S_acc, "X must not alias an output");
     if (num_rows == 0) return RSX_OK;
     int rc = spmm_launch(seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, indices_dev, vals_dev, X, Y, S_acc, num_rows, d,
-                         x_row_nonzero_dev, (hipStream_t)stream);
+                         x_row_nonzero_dev, nullptr, (hipStream_t)stream);
+    if (rc != RSX_OK) return rc;
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+}
+
+RSX_API int rsx_spmm_csr_select_rows(const int32_t *seg_row_dev, const int64_t *seg_begin_dev, const int32_t *seg_len_dev,
+                                     int64_t num_segs, const int64_t *indptr_dev, const int32_t *indices_dev,
+                                     const float *vals_dev, const float *X, const uint8_t *y_row_wanted_dev, float *Y,
+                                     float *S_acc, int64_t num_rows, int d, rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(seg_row_dev && seg_begin_dev && seg_len_dev && indptr_dev && indices_dev && vals_dev && X && Y && y_row_wanted_dev,
+                  "null pointer");
+    RSX_CHECK_ARG(rsx_dim_ok(d) && num_rows >= 0 && num_segs >= 0, "bad shape");
+    RSX_CHECK_ARG(X != Y && X != S_acc, "X must not alias an output");
+    if (num_rows == 0) return RSX_OK;
+    int rc = spmm_launch(seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, indices_dev, vals_dev, X, Y, S_acc, num_rows, d,
+                         nullptr, y_row_wanted_dev, (hipStream_t)stream);
     if (rc != RSX_OK) return rc;
     RSX_CHECK_LAUNCH();
     return RSX_OK;

@@ -90,9 +90,11 @@ class LightGCN(BaseModel):
         return torch.as_tensor(t).to(device=self.device, dtype=torch.int32).contiguous()
 
     # -- models/LightGCN.py:174-202 ----------------------------------------------------------------
-    def _propagate(self, src, acc, src_nonzero=None):
+    def _propagate(self, src, acc, src_nonzero=None, out_wanted=None):
         """acc = mean_{k=0..L} A_hat^k src   (src untouched).  src_nonzero (uint8 per row, 0 = the row of src is entirely
-        zero) lets the FIRST product skip the fetch of such rows (bit-identical; include/rsx.h: rsx_spmm_csr_sparse_rows)"""
+        zero) lets the FIRST product skip the fetch of such rows (bit-identical; include/rsx.h: rsx_spmm_csr_sparse_rows);
+        out_wanted (uint8 per row) lets the LAST product compute only the rows of acc the caller will read (the others are then
+        NOT the propagation: include/rsx.h: rsx_spmm_csr_select_rows)"""
         k = self._k
         if self.Graph is None:
             raise RuntimeError("no graph yet: call fit() or getSparseGraph(train_matrix) first "
@@ -102,6 +104,8 @@ class LightGCN(BaseModel):
         for layer in range(self.num_layers):
             if layer == 0 and src_nonzero is not None and hasattr(k, "lib"):
                 k.spmm(self.Graph, cur, nxt, S_acc=acc, x_nonzero=src_nonzero)
+            elif layer == self.num_layers - 1 and out_wanted is not None and hasattr(k, "lib"):
+                k.spmm(self.Graph, cur, nxt, S_acc=acc, y_wanted=out_wanted)
             else:
                 k.spmm(self.Graph, cur, nxt, S_acc=acc)
             cur, nxt = nxt, (self._tb if nxt is self._ta else self._ta)
@@ -123,15 +127,18 @@ class LightGCN(BaseModel):
     def train_step(self, users, pos, neg):
         k, U = self._k, self.num_users
         u, i, j = self._idx(users), self._idx(pos), self._idx(neg)
-        self.update_lightgcn_embedding()
-        acc = torch.zeros(k.RSX_LOSS_SLOTS, dtype=torch.float32, device=self.device)
-        k.bpr_grad(self._out[:U], self._out[U:], self._dout[:U], self._dout[U:], u, i, j, 1.0 / max(1, u.numel()),
-                   loss_acc=acc)
-        # back through the L products; dL/dOut is non-zero only in the rows of the batch's users and items, so the first
-        # product is told which rows to fetch at all (65 536 of 1M users in a batch: 93 % of the rows an item row gathers)
+        # the rows of the stacked [users; items] table this batch touches: the loss reads the propagated tables there and nowhere
+        # else (models/LightGCN.py:117-123), and dL/dOut is non-zero there and nowhere else
         if self._nz is None:
             self._nz = torch.zeros(self._E0.shape[0], dtype=torch.uint8, device=self.device)
         k.mark_batch_rows(self._nz, u, i, j, U)
+        # forward: L products, the last one only for the batch's rows (65 536 of 1M users in a batch: 93 % of its user rows unread)
+        self._propagate(self._E0, self._out, out_wanted=self._nz)
+        self._fresh = False               # (self._out holds the propagation at the batch's rows only)
+        acc = torch.zeros(k.RSX_LOSS_SLOTS, dtype=torch.float32, device=self.device)
+        k.bpr_grad(self._out[:U], self._out[U:], self._dout[:U], self._dout[U:], u, i, j, 1.0 / max(1, u.numel()),
+                   loss_acc=acc)
+        # back through the L products; the first one is told which rows of dL/dOut to fetch at all
         self._propagate(self._dout, self._g, src_nonzero=self._nz)
         self._dout.zero_()
         self._t += 1

@@ -51,6 +51,7 @@ SIGNATURES = {
     "rsx_spmm_plan": (_I64, [_P, _I64, _I32, _P, _P, _P]),
     "rsx_spmm_csr": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
     "rsx_spmm_csr_sparse_rows": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
+    "rsx_spmm_csr_select_rows": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
     "rsx_scale": (C.c_int, [_P, _I64, _F, _P]),
     "rsx_spmm_mark_batch_rows": (C.c_int, [_P, _I64, _P, _P, _P, _I64, _I64, _P]),
     "rsx_pair_score": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P]),
@@ -266,15 +267,20 @@ class SpmmGraph:
         self.vals = to(np.ascontiguousarray(csr.data, dtype=np.float32))
 
 
-def spmm(graph, X, Y, S_acc=None, x_nonzero=None):
+def spmm(graph, X, Y, S_acc=None, x_nonzero=None, y_wanted=None):
     """Y = A X (and S_acc += A X) -- include/rsx.h:rsx_spmm_csr; x_nonzero (uint8 [N], 0 = that row of X is entirely zero):
-    rsx_spmm_csr_sparse_rows, which does not fetch such rows"""
+    rsx_spmm_csr_sparse_rows, which does not fetch such rows; y_wanted (uint8 [N]): rsx_spmm_csr_select_rows, which computes
+    only the flagged rows of Y / S_acc (the others keep what they held)"""
+    if x_nonzero is not None and y_wanted is not None:
+        raise RsxError("spmm: x_nonzero and y_wanted are two different products (one or the other)")
     common = (_dev(graph.seg_row, torch.int32, "seg_row"), _dev(graph.seg_begin, torch.int64, "seg_begin"),
               _dev(graph.seg_len, torch.int32, "seg_len"), graph.num_segs, _dev(graph.indptr, torch.int64, "indptr"),
               _dev(graph.indices, torch.int32, "indices"), _dev(graph.vals, torch.float32, "vals"), _dev(X, torch.float32, "X"))
     tail = (_dev(Y, torch.float32, "Y"), _dev(S_acc, torch.float32, "S_acc") if S_acc is not None else None, graph.n, X.shape[1],
             _stream())
-    if x_nonzero is None:
+    if y_wanted is not None:
+        _check(lib().rsx_spmm_csr_select_rows(*common, _dev(y_wanted, torch.uint8, "y_wanted"), *tail), "rsx_spmm_csr_select_rows")
+    elif x_nonzero is None:
         _check(lib().rsx_spmm_csr(*common, *tail), "rsx_spmm_csr")
     else:
         _check(lib().rsx_spmm_csr_sparse_rows(*common, _dev(x_nonzero, torch.uint8, "x_nonzero"), *tail), "rsx_spmm_csr_sparse_rows")

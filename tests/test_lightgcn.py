@@ -129,6 +129,17 @@ def test_hip_spmm_long_rows_vs_oracle(oracle_mod, max_seg):
         Xp = Xs.clone(); Xp[part == 0] = 0.0
         rsx.spmm(G, Xp, Ya)
         assert torch.equal(Ya[short], Yb[short])
+        # only SOME rows of the result wanted (rsx_spmm_csr_select_rows: the last forward product of a LightGCN step): those rows
+        # equal the full product's (bit for bit where a row is one segment), the others keep what they held -- in Y and in S_acc
+        want = torch.from_numpy((np.random.default_rng(77 + d).random(N) < 0.2).astype(np.uint8)).cuda()   # (own generator: the draws above stay what they were)
+        want[7] = 1; want[11] = 0                                # one of the long (split) rows wanted, the other not
+        Yw, Sw = torch.full_like(Xd, 7.0), torch.full_like(Xd, -3.0)
+        rsx.spmm(G, Xd, Yw, S_acc=Sw, y_wanted=want)
+        w = want.bool()
+        assert torch.equal(Yw[w & short], Y[w & short]) and float((Yw[w] - Y[w]).abs().max()) <= 2e-6 * float(Y.abs().max())
+        assert float((Sw[w] - (Y[w] - 3.0)).abs().max()) <= 4e-6 * float(Y.abs().max() + 3.0)
+        keep = ~w & short                                        # (an unwanted SPLIT row is cleared like every split row, then left alone)
+        assert bool((Yw[keep] == 7.0).all()) and bool((Sw[~w] == -3.0).all())
 
 
 @pytest.mark.gpu
