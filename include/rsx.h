@@ -559,6 +559,16 @@ int rsx_spmm_csr_sparse_rows(const int32_t *seg_row_dev, const int64_t *seg_begi
                              int64_t num_segs, const int64_t *indptr_dev, const int32_t *indices_dev,
                              const float *vals_dev, const float *X, const uint8_t *x_row_nonzero_dev, float *Y,
                              float *S_acc, int64_t num_rows, int d, rsx_stream_t stream);
+/* rsx_spmm_csr_init: the FIRST product of a propagation, fused with the start of the running layer sum: Y = A X and
+ *   S_out = S_init + A X (S_out is overwritten; S_init, usually X itself, is only read) -- instead of copying the source table into
+ *   the sum and then adding.  x_row_nonzero_dev: NULL, or the row flags of rsx_spmm_csr_sparse_rows.  Same sums as the two-step form. */
+int rsx_spmm_csr_init(const int32_t *seg_row_dev, const int64_t *seg_begin_dev, const int32_t *seg_len_dev,
+                      int64_t num_segs, const int64_t *indptr_dev, const int32_t *indices_dev,
+                      const float *vals_dev, const float *X, const uint8_t *x_row_nonzero_dev, const float *S_init,
+                      float *Y, float *S_out, int64_t num_rows, int d, rsx_stream_t stream);
+/* rsx_spmm_zero_rows: X[row] = 0 for the flagged rows (uint8 [num_rows]) -- clears the dense gradient of a batch where it is
+ *   non-zero (the rows rsx_spmm_mark_batch_rows flagged) instead of sweeping the whole table.                          */
+int rsx_spmm_zero_rows(float *X, const uint8_t *flags_dev, int64_t num_rows, int d, rsx_stream_t stream);
 /* rsx_spmm_csr_select_rows: the same product for a caller who reads only SOME rows of the result; y_row_wanted_dev (uint8 [N]) is
  *   non-zero for those: the other rows of Y (and of S_acc) are NOT written and hold whatever they held.  The wanted rows are
  *   bit-identical to rsx_spmm_csr's.  The LAST forward product of a LightGCN training step: the loss indexes the propagated

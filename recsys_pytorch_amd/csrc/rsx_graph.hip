@@ -39,7 +39,8 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(
     const int32_t *__restrict__ seg_row, const int64_t *__restrict__ seg_begin,
     const int32_t *__restrict__ seg_len, int64_t num_segs, const int64_t *__restrict__ indptr,
     const int32_t *__restrict__ indices, const float *__restrict__ vals, const float *__restrict__ X,
-    float *__restrict__ Y, float *__restrict__ S, const uint8_t *__restrict__ nz, const uint8_t *__restrict__ want)
+    float *__restrict__ Y, float *__restrict__ S, const uint8_t *__restrict__ nz, const uint8_t *__restrict__ want,
+    const float *__restrict__ Sinit)
 {
     constexpr int LPR = D / 4;
     constexpr int GPW = 64 / LPR;                 // lane groups (segments) per wavefront
@@ -118,8 +119,10 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(
         if (whole) {
             *reinterpret_cast<float4 *>(y) = acc;
             if (S != nullptr) {
+                // S_init (nullable): S = S_init + A X instead of S += A X -- the first product of a propagation, whose running layer
+                // sum starts as the source table itself (saves the copy of the table into S beforehand)
                 float4 *sp = reinterpret_cast<float4 *>(S + (size_t)row * D) + k;
-                float4 t = *sp;
+                float4 t = Sinit != nullptr ? reinterpret_cast<const float4 *>(Sinit + (size_t)row * D)[k] : *sp;
                 t.x += acc.x; t.y += acc.y; t.z += acc.z; t.w += acc.w;
                 *sp = t;
             }
@@ -147,7 +150,8 @@ __global__ __launch_bounds__(kBlock) void scale_kernel(float4 *__restrict__ X, i
 template <int D>
 __global__ __launch_bounds__(kBlock) void zero_split_rows_kernel(const int32_t *__restrict__ seg_row, const int64_t *__restrict__ seg_begin,
                                                                  const int32_t *__restrict__ seg_len, int64_t num_segs,
-                                                                 const int64_t *__restrict__ indptr, float *__restrict__ Y)
+                                                                 const int64_t *__restrict__ indptr, float *__restrict__ Y,
+                                                                 float *__restrict__ S, const float *__restrict__ Sinit)
 {
     // one thread per segment decides; the few that start a split row clear it (a thread per quad of every segment -- 35M threads
     // at the configs[4] shape -- took 99 us, more than the memset it had replaced)
@@ -159,6 +163,12 @@ __global__ __launch_bounds__(kBlock) void zero_split_rows_kernel(const int32_t *
         float4 *y = reinterpret_cast<float4 *>(Y + (size_t)row * D);
 #pragma unroll 8
         for (int k = 0; k < D / 4; ++k) y[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (S != nullptr && Sinit != nullptr) {      // S = S_init + A X: the split row's pieces add atomically into the initial row
+            float4 *sp = reinterpret_cast<float4 *>(S + (size_t)row * D);
+            const float4 *ip = reinterpret_cast<const float4 *>(Sinit + (size_t)row * D);
+#pragma unroll 8
+            for (int k = 0; k < D / 4; ++k) sp[k] = ip[k];
+        }
     }
 }
 
@@ -195,20 +205,20 @@ RSX_API int64_t rsx_spmm_plan(const int64_t *indptr_host, int64_t num_rows, int 
 static int spmm_launch(const int32_t *seg_row_dev, const int64_t *seg_begin_dev, const int32_t *seg_len_dev,
                        int64_t num_segs, const int64_t *indptr_dev, const int32_t *indices_dev, const float *vals_dev,
                        const float *X, float *Y, float *S_acc, int64_t num_rows, int d, const uint8_t *nz, const uint8_t *want,
-                       hipStream_t st)
+                       const float *S_init, hipStream_t st)
 {
     {   // split rows add into zeros (whole rows are stored)
         const unsigned zb = (unsigned)((num_segs + kBlock - 1) / kBlock);
         switch (d) {
-        case 32: hipLaunchKernelGGL(zero_split_rows_kernel<32>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y); break;
-        case 64: hipLaunchKernelGGL(zero_split_rows_kernel<64>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y); break;
-        default: hipLaunchKernelGGL(zero_split_rows_kernel<128>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y); break;
+        case 32: hipLaunchKernelGGL(zero_split_rows_kernel<32>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y, S_acc, S_init); break;
+        case 64: hipLaunchKernelGGL(zero_split_rows_kernel<64>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y, S_acc, S_init); break;
+        default: hipLaunchKernelGGL(zero_split_rows_kernel<128>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y, S_acc, S_init); break;
         }
     }
     const int gpw = 64 / (d / 4);
     const unsigned g = grid_for((num_segs + gpw - 1) / gpw * 64);
-#define RSX_SPMM(D_) do { if (nz) hipLaunchKernelGGL((spmm_csr_kernel<D_, true>), dim3(g), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, indices_dev, vals_dev, X, Y, S_acc, nz, want); \
-                           else hipLaunchKernelGGL((spmm_csr_kernel<D_, false>), dim3(g), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, indices_dev, vals_dev, X, Y, S_acc, nz, want); } while (0)
+#define RSX_SPMM(D_) do { if (nz) hipLaunchKernelGGL((spmm_csr_kernel<D_, true>), dim3(g), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, indices_dev, vals_dev, X, Y, S_acc, nz, want, S_init); \
+                           else hipLaunchKernelGGL((spmm_csr_kernel<D_, false>), dim3(g), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, indices_dev, vals_dev, X, Y, S_acc, nz, want, S_init); } while (0)
     switch (d) {
     case 32: RSX_SPMM(32); break;
     case 64: RSX_SPMM(64); break;
@@ -229,7 +239,7 @@ RSX_API int rsx_spmm_csr(const int32_t *seg_row_dev, const int64_t *seg_begin_de
     RSX_CHECK_ARG(X != Y && X != S_acc, "X must not alias an output");
     if (num_rows == 0) return RSX_OK;
     int rc = spmm_launch(seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, indices_dev, vals_dev, X, Y, S_acc, num_rows, d,
-                         nullptr, nullptr, (hipStream_t)stream);
+                         nullptr, nullptr, nullptr, (hipStream_t)stream);
     if (rc != RSX_OK) return rc;
     RSX_CHECK_LAUNCH();
     return RSX_OK;
@@ -246,7 +256,24 @@ RSX_API int rsx_spmm_csr_sparse_rows(const int32_t *seg_row_dev, const int64_t *
     RSX_CHECK_ARG(X != Y && X != S_acc, "X must not alias an output");
     if (num_rows == 0) return RSX_OK;
     int rc = spmm_launch(seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, indices_dev, vals_dev, X, Y, S_acc, num_rows, d,
-                         x_row_nonzero_dev, nullptr, (hipStream_t)stream);
+                         x_row_nonzero_dev, nullptr, nullptr, (hipStream_t)stream);
+    if (rc != RSX_OK) return rc;
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+}
+
+RSX_API int rsx_spmm_csr_init(const int32_t *seg_row_dev, const int64_t *seg_begin_dev, const int32_t *seg_len_dev,
+                              int64_t num_segs, const int64_t *indptr_dev, const int32_t *indices_dev,
+                              const float *vals_dev, const float *X, const uint8_t *x_row_nonzero_dev, const float *S_init,
+                              float *Y, float *S_out, int64_t num_rows, int d, rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(seg_row_dev && seg_begin_dev && seg_len_dev && indptr_dev && indices_dev && vals_dev && X && Y && S_init && S_out,
+                  "null pointer");
+    RSX_CHECK_ARG(rsx_dim_ok(d) && num_rows >= 0 && num_segs >= 0, "bad shape");
+    RSX_CHECK_ARG(X != Y && X != S_out && S_init != S_out && S_init != Y, "X and S_init must not alias an output");
+    if (num_rows == 0) return RSX_OK;
+    int rc = spmm_launch(seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, indices_dev, vals_dev, X, Y, S_out, num_rows, d,
+                         x_row_nonzero_dev, nullptr, S_init, (hipStream_t)stream);
     if (rc != RSX_OK) return rc;
     RSX_CHECK_LAUNCH();
     return RSX_OK;
@@ -263,7 +290,7 @@ RSX_API int rsx_spmm_csr_select_rows(const int32_t *seg_row_dev, const int64_t *
     RSX_CHECK_ARG(X != Y && X != S_acc, "X must not alias an output");
     if (num_rows == 0) return RSX_OK;
     int rc = spmm_launch(seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, indices_dev, vals_dev, X, Y, S_acc, num_rows, d,
-                         nullptr, y_row_wanted_dev, (hipStream_t)stream);
+                         nullptr, y_row_wanted_dev, nullptr, (hipStream_t)stream);
     if (rc != RSX_OK) return rc;
     RSX_CHECK_LAUNCH();
     return RSX_OK;
@@ -296,6 +323,31 @@ RSX_API int rsx_spmm_mark_batch_rows(uint8_t *flags_dev, int64_t num_rows, const
     int64_t blocks = (batch + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(mark_batch_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, flags_dev, u_dev, i_dev, j_dev, batch, item_offset);
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+}
+
+template <int D4>
+__global__ __launch_bounds__(256) void zero_flagged_rows_kernel(float4 *__restrict__ X, const uint8_t *__restrict__ flags, int64_t num_rows)
+{
+    // one thread per quad of a row: a flagged row's D / 4 quads are cleared by D / 4 consecutive threads
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = t / D4;
+    if (row < num_rows && flags[row] != 0) X[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+RSX_API int rsx_spmm_zero_rows(float *X, const uint8_t *flags_dev, int64_t num_rows, int d, rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(X && flags_dev && num_rows >= 0 && rsx_dim_ok(d), "bad arguments");
+    if (num_rows == 0) return RSX_OK;
+    const int64_t threads = num_rows * (d / 4);
+    const unsigned g = (unsigned)((threads + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (d) {
+    case 32: hipLaunchKernelGGL(zero_flagged_rows_kernel<8>, dim3(g), dim3(256), 0, st, (float4 *)X, flags_dev, num_rows); break;
+    case 64: hipLaunchKernelGGL(zero_flagged_rows_kernel<16>, dim3(g), dim3(256), 0, st, (float4 *)X, flags_dev, num_rows); break;
+    default: hipLaunchKernelGGL(zero_flagged_rows_kernel<32>, dim3(g), dim3(256), 0, st, (float4 *)X, flags_dev, num_rows); break;
+    }
     RSX_CHECK_LAUNCH();
     return RSX_OK;
 }

@@ -90,26 +90,33 @@ class LightGCN(BaseModel):
         return torch.as_tensor(t).to(device=self.device, dtype=torch.int32).contiguous()
 
     # -- models/LightGCN.py:174-202 ----------------------------------------------------------------
-    def _propagate(self, src, acc, src_nonzero=None, out_wanted=None):
+    def _propagate(self, src, acc, src_nonzero=None, out_wanted=None, scale=True):
         """acc = mean_{k=0..L} A_hat^k src   (src untouched).  src_nonzero (uint8 per row, 0 = the row of src is entirely
         zero) lets the FIRST product skip the fetch of such rows (bit-identical; include/rsx.h: rsx_spmm_csr_sparse_rows);
         out_wanted (uint8 per row) lets the LAST product compute only the rows of acc the caller will read (the others are then
-        NOT the propagation: include/rsx.h: rsx_spmm_csr_select_rows)"""
+        NOT the propagation: include/rsx.h: rsx_spmm_csr_select_rows); scale = False leaves out the 1 / (L + 1) of the layer mean
+        (a caller who has folded it into src: the product is linear)"""
         k = self._k
         if self.Graph is None:
             raise RuntimeError("no graph yet: call fit() or getSparseGraph(train_matrix) first "
                                "(the reference builds it in fit, models/LightGCN.py:70)")
-        acc.copy_(src)
+        native = hasattr(k, "lib")
+        fuse_first = native and (self.num_layers > 1 or out_wanted is None)      # the first product starts the running sum: acc = src + A src
+        if not fuse_first:
+            acc.copy_(src)
         cur, nxt = src, self._ta
         for layer in range(self.num_layers):
-            if layer == 0 and src_nonzero is not None and hasattr(k, "lib"):
+            if layer == 0 and fuse_first:
+                k.spmm(self.Graph, cur, nxt, S_acc=acc, x_nonzero=src_nonzero, S_init=src)
+            elif layer == 0 and src_nonzero is not None and native:
                 k.spmm(self.Graph, cur, nxt, S_acc=acc, x_nonzero=src_nonzero)
-            elif layer == self.num_layers - 1 and out_wanted is not None and hasattr(k, "lib"):
+            elif layer == self.num_layers - 1 and out_wanted is not None and native:
                 k.spmm(self.Graph, cur, nxt, S_acc=acc, y_wanted=out_wanted)
             else:
                 k.spmm(self.Graph, cur, nxt, S_acc=acc)
             cur, nxt = nxt, (self._tb if nxt is self._ta else self._ta)
-        k.scale(acc, 1.0 / (self.num_layers + 1))
+        if scale:
+            k.scale(acc, 1.0 / (self.num_layers + 1))
 
     def update_lightgcn_embedding(self):
         self._propagate(self._E0, self._out)
@@ -136,11 +143,14 @@ class LightGCN(BaseModel):
         self._propagate(self._E0, self._out, out_wanted=self._nz)
         self._fresh = False               # (self._out holds the propagation at the batch's rows only)
         acc = torch.zeros(k.RSX_LOSS_SLOTS, dtype=torch.float32, device=self.device)
-        k.bpr_grad(self._out[:U], self._out[U:], self._dout[:U], self._dout[U:], u, i, j, 1.0 / max(1, u.numel()),
+        # dL/dOut carries the 1 / (L + 1) of the layer mean already (the propagation is linear: mean_k A^k (a g) = a mean_k A^k g), so
+        # the backward pass needs no sweep over the table to scale its result
+        alpha = 1.0 / (self.num_layers + 1)
+        k.bpr_grad(self._out[:U], self._out[U:], self._dout[:U], self._dout[U:], u, i, j, alpha / max(1, u.numel()),
                    loss_acc=acc)
         # back through the L products; the first one is told which rows of dL/dOut to fetch at all
-        self._propagate(self._dout, self._g, src_nonzero=self._nz)
-        self._dout.zero_()
+        self._propagate(self._dout, self._g, src_nonzero=self._nz, scale=False)
+        k.zero_rows(self._dout, self._nz)           # dL/dOut is non-zero in the batch's rows only: clear those, not the table
         self._t += 1
         k.adam_apply(self._E0, self._m, self._v, self._g, self.lr, self._t)
         self._fresh = False

@@ -52,6 +52,8 @@ SIGNATURES = {
     "rsx_spmm_csr": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
     "rsx_spmm_csr_sparse_rows": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
     "rsx_spmm_csr_select_rows": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
+    "rsx_spmm_csr_init": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
+    "rsx_spmm_zero_rows": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "rsx_scale": (C.c_int, [_P, _I64, _F, _P]),
     "rsx_spmm_mark_batch_rows": (C.c_int, [_P, _I64, _P, _P, _P, _I64, _I64, _P]),
     "rsx_pair_score": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P]),
@@ -267,12 +269,21 @@ class SpmmGraph:
         self.vals = to(np.ascontiguousarray(csr.data, dtype=np.float32))
 
 
-def spmm(graph, X, Y, S_acc=None, x_nonzero=None, y_wanted=None):
+def spmm(graph, X, Y, S_acc=None, x_nonzero=None, y_wanted=None, S_init=None):
     """Y = A X (and S_acc += A X) -- include/rsx.h:rsx_spmm_csr; x_nonzero (uint8 [N], 0 = that row of X is entirely zero):
     rsx_spmm_csr_sparse_rows, which does not fetch such rows; y_wanted (uint8 [N]): rsx_spmm_csr_select_rows, which computes
-    only the flagged rows of Y / S_acc (the others keep what they held)"""
-    if x_nonzero is not None and y_wanted is not None:
-        raise RsxError("spmm: x_nonzero and y_wanted are two different products (one or the other)")
+    only the flagged rows of Y / S_acc (the others keep what they held); S_init: rsx_spmm_csr_init, S_acc = S_init + A X (S_acc is
+    overwritten: the first product of a propagation, without the copy of the source into the running sum)"""
+    if (x_nonzero is not None or S_init is not None) and y_wanted is not None:
+        raise RsxError("spmm: y_wanted does not combine with x_nonzero / S_init (different products)")
+    if S_init is not None:
+        _check(lib().rsx_spmm_csr_init(
+            _dev(graph.seg_row, torch.int32, "seg_row"), _dev(graph.seg_begin, torch.int64, "seg_begin"),
+            _dev(graph.seg_len, torch.int32, "seg_len"), graph.num_segs, _dev(graph.indptr, torch.int64, "indptr"),
+            _dev(graph.indices, torch.int32, "indices"), _dev(graph.vals, torch.float32, "vals"), _dev(X, torch.float32, "X"),
+            _dev(x_nonzero, torch.uint8, "x_nonzero") if x_nonzero is not None else None, _dev(S_init, torch.float32, "S_init"),
+            _dev(Y, torch.float32, "Y"), _dev(S_acc, torch.float32, "S_acc"), graph.n, X.shape[1], _stream()), "rsx_spmm_csr_init")
+        return
     common = (_dev(graph.seg_row, torch.int32, "seg_row"), _dev(graph.seg_begin, torch.int64, "seg_begin"),
               _dev(graph.seg_len, torch.int32, "seg_len"), graph.num_segs, _dev(graph.indptr, torch.int64, "indptr"),
               _dev(graph.indices, torch.int32, "indices"), _dev(graph.vals, torch.float32, "vals"), _dev(X, torch.float32, "X"))
@@ -291,6 +302,12 @@ def mark_batch_rows(flags, u, i, j, item_offset):
     _check(lib().rsx_spmm_mark_batch_rows(_dev(flags, torch.uint8, "flags"), flags.numel(), _dev(u, torch.int32, "u"),
                                           _dev(i, torch.int32, "i"), _dev(j, torch.int32, "j"), u.numel(), int(item_offset),
                                           _stream()), "rsx_spmm_mark_batch_rows")
+
+
+def zero_rows(X, flags):
+    """include/rsx.h:rsx_spmm_zero_rows -- X[row] = 0 where flags[row] != 0"""
+    _check(lib().rsx_spmm_zero_rows(_dev(X, torch.float32, "X"), _dev(flags, torch.uint8, "flags"), X.shape[0], X.shape[1], _stream()),
+           "rsx_spmm_zero_rows")
 
 
 def scale(X, alpha):

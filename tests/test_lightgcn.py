@@ -129,6 +129,16 @@ def test_hip_spmm_long_rows_vs_oracle(oracle_mod, max_seg):
         Xp = Xs.clone(); Xp[part == 0] = 0.0
         rsx.spmm(G, Xp, Ya)
         assert torch.equal(Ya[short], Yb[short])
+        # the first product of a propagation fused with the start of the running sum (rsx_spmm_csr_init): S = S_init + A X
+        Si = torch.full_like(Xd, 123.0)
+        Yi = torch.empty_like(Xd)
+        rsx.spmm(G, Xd, Yi, S_acc=Si, S_init=Xd)
+        assert torch.equal(Yi[short], Y[short]) and torch.equal(Si[short], S[short])     # S above = X.clone() then += A X
+        assert float((Si - S).abs().max()) <= 4e-6 * float(S.abs().max())
+        Zr = Xd.clone()
+        fl = torch.from_numpy((np.random.default_rng(5 + d).random(N) < 0.3).astype(np.uint8)).cuda()
+        rsx.zero_rows(Zr, fl)
+        assert float(Zr[fl.bool()].abs().max()) == 0.0 and torch.equal(Zr[~fl.bool()], Xd[~fl.bool()])
         # only SOME rows of the result wanted (rsx_spmm_csr_select_rows: the last forward product of a LightGCN step): those rows
         # equal the full product's (bit for bit where a row is one segment), the others keep what they held -- in Y and in S_acc
         want = torch.from_numpy((np.random.default_rng(77 + d).random(N) < 0.2).astype(np.uint8)).cuda()   # (own generator: the draws above stay what they were)
