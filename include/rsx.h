@@ -566,9 +566,11 @@ int rsx_spmm_csr_init(const int32_t *seg_row_dev, const int64_t *seg_begin_dev, 
                       int64_t num_segs, const int64_t *indptr_dev, const int32_t *indices_dev,
                       const float *vals_dev, const float *X, const uint8_t *x_row_nonzero_dev, const float *S_init,
                       float *Y, float *S_out, int64_t num_rows, int d, rsx_stream_t stream);
-/* rsx_spmm_zero_rows: X[row] = 0 for the flagged rows (uint8 [num_rows]) -- clears the dense gradient of a batch where it is
- *   non-zero (the rows rsx_spmm_mark_batch_rows flagged) instead of sweeping the whole table.                          */
-int rsx_spmm_zero_rows(float *X, const uint8_t *flags_dev, int64_t num_rows, int d, rsx_stream_t stream);
+/* rsx_spmm_scale_rows: X[row] *= alpha for the flagged rows (uint8 [num_rows]); alpha = 0 stores zeros.  Two sweeps of a LightGCN
+ *   step that concern the batch's rows only (the rows rsx_spmm_mark_batch_rows flagged): the 1 / (L + 1) of the forward layer mean
+ *   (the loss reads the propagated tables at those rows and nowhere else), and clearing the dense gradient dL/dOut where it is
+ *   non-zero.                                                                                                          */
+int rsx_spmm_scale_rows(float *X, const uint8_t *flags_dev, int64_t num_rows, int d, float alpha, rsx_stream_t stream);
 /* rsx_spmm_csr_select_rows: the same product for a caller who reads only SOME rows of the result; y_row_wanted_dev (uint8 [N]) is
  *   non-zero for those: the other rows of Y (and of S_acc) are NOT written and hold whatever they held.  The wanted rows are
  *   bit-identical to rsx_spmm_csr's.  The LAST forward product of a LightGCN training step: the loss indexes the propagated

@@ -328,15 +328,20 @@ RSX_API int rsx_spmm_mark_batch_rows(uint8_t *flags_dev, int64_t num_rows, const
 }
 
 template <int D4>
-__global__ __launch_bounds__(256) void zero_flagged_rows_kernel(float4 *__restrict__ X, const uint8_t *__restrict__ flags, int64_t num_rows)
+__global__ __launch_bounds__(256) void scale_flagged_rows_kernel(float4 *__restrict__ X, const uint8_t *__restrict__ flags, int64_t num_rows,
+                                                                 float alpha)
 {
-    // one thread per quad of a row: a flagged row's D / 4 quads are cleared by D / 4 consecutive threads
+    // one thread per quad of a row: a flagged row's D / 4 quads are handled by D / 4 consecutive threads; alpha == 0 stores zeros
+    // (whatever the row held)
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t row = t / D4;
-    if (row < num_rows && flags[row] != 0) X[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row >= num_rows || flags[row] == 0) return;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (alpha != 0.0f) { v = X[t]; v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha; }
+    X[t] = v;
 }
 
-RSX_API int rsx_spmm_zero_rows(float *X, const uint8_t *flags_dev, int64_t num_rows, int d, rsx_stream_t stream)
+RSX_API int rsx_spmm_scale_rows(float *X, const uint8_t *flags_dev, int64_t num_rows, int d, float alpha, rsx_stream_t stream)
 {
     RSX_CHECK_ARG(X && flags_dev && num_rows >= 0 && rsx_dim_ok(d), "bad arguments");
     if (num_rows == 0) return RSX_OK;
@@ -344,9 +349,9 @@ RSX_API int rsx_spmm_zero_rows(float *X, const uint8_t *flags_dev, int64_t num_r
     const unsigned g = (unsigned)((threads + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
     switch (d) {
-    case 32: hipLaunchKernelGGL(zero_flagged_rows_kernel<8>, dim3(g), dim3(256), 0, st, (float4 *)X, flags_dev, num_rows); break;
-    case 64: hipLaunchKernelGGL(zero_flagged_rows_kernel<16>, dim3(g), dim3(256), 0, st, (float4 *)X, flags_dev, num_rows); break;
-    default: hipLaunchKernelGGL(zero_flagged_rows_kernel<32>, dim3(g), dim3(256), 0, st, (float4 *)X, flags_dev, num_rows); break;
+    case 32: hipLaunchKernelGGL(scale_flagged_rows_kernel<8>, dim3(g), dim3(256), 0, st, (float4 *)X, flags_dev, num_rows, alpha); break;
+    case 64: hipLaunchKernelGGL(scale_flagged_rows_kernel<16>, dim3(g), dim3(256), 0, st, (float4 *)X, flags_dev, num_rows, alpha); break;
+    default: hipLaunchKernelGGL(scale_flagged_rows_kernel<32>, dim3(g), dim3(256), 0, st, (float4 *)X, flags_dev, num_rows, alpha); break;
     }
     RSX_CHECK_LAUNCH();
     return RSX_OK;

@@ -140,7 +140,8 @@ class LightGCN(BaseModel):
             self._nz = torch.zeros(self._E0.shape[0], dtype=torch.uint8, device=self.device)
         k.mark_batch_rows(self._nz, u, i, j, U)
         # forward: L products, the last one only for the batch's rows (65 536 of 1M users in a batch: 93 % of its user rows unread)
-        self._propagate(self._E0, self._out, out_wanted=self._nz)
+        self._propagate(self._E0, self._out, out_wanted=self._nz, scale=False)
+        k.scale_rows(self._out, self._nz, 1.0 / (self.num_layers + 1))      # the layer mean, where the loss reads it
         self._fresh = False               # (self._out holds the propagation at the batch's rows only)
         acc = torch.zeros(k.RSX_LOSS_SLOTS, dtype=torch.float32, device=self.device)
         # dL/dOut carries the 1 / (L + 1) of the layer mean already (the propagation is linear: mean_k A^k (a g) = a mean_k A^k g), so
@@ -150,7 +151,7 @@ class LightGCN(BaseModel):
                    loss_acc=acc)
         # back through the L products; the first one is told which rows of dL/dOut to fetch at all
         self._propagate(self._dout, self._g, src_nonzero=self._nz, scale=False)
-        k.zero_rows(self._dout, self._nz)           # dL/dOut is non-zero in the batch's rows only: clear those, not the table
+        k.scale_rows(self._dout, self._nz, 0.0)     # dL/dOut is non-zero in the batch's rows only: clear those, not the table
         self._t += 1
         k.adam_apply(self._E0, self._m, self._v, self._g, self.lr, self._t)
         self._fresh = False

@@ -53,7 +53,7 @@ SIGNATURES = {
     "rsx_spmm_csr_sparse_rows": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
     "rsx_spmm_csr_select_rows": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
     "rsx_spmm_csr_init": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
-    "rsx_spmm_zero_rows": (C.c_int, [_P, _P, _I64, _I32, _P]),
+    "rsx_spmm_scale_rows": (C.c_int, [_P, _P, _I64, _I32, _F, _P]),
     "rsx_scale": (C.c_int, [_P, _I64, _F, _P]),
     "rsx_spmm_mark_batch_rows": (C.c_int, [_P, _I64, _P, _P, _P, _I64, _I64, _P]),
     "rsx_pair_score": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P]),
@@ -304,10 +304,10 @@ def mark_batch_rows(flags, u, i, j, item_offset):
                                           _stream()), "rsx_spmm_mark_batch_rows")
 
 
-def zero_rows(X, flags):
-    """include/rsx.h:rsx_spmm_zero_rows -- X[row] = 0 where flags[row] != 0"""
-    _check(lib().rsx_spmm_zero_rows(_dev(X, torch.float32, "X"), _dev(flags, torch.uint8, "flags"), X.shape[0], X.shape[1], _stream()),
-           "rsx_spmm_zero_rows")
+def scale_rows(X, flags, alpha):
+    """include/rsx.h:rsx_spmm_scale_rows -- X[row] *= alpha where flags[row] != 0 (alpha = 0: the rows are cleared)"""
+    _check(lib().rsx_spmm_scale_rows(_dev(X, torch.float32, "X"), _dev(flags, torch.uint8, "flags"), X.shape[0], X.shape[1],
+                                     float(alpha), _stream()), "rsx_spmm_scale_rows")
 
 
 def scale(X, alpha):

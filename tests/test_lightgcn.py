@@ -137,7 +137,11 @@ def test_hip_spmm_long_rows_vs_oracle(oracle_mod, max_seg):
         assert float((Si - S).abs().max()) <= 4e-6 * float(S.abs().max())
         Zr = Xd.clone()
         fl = torch.from_numpy((np.random.default_rng(5 + d).random(N) < 0.3).astype(np.uint8)).cuda()
-        rsx.zero_rows(Zr, fl)
+        rsx.scale_rows(Zr, fl, 0.25)
+        assert torch.equal(Zr[fl.bool()], Xd[fl.bool()] * 0.25) and torch.equal(Zr[~fl.bool()], Xd[~fl.bool()])
+        Zr[0, 0] = float("inf")
+        fl[0] = 1
+        rsx.scale_rows(Zr, fl, 0.0)                               # alpha = 0 CLEARS (whatever the row held)
         assert float(Zr[fl.bool()].abs().max()) == 0.0 and torch.equal(Zr[~fl.bool()], Xd[~fl.bool()])
         # only SOME rows of the result wanted (rsx_spmm_csr_select_rows: the last forward product of a LightGCN step): those rows
         # equal the full product's (bit for bit where a row is one segment), the others keep what they held -- in Y and in S_acc
