@@ -559,7 +559,8 @@ int rsx_spmm_csr_sparse_rows(const int32_t *seg_row_dev, const int64_t *seg_begi
                              int64_t num_segs, const int64_t *indptr_dev, const int32_t *indices_dev,
                              const float *vals_dev, const float *X, const uint8_t *x_row_nonzero_dev, float *Y,
                              float *S_acc, int64_t num_rows, int d, rsx_stream_t stream);
-/* rsx_spmm_csr_init: the FIRST product of a propagation, fused with the start of the running layer sum: Y = A X and
+/* rsx_spmm_csr_init: the FIRST product of a propagation (models/LightGCN.py:179-197: embs = [all_emb], then one torch.sparse.mm per
+ *   layer; :198-200 their mean), fused with the start of the running layer sum: Y = A X and
  *   S_out = S_init + A X (S_out is overwritten; S_init, usually X itself, is only read) -- instead of copying the source table into
  *   the sum and then adding.  x_row_nonzero_dev: NULL, or the row flags of rsx_spmm_csr_sparse_rows.  Same sums as the two-step form. */
 int rsx_spmm_csr_init(const int32_t *seg_row_dev, const int64_t *seg_begin_dev, const int32_t *seg_len_dev,
