@@ -391,6 +391,10 @@ def main():
         fn = rsx.lib().rsx_debug_set_exchange_delay
         fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_int]
         assert fn(int(os.environ["RSX_EXCHANGE_DELAY_US"])) == 0
+        if os.environ.get("RSX_EXCHANGE_TRAFFIC") == "1":     # ... and it moves the message through HBM while it holds the stream
+            fn2 = rsx.lib().rsx_debug_set_exchange_traffic
+            fn2.restype, fn2.argtypes = ctypes.c_int, [ctypes.c_int]
+            assert fn2(1) == 0
     if os.environ.get("RSX_SAMPLER_REPLAY") == "1":  # DEVELOPMENT library only: the loop without a sampler beside it (3 batches replayed)
         import ctypes
         fn = rsx.lib().rsx_debug_set_sampler_replay

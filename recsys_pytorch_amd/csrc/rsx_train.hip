@@ -125,16 +125,39 @@ int64_t *chunk_pos_ptr(const rsx_bpr_trainer *t, int slot) { return t->c.chunk_p
 // has no such switch: there the function below is empty.
 #ifdef RSX_ABLATE
 static int g_exchange_delay_us = 0;
+static int g_exchange_traffic = 0;
 RSX_API int rsx_debug_set_exchange_delay(int us) { g_exchange_delay_us = us < 0 ? 0 : us; return RSX_OK; }
-__global__ __launch_bounds__(256) void exchange_delay_kernel(uint64_t ticks)
+// `rsx_debug_set_exchange_traffic(1)`: the stand-in also MOVES the message while it holds the stream -- its eight workgroups read
+// the exchanged rows and write the same values back (idempotent), paced over the delay: the HBM side of what an in-place all-reduce
+// does to its own buffer (the peers' reads of it over xGMI come on top and are not modelled)
+RSX_API int rsx_debug_set_exchange_traffic(int on) { g_exchange_traffic = on; return RSX_OK; }
+__global__ __launch_bounds__(256) void exchange_delay_kernel(uint64_t ticks, float4 *buf, int64_t n4)
 {
     const uint64_t t0 = wall_clock64();          // 100 MHz
+    if (buf != nullptr) {
+        // this workgroup's slice in 32 pieces, piece q not before q / 32 of the delay has passed; eight quads per thread in flight
+        const int64_t per = (n4 + gridDim.x - 1) / gridDim.x, lo = (int64_t)blockIdx.x * per, hi = (lo + per < n4) ? lo + per : n4;
+        const int64_t piece = (per + 31) / 32;
+        for (int q = 0; q < 32; ++q) {
+            while (wall_clock64() - t0 < ticks * (uint64_t)q / 32) __builtin_amdgcn_s_sleep(8);
+            const int64_t a = lo + q * piece, b = (a + piece < hi) ? a + piece : hi;
+            for (int64_t e0 = a + threadIdx.x; e0 < b; e0 += 256 * 8) {
+                float4 v[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) if (e0 + c * 256 < b) v[c] = buf[e0 + c * 256];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) if (e0 + c * 256 < b) { asm volatile("" : "+v"(v[c].x), "+v"(v[c].y), "+v"(v[c].z), "+v"(v[c].w)); buf[e0 + c * 256] = v[c]; }
+            }
+        }
+    }
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
 }
-static int rsx_debug_exchange_delay(hipStream_t st, int parts)
+static int rsx_debug_exchange_delay(hipStream_t st, int parts, float *buf = nullptr, int64_t n = 0)
 {
     if (g_exchange_delay_us <= 0) return RSX_OK;
-    hipLaunchKernelGGL(exchange_delay_kernel, dim3(8), dim3(256), 0, st, (uint64_t)g_exchange_delay_us * 100ull / (uint64_t)parts);
+    // (with traffic: 32 workgroups -- the channels a collective of this size runs on -- instead of 8)
+    hipLaunchKernelGGL(exchange_delay_kernel, dim3(g_exchange_traffic ? 32 : 8), dim3(256), 0, st,
+                       (uint64_t)g_exchange_delay_us * 100ull / (uint64_t)parts, g_exchange_traffic ? (float4 *)buf : (float4 *)nullptr, n / 4);
     return RSX_OK;
 }
 // `rsx_debug_set_sampler_replay(1)`: once every slot of the ring holds a batch, the sampler kernels are no longer launched and
@@ -143,7 +166,7 @@ static int rsx_debug_exchange_delay(hipStream_t st, int parts)
 static int g_sampler_replay = 0;
 RSX_API int rsx_debug_set_sampler_replay(int on) { g_sampler_replay = on; return RSX_OK; }
 #else
-static inline int rsx_debug_exchange_delay(hipStream_t, int) { return RSX_OK; }
+static inline int rsx_debug_exchange_delay(hipStream_t, int, float * = nullptr, int64_t = 0) { return RSX_OK; }
 #endif
 #define RSX_HIP(call)                                                                          \
     do {                                                                                       \
@@ -365,7 +388,7 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
         }
         RSX_HIP(hipEventRecord(t->ev_g, st));
         RSX_HIP(hipStreamWaitEvent(t->aux, t->ev_g, 0));
-        if (!sg) { RSX_TRY(rsx_comm_all_reduce(c.comm, Gbuf, c.num_items * c.d, t->aux)); RSX_TRY(rsx_debug_exchange_delay(t->aux, 1)); }
+        if (!sg) { RSX_TRY(rsx_comm_all_reduce(c.comm, Gbuf, c.num_items * c.d, t->aux)); RSX_TRY(rsx_debug_exchange_delay(t->aux, 1, Gbuf, c.num_items * c.d)); }
         else RSX_TRY(rsx_comm_reduce_scatter(c.comm, Gbuf, c.item_rows_padded / world_size * c.d, t->aux));
         RSX_HIP(hipEventRecord(t->ev_x[which], t->aux));
         return RSX_OK;
@@ -459,7 +482,7 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
                         rsx_set_error("rsx_bpr_trainer_run: exchange_range failed (range %d)", k);
                         return RSX_E_INVALID;
                     }
-                    RSX_TRY(rsx_debug_exchange_delay(t->aux, c.chunks));
+                    RSX_TRY(rsx_debug_exchange_delay(t->aux, c.chunks, Gk, g.Ic * c.d));
                     if (t->apply_st != nullptr) {       // the apply off the collective stream: the next range's collective follows at once
                         RSX_HIP(hipEventRecord(t->ev_r[k], t->aux));
                         RSX_HIP(hipStreamWaitEvent(t->apply_st, t->ev_r[k], 0));

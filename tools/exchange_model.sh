@@ -19,3 +19,7 @@ run "two passes (exchange under users)" RSX_TWO_PASS=1 --
 run "item ranges x2" RSX_TWO_PASS=0 -- --chunks 2
 run "item ranges x3" RSX_TWO_PASS=0 -- --chunks 3
 run "one step stale (not synchronous)" RSX_TWO_PASS=0 RSX_STALE_EXCHANGE=1 --
+# the same with the stand-in MOVING the message through HBM while it holds the stream (read + write back of the exchanged rows)
+run "one pass, stand-in with traffic" RSX_TWO_PASS=0 RSX_EXCHANGE_TRAFFIC=1 --
+run "two passes, stand-in with traffic" RSX_TWO_PASS=1 RSX_EXCHANGE_TRAFFIC=1 --
+run "item ranges x2, stand-in with traffic" RSX_TWO_PASS=0 RSX_EXCHANGE_TRAFFIC=1 -- --chunks 2

@@ -24,3 +24,6 @@ run "item ranges x2, applies on the collective stream" RSX_TWO_PASS=0 RSX_APPLY_
 run "item ranges x2, applies on their own stream" RSX_TWO_PASS=0 RSX_APPLY_STREAM=1 -- --chunks 2
 run "item ranges x3, own apply stream" RSX_TWO_PASS=0 RSX_APPLY_STREAM=1 -- --chunks 3
 run "item ranges x4, own apply stream" RSX_TWO_PASS=0 RSX_APPLY_STREAM=1 -- --chunks 4
+# the same with the stand-in MOVING the message through HBM while it holds the stream
+run "one pass, stand-in with traffic" RSX_TWO_PASS=0 RSX_EXCHANGE_TRAFFIC=1 --
+run "item ranges x2, stand-in with traffic" RSX_TWO_PASS=0 RSX_APPLY_STREAM=0 RSX_EXCHANGE_TRAFFIC=1 -- --chunks 2
