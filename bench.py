@@ -25,6 +25,12 @@ Prints ONE JSON line (rank 0).
                 reported as `algorithmic_bytes_per_launch` / `algorithmic_GBs` / `algorithmic_rate_over_peak`:
                 the blocked kernel sums item-side gradients on chip, so those bytes are not all moved and that
                 ratio is NOT a fraction of anything (it exceeds 1 at the headline shape).
+                `traffic_source.stale`: the kernel sources hash differently from the ones the profile was taken on.
+                `roofline.configs`: every BASELINE config's {value, ms_per_step, kernel_ms, frac, frac_end_to_end} in compact form (the
+                driver keeps `roofline`, `config` and `cpu_baseline` of this line and drops the rest).
+  value         the MEDIAN of three back-to-back timed regions of --steps steps each (`timed_regions`: every region, min, max).
+  hbm_utilisation_end_to_end   everything a step moves at the fabric side (step kernel + apply + the sampler beside them, PMC) over the
+                whole step, as a fraction of the 8 TB/s peak: how busy the loop as a whole keeps HBM.
   legs          the other section-8d measurements, each with its own roofline: SURVEY's base batch
                 B = 65 536, independent uniform negatives, uniform item popularity, a batch sweep, the
                 configs[1] (d=64) shape, and the configs[3] one-rank slice (1.25M users x 1M items).
