@@ -298,3 +298,58 @@ def test_chunked_sampler_on_random_shapes():
             row = rows[ua[p]]
             k = int(np.searchsorted(cpa, p, side="right") - 1)
             assert np.isin(k * Ic + np.arange(n_real[k]), row).mean() > 0.9, ctx
+
+
+def test_exchange_range_callback_sees_every_range_in_order_and_its_errors_surface():
+    """include/rsx.h: exchange_range -- one process, no process group: a chunked trainer with a callback that records what it is handed
+    (range k, first row, rows, a stream handle) and does nothing else is the sharded schedule with an identity exchange: it must
+    end at the tables of the unsharded chunked trainer on the same triplets; a callback that raises makes run() raise THAT exception
+    (it must not unwind through the C frames, and nothing may hang)"""
+    from recsys_pytorch_amd import rsx
+    U, I, d, B, C = 20_000, 3_000, 64, 12_000, 3
+    lr = resolvable_lr(B)
+
+    def make():
+        eng, P, Q, ip, ix = _engine(U, I, d, B, 8, C, lr, seed=9, hot=16)
+        r = eng._build_relabel(ip, ix)
+        eng._items_to_relabelled()
+        return eng, P, r, ip
+
+    def trainer(eng, P, r, ip, cb):
+        return rsx.BPRTrainer(P, r["Q"], r["G"], ip, r["indices"], lr, B, seed=eng.seed, seed_key=eng.seed, neg_block=eng.neg_block,
+                              hot=r["hot"], user_sig=r["sig"], item_cdf=r["cdf"], chunks=C, items_real=I, exchange_range=cb)
+
+    eng, P, r, ip = make()
+    plain = trainer(eng, P, r, ip, None)
+    plain.run(3)
+    torch.cuda.synchronize()
+    plain.check()
+    P_ref, Q_ref = P.clone(), r["Q"].clone()
+    plain.close()
+
+    calls = []
+    eng2, P2, r2, ip2 = make()
+    P0, Q0 = P2.clone(), r2["Q"].clone()
+    tr = trainer(eng2, P2, r2, ip2, lambda k, first, rows, stream: calls.append((k, first, rows, stream != 0)))
+    tr.run(3)
+    torch.cuda.synchronize()
+    tr.check()
+    Ic = r2["Ic"]
+    assert calls == [(k, k * Ic, Ic, True) for _ in range(3) for k in range(C)]          # every range of every step, in range order
+    assert_update(P2.cpu().numpy(), P0.cpu().numpy(), P_ref.cpu().numpy(), "P (identity exchange_range vs no exchange)")
+    assert_update(r2["Q"].cpu().numpy(), Q0.cpu().numpy(), Q_ref.cpu().numpy(), "Q (identity exchange_range vs no exchange)")
+    assert float(r2["G"].abs().max()) == 0.0
+    tr.close()
+
+    class Boom(RuntimeError):
+        pass
+
+    def bad(k, first, rows, stream):
+        if k == 1:
+            raise Boom("range 1")
+    eng3, P3, r3, ip3 = make()
+    tr = trainer(eng3, P3, r3, ip3, bad)
+    with pytest.raises(Boom):
+        tr.run(1)
+    torch.cuda.synchronize()                                 # what was queued before the failure drains: nothing hangs
+    tr.close()
