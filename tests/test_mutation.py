@@ -28,6 +28,8 @@ ORACLE = ["tests/test_gpu_model.py::test_sorted_blocked_sampled_path_replays_thr
           "tests/test_gpu_model.py::test_native_trainer_steps_replay_through_the_oracle",
           "tests/test_gpu_model.py::test_blocked_kernel_is_exact_on_foreign_triplets",
           "tests/test_gpu_chunks.py::test_chunked_native_steps_follow_the_range_rule_and_replay_through_the_oracle[30000-5000-128-30000-12-4-32]",
+          # (the item ranges WITHOUT blocks: the TILE = false walk launched per range, round 4)
+          "tests/test_gpu_chunks.py::test_chunked_native_steps_follow_the_range_rule_and_replay_through_the_oracle[30000-40000-128-30000-12-2-32]",
           "tests/test_gpu_parity.py::test_step_kernels_on_random_shapes",
           "tests/test_gpu_parity.py::test_bpr_step_matches_reference_golden[g1c_sgd_biglr_400x250_d128_b512]"]
 
