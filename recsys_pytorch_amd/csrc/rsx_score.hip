@@ -142,7 +142,11 @@ __device__ __forceinline__ void score_tile_body(const float *__restrict__ P,
         }
         __syncthreads();          // (carries the vmcnt(0) of the DMA: the chunk has landed for every wavefront)
         float a0 = ap[xs], a1 = ap[32 * BK + 4 * P8 + xs], b0 = bp[xs], b1 = bp[32 * BK + 4 * P8 + xs];
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        // (the fragments of a step are FOUR ds_read_b32 with the padded tiles -- rows r and r + 32 are 4 096 + 16 bytes apart, which no
+        //  ds_read2 form can address -- and two ds_read2st64_b32 without: the group sizes below must say so, or the reads of step k + 1
+        //  drift behind the MFMAs of step k and are waited for at once)
+        constexpr int kDsPerStep = RSX_SCORE_LDS_PAD ? 4 : 2;
+        __builtin_amdgcn_sched_group_barrier(0x100, kDsPerStep, 0);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
@@ -155,7 +159,7 @@ __device__ __forceinline__ void score_tile_body(const float *__restrict__ P,
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, kDsPerStep, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
         }
