@@ -367,20 +367,117 @@ def cpu_baseline(args, U, I, d, batches):
             "legs": legs}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment (the driver's plain command): start N fresh ranks of this
+    file -- one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous on a free port -- BEFORE this
+    process has touched the GPU (it never does: it only relays), pass rank 0's single JSON line on, and leave with the first
+    non-zero status of a rank.  Children, never a re-exec.  (The reference pins one device: main.py:24-27.)"""
+    import socket
+    import subprocess
+    import threading
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    limit = float(os.environ.get("RSX_LAUNCH_LIMIT_S", "3000"))
+    procs = []
+    for r in range(n):
+        env = {**os.environ, "RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+               "RSX_LAUNCHED_BY": "bench.py"}
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+    lines = []
+
+    def relay():                      # rank 0's stdout: JSON lines are this process's output, anything else goes to stderr
+        for line in procs[0].stdout:
+            if line.startswith("{"):
+                lines.append(line)
+                sys.stdout.write(line)
+                sys.stdout.flush()
+            else:
+                sys.stderr.write(line)
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    t0, rc, why = time.time(), 0, None
+    live = set(range(n))
+    while live and rc == 0:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is not None:
+                live.discard(r)
+                if c != 0 and rc == 0:
+                    rc, why = c, f"rank {r} left with status {c}"
+        if time.time() - t0 > limit and live:
+            rc, why = 4, f"ranks {sorted(live)} still running after {limit:.0f} s (RSX_LAUNCH_LIMIT_S)"
+        time.sleep(0.2)
+    if rc != 0:                       # one rank failed: the others sit in a collective -- end exactly the processes started here
+        grace = time.time() + 10.0    # (their own watchdogs get a moment to print their error line)
+        while time.time() < grace and any(p.poll() is None for p in procs):
+            time.sleep(0.2)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for p in procs:
+        p.wait()
+    t.join(timeout=10)
+    if rc != 0 and not lines:
+        print(json.dumps({"metric": "bpr_triplet_updates_per_sec", "value": None, "unit": "triplets/s", "n_gpus": n,
+                          "error": f"bench.py launcher: {why}"}), flush=True)
+    return rc
+
+
+class Watchdog:
+    """A hang must be impossible to miss: the N > 1 run sits under a deadline that is RE-ARMED at every leg boundary (a slow full
+    run is not a stuck one) and names the leg it caught; on expiry rank 0 prints a JSON error line and every rank leaves with
+    status 3 (os._exit: no re-exec, no GPU teardown from a process whose queues are stuck)"""
+
+    def __init__(self, limit, rank, world, info):
+        import threading
+        self.limit, self.rank, self.world, self.info = limit, rank, world, info
+        self.leg, self.deadline, self.done = "start", time.time() + limit, threading.Event()
+        self.t = threading.Thread(target=self._bark, daemon=True)
+        self.t.start()
+
+    def arm(self, leg):
+        self.leg, self.deadline = leg, time.time() + self.limit
+
+    def stop(self):
+        self.done.set()
+
+    def _bark(self):
+        while not self.done.wait(0.25 if self.limit > 0 else 0.0):
+            if time.time() >= self.deadline:
+                msg = {"metric": "bpr_triplet_updates_per_sec", "value": None, "unit": "triplets/s", "n_gpus": self.world,
+                       "error": f"watchdog: rank {self.rank} did not finish leg '{self.leg}' within {self.limit:.0f} s (a collective "
+                                "or a stream wait is stuck)", "config": self.info()}
+                if self.rank == 0:
+                    print(json.dumps(msg), flush=True)
+                sys.stderr.write(msg["error"] + "\n")
+                sys.stderr.flush()
+                os._exit(3)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))        # (nothing above or in launch_ranks touches the GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
-        args.gpus = world
+    args.gpus = world
     ndev = max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank % ndev)
     dev = torch.device("cuda", local_rank % ndev)
     global SHARDED
     SHARDED = world > 1 or os.environ.get("RSX_FORCE_SHARDED") == "1"
+    watchdog = None
+    if world > 1:       # started BEFORE the rendezvous and the communicator: a rank that dies inside the collective rsx_comm_create
+        #                 (or never arrives) leaves the others blocked
+        watchdog = Watchdog(float(os.environ.get("RSX_WATCHDOG_S", "900")), rank, world,
+                            lambda: {"item_chunks": args.chunks, "exchange_issued_by": "library (RCCL from librsx)" if COMM is not None
+                                     else "torch.distributed callbacks"})
+        watchdog.arm("rendezvous + communicator")
     if SHARDED:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -418,7 +515,7 @@ def main():
             ok = torch.ones(1, device=dev)
             COMM.all_reduce(ok)                         # one real collective through it, checked
             torch.cuda.synchronize()
-            good = float(ok.item()) == float(world)
+            good = float(ok.item()) == float(world) and COMM.info() == (rank, world)
             err = None if good else f"all-reduce of ones over {world} ranks returned {float(ok.item())}"
         except Exception as e:       # noqa: BLE001
             good, err = False, repr(e)
@@ -462,27 +559,8 @@ def main():
         # N > 1: two item ranges (they beat three at every exchange length), with the library's RCCL or -- the
         # fallback above, and what tests/test_sharded_gloo.py runs with two ranks -- the per-range callbacks
         args.chunks = 2 if world > 1 else 0
-    # A hang must be impossible to miss: the N > 1 legs run under a watchdog that prints a JSON error line and leaves with a
-    # non-zero status (os._exit: no re-exec, no GPU teardown from a process whose queues are stuck)
-    watchdog = None
-    if world > 1:
-        import threading
-        limit = float(os.environ.get("RSX_WATCHDOG_S", "900"))
-        done = threading.Event()
-
-        def bark():
-            if not done.wait(limit):
-                msg = {"metric": "bpr_triplet_updates_per_sec", "value": None, "unit": "triplets/s", "n_gpus": world,
-                       "error": f"watchdog: rank {rank} did not finish the N > 1 legs within {limit:.0f} s (a collective or a stream "
-                                "wait is stuck)", "config": {"item_chunks": args.chunks,
-                                                             "exchange_issued_by": "library (RCCL from librsx)" if COMM is not None else "torch.distributed callbacks"}}
-                if rank == 0:
-                    print(json.dumps(msg), flush=True)
-                sys.stderr.write(msg["error"] + "\n")
-                sys.stderr.flush()
-                os._exit(3)
-        watchdog = (threading.Thread(target=bark, daemon=True), done)
-        watchdog[0].start()
+    arm = watchdog.arm if watchdog is not None else (lambda leg: None)
+    arm("headline")
     head = step_leg(P, Q, indptr, indices, args.lr, B, args.neg_block, args.hot, args.hot_replicas, args.steps, args.warmup,
                     world, rank, args.popularity, two_pass=two_pass, chunks=args.chunks, regions=3)
     Q = head.pop("_Q")
@@ -527,6 +605,7 @@ def main():
         # user, B = 1.25M per GPU (B < 2 I: the ordered batch without blocks); with N > 1 the 512 MB exchange per step travels
         # range by range under the other range's kernels (item ranges without blocks, like the headline's with them)
         if (args.users, args.items, args.dim) == (1_000_000, 100_000, 128):
+            arm("config3_slice_1.25Mx1M")
             P4, Q4, ip4, ix4 = tables(1_250_000, 1_000_000, 128, 10, args.popularity)
             legs["config3_slice_1.25Mx1M"] = leg(P4, Q4, ip4, ix4, args.lr, 1_250_000, args.neg_block, args.hot,
                                                       args.hot_replicas, 10, 2, world, rank, args.popularity, two_pass=two_pass,
@@ -542,6 +621,7 @@ def main():
     # N > 1: every rank scores ITS users (user rows sharded, items replicated: no collective), all ranks at the same
     # time; the job's rate is all ranks' scores over the slowest rank's time
     if args.score_tiles > 0 and (rank == 0 or SHARDED):
+        arm("scoring")
         tiles, K = args.score_tiles, args.topk
         users = torch.arange(1024 * tiles, device=dev, dtype=torch.int32) % U
         ws = torch.empty(rsx.lib().rsx_score_topk_workspace(users.numel(), I) // 4 + 64, dtype=torch.float32, device=dev)
@@ -569,10 +649,11 @@ def main():
                                 "peak": MFMA_F32_PEAK_TFLOPS * world, "unit": "TFLOP/s",
                                 "frac": n_scores * 2 * d / dt / 1e12 / (MFMA_F32_PEAK_TFLOPS * world)},
                    "topk_rows": int(top.shape[0])}
+    arm("final barrier")
     if SHARDED:
         dist.barrier()
     if watchdog is not None:
-        watchdog[1].set()
+        watchdog.stop()
 
     if rank == 0:
         nb = head["neg_block"]
@@ -589,6 +670,10 @@ def main():
                        "sampler": "on device, two steps ahead on a lowest-priority side stream",
                        "loop": "native (rsx_bpr_trainer_run): no interpreter between the kernels of the timed region",
                        "item_chunks": head["chunks"], "exchange_issued_by": head["exchange_issued_by"],
+                       # what RCCL's own communicator says (rsx_comm_info), not what the environment asked for
+                       "rccl_world": COMM.info()[1] if COMM is not None else None,
+                       "launched_by": os.environ.get("RSX_LAUNCHED_BY", "torch.distributed.run" if world > 1 else "python bench.py"),
+                       "dist_backend": os.environ.get("RSX_DIST_BACKEND", "nccl") if SHARDED else None,
                        **({"exchange_note": comm_note} if comm_note else {}),
                        **({"negatives_with_item_ranges": "a position's negative is uniform over the real items of the item range its "
                            f"positive fell in (1/{head['chunks']} of the catalog under a seeded relabelling, redrawn between native "
@@ -628,6 +713,25 @@ def main():
                                "frac": sig(scoring["roofline"]["frac"]), "frac_end_to_end": sig(scoring["roofline"]["frac"])}
         if cfgs:
             out["roofline"] = {**out["roofline"], "configs": cfgs}
+        # ... and the same figures once more as FLAT scalars (the driver's record keeps the scalars of `roofline` / `config` and
+        # drops nested objects): every BASELINE config readable from BENCH_rNN.parsed alone
+        flat = {"frac_e2e": sig(head["frac_end_to_end"])}
+        for pre, name in (("base65536", "base_batch_65536"), ("d64", "config1_d64"), ("config3", "config3_slice")):
+            if name in cfgs:
+                flat.update({f"{pre}_value": cfgs[name]["value"], f"{pre}_ms_per_step": cfgs[name]["ms_per_step"],
+                             f"{pre}_frac": cfgs[name]["frac"], f"{pre}_frac_e2e": cfgs[name]["frac_end_to_end"]})
+        if "config4_lightgcn" in cfgs:
+            flat.update({"lightgcn_ms_per_step": cfgs["config4_lightgcn"]["ms_per_step"], "lightgcn_value": cfgs["config4_lightgcn"]["value"],
+                         "lightgcn_product_ms": cfgs["config4_lightgcn"]["kernel_ms"], "lightgcn_product_frac": cfgs["config4_lightgcn"]["frac"]})
+        if scoring is not None:
+            flat.update({"scoring_value": cfgs["scoring"]["value"], "scoring_frac": cfgs["scoring"]["frac"],
+                         "scoring_ms_per_1024_users": cfgs["scoring"]["ms_per_step"]})
+        srcs = [x for x in [head["roofline"].get("traffic_source")] + [g.get("roofline", {}).get("traffic_source") for g in legs.values()
+                                                                       if isinstance(g, dict)] if x]
+        flat["traffic_stale"] = (any(x["stale"] is True for x in srcs) or (None if any(x["stale"] is None for x in srcs) else False)) if srcs else None
+        flat["traffic_commit"] = (head["roofline"].get("traffic_source") or {}).get("taken_at_commit")
+        out["roofline"] = {**out["roofline"], **flat}
+        out["config"] = {**out["config"], **{"roofline_" + k: v for k, v in flat.items()}}
         out["timed_regions"] = head["timed_regions"]
         if legs:
             out["legs"] = legs

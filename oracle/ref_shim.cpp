@@ -7,7 +7,8 @@
 //   evaluation/backend/cython/include/holdout.h:20  evaluate_holdout
 //   evaluation/backend/cython/include/loo.h:19      evaluate_loo
 // Built only when /root/reference exists (oracle/Makefile target `ref`), output
-// oracle/_ref/libref_eval.so (git-ignored, travels to the GPU box prebuilt).
+// oracle/_ref/libref_eval.so (git-ignored AND gpurun-ignored: it exists in the build container only, the tests that
+// use it skip on the GPU box).
 // Used to pin oracle/mf_oracle.c (orc_topk / orc_holdout) and as the
 // "reference" CPU baseline for top-k.
 #include "func.h"

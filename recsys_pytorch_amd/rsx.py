@@ -437,13 +437,25 @@ class Comm:
         import torch.distributed as dist
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         ident = C.create_string_buffer(RSX_COMM_ID_BYTES)
+        err = None
         if self.rank == 0:
-            _check(lib().rsx_comm_unique_id(ident), "rsx_comm_unique_id")
-        box = [ident.raw]
+            # a failure here must still reach the broadcast below: the other ranks are waiting in it
+            if lib().rsx_comm_unique_id(ident) != 0:
+                err = "rsx_comm_unique_id failed: " + lib().rsx_last_error().decode()
+        box = [(err, ident.raw)]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        err, raw = box[0]
+        if err is not None:                            # every rank raises the same error: nobody is left inside a collective
+            raise RsxError(err)
         self._h = C.c_void_p()
-        _check(lib().rsx_comm_create(C.create_string_buffer(box[0], RSX_COMM_ID_BYTES), self.rank, self.world, C.byref(self._h)),
+        _check(lib().rsx_comm_create(C.create_string_buffer(raw, RSX_COMM_ID_BYTES), self.rank, self.world, C.byref(self._h)),
                "rsx_comm_create")
+
+    def info(self):
+        """(rank, world) as RCCL's communicator reports them (include/rsx.h: rsx_comm_info)"""
+        r, w = C.c_int(-1), C.c_int(-1)
+        _check(lib().rsx_comm_info(self._h, C.byref(r), C.byref(w)), "rsx_comm_info")
+        return int(r.value), int(w.value)
 
     @property
     def handle(self):

@@ -57,6 +57,12 @@ def test_bench_json_contract_small_shape():
     assert {"base_batch_65536", "config1_d64", "scoring"} <= set(cf) and len(json.dumps(cf)) <= 700
     for v in cf.values():
         assert set(v) == {"value", "ms_per_step", "kernel_ms", "frac", "frac_end_to_end"} and v["value"] > 0
+    # ... and flat: the driver's record keeps scalars of `roofline` / `config` only
+    for k in ("base65536_value", "base65536_frac", "base65536_frac_e2e", "d64_value", "d64_frac", "d64_frac_e2e", "scoring_value",
+              "scoring_frac", "traffic_stale", "traffic_commit", "frac_e2e"):
+        assert k in r and not isinstance(r[k], (dict, list)), k
+        assert d["config"]["roofline_" + k] == r[k]
+    assert r["base65536_value"] == cf["base_batch_65536"]["value"] and r["scoring_frac"] == cf["scoring"]["frac"]
 
 
 @pytest.mark.gpu
@@ -86,6 +92,43 @@ def test_bench_two_ranks_on_one_gpu(two_pass, exchange, chunks):
     if chunks is None:           # scoring: every rank its own users, the job's rate = all ranks' scores / the slowest rank's time
         sc = d["scoring"]
         assert sc["n_gpus"] == 2 and sc["value"] > 0 and sc["roofline"]["peak"] == 2 * 157.3 and 0 < sc["roofline"]["frac"] < 1
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_plain_command_starts_its_own_ranks():
+    """the driver's command for the scaling run is the PLAIN `python bench.py --gpus N ...` (no torch.distributed.run around
+    it): bench.py starts its N ranks itself before it touches the GPU and relays rank 0's one JSON line.  Two ranks on the
+    box's one GPU, gloo moving G: a does-it-run-and-agree check of bench.py's own N > 1 default (two item ranges)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
+                          "--users", "120000", "--batch", "120000", "--items", "30000", "--score-tiles", "1", "--no-legs"],
+                         capture_output=True, text=True, timeout=800, cwd=ROOT,
+                         env={**env, "RSX_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "RSX_CHUNKS": "-1"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["config"]["global_batch"] == 240000
+    assert d["config"]["item_replicas_identical"] is True and d["config"]["item_chunks"] == 2
+    assert d["config"]["launched_by"] == "bench.py" and d["config"]["dist_backend"] == "gloo"
+    assert d["config"]["rccl_world"] is None            # gloo: the callbacks moved G; over "nccl" this is RCCL's own world size
+    assert d["scoring"]["n_gpus"] == 2
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """a rank that cannot start (here: no GPU in this container; on a GPU box: a launcher limit of zero seconds) must give a
+    non-zero status and ONE JSON error line, not silence"""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    if torch.cuda.is_available():
+        env["RSX_LAUNCH_LIMIT_S"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--users", "50000", "--batch", "50000", "--items", "20000", "--score-tiles", "0", "--no-legs"],
+                         capture_output=True, text=True, timeout=280, cwd=ROOT, env={**env, "RSX_DIST_BACKEND": "gloo"})
+    assert out.returncode != 0
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["value"] is None and lines[0]["n_gpus"] == 2 and "error" in lines[0]
 
 
 @pytest.mark.gpu
