@@ -56,6 +56,50 @@ def pick_neg_block(num_items, max_block, wave_slots, batch=None, min_block=2):
     return best
 
 
+def deal_items_to_ranges(mass, cap, rng, heavy=4096):
+    """which item range every item sits in for one relabelling round: `assign[item] in [0, C)`, exactly `cap[k]` items in
+    range k, the ranges' sampling masses balanced, and -- what the redraw exists for -- a DIFFERENT membership every round
+    for the heavy items too (two items meet as positive / negative only while they share a range):
+
+      1. the 16 C heaviest items, in random order, each to a range drawn uniformly among those with a free seat whose load
+         stays within 0.9 of a range's share of the heavy mass (none: the lightest) -- the heads of a skewed catalog are not pinned to "one per
+         range";
+      2. the other heavy items (up to `heavy` in all) greedily to the currently lightest range, visited in mass order
+         shuffled inside windows of 8 C (a strict mass order makes neighbours in rank alternate between the ranges for ever),
+         ties between equally light ranges broken at random;
+      3. the rest at random.
+
+    A function of the global masses and the seeded rng only: identical on every rank."""
+    import numpy as np
+    mass = np.asarray(mass, dtype=np.float64)
+    cap = np.asarray(cap, dtype=np.int64)
+    I, C = mass.shape[0], cap.shape[0]
+    order = np.argsort(-mass, kind="stable")
+    H = min(I, int(heavy))
+    T = min(H, 16 * C)
+    assign = np.full(I, -1, dtype=np.int64)
+    load, cnt = np.zeros(C), np.zeros(C, dtype=np.int64)
+    target = 0.9 * float(mass[order[:H]].sum()) / C      # (of the HEAVY mass: the rest arrives evenly, by seats)
+    for it in rng.permutation(order[:T]):
+        free = cnt < cap
+        ok = np.flatnonzero(free & (load + mass[it] <= target))
+        k = int(rng.choice(ok)) if ok.size else int(np.argmin(np.where(free, load, np.inf)))
+        assign[it] = k; load[k] += mass[it]; cnt[k] += 1
+    mid = order[T:H].copy()
+    win = 8 * C
+    for a in range(0, mid.size, win):
+        rng.shuffle(mid[a:a + win])
+    for it in mid:
+        lo = np.where(cnt < cap, load, np.inf)
+        ties = np.flatnonzero(lo <= lo.min() * (1 + 1e-12))
+        k = int(ties[rng.integers(ties.size)]) if ties.size > 1 else int(ties[0])
+        assign[it] = k; load[k] += mass[it]; cnt[k] += 1
+    seats = np.repeat(np.arange(C), cap - cnt)
+    rng.shuffle(seats)
+    assign[order[H:]] = seats
+    return assign
+
+
 class BPREngine:
     """Owns the step sequence  sample/replay -> bpr_step -> all-reduce(G) -> apply.
 
@@ -246,9 +290,9 @@ class BPREngine:
         # Which item goes to which range.  The ranges should carry the same share of the batch (their kernels then take
         # the same time and finish staggered by their priorities alone), so the relabelling balances the SAMPLING MASS of
         # the ranges -- item i is the sampled positive with weight sum over its users of 1 / deg(u), summed over the ranks --
-        # not just their sizes: the few thousand heaviest items are dealt greedily to the currently lightest range
-        # (a popularity-skewed catalog has single items of several percent), the rest at random.  Seeded, and a function of
-        # the global masses only: identical on every rank.
+        # not just their sizes (deal_items_to_ranges: the heads at random within the target, the other heavy items greedily to
+        # the lightest range in a shuffled order, the rest at random -- every round another membership, for the heavy items
+        # too).  Seeded, and a function of the global masses only: identical on every rank.
         import numpy as np
         U = indptr.numel() - 1
         deg = (indptr[1:] - indptr[:-1]).double()
@@ -261,17 +305,7 @@ class BPREngine:
         mass = mass.cpu().numpy()
         rng = np.random.default_rng(self.seed * 7919 + 13 + 104729 * self._relabel_round)
         cap = np.array([base + (k < rem) for k in range(C)], dtype=np.int64)      # real items per range
-        order = np.argsort(-mass, kind="stable")
-        heavy = order[:min(I, 4096)]
-        assign = np.full(I, -1, dtype=np.int64)
-        load, cnt = np.zeros(C), np.zeros(C, dtype=np.int64)
-        for it in heavy:
-            k = int(np.argmin(np.where(cnt < cap, load, np.inf)))
-            assign[it] = k; load[k] += mass[it]; cnt[k] += 1
-        rest = order[len(heavy):]
-        seats = np.repeat(np.arange(C), cap - cnt)
-        rng.shuffle(seats)
-        assign[rest] = seats
+        assign = deal_items_to_ranges(mass, cap, rng)
         perm_parts = []
         for k in range(C):
             members = np.flatnonzero(assign == k)

@@ -902,8 +902,27 @@ def test_item_ranges_rank_as_well_for_users_with_one_to_three_positives():
                 m._P.mul_(0.1); m._Q.mul_(0.1)
             if (arm, seed) == ("iid", 1):
                 untrained = ev.evaluate(m)
+            members = {}                                                        # relabelling round -> the range of every item
+            if chunks:
+                build = m._engine._build_relabel
+
+                def recording(ip, ix, build=build, members=members):
+                    r = build(ip, ix)
+                    members.setdefault(r["round"], (r["item_rank"] // r["Ic"]).cpu().numpy())
+                    return r
+                m._engine._build_relabel = recording
             sc = m.fit(ds, cfg, evaluator=ev)["scores"]
             assert m._engine.chunks == chunks and (m._engine._relabel_round > 0) == (redraw > 0)
+            if redraw:
+                # the redraw really is another partition -- I = 1500 <= 4096: every item is "heavy" here, and round 4's greedy deal
+                # gave the identical membership every round (sharded.deal_items_to_ranges)
+                rounds = [members[k] for k in sorted(members)]
+                assert len(rounds) >= 5, sorted(members)
+                for a, b in zip(rounds[:-1], rounds[1:]):
+                    assert np.array_equal(np.bincount(a, minlength=chunks), np.bincount(b, minlength=chunks))
+                    assert 0.3 < np.mean(a != b) < 0.7, np.mean(a != b)         # two ranges: about half of the items change sides
+            elif chunks:
+                assert sorted(members) == [0]
             res[(arm, seed)] = (float(sc["Recall@20"]), float(sc["NDCG@20"]))
     print({k: tuple(round(x, 4) for x in v) for k, v in res.items()}, "untrained", {k: round(float(v), 4) for k, v in untrained.items()})
     for metric in (0, 1):

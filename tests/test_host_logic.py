@@ -195,3 +195,33 @@ def test_pointwise_fit_loop_assembles_the_reference_generators_batches():
             pairs.update(zip(u[:n_pos].tolist(), i[:n_pos].tolist()))
         assert len(pairs) == nnz                                            # the whole matrix once per epoch
     assert logged[-1]["loss"] < logged[0]["loss"]
+
+
+@pytest.mark.parametrize("I,C,pop", [(100_000, 2, "zipf"), (100_000, 4, "zipf"), (1500, 2, "zipf"), (3000, 3, "uniform"), (7, 2, "zipf")])
+def test_item_range_redraw_moves_heavy_items_and_keeps_the_balance(I, C, pop):
+    """sharded.deal_items_to_ranges: two items meet as positive / negative only while they share an item range, so the redraw
+    must change the membership of the HEAVY items too (round 4 dealt the 4096 heaviest by a greedy loop that depended on the
+    masses alone: identical every round, and for I <= 4096 the whole partition was) -- while every range keeps its seat count
+    and its share of the sampling mass"""
+    from recsys_pytorch_amd.sharded import deal_items_to_ranges
+    mass = 1.0 / (np.arange(I) + 1.0) if pop == "zipf" else np.ones(I)
+    base, rem = divmod(I, C)
+    cap = np.array([base + (k < rem) for k in range(C)])
+    rounds = [deal_items_to_ranges(mass, cap, np.random.default_rng(2020 * 7919 + 13 + 104729 * r)) for r in range(6)]
+    again = deal_items_to_ranges(mass, cap, np.random.default_rng(2020 * 7919 + 13))
+    assert np.array_equal(rounds[0], again)                       # a function of (mass, seed, round): every rank draws the same
+    for a in rounds:
+        assert a.min() >= 0 and np.array_equal(np.bincount(a, minlength=C), cap)
+        if I >= 1000:
+            load = np.bincount(a, weights=mass, minlength=C)
+            assert load.max() / load.mean() < 1.02, load / load.sum()
+    if I < 1000:
+        return
+    heavy = np.argsort(-mass, kind="stable")[:min(I, 4096)]
+    for a, b in zip(rounds[:-1], rounds[1:]):
+        moved = np.mean(a[heavy] != b[heavy])
+        assert moved > 0.8 * (1 - 1.0 / C) , moved                # membership of the heavy items is redrawn (expected: 1 - 1/C)
+    # over a handful of rounds the two heaviest items share a range at least once, and any heavy pair does
+    together = lambda x, y: sum(int(a[x] == a[y]) for a in rounds)
+    pairs = [(heavy[k], heavy[k + 1]) for k in range(0, 64, 2)]
+    assert np.mean([together(x, y) > 0 for x, y in pairs]) > 0.8
