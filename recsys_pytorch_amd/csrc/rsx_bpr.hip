@@ -169,14 +169,22 @@ __device__ __forceinline__ float softplus_neg(float x, float one_plus_e)
 template <int EPL>
 __device__ __forceinline__ void tile_load(const float *cell, float (&a)[EPL])
 {
-    if constexpr (EPL == 4) { const float4 t = *reinterpret_cast<const float4 *>(cell); a[0] = t.x; a[1] = t.y; a[2] = t.z; a[3] = t.w; }
+    if constexpr (EPL == 8) {
+        const float4 t = *reinterpret_cast<const float4 *>(cell), w = *reinterpret_cast<const float4 *>(cell + 4);
+        a[0] = t.x; a[1] = t.y; a[2] = t.z; a[3] = t.w; a[4] = w.x; a[5] = w.y; a[6] = w.z; a[7] = w.w;
+    }
+    else if constexpr (EPL == 4) { const float4 t = *reinterpret_cast<const float4 *>(cell); a[0] = t.x; a[1] = t.y; a[2] = t.z; a[3] = t.w; }
     else if constexpr (EPL == 2) { const float2 t = *reinterpret_cast<const float2 *>(cell); a[0] = t.x; a[1] = t.y; }
     else { a[0] = *cell; }
 }
 template <int EPL>
 __device__ __forceinline__ void tile_store(float *cell, const float (&a)[EPL])
 {
-    if constexpr (EPL == 4) *reinterpret_cast<float4 *>(cell) = make_float4(a[0], a[1], a[2], a[3]);
+    if constexpr (EPL == 8) {
+        *reinterpret_cast<float4 *>(cell) = make_float4(a[0], a[1], a[2], a[3]);
+        *reinterpret_cast<float4 *>(cell + 4) = make_float4(a[4], a[5], a[6], a[7]);
+    }
+    else if constexpr (EPL == 4) *reinterpret_cast<float4 *>(cell) = make_float4(a[0], a[1], a[2], a[3]);
     else if constexpr (EPL == 2) *reinterpret_cast<float2 *>(cell) = make_float2(a[0], a[1]);
     else *cell = a[0];
 }
@@ -348,8 +356,11 @@ struct ChunkRun {
     uint32_t *progress;          // [RSX_PROGRESS_WORDS]: contract violations (RSX_PROGRESS_VIOLATIONS)
 };
 
+// (D = 256, round 5: a row is 8 floats per lane -- six rows in flight are 48 registers before anything else -- so the kernel is
+//  compiled for 4 wavefronts per SIMD there; the BASELINE shapes, d <= 128, keep RSX_BLOCKED_WAVES.  The 64-bit-offset form --
+//  tables of 4 GB and more -- gets one wavefront less than that: at 6 it spilled 6 VGPRs into scratch inside the trip loop)
 template <int D, int PASS, typename OffT, bool TILE>
-__global__ __launch_bounds__(kBlock, RSX_BLOCKED_WAVES) void bpr_step_blocked_kernel(
+__global__ __launch_bounds__(kBlock, (D > 128 ? 4 : (sizeof(OffT) == 8 ? RSX_BLOCKED_WAVES - 1 : RSX_BLOCKED_WAVES))) void bpr_step_blocked_kernel(
     float *__restrict__ P, const float *__restrict__ Q, float *__restrict__ G,
     const int32_t *__restrict__ U_idx, const int32_t *__restrict__ I_idx,
     const int32_t *__restrict__ J_idx, int64_t B, int64_t num_items, int c, int64_t span, uint64_t neg_key, float lr,
@@ -645,6 +656,7 @@ __global__ __launch_bounds__(kBlock) void pointwise_grad_kernel(const float *__r
             g = (sigmoid_neg(-x, ope) - y) * inv_n;                                  // sigmoid(x) - y
             if (loss_acc != nullptr && k == 0) loss_local += softplus_neg(-x, ope) - x * y;   // max(x, 0) - x y + log(1 + exp(-|x|))
         }
+        if (RSX_ABL(1024)) g *= 1.01f;  // (dev build only: a planted 1 % error, tests/test_mutation.py)
         if (GP != nullptr) {           // (NULL gradient buffers: the loss alone -- MF.process_one_batch on the pointwise branch)
             q.atomic_axpy_at(GP, u_off, g);
             p.atomic_axpy_at(GQ, i_off, g);
@@ -891,7 +903,8 @@ void dispatch_step(int d, bool wide, float *P, const float *Q, float *G, const i
     switch (d) {
     case 32: RSX_LAUNCH(32); break;
     case 64: RSX_LAUNCH(64); break;
-    default: RSX_LAUNCH(128); break;
+    case 128: RSX_LAUNCH(128); break;
+    default: RSX_LAUNCH(256); break;
     }
 #undef RSX_LAUNCH
 }
@@ -931,7 +944,8 @@ void dispatch_blocked(int d, bool wide, unsigned blocks, size_t lds, hipStream_t
     switch (d) {
     case 32: RSX_LAUNCH(32); break;
     case 64: RSX_LAUNCH(64); break;
-    default: RSX_LAUNCH(128); break;
+    case 128: RSX_LAUNCH(128); break;
+    default: RSX_LAUNCH(256); break;
     }
 #undef RSX_LAUNCH
 }
@@ -947,11 +961,19 @@ int64_t grid_1d(int64_t n)
 }  // namespace
 
 #ifdef RSX_ABLATE
-// dev build only (librsx_dev.so): write/load switches for tools/ablate*.py
+// dev build only (librsx_dev.so): write/load switches for tools/ablate*.py and the planted errors of tests/test_mutation.py
+//   128 / 256   1 % on the user-row update / on the item gradients of the step kernels
+//   512         Adam: the bias corrections of step t + 1 instead of t (host side)
+//   1024        the pointwise branch: 1 % on dL/dx
+static int g_ablate_host = 0;
 RSX_API int rsx_debug_set_ablation(int mask)
 {
+    g_ablate_host = mask;
     return hipMemcpyToSymbol(HIP_SYMBOL(c_rsx_ablate), &mask, sizeof(int)) == hipSuccess ? RSX_OK : RSX_E_HIP;
 }
+#define RSX_ABL_HOST(mask) ((g_ablate_host & (mask)) != 0)
+#else
+#define RSX_ABL_HOST(mask) false
 #endif
 
 RSX_API int64_t rsx_bpr_step_workspace(int64_t num_users, int64_t max_batch, int d)
@@ -968,7 +990,7 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
                          float *G_hot, int hot_replicas, int neg_block, uint64_t neg_key, rsx_stream_t stream)
 {
     RSX_CHECK_ARG(P && Q && (G || (flags & RSX_NO_UPDATE)), "null table pointer");
-    RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64 or 128");
+    RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64, 128 or 256");
     RSX_CHECK_ARG(batch >= 0 && num_users > 0 && num_items > 0, "negative size");
     if (batch == 0) return RSX_OK;
     RSX_CHECK_ARG(u_dev && i_dev && j_dev, "null index pointer");
@@ -1046,7 +1068,8 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
     switch (d) {
     case 32: hipLaunchKernelGGL(bpr_apply_user_kernel<32>, dim3(g2), dim3(kBlock), 0, st, P, u_dev, i_dev, batch, owner, GU); break;
     case 64: hipLaunchKernelGGL(bpr_apply_user_kernel<64>, dim3(g2), dim3(kBlock), 0, st, P, u_dev, i_dev, batch, owner, GU); break;
-    default: hipLaunchKernelGGL(bpr_apply_user_kernel<128>, dim3(g2), dim3(kBlock), 0, st, P, u_dev, i_dev, batch, owner, GU); break;
+    case 128: hipLaunchKernelGGL(bpr_apply_user_kernel<128>, dim3(g2), dim3(kBlock), 0, st, P, u_dev, i_dev, batch, owner, GU); break;
+    default: hipLaunchKernelGGL(bpr_apply_user_kernel<256>, dim3(g2), dim3(kBlock), 0, st, P, u_dev, i_dev, batch, owner, GU); break;
     }
     hipLaunchKernelGGL(bpr_release_kernel, dim3(g1), dim3(kBlock), 0, st, u_dev, i_dev, batch, owner);
     RSX_CHECK_LAUNCH();
@@ -1059,7 +1082,7 @@ RSX_API int rsx_bpr_grad(const float *P, const float *Q, float *GP, float *GQ, i
                          rsx_stream_t stream)
 {
     RSX_CHECK_ARG(P && Q && GP && GQ, "null table pointer");
-    RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64 or 128");
+    RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64, 128 or 256");
     RSX_CHECK_ARG(batch >= 0 && num_users > 0 && num_items > 0, "negative size");
     if (batch == 0) return RSX_OK;
     RSX_CHECK_ARG(u_dev && i_dev && j_dev, "null index pointer");
@@ -1074,7 +1097,7 @@ RSX_API int rsx_pointwise_grad(const float *P, const float *Q, float *GP, float 
                                float inv_n, int loss_kind, float *loss_acc, rsx_stream_t stream)
 {
     RSX_CHECK_ARG(P && Q && ((GP && GQ) || (!GP && !GQ && loss_acc)), "null table pointer (GP and GQ may both be NULL for the loss alone)");
-    RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64 or 128");
+    RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64, 128 or 256");
     RSX_CHECK_ARG(n >= 0 && num_users > 0 && num_items > 0, "negative size");
     RSX_CHECK_ARG(loss_kind == 0 || loss_kind == 1, "loss_kind: 0 = binary cross entropy with logits, 1 = mean squared error");
     if (n == 0) return RSX_OK;
@@ -1090,7 +1113,9 @@ RSX_API int rsx_pointwise_grad(const float *P, const float *Q, float *GP, float 
     case 128: RSX_PW(64, 0); break;
     case 129: RSX_PW(64, 1); break;
     case 256: RSX_PW(128, 0); break;
-    default: RSX_PW(128, 1); break;
+    case 257: RSX_PW(128, 1); break;
+    case 512: RSX_PW(256, 0); break;
+    default: RSX_PW(256, 1); break;
     }
 #undef RSX_PW
     RSX_CHECK_LAUNCH();
@@ -1103,8 +1128,9 @@ RSX_API int rsx_adam_apply(float *W, float *M, float *V, float *G, int64_t n, fl
     RSX_CHECK_ARG(W && M && V && G, "null pointer");
     RSX_CHECK_ARG(n >= 0 && n % 4 == 0 && t >= 1, "n must be a multiple of 4 and t >= 1");
     if (n == 0) return RSX_OK;
-    const double bc1 = 1.0 - pow((double)beta1, (double)t);
-    const double bc2 = 1.0 - pow((double)beta2, (double)t);
+    const double tb = (double)t + (RSX_ABL_HOST(512) ? 1.0 : 0.0);      // (dev build only: a planted error, tests/test_mutation.py)
+    const double bc1 = 1.0 - pow((double)beta1, tb);
+    const double bc2 = 1.0 - pow((double)beta2, tb);
     hipLaunchKernelGGL(adam_apply_kernel, dim3((unsigned)grid_1d(n / 4)), dim3(kBlock), 0, (hipStream_t)stream,
                        (float4 *)W, (float4 *)M, (float4 *)V, (float4 *)G, n / 4, beta1, beta2, eps,
                        (float)((double)lr / bc1), (float)sqrt(bc2));
@@ -1124,7 +1150,8 @@ RSX_API int rsx_pair_score(const float *P, const float *Q, const int32_t *u_dev,
     switch (d) {
     case 32: hipLaunchKernelGGL(pair_score_kernel<32>, dim3(g), dim3(kBlock), 0, st, P, Q, u_dev, i_dev, n, r_out); break;
     case 64: hipLaunchKernelGGL(pair_score_kernel<64>, dim3(g), dim3(kBlock), 0, st, P, Q, u_dev, i_dev, n, r_out); break;
-    default: hipLaunchKernelGGL(pair_score_kernel<128>, dim3(g), dim3(kBlock), 0, st, P, Q, u_dev, i_dev, n, r_out); break;
+    case 128: hipLaunchKernelGGL(pair_score_kernel<128>, dim3(g), dim3(kBlock), 0, st, P, Q, u_dev, i_dev, n, r_out); break;
+    default: hipLaunchKernelGGL(pair_score_kernel<256>, dim3(g), dim3(kBlock), 0, st, P, Q, u_dev, i_dev, n, r_out); break;
     }
     RSX_CHECK_LAUNCH();
     return RSX_OK;
@@ -1142,7 +1169,8 @@ RSX_API int rsx_fold_hot_grad(float *G, float *G_hot, const int32_t *hot_items_d
     switch (d) {
     case 32: hipLaunchKernelGGL(fold_hot_kernel<32>, dim3(g), dim3(kBlock), 0, st, G, G_hot, hot_items_dev, n_hot, hot_replicas); break;
     case 64: hipLaunchKernelGGL(fold_hot_kernel<64>, dim3(g), dim3(kBlock), 0, st, G, G_hot, hot_items_dev, n_hot, hot_replicas); break;
-    default: hipLaunchKernelGGL(fold_hot_kernel<128>, dim3(g), dim3(kBlock), 0, st, G, G_hot, hot_items_dev, n_hot, hot_replicas); break;
+    case 128: hipLaunchKernelGGL(fold_hot_kernel<128>, dim3(g), dim3(kBlock), 0, st, G, G_hot, hot_items_dev, n_hot, hot_replicas); break;
+    default: hipLaunchKernelGGL(fold_hot_kernel<256>, dim3(g), dim3(kBlock), 0, st, G, G_hot, hot_items_dev, n_hot, hot_replicas); break;
     }
     RSX_CHECK_LAUNCH();
     return RSX_OK;
@@ -1185,7 +1213,7 @@ RSX_API int rsx_bpr_step_chunked(float *P, const float *Q, float *G, int64_t num
 {
     RSX_CHECK_ARG(P && Q && G && chunk_pos_dev && progress_dev, "null pointer");
     RSX_CHECK_ARG(first_range >= 0 && num_ranges >= 1 && first_range + num_ranges <= chunks, "ranges [first, first + count) must lie in [0, chunks)");
-    RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64 or 128");
+    RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64, 128 or 256");
     RSX_CHECK_ARG(chunks >= 2 && chunks <= RSX_MAX_CHUNKS, "chunks must be in [2, RSX_MAX_CHUNKS]");
     RSX_CHECK_ARG(neg_block >= 0 && neg_block <= kMaxNegBlock, "neg_block must be in [0, 16]");
     RSX_CHECK_ARG(batch >= 0 && num_users > 0 && items_real > 0, "negative size");
@@ -1233,7 +1261,8 @@ int rsx_fold_hot_grad_range(float *G, float *G_hot, const int32_t *hot_items_dev
     switch (d) {
     case 32: hipLaunchKernelGGL(fold_hot_range_kernel<32>, dim3(g), dim3(kBlock), 0, st, G, G_hot, hot_items_dev, n_hot, hot_replicas, row_lo, row_hi); break;
     case 64: hipLaunchKernelGGL(fold_hot_range_kernel<64>, dim3(g), dim3(kBlock), 0, st, G, G_hot, hot_items_dev, n_hot, hot_replicas, row_lo, row_hi); break;
-    default: hipLaunchKernelGGL(fold_hot_range_kernel<128>, dim3(g), dim3(kBlock), 0, st, G, G_hot, hot_items_dev, n_hot, hot_replicas, row_lo, row_hi); break;
+    case 128: hipLaunchKernelGGL(fold_hot_range_kernel<128>, dim3(g), dim3(kBlock), 0, st, G, G_hot, hot_items_dev, n_hot, hot_replicas, row_lo, row_hi); break;
+    default: hipLaunchKernelGGL(fold_hot_range_kernel<256>, dim3(g), dim3(kBlock), 0, st, G, G_hot, hot_items_dev, n_hot, hot_replicas, row_lo, row_hi); break;
     }
     RSX_CHECK_LAUNCH();
     return RSX_OK;

@@ -27,7 +27,7 @@ void rsx_set_error(const char *fmt, ...);
         }                                                                            \
     } while (0)
 
-static inline bool rsx_dim_ok(int d) { return d == 32 || d == 64 || d == 128; }
+static inline bool rsx_dim_ok(int d) { return d == 32 || d == 64 || d == 128 || d == 256; }
 
 // number of CUs on the current device (cached)
 int rsx_num_cus();

@@ -207,7 +207,8 @@ int rsx_bpr_step_deterministic(float *P, const float *Q, float *G, int64_t num_i
     switch (d) {
     case 32: RSX_DET(32) break;
     case 64: RSX_DET(64) break;
-    default: RSX_DET(128) break;
+    case 128: RSX_DET(128) break;
+    default: RSX_DET(256) break;
     }
 #undef RSX_DET
     if (loss_acc != nullptr) hipLaunchKernelGGL(det_sum_kernel, dim3(1), dim3(kBlock), 0, st, lossv, batch, loss_acc);

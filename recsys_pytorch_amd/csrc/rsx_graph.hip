@@ -22,7 +22,7 @@ constexpr int kBlock = 256;
 // what a flagged-off neighbour reads instead of its row: ONE shared all-zero row (always an L1 / L2 hit).  Selecting the ADDRESS
 // keeps every fetch an unconditional dwordx4; selecting the VALUE (`flag ? load : zero`) made the compiler split each fetch into
 // four exec-masked dword loads behind their own branches, which cost what the skipped rows saved (round 3, measured: no gain).
-__device__ __attribute__((aligned(16))) float g_zero_row[128];
+__device__ __attribute__((aligned(16))) float g_zero_row[256];
 
 // SKIP: `nz` flags the rows of X that are not entirely zero; a flagged-off neighbour row is not fetched (a * 0 adds nothing:
 // the result is bit-identical).  The first backward product of a LightGCN step multiplies A_hat with the dense gradient of the
@@ -54,6 +54,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(
         // `want` (nullable): only the flagged rows of Y are computed -- the LAST forward product of a LightGCN training step, whose
         // result is read at the batch's users and items only (models/LightGCN.py:117-123 indexes the propagated tables by the batch)
         if (want != nullptr && want[row] == 0) continue;
+        if (RSX_ABL(1) && s == 1) continue;       // (dev build only: one segment of the product dropped, tests/test_mutation.py)
         const int64_t pb = seg_begin[s];
         const int len = seg_len[s];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -182,6 +183,13 @@ unsigned grid_for(int64_t threads)
 
 }  // namespace
 
+#ifdef RSX_ABLATE
+RSX_API int rsx_debug_set_graph_ablation(int mask)     // dev build only (librsx_dev.so): 1 = segment 1 of every product dropped
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_rsx_ablate), &mask, sizeof(int)) == hipSuccess ? RSX_OK : RSX_E_HIP;
+}
+#endif
+
 // HOST: cut CSR rows into segments of at most max_seg non-zeros (empty rows get one empty
 // segment so that Y[row] is written).  Call with out arrays NULL to get the count.
 RSX_API int64_t rsx_spmm_plan(const int64_t *indptr_host, int64_t num_rows, int max_seg,
@@ -212,7 +220,8 @@ static int spmm_launch(const int32_t *seg_row_dev, const int64_t *seg_begin_dev,
         switch (d) {
         case 32: hipLaunchKernelGGL(zero_split_rows_kernel<32>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y, S_acc, S_init); break;
         case 64: hipLaunchKernelGGL(zero_split_rows_kernel<64>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y, S_acc, S_init); break;
-        default: hipLaunchKernelGGL(zero_split_rows_kernel<128>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y, S_acc, S_init); break;
+        case 128: hipLaunchKernelGGL(zero_split_rows_kernel<128>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y, S_acc, S_init); break;
+        default: hipLaunchKernelGGL(zero_split_rows_kernel<256>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y, S_acc, S_init); break;
         }
     }
     const int gpw = 64 / (d / 4);
@@ -222,7 +231,8 @@ static int spmm_launch(const int32_t *seg_row_dev, const int64_t *seg_begin_dev,
     switch (d) {
     case 32: RSX_SPMM(32); break;
     case 64: RSX_SPMM(64); break;
-    default: RSX_SPMM(128); break;
+    case 128: RSX_SPMM(128); break;
+    default: RSX_SPMM(256); break;
     }
 #undef RSX_SPMM
     return RSX_OK;
@@ -351,7 +361,8 @@ RSX_API int rsx_spmm_scale_rows(float *X, const uint8_t *flags_dev, int64_t num_
     switch (d) {
     case 32: hipLaunchKernelGGL(scale_flagged_rows_kernel<8>, dim3(g), dim3(256), 0, st, (float4 *)X, flags_dev, num_rows, alpha); break;
     case 64: hipLaunchKernelGGL(scale_flagged_rows_kernel<16>, dim3(g), dim3(256), 0, st, (float4 *)X, flags_dev, num_rows, alpha); break;
-    default: hipLaunchKernelGGL(scale_flagged_rows_kernel<32>, dim3(g), dim3(256), 0, st, (float4 *)X, flags_dev, num_rows, alpha); break;
+    case 128: hipLaunchKernelGGL(scale_flagged_rows_kernel<32>, dim3(g), dim3(256), 0, st, (float4 *)X, flags_dev, num_rows, alpha); break;
+    default: hipLaunchKernelGGL(scale_flagged_rows_kernel<64>, dim3(g), dim3(256), 0, st, (float4 *)X, flags_dev, num_rows, alpha); break;
     }
     RSX_CHECK_LAUNCH();
     return RSX_OK;

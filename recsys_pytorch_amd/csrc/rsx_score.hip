@@ -113,8 +113,10 @@ __device__ __forceinline__ void score_tile_body(const float *__restrict__ P,
         b_off[n] = (uint32_t)(it * item_stride) * (uint32_t)(D * 4) + (uint32_t)(16 * gq);
     }
     if constexpr (FILTER) {
-        if (tid < BM) tau_s[tid] = (row0 + tid < num_rows) ? tau[row0 + tid] : INFINITY;
+        // (dev build only, tests/test_mutation.py: mask 16 lifts a positive threshold by a quarter -- true Top-K items are filtered out)
+        if (tid < BM) tau_s[tid] = (row0 + tid < num_rows) ? tau[row0 + tid] * ((RSX_ABL(16) && tau[row0 + tid] > 0.f) ? 1.25f : 1.0f) : INFINITY;
     }
+    const int k_end = RSX_ABL(8) ? D - BK : D;      // (dev build only: mask 8 drops the last K chunk of the product)
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -131,7 +133,7 @@ __device__ __forceinline__ void score_tile_body(const float *__restrict__ P,
     constexpr int P8 = RSX_SCORE_LDS_PAD ? 1 : 0;      // dwords of padding per 8-row group
     const float *ap = As + (wr * 64 + l31) * BK + ((wr * 64 + l31) >> 3) * P8 + hi;
     const float *bp = Bs + (wc * 64 + l31) * BK + ((wc * 64 + l31) >> 3) * P8 + hi;
-    for (int k0 = 0; k0 < D; k0 += BK) {
+    for (int k0 = 0; k0 < k_end; k0 += BK) {
         // 8 rows x 128 B per wave instruction, rows 32 n + 8 wid .. + 8 of each tile
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -173,7 +175,7 @@ __device__ __forceinline__ void score_tile_body(const float *__restrict__ P,
         rb[n] = *reinterpret_cast<const float4 *>(b_src[n]);
     }
 
-    for (int k0 = 0; k0 < D; k0 += BK) {
+    for (int k0 = 0; k0 < k_end; k0 += BK) {
         // registers -> LDS, transposed to K-major
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -185,7 +187,7 @@ __device__ __forceinline__ void score_tile_body(const float *__restrict__ P,
         }
         __syncthreads();
         // issue the next chunk's global loads; they fly under the MFMAs below
-        if (k0 + BK < D) {
+        if (k0 + BK < k_end) {
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 ra[n] = *reinterpret_cast<const float4 *>(a_src[n] + k0 + BK);
@@ -509,7 +511,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float *__re
         }
     }
     for (int t = tid; t < K; t += TK_THREADS) {
-        const unsigned long long e = cand[t];
+        // (dev build only, tests/test_mutation.py: mask 64 hands out the (K+1)-th candidate in the K-th place)
+        const unsigned long long e = cand[(RSX_ABL(64) && t == K - 1 && (uint32_t)K < ncand) ? t + 1 : t];
         out_idx[(size_t)blockIdx.x * K + t] = (t < (int)ncand) ? (int32_t)(0xFFFFFFFFu - (uint32_t)e) : -1;
         if (out_val) out_val[(size_t)blockIdx.x * K + t] = (t < (int)ncand) ? key2f((uint32_t)(e >> 32)) : -INFINITY;
     }
@@ -790,6 +793,7 @@ __global__ __launch_bounds__(MG_THREADS) void merge_candidates_kernel(
             while (a < z) { const int64_t m = (a + z) >> 1; if (indices[m] < it) a = m + 1; else z = m; }
             is_seen = a < hi && indices[a] == it;
         }
+        if (RSX_ABL(32)) is_seen = false;       // (dev build only: the seen-item test of the merge skipped, tests/test_mutation.py)
         cand[t] = is_seen ? 0ull : ((e & 0xFFFFFFFF00000000ull) | (uint32_t)(0xFFFFFFFFu - (uint32_t)it));
         if (is_seen) atomicAdd(&s_m, 1u);
     }
@@ -833,7 +837,8 @@ int launch_score(const float *P, const int32_t *users, int64_t rows, const float
     switch (d) {
     case 32: RSX_SCORE_LAUNCH(32); break;
     case 64: RSX_SCORE_LAUNCH(64); break;
-    default: RSX_SCORE_LAUNCH(128); break;
+    case 128: RSX_SCORE_LAUNCH(128); break;
+    default: RSX_SCORE_LAUNCH(256); break;
     }
 #undef RSX_SCORE_LAUNCH
     return 0;
@@ -871,7 +876,10 @@ LanePool *lane_pool()
 }  // namespace
 
 #ifdef RSX_ABLATE
-RSX_API int rsx_debug_set_score_ablation(int mask)     // dev build only (librsx_dev.so)
+// dev build only (librsx_dev.so).  2 / 4: write switches of tools/ablate_score.py; planted errors of tests/test_mutation.py:
+//   8 the last K chunk of the product dropped, 16 the filter threshold lifted, 32 the merge's seen-item test skipped,
+//   64 the dense row Top-K hands out the (K+1)-th candidate in the K-th place
+RSX_API int rsx_debug_set_score_ablation(int mask)
 {
     return hipMemcpyToSymbol(HIP_SYMBOL(c_rsx_ablate), &mask, sizeof(int)) == hipSuccess ? RSX_OK : RSX_E_HIP;
 }
@@ -887,7 +895,7 @@ RSX_API int rsx_score(const float *P, const int32_t *user_ids_dev, int64_t num_r
                       const int32_t *mask_indices_dev, float *scores_out, rsx_stream_t stream)
 {
     RSX_CHECK_ARG(P && Q && user_ids_dev && scores_out, "null pointer");
-    RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64 or 128");
+    RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64, 128 or 256");
     RSX_CHECK_ARG(num_rows >= 0 && num_items > 0, "bad shape");
     RSX_CHECK_ARG((mask_indptr_dev == nullptr) == (mask_indices_dev == nullptr), "mask needs both CSR arrays");
     if (num_rows == 0) return RSX_OK;
@@ -988,7 +996,7 @@ RSX_API int64_t rsx_score_topk_workspace(int64_t num_rows, int64_t num_items)
     const int64_t frows = num_rows < kFusedRows ? num_rows : kFusedRows;
     const int64_t passes = (num_rows + kFusedRows - 1) / kFusedRows;
     const int64_t lanes = passes < kMaxLanes ? passes : kMaxLanes;   // passes in flight (one stream each)
-    const int64_t fused = lanes * carve(nullptr, frows, num_rows, num_items, 512).bytes + a256(num_items * 128 * 4);   // + Qp
+    const int64_t fused = lanes * carve(nullptr, frows, num_rows, num_items, 512).bytes + a256(num_items * 256 * 4);   // + Qp (d <= 256)
     return fused > dense ? fused : dense;   // (K > 512 still takes the dense path)
 }
 
@@ -1021,7 +1029,7 @@ RSX_API int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t 
         return RSX_OK;
     }
     RSX_CHECK_ARG(P && Q && user_ids_dev, "null pointer");
-    RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64 or 128");
+    RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64, 128 or 256");
     RSX_CHECK_ARG(K >= 1 && K <= num_items, "K must be in [1, num_items]");
     RSX_CHECK_ARG((mask_indptr_dev == nullptr) == (mask_indices_dev == nullptr), "mask needs both CSR arrays");
     const int64_t tile_rows = num_rows < kFusedRows ? num_rows : kFusedRows;

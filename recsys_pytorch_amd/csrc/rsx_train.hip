@@ -18,6 +18,11 @@
 // The last item range runs on the caller's stream instead of a stream of its own: the run stream only joins in a chunked run, and
 // every HIP stream more is one more client of the runtime's four hardware queues.  Same box, us per step at C = 2 / 3 / 4 ranges:
 // a stream per range 350 / 432 / 525, the last range on the run stream 350 / 425 / 488 (profiles/r03_exp_sampler_placement.txt, block Q).
+// RSX_SAMPLER_BEHIND_KERNEL = 1 (development A/B, round 5): the sampler of step t + 2 is held back until the step kernel of step t has
+// ended -- it then starts beside the apply sweep and the gap behind it, where the chip is emptier, instead of beside the kernel
+#ifndef RSX_SAMPLER_BEHIND_KERNEL
+#define RSX_SAMPLER_BEHIND_KERNEL 0
+#endif
 #ifndef RSX_RANGE_ON_RUN_STREAM
 #define RSX_RANGE_ON_RUN_STREAM 1
 #endif
@@ -221,7 +226,7 @@ RSX_API int rsx_bpr_trainer_create(const rsx_bpr_trainer_config *cfg, rsx_bpr_tr
 {
     RSX_CHECK_ARG(cfg != nullptr && out != nullptr, "null pointer");
     RSX_CHECK_ARG(cfg->P && cfg->Q && cfg->G && cfg->indptr && cfg->indices && cfg->triplets, "null device pointer");
-    RSX_CHECK_ARG(rsx_dim_ok(cfg->d), "d must be 32, 64 or 128");
+    RSX_CHECK_ARG(rsx_dim_ok(cfg->d), "d must be 32, 64, 128 or 256");
     RSX_CHECK_ARG(cfg->num_users > 0 && cfg->num_items > 0 && cfg->batch > 0 && cfg->batch <= cfg->num_users,
                   "batch must be in [1, num_users]");
     RSX_CHECK_ARG(cfg->neg_block >= 0 && cfg->neg_block <= kMaxNegBlock, "neg_block must be in [0, 16]");
@@ -420,7 +425,9 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
     for (int64_t s = 0; s < n_steps; ++s) {
         const int cur = t->cur;
         RSX_HIP(hipStreamWaitEvent(st, t->ready[cur], 0));
+#if !RSX_SAMPLER_BEHIND_KERNEL
         if (!sharded) RSX_TRY(top_up());                                       // beside this step's kernel
+#endif
         const int32_t *u = slot_ptr(t, cur, 0), *i = slot_ptr(t, cur, 1), *j = slot_ptr(t, cur, 2);
         const int nb = t->slot_nb[cur];
         const uint64_t key = t->slot_key[cur];
@@ -454,7 +461,7 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
                 for (int k = 0; k < c.chunks; ++k) RSX_HIP(hipStreamWaitEvent(RSX_RANGE_STREAM(k), t->ev_start, 0));
                 t->kernels_in_flight = false;
             }
-            if (sharded) RSX_TRY(top_up());
+            if (sharded || RSX_SAMPLER_BEHIND_KERNEL) RSX_TRY(top_up());
             for (int k = 0; k < c.chunks; ++k) {
                 hipStream_t ck = RSX_RANGE_STREAM(k);
                 RSX_HIP(hipStreamWaitEvent(ck, t->ready[cur], 0));
@@ -522,6 +529,13 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
                              nullptr, 0, c.hot_slot, c.G_hot, c.hot_replicas, nb, key, stream));
         RSX_TRY(time_end(st));
         if (timed) ++t->timed;
+#if RSX_SAMPLER_BEHIND_KERNEL
+        if (!sharded) {    // (development A/B) the sampler of step t + 2 starts when THIS kernel has ended: beside the apply
+            RSX_HIP(hipEventRecord(t->fork, st));
+            RSX_HIP(hipStreamWaitEvent(t->side, t->fork, 0));
+            RSX_TRY(top_up());
+        }
+#endif
         if (!sharded) {
             RSX_TRY(rsx_apply_item_grad_ex(c.Q, c.G, c.num_items, c.d, c.lr, c.hot_slot, c.G_hot, c.hot_replicas, batch >= c.num_items, st));
         } else {

@@ -91,14 +91,17 @@ def split_pointwise(g):
 def _planted_error():
     """tests/test_mutation.py re-runs selected parity tests in a child process against the DEVELOPMENT library
     (RSX_LIB=librsx_dev.so, -DRSX_ABLATE) with a 1 % error planted in the user-row update (mask 128) or in the item
-    gradients (mask 256), and expects them to FAIL.  Nothing happens unless RSX_ABLATION is set."""
-    mask = int(os.environ.get("RSX_ABLATION", "0"))
-    if mask:
-        import ctypes
-        from recsys_pytorch_amd import rsx
-        fn = rsx.lib().rsx_debug_set_ablation          # only the dev build exports it
-        fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_int]
-        assert fn(mask) == 0
+    gradients (mask 256) -- or one of the faults of the other kernels (Adam, pointwise, scoring / top-k, the graph product:
+    RSX_SCORE_ABLATION, RSX_GRAPH_ABLATION) -- and expects them to FAIL.  Nothing happens unless one of the variables is set."""
+    import ctypes
+    for env, setter in (("RSX_ABLATION", "rsx_debug_set_ablation"), ("RSX_SCORE_ABLATION", "rsx_debug_set_score_ablation"),
+                        ("RSX_GRAPH_ABLATION", "rsx_debug_set_graph_ablation")):
+        mask = int(os.environ.get(env, "0"))
+        if mask:
+            from recsys_pytorch_amd import rsx
+            fn = getattr(rsx.lib(), setter)                 # only the dev build exports it
+            fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_int]
+            assert fn(mask) == 0
     yield
 
 

@@ -440,6 +440,46 @@ def test_fused_score_topk_equals_dense_path(rsx, oracle_mod, d, I, rows, K):
     assert not torch.isinf(val).any()
 
 
+@pytest.mark.timeout(900)
+def test_fused_score_topk_at_the_bench_shape(rsx, oracle_mod):
+    """the scoring workload bench.py TIMES (64 tiles of 1024 users x 100 000 items, d = 128, K = 50, the users'
+    20 positives masked, Zipf popularity): the fused path == dense scoring + mask + row top-k slab by slab (bit for bit), the first 64
+    rows against the CPU oracle's own product / mask / partial sort (models/MF.py:109-112, :130, func.h:12-31), and the checksum
+    bench.py prints is the checksum of these indices"""
+    from recsys_pytorch_amd.data import synthetic_csr
+    U, I, d, K, rows = 1_000_000, 100_000, 128, 50, 65_536
+    torch.manual_seed(2020)
+    P = (torch.randn(U, d, device="cuda") * 0.1).contiguous()
+    Q = (torch.randn(I, d, device="cuda") * 0.1).contiguous()
+    mask = synthetic_csr(U, I, 20, "cuda", seed=2020, popularity="zipf")
+    users = torch.arange(rows, device="cuda", dtype=torch.int32) % U
+    idx, val = rsx.score_topk(P, Q, users, K, mask=mask, want_values=True)
+    assert idx.shape == (rows, K) and int(idx.min()) >= 0 and not torch.isinf(val).any()
+    for r0 in range(0, rows, 2048):                              # dense reference in slabs of 2048 x 100K scores (0.8 GB)
+        sl = slice(r0, r0 + 2048)
+        S = rsx.score(P, Q, users[sl], mask=mask)
+        ref_i, ref_v = rsx.topk(S, K, want_values=True)
+        assert torch.equal(val[sl], ref_v) and torch.equal(idx[sl], ref_i), r0
+        if r0 == 0:
+            n = 64
+            ip, ix = mask[0].cpu().numpy(), mask[1].cpu().numpy()
+            So = oracle_mod.mask_seen(oracle_mod.score(P[:n].cpu().numpy(), Q.cpu().numpy(), np.arange(n)), np.arange(n), ip, ix)
+            assert np.array_equal(np.isneginf(S[:n].cpu().numpy()), np.isneginf(So))        # the mask, exactly
+            fin = np.isfinite(So)
+            assert np.max(np.abs(S[:n].cpu().numpy()[fin] - So[fin])) < 2e-6 * np.abs(So[fin]).max()
+            want = oracle_mod.topk(So, K)                                                   # the oracle's OWN scores, its own sort
+            got = idx[:n].cpu().numpy()
+            srt = -np.sort(-np.where(fin, So, -np.inf), axis=1)
+            safe = srt[:, K - 1] - srt[:, K] > 1e-5
+            assert safe.mean() > 0.9
+            for r in range(n):
+                if safe[r]:
+                    assert set(got[r]) == set(want[r]), r
+                else:                                                                       # fp32 near-tie at the K-th place
+                    for x in set(got[r]) ^ set(want[r]):
+                        assert abs(float(So[r, x]) - float(srt[r, K - 1])) <= 1e-5 + 2e-6 * np.abs(So[fin]).max(), (r, x)
+
+
 @pytest.mark.parametrize("order", ["ascending", "descending"])
 def test_fused_score_topk_when_scores_follow_the_item_id(rsx, order):
     """the threshold of the fused path comes from a sample of the catalog: the sample is the first rows of a PERMUTED

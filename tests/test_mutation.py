@@ -34,8 +34,8 @@ ORACLE = ["tests/test_gpu_model.py::test_sorted_blocked_sampled_path_replays_thr
           "tests/test_gpu_parity.py::test_bpr_step_matches_reference_golden[g1c_sgd_biglr_400x250_d128_b512]"]
 
 
-def run_child(tests, mask):
-    env = dict(os.environ, RSX_LIB=DEV_LIB, RSX_ABLATION=str(mask), COLUMNS="2000")     # (wide: -rf lines are not truncated)
+def run_child(tests, mask, var="RSX_ABLATION"):
+    env = dict(os.environ, RSX_LIB=DEV_LIB, COLUMNS="2000", **{var: str(mask)})     # (wide: -rf lines are not truncated)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider", "--no-header", "--tb=line", "-rf",
                         *tests], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     return r.returncode, r.stdout[-20000:] + r.stderr[-2000:]
@@ -77,3 +77,62 @@ def test_one_percent_error_is_caught_by_every_selected_parity_test(dev_lib, mask
     # the loss of a later step, which the wrong tables of the step before have moved), not by crashing
     for t, why in got.items():
         assert "assert" in why.lower(), (t, why)
+
+
+# ---- the kernels beside the step: the same question for scoring / top-k, the graph product, Adam and the pointwise branch ------
+P_ = "tests/test_gpu_parity.py::"
+OTHER = [
+    # (variable, mask, the fault, parity tests that must each fail)
+    ("RSX_SCORE_ABLATION", 8, "the product drops its last K chunk (models/MF.py:109-112)",
+     [P_ + "test_score_mask_topk_match_reference_golden[g1_sgd_400x250_d128_b512-g23_400x250_d128_b512]",
+      P_ + "test_score_mask_topk_match_reference_golden[g1_sgd_500x300_d64_b257-g23_500x300_d64_b257]",
+      P_ + "test_score_large_tile_vs_torch_fp64", P_ + "test_fused_score_topk_at_the_bench_shape"]),
+    ("RSX_SCORE_ABLATION", 16, "the filter threshold of the fused path lifted by a quarter: true Top-K items are filtered out",
+     # (not the 1M-item case: there the sample's K-th score sits 1.5x below the catalog's and a quarter is not enough to cut into it)
+     [P_ + "test_fused_score_topk_equals_dense_path[128-65537-1500-10]", P_ + "test_fused_score_topk_equals_dense_path[64-40001-300-50]",
+      P_ + "test_fused_score_topk_on_random_shapes", P_ + "test_fused_score_topk_at_the_bench_shape"]),
+    ("RSX_SCORE_ABLATION", 32, "the merge does not drop seen items (models/MF.py:130)",
+     [P_ + "test_fused_score_topk_equals_dense_path[64-40001-300-50]", P_ + "test_fused_score_topk_with_long_seen_rows",
+      P_ + "test_fused_score_topk_at_the_bench_shape"]),
+    ("RSX_SCORE_ABLATION", 64, "the row Top-K hands out the (K+1)-th best in the K-th place (func.h:12-31)",
+     [P_ + "test_topk_vs_oracle_shapes[37-1000-50]", P_ + "test_topk_vs_oracle_shapes[2-100003-50]",
+      P_ + "test_score_mask_topk_match_reference_golden[g1_sgd_ml100k_d32_b256-g23_ml100k_d32_b256]", P_ + "test_topk_ties_and_masked_rows"]),
+    ("RSX_GRAPH_ABLATION", 1, "one segment of the propagation product dropped (models/LightGCN.py:188-197)",
+     ["tests/test_lightgcn.py::test_hip_lightgcn_matches_reference_golden", "tests/test_lightgcn.py::test_hip_spmm_long_rows_vs_oracle",
+      "tests/test_lightgcn.py::test_hip_lightgcn_full_size_config5_properties"]),
+    ("RSX_ABLATION", 512, "Adam with the bias corrections of step t + 1 (models/MF.py:30)",
+     [P_ + "test_adam_as_shipped_matches_reference_golden", "tests/test_gpu_model.py::test_model_adam_as_shipped_matches_reference_golden",
+      "tests/test_lightgcn.py::test_hip_lightgcn_matches_reference_golden"]),
+    ("RSX_ABLATION", 1024, "the pointwise branch with 1 % on dL/dx (models/MF.py:99-102)",
+     [P_ + "test_pointwise_branch_matches_reference_golden", "tests/test_gpu_model.py::test_pointwise_model_replays_the_reference_batches"]),
+]
+
+
+def outcomes_by_prefix(text, tests):
+    """like outcomes(), for ids given without their parameters: every parametrization of such a test must fail"""
+    failed = [line[len("FAILED "):].split(" ", 1) for line in text.splitlines() if line.startswith("FAILED ")]
+    passed = "passed" in text.splitlines()[-1] if text.strip() else False
+    got = {}
+    for t in tests:
+        hits = [(f[0], f[1] if len(f) > 1 else "failed") for f in failed if f[0] == t or f[0].startswith(t + "[")]
+        got[t] = hits
+    return got, passed
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("var,mask,what,tests", OTHER, ids=[f"{o[0][4:-9].lower() or 'step'}{o[1]}" for o in OTHER])
+def test_planted_faults_in_the_other_kernels_are_caught(dev_lib, var, mask, what, tests):
+    rc, text = run_child(tests, mask, var)
+    got, _ = outcomes_by_prefix(text, tests)
+    assert rc != 0 and all(got[t] for t in tests), (what, {t: got[t] for t in tests}, text[-3000:])
+    import re
+    m = re.search(r"(\d+) failed(?:, (\d+) passed)?", text)
+    assert m and m.group(2) is None, (what, "some parametrization passed with the fault planted", text[-3000:])
+    for t in tests:
+        for _, why in got[t]:
+            assert "assert" in why.lower(), (t, why)
+
+
+def test_dev_library_without_a_planted_fault_passes_the_other_kernels_tests(dev_lib):
+    rc, text = run_child([t for o in OTHER for t in o[3] if "bench_shape" not in t and "full_size" not in t], 0)
+    assert rc == 0, text[-3000:]
