@@ -28,6 +28,9 @@ Prints ONE JSON line (rank 0).
                 `traffic_source.stale`: the kernel sources hash differently from the ones the profile was taken on.
                 `roofline.configs`: every BASELINE config's {value, ms_per_step, kernel_ms, frac, frac_end_to_end} in compact form (the
                 driver keeps `roofline`, `config` and `cpu_baseline` of this line and drops the rest).
+  N > 1         RSX_EXCHANGE=allreduce (default: RCCL all-reduce issued by the library) | scatter_gather | direct (the library's own
+                full mesh over HIP IPC / xGMI, include/rsx.h rsx_mesh_*: reduce-scatter + all-gather by direct peer reads);
+                config.exchange_issued_by / config.exchange say which one ran.
   value         the MEDIAN of three back-to-back timed regions of --steps steps each (`timed_regions`: every region, min, max).
   hbm_utilisation_end_to_end   everything a step moves at the fabric side (step kernel + apply + the sampler beside them, PMC) over the
                 whole step, as a fraction of the 8 TB/s peak: how busy the loop as a whole keeps HBM.
@@ -181,14 +184,14 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
                     force_sharded=SHARDED, comm=COMM)
     Q = eng.Q                                            # (scatter_gather may re-home the item table)
     if two_pass is not None:
-        eng.overlap_exchange = bool(two_pass) and SHARDED
+        eng.overlap_exchange = bool(two_pass) and SHARDED and eng.exchange != "direct"      # (the mesh sums and applies in one go)
     # OPT-IN, never the default: RSX_STALE_EXCHANGE=1 lets a step's exchange travel under the NEXT step kernel (item
     # table one step stale: not the reference's batch-synchronous step; flagged in the JSON line)
     eng.stale_exchange = SHARDED and os.environ.get("RSX_STALE_EXCHANGE") == "1"
     nb = eng.set_neg_block(B, want_nb) if want_nb > 0 else 0
     if hot > 0:
         eng.set_hot_items(torch.bincount(indices.long(), minlength=I), hot, hot_replicas or None)
-    if chunks > 1 and want_nb > 0 and not eng.stale_exchange and eng.exchange == "allreduce":
+    if chunks > 1 and want_nb > 0 and not eng.stale_exchange and eng.exchange in ("allreduce", "direct"):
         # (B >= 2 I: blocked negatives inside the ranges; below: the ranges without blocks -- include/rsx.h "item chunks")
         eng.set_chunks(chunks)
         eng.overlap_exchange = False                     # the range pipeline replaces the two-pass step
@@ -218,6 +221,8 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     ran_chunks = getattr(tr, "chunks", 0)
     eng.adopt(tr)                                        # (a chunked run: checks it and copies the item rows back into Q)
     tr.close()
+    mesh_exchanges = eng._mesh[0].info()[2] if eng._mesh is not None else None
+    eng.close_mesh()                                     # (RSX_EXCHANGE=direct: collective -- no wait gave up, barrier, unmap the peers)
     assert torch.isfinite(P).all() and torch.isfinite(Q).all()
     mean_loss = float(loss.double().sum()) / (B * steps * len(runs))            # this rank's triplets
     assert np.isfinite(mean_loss) and 0.0 < mean_loss < 5.0, mean_loss
@@ -235,8 +240,10 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     # (the walk of the blocked kernel without its negative-side LDS tile when only the positives are ordered)
     kernel = "bpr_step_blocked_kernel" if nb else ("bpr_step_blocked_kernel<TILE=false>" if eng._sorts(B) else "bpr_step_kernel")
     key = f"U{U}_I{I}_d{d}_B{B}_{popularity}_nb{nb}" + (f"_c{ran_chunks}" if ran_chunks > 1 else "")
-    return {"batch_per_gpu": B, "chunks": ran_chunks, "exchange_issued_by": ("library (RCCL from librsx)" if COMM is not None else
-                                                                             "torch.distributed callbacks" + (", range by range" if ran_chunks > 1 else "")) if SHARDED else None, "global_batch": gb, "value": gb * steps / elapsed, "unit": "triplets/s",
+    return {"batch_per_gpu": B, "chunks": ran_chunks, "mesh_exchanges": mesh_exchanges,
+            "exchange_issued_by": (("library (own full mesh over HIP IPC / xGMI: rsx_mesh)" if eng.exchange == "direct" else
+                                    "library (RCCL from librsx)" if COMM is not None else "torch.distributed callbacks")
+                                   + (", range by range" if ran_chunks > 1 else "")) if SHARDED else None, "global_batch": gb, "value": gb * steps / elapsed, "unit": "triplets/s",
             "ms_per_step": elapsed / steps * 1e3, "steps": steps, "neg_block": nb, "mean_bpr_loss": mean_loss,
             "timed_regions": {"count": len(runs), "ms_per_step_each": region_ms, "min": min(region_ms), "max": max(region_ms),
                               "reported": "median"},
@@ -505,7 +512,8 @@ def main():
         assert fn(1) == 0
     global COMM
     comm_note = None
-    if SHARDED and os.environ.get("RSX_DIST_BACKEND", "nccl") == "nccl" and os.environ.get("RSX_NATIVE_RCCL", "1") == "1":
+    if SHARDED and os.environ.get("RSX_DIST_BACKEND", "nccl") == "nccl" and os.environ.get("RSX_NATIVE_RCCL", "1") == "1" \
+            and os.environ.get("RSX_EXCHANGE", "allreduce") != "direct":
         # the exchange is then issued by librsx on the trainer's own stream: no interpreter in the timed region.  Creating the
         # communicator is collective: every rank tries, the ranks agree on the outcome, and if ANY rank failed (librccl not
         # loadable, init error) ALL fall back to the torch.distributed collectives handed in as callbacks -- the same schedule
@@ -672,6 +680,7 @@ def main():
                        "item_chunks": head["chunks"], "exchange_issued_by": head["exchange_issued_by"],
                        # what RCCL's own communicator says (rsx_comm_info), not what the environment asked for
                        "rccl_world": COMM.info()[1] if COMM is not None else None,
+                       "exchange": head["exchange"], "mesh_exchanges": head["mesh_exchanges"],
                        "launched_by": os.environ.get("RSX_LAUNCHED_BY", "torch.distributed.run" if world > 1 else "python bench.py"),
                        "dist_backend": os.environ.get("RSX_DIST_BACKEND", "nccl") if SHARDED else None,
                        **({"exchange_note": comm_note} if comm_note else {}),
@@ -684,6 +693,8 @@ def main():
                        "hot_items": args.hot, "hot_replicas": head["hot_replicas"],
                        "parallelism": (f"user-sharded x{world}, items replicated, "
                                        + ("1 all-reduce(G)/step" if head["exchange"] == "allreduce" else
+                                          "direct full-mesh reduce-scatter(G) by peer reads + own item slice applied + all-gather(Q rows) by peer reads"
+                                          if head["exchange"] == "direct" else
                                           "reduce-scatter(G) + own item shard applied + all-gather(Q rows) per step")
                                        + (", under the user pass of a two-pass step" if head["two_pass"] else "")
                                        + (", ONE STEP STALE (opt-in RSX_STALE_EXCHANGE: the exchange travels under the next step "

@@ -14,7 +14,9 @@
  *     launches are asynchronous on it.  Nothing here synchronises.
  *   - return value: 0 = ok, <0 = error (RSX_E_*); text via rsx_last_error()
  *     (thread-local).  No exceptions cross the ABI.
- *   - tables are row-major fp32: P [U x d], Q [I x d]; d in {32, 64, 128};
+ *   - tables are row-major fp32: P [U x d], Q [I x d]; d in {32, 64, 128, 256}
+ *     (the reference takes any hidden_dim, models/MF.py:19,23-24: the host side
+ *     stores other widths with zero columns behind them, which stay zero);
  *     row indices are int32.
  */
 #ifndef RSX_H
@@ -26,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RSX_ABI_VERSION 5
+#define RSX_ABI_VERSION 6
 
 #define RSX_OK 0
 #define RSX_E_INVALID (-1)   /* bad argument (null pointer, unsupported d, K ...) */
@@ -337,6 +339,35 @@ void rsx_comm_destroy(rsx_comm *c);
 int rsx_comm_info(const rsx_comm *c, int *rank, int *world);
 int rsx_comm_all_reduce_f32(rsx_comm *c, float *buf_dev, int64_t n, rsx_stream_t stream);   /* sum, in place */
 
+/* ---- the library's own exchange: a direct full mesh over xGMI ---------------------------------
+ * "reduce-scatter + all-gather with all 7 peers concurrently rather than a ring".  The reference has
+ * no multi-device code (main.py:24-27); what is preserved is its batch-synchronous step (models/MF.py:64-68).
+ * Every rank maps the peers' Q, G and a mailbox (hipIpcOpenMemHandle); the rows of one exchange are cut into `world` slices;
+ * rank r sums ITS slice of G by reading the peers' partial sums directly (N - 1 links at once), applies it to its slice of Q,
+ * and every rank then copies the other slices' updated rows from their owners.  Every row is computed by one rank and copied:
+ * replicas identical by construction.  Ordering between the ranks is device side (sequence-numbered flags, system-scope
+ * release / acquire); no host thread takes part once the launches are queued.
+ *   rsx_mesh_local     allocates the rank's mailbox, describes its tables -> desc_out (RSX_MESH_DESC_BYTES).  Q and G
+ *                      [rows x d] are BORROWED and must stay allocated until rsx_mesh_destroy on EVERY rank.
+ *   rsx_mesh_connect   after the caller has gathered all ranks' descriptors in rank order (host bootstrap, e.g.
+ *                      torch.distributed.all_gather_object): opens the peers' buffers.  world <= 16.
+ *   rsx_mesh_exchange_apply(first_row, rows, lr)   collective in the sense that every rank must queue the same sequence
+ *                      of calls: afterwards (stream order) Q[first_row .. +rows) -= lr * sum over the ranks of G[...] on
+ *                      every rank, and those rows of G are zero.  What precedes it on `stream` must have completed G.
+ *   rsx_mesh_check     synchronises `stream`; fails if a wait for a peer's signal gave up (rsx_mesh_set_wait_limit, default
+ *                      20 s): such an exchange leaves wrong rows and says so -- it never hangs the GPU.
+ *   rsx_mesh_destroy   the caller makes sure (host barrier) that no peer still reads this rank's buffers.
+ * Handed to rsx_bpr_trainer_create as config.mesh, the native loop issues it per step or per item range.            */
+#define RSX_MESH_DESC_BYTES 512
+typedef struct rsx_mesh rsx_mesh;
+int rsx_mesh_local(float *Q, float *G, int64_t rows, int d, void *desc_out, rsx_mesh **out);
+int rsx_mesh_connect(rsx_mesh *m, int rank, int world, const void *all_desc);
+int rsx_mesh_exchange_apply(rsx_mesh *m, int64_t first_row, int64_t rows, float lr, rsx_stream_t stream);
+int rsx_mesh_set_wait_limit(rsx_mesh *m, double seconds);
+int rsx_mesh_info(const rsx_mesh *m, int *rank, int *world, int64_t *exchanges);
+int rsx_mesh_check(rsx_mesh *m, rsx_stream_t stream);
+void rsx_mesh_destroy(rsx_mesh *m);
+
 /* ---- the native batch loop -----------------------------------------------------------
  * Replaces the reference's inner training loop and the generator feeding it:
  *   models/MF.py:61-72         for b, (users, pos, neg) in enumerate(batch_generator):
@@ -406,6 +437,10 @@ int rsx_comm_all_reduce_f32(rsx_comm *c, float *buf_dev, int64_t n, rsx_stream_t
  *                        the other streams.  Return 0 on success.  This is how the schedule that rsx_comm runs over RCCL is
  *                        driven over any other transport (torch.distributed: tests/test_sharded_gloo.py runs it with two
  *                        ranks).
+ *   mesh                 (no comm, no callbacks) the library's own exchange (rsx_mesh_*) over the tables Q and G of THIS config:
+ *                        one rsx_mesh_exchange_apply per step, or per item range with chunks > 1 (on the trainer's collective
+ *                        stream, under the other ranges' kernels); it applies the summed gradient itself.  Not with two_pass /
+ *                        stale_exchange.
  *   stale_exchange / G_alt   OPT-IN, needs an exchange (callbacks or comm) and a second zeroed [num_items x d] buffer.
  *                        != 0: the exchange of step t's item gradients travels under the step kernel of
  *                        step t+1, which therefore reads an item table that lacks step t's update (ONE STEP
@@ -474,6 +509,7 @@ typedef struct rsx_bpr_trainer_config {
     int64_t *chunk_pos;
     uint32_t *progress;
     rsx_exchange_range_fn exchange_range;   /* chunks > 1 without comm: the caller's all-reduce of one item range  */
+    rsx_mesh *mesh;                         /* the library's own exchange over xGMI (see rsx_mesh_*), or NULL        */
 } rsx_bpr_trainer_config;
 
 #define RSX_EXCHANGE_ALLREDUCE 1

@@ -127,6 +127,49 @@ def csr_pack(m):
     return m.indptr.astype(np.int64), m.indices.astype(np.int32)
 
 
+def g23_case(name, m, mask=None):
+    """G2 / G3 for one trained reference model: predict_batch_users (models/MF.py:109-112), predict's -inf mask (:114-132), top-k of
+    both backends (python/func.py:4-17, func.h:12-31 via oracle/_ref) + the K-th gap; asserts oracle == reference while generating.
+    mask = None: a random 8 % CSR mask"""
+    Un, In = m.num_users, m.num_items
+    users = np.arange(Un, dtype=np.int64)
+    with torch.no_grad():
+        S = m.predict_batch_users(torch.from_numpy(users)).numpy().astype(np.float32)
+    So = oracle.score(m.user_embedding.weight.detach().numpy(),
+                      m.item_embedding.weight.detach().numpy(), users)
+    assert rel_err(So, S) < 2e-6, "oracle score != reference"
+    if mask is None:
+        mrng = np.random.default_rng(7)
+        import scipy.sparse as sp
+        mask = sp.random(Un, In, density=0.08, format="csr", random_state=mrng)
+        mask.data[:] = 1.0
+    pred = m.predict(users, mask, 64)  # float64 [U x I] with -inf at mask nonzeros
+    mp, mi = csr_pack(mask)
+    chk = oracle.mask_seen(S.copy(), users, mp, mi)
+    assert np.array_equal(np.isneginf(chk), np.isneginf(pred)), "mask positions differ"
+    assert np.array_equal(chk[~np.isneginf(chk)], pred.astype(np.float32)[~np.isneginf(chk)])
+    pred32 = pred.astype(np.float32)  # evaluator.py:37
+    save = {"mask_indptr": mp, "mask_indices": mi.astype(np.int32)}
+    rows = users if Un * In <= 200_000 else users[:: max(1, Un // 48)]
+    save["score_rows"] = rows.astype(np.int32)
+    save["S"] = S[rows]
+    for K in (5, 10, 50):
+        py = predict_topk_py(pred32, K).astype(np.int32)
+        cy = oracle.ref_topk(pred32, K)
+        oc = oracle.topk(pred32, K)
+        srt = -np.sort(-pred32, axis=1)
+        gap = (srt[:, K - 1] - srt[:, K]).astype(np.float32)
+        same_set = lambda a, b: all(set(a[r]) == set(b[r]) for r in range(len(a)))
+        assert same_set(py, cy) and same_set(py, oc), "top-k sets differ between backends"
+        vals = lambda t: np.take_along_axis(pred32, t.astype(np.int64), 1)
+        assert np.array_equal(vals(cy), vals(oc)) and np.array_equal(vals(py), vals(oc))
+        save[f"topk_py_{K}"] = py
+        save[f"topk_cy_{K}"] = cy
+        save[f"gap_{K}"] = gap
+    np.savez_compressed(os.path.join(OUT, name.replace("g1_sgd", "g23") + ".npz"), **save)
+    print(f"G2/G3 {name}: rows saved {len(rows)}, min gap@50 {save['gap_50'].min():.3e}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     oracle.build()
@@ -185,45 +228,7 @@ def main():
 
     # ---------------- G2 / G3: scoring, masking, top-k on the G1 end states --
     for name, m in models.items():
-        Un, In = m.num_users, m.num_items
-        users = np.arange(Un, dtype=np.int64)
-        with torch.no_grad():
-            S = m.predict_batch_users(torch.from_numpy(users)).numpy().astype(np.float32)
-        So = oracle.score(m.user_embedding.weight.detach().numpy(),
-                          m.item_embedding.weight.detach().numpy(), users)
-        assert rel_err(So, S) < 2e-6, "oracle score != reference"
-        if Un == U and In == I:
-            mask = ds.train_data
-        else:
-            mrng = np.random.default_rng(7)
-            import scipy.sparse as sp
-            mask = sp.random(Un, In, density=0.08, format="csr", random_state=mrng)
-            mask.data[:] = 1.0
-        pred = m.predict(users, mask, 64)  # float64 [U x I] with -inf at mask nonzeros
-        mp, mi = csr_pack(mask)
-        chk = oracle.mask_seen(S.copy(), users, mp, mi)
-        assert np.array_equal(np.isneginf(chk), np.isneginf(pred)), "mask positions differ"
-        assert np.array_equal(chk[~np.isneginf(chk)], pred.astype(np.float32)[~np.isneginf(chk)])
-        pred32 = pred.astype(np.float32)  # evaluator.py:37
-        save = {"mask_indptr": mp, "mask_indices": mi.astype(np.int32)}
-        rows = users if Un * In <= 200_000 else users[:: max(1, Un // 48)]
-        save["score_rows"] = rows.astype(np.int32)
-        save["S"] = S[rows]
-        for K in (5, 10, 50):
-            py = predict_topk_py(pred32, K).astype(np.int32)
-            cy = oracle.ref_topk(pred32, K)
-            oc = oracle.topk(pred32, K)
-            srt = -np.sort(-pred32, axis=1)
-            gap = (srt[:, K - 1] - srt[:, K]).astype(np.float32)
-            same_set = lambda a, b: all(set(a[r]) == set(b[r]) for r in range(len(a)))
-            assert same_set(py, cy) and same_set(py, oc), "top-k sets differ between backends"
-            vals = lambda t: np.take_along_axis(pred32, t.astype(np.int64), 1)
-            assert np.array_equal(vals(cy), vals(oc)) and np.array_equal(vals(py), vals(oc))
-            save[f"topk_py_{K}"] = py
-            save[f"topk_cy_{K}"] = cy
-            save[f"gap_{K}"] = gap
-        np.savez_compressed(os.path.join(OUT, name.replace("g1_sgd", "g23") + ".npz"), **save)
-        print(f"G2/G3 {name}: rows saved {len(rows)}, min gap@50 {save['gap_50'].min():.3e}")
+        g23_case(name, m, ds.train_data if (m.num_users == U and m.num_items == I) else None)
 
     # ---------------- G4: Evaluator.evaluate on the ml-100k end state --------
     m = models["g1_sgd_ml100k_d32_b256"]

@@ -27,6 +27,20 @@ int rsx_num_cus()
     return cus[dev];
 }
 
+// LDS per CU of the current device in bytes (cached; 0 if the runtime does not say)
+int rsx_lds_per_cu()
+{
+    static int lds[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (lds[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || n <= 0) n = -1;
+        lds[dev] = n;
+    }
+    return lds[dev] > 0 ? lds[dev] : 0;
+}
+
 int g_rsx_score_lanes = 2;
 int g_rsx_sort_cap = 0;
 int g_rsx_apply_stream = 0;

@@ -909,8 +909,8 @@ void dispatch_step(int d, bool wide, float *P, const float *Q, float *G, const i
 #undef RSX_LAUNCH
 }
 
-// Resident wavefronts per SIMD of the blocked kernel, by LDS reservation (a 256-thread workgroup = one wavefront per SIMD; a CU has
-// 160 KB of LDS).  Round 4: with the transcendental-unit loss the kernel needs 64 VGPRs at d = 128 (47 at d = 64) and would run 8
+// Resident wavefronts per SIMD of the blocked kernel, by LDS reservation (a 256-thread workgroup = one wavefront per SIMD; the CU's
+// LDS -- 160 KB on MI355X -- is read from the device).  Round 4: with the transcendental-unit loss the kernel needs 64 VGPRs at d = 128 (47 at d = 64) and would run 8
 // wavefronts per SIMD -- its own duration hardly changes between 5 and 8, but the sampler of the next step, which runs in what the
 // step kernel leaves free, is squeezed out and the step's PERIOD grows (same box, headline: 8 resident -> 337-352 us per step
 // against 314-317 at 6; profiles/r04_exp_step_valu.txt).  rsx_set_option("step_waves") overrides.
@@ -923,9 +923,11 @@ void dispatch_step(int d, bool wide, float *P, const float *Q, float *G, const i
 static size_t lds_for_residency(size_t need, int d)
 {
     int waves = g_rsx_step_waves > 0 ? g_rsx_step_waves : (d >= 128 ? RSX_STEP_WAVES_D128 : RSX_STEP_WAVES_D64);
-    if (waves >= 8) return need;
-    // the smallest reservation with which waves + 1 workgroups no longer fit a CU's 160 KB (allocation granule 512 B... 1 KB to be safe)
-    const size_t cu = 160 * 1024;
+    // the CU's LDS as the runtime reports it (MI355X: 160 KB); unknown: no reservation -- the kernel then runs at whatever its
+    // registers allow, the result is the same
+    const size_t cu = (size_t)rsx_lds_per_cu();
+    if (waves >= 8 || cu == 0) return need;
+    // the smallest reservation with which waves + 1 workgroups no longer fit the CU (allocation granule 512 B... 1 KB to be safe)
     size_t lds = cu / (size_t)(waves + 1) + 1024;
     lds = (lds + 1023) / 1024 * 1024;
     if (lds * (size_t)waves > cu) lds = cu / (size_t)waves / 1024 * 1024;

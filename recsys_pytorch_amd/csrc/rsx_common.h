@@ -31,6 +31,8 @@ static inline bool rsx_dim_ok(int d) { return d == 32 || d == 64 || d == 128 || 
 
 // number of CUs on the current device (cached)
 int rsx_num_cus();
+// LDS bytes per CU of the current device (cached; 0 = unknown)
+int rsx_lds_per_cu();
 
 // fp32 hardware atomic add without return (global_atomic_add_f32); the file is
 // built with -munsafe-fp-atomics so this never lowers to a CAS loop.

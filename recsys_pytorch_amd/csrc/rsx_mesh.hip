@@ -1,0 +1,292 @@
+// rsx_mesh.hip -- the step's exchange of the item gradients as a DIRECT full-mesh reduce-scatter + all-gather over xGMI
+// ("reduce-scatter + all-gather with all 7 peers concurrently rather than a ring"), without RCCL.
+//
+// The reference has no multi-device code (main.py:24-27 pins one device); what must be preserved is its batch-synchronous
+// step (models/MF.py:64-68): every rank applies the SAME summed item gradient before the next step reads the item table.
+//
+// Every rank maps the peers' item table Q, gradient buffer G and a small mailbox into its address space
+// (hipIpcGetMemHandle / hipIpcOpenMemHandle; xGMI is point to point, so the N - 1 peers are read over N - 1 different
+// links at once).  The rows [first, first + rows) of one exchange are cut into `world` equal slices; rank r OWNS slice r:
+//   phase 1  signal READY(seq) to every peer (my G is complete) -> wait for every peer's READY(seq) ->
+//            sum = G_mine[slice r] + sum over the peers p of G_p[slice r], read directly from the peers ->
+//            Q_mine[slice r] -= lr * sum;  G_mine[slice r] = 0
+//   phase 2  signal APPLIED(seq) -> wait for every peer's APPLIED(seq) ->
+//            for every other slice q: Q_mine[slice q] = Q_q[slice q] (copied from its owner), G_mine[slice q] = 0
+// Every item row is computed by exactly ONE rank, in one fixed order (own rows first, then the peers in rank order), and copied to
+// the others: the replicas are identical by construction.  No host thread takes part after the launches are queued.
+//
+// Ordering between the ranks (all device side).  `seq` counts the exchanges of a mesh; every rank issues the same sequence.
+// The mailbox of rank r holds, per peer p, the latest READY / APPLIED sequence number p has signalled TO r (p writes it with a
+// system-scope release store into r's memory; r polls its own memory).  What a signal covers is what the signalling rank's
+// stream had completed before the signal kernel: kernels end with their writes written back to memory (the XCDs' L2s are
+// not shared, so the end-of-kernel release is a write-back on gfx950), a peer reads memory over xGMI, and every workgroup that
+// reads a peer's rows first executes a system-scope ACQUIRE after it has seen the flag (stale lines of the same rows from
+// the step before are dropped from its L2).
+//   * G_p[slice r] is read by r in phase 1 after READY_p(seq); p clears it in ITS phase 2, after APPLIED_r(seq): r is done.
+//   * Q_q[slice q] is read by the others in phase 2 after APPLIED_q(seq); q writes it next in phase 1 of a LATER exchange, which
+//     waits for every peer's READY of that exchange -- signalled by a peer only after its own phase 2 of this one (stream order).
+// A wait that lasts longer than the mesh's limit (default 20 s) gives up, raises the mesh's error word and lets the kernel
+// finish -- wrong rows, loudly reported by rsx_mesh_check, never a hung GPU.
+#include <string.h>
+#include <unistd.h>
+
+#include <vector>
+
+#include "rsx_common.h"
+
+namespace {
+
+constexpr int kMaxWorld = 16;
+constexpr int kMeshBlock = 256;
+constexpr int kFlagStride = 16;       // uint32 per flag slot: one 64-byte line each
+
+struct MeshDesc {                     // what a rank tells the others (RSX_MESH_DESC_BYTES, plain old data)
+    hipIpcMemHandle_t hQ, hG, hF;     // handles of the ALLOCATIONS that hold Q, G and the mailbox
+    uint64_t offQ, offG;              // byte offsets of the tables inside those allocations
+    uint64_t baseQ, baseG;            // the exporting process's addresses of the allocations (to recognise a shared one)
+    int64_t rows;
+    int32_t d, device;
+    int64_t pid;
+};
+static_assert(sizeof(MeshDesc) <= RSX_MESH_DESC_BYTES, "RSX_MESH_DESC_BYTES too small");
+
+struct PeerPtrs {
+    const float *Q[kMaxWorld];        // peers' item tables (own entry: the local one)
+    const float *G[kMaxWorld];
+    uint32_t *flags[kMaxWorld];       // peers' mailboxes (own entry: the local one)
+};
+
+}  // namespace
+
+struct rsx_mesh {
+    int rank = -1, world = 0, device = 0;
+    float *Q = nullptr, *G = nullptr;
+    int64_t rows = 0;
+    int d = 0;
+    uint32_t *flags = nullptr;        // own mailbox: [kMaxWorld][2] slots of kFlagStride words + the error word at the end
+    uint32_t seq = 0;
+    uint64_t limit_ticks = 20ull * 100000000ull;     // wall_clock64 runs at 100 MHz
+    PeerPtrs peers{};
+    std::vector<void *> opened;       // what hipIpcOpenMemHandle returned (closed by rsx_mesh_destroy)
+    bool connected = false;
+};
+
+namespace {
+
+constexpr int kReady = 0, kApplied = 1;
+__host__ __device__ inline int flag_slot(int from, int kind) { return (from * 2 + kind) * kFlagStride; }
+constexpr int kErrorWord = kMaxWorld * 2 * kFlagStride;
+constexpr size_t kMailboxBytes = (size_t)(kErrorWord + kFlagStride) * sizeof(uint32_t);
+
+// one thread per peer: everything this rank's stream completed before this kernel is in memory; tell the peer
+__global__ void mesh_signal_kernel(PeerPtrs p, int rank, int world, int kind, uint32_t seq)
+{
+    const int q = threadIdx.x;
+    if (q >= world || q == rank) return;
+    __threadfence_system();
+    __hip_atomic_store(p.flags[q] + flag_slot(rank, kind), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// every workgroup: wait until every peer has signalled `kind` for exchange `seq` (own mailbox), then acquire
+__device__ __forceinline__ void mesh_wait(uint32_t *flags, int rank, int world, int kind, uint32_t seq, uint64_t limit)
+{
+    const int q = threadIdx.x;
+    if (q < world && q != rank) {
+        const uint64_t t0 = wall_clock64();
+        // (seq is monotonic and compared as a signed distance: it may wrap)
+        while ((int32_t)(__hip_atomic_load(flags + flag_slot(q, kind), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+            if (wall_clock64() - t0 > limit) { atomicOr(flags + kErrorWord, 1u << kind); break; }
+            __builtin_amdgcn_s_sleep(32);
+        }
+    }
+    __syncthreads();
+    __threadfence_system();                          // acquire at system scope in EVERY wavefront that goes on to read peer rows
+}
+
+// phase 1: this rank's slice [lo4, hi4) (in float4 units from the table's base): sum the peers' partial sums onto mine, apply, clear
+__global__ __launch_bounds__(kMeshBlock) void mesh_reduce_apply_kernel(PeerPtrs p, uint32_t *flags, int rank, int world, uint32_t seq,
+                                                                       uint64_t limit, float4 *Q, float4 *G, int64_t lo4, int64_t hi4,
+                                                                       float lr)
+{
+    mesh_wait(flags, rank, world, kReady, seq, limit);
+    const int64_t stride = (int64_t)gridDim.x * kMeshBlock;
+    for (int64_t n = lo4 + (int64_t)blockIdx.x * kMeshBlock + threadIdx.x; n < hi4; n += stride) {
+        float4 s = G[n];
+        float4 v[kMaxWorld];
+        // the peers' quads are requested together (one per link), then added in rank order: the same order on whatever rank owns the row
+#pragma unroll
+        for (int q = 0; q < kMaxWorld; ++q)
+            if (q < world && q != rank) v[q] = reinterpret_cast<const float4 *>(p.G[q])[n];
+#pragma unroll
+        for (int q = 0; q < kMaxWorld; ++q)
+            if (q < world && q != rank) { s.x += v[q].x; s.y += v[q].y; s.z += v[q].z; s.w += v[q].w; }
+        float4 w = Q[n];
+        w.x = fmaf(-lr, s.x, w.x); w.y = fmaf(-lr, s.y, w.y); w.z = fmaf(-lr, s.z, w.z); w.w = fmaf(-lr, s.w, w.w);
+        Q[n] = w;
+        G[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// phase 2: every other rank's slice: copy the updated rows from their owner, clear my partial sums of them (the owner has read them)
+__global__ __launch_bounds__(kMeshBlock) void mesh_gather_kernel(PeerPtrs p, uint32_t *flags, int rank, int world, uint32_t seq,
+                                                                 uint64_t limit, float4 *Q, float4 *G, int64_t first4, int64_t slice4,
+                                                                 int64_t end4)
+{
+    mesh_wait(flags, rank, world, kApplied, seq, limit);
+    const int64_t stride = (int64_t)gridDim.x * kMeshBlock;
+    // the slices of the other ranks, walked interleaved (thread t of a trip reads from owner (t / slice) -- consecutive workgroups hit
+    // different links only through the grid stride; with N - 1 peers and hundreds of workgroups every link is busy)
+    for (int64_t n = first4 + (int64_t)blockIdx.x * kMeshBlock + threadIdx.x; n < end4; n += stride) {
+        const int owner = (int)((n - first4) / slice4);
+        if (owner == rank) continue;
+        Q[n] = reinterpret_cast<const float4 *>(p.Q[owner])[n];
+        G[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+int mesh_fail(const char *what, hipError_t e)
+{
+    rsx_set_error("%s: %s", what, hipGetErrorString(e));
+    return RSX_E_HIP;
+}
+
+}  // namespace
+
+RSX_API int rsx_mesh_local(float *Q, float *G, int64_t rows, int d, void *desc_out, rsx_mesh **out)
+{
+    RSX_CHECK_ARG(Q && G && desc_out && out, "null pointer");
+    RSX_CHECK_ARG(rows > 0 && rsx_dim_ok(d), "bad shape");
+    rsx_mesh *m = new (std::nothrow) rsx_mesh();
+    if (m == nullptr) { rsx_set_error("rsx_mesh_local: out of memory"); return RSX_E_INVALID; }
+    m->Q = Q; m->G = G; m->rows = rows; m->d = d;
+    hipError_t e = hipGetDevice(&m->device);
+    // the mailbox: polled by this rank's kernels while the peers store into it -- uncached device memory where the runtime has it
+    if (e == hipSuccess) {
+        e = hipExtMallocWithFlags((void **)&m->flags, kMailboxBytes, hipDeviceMallocUncached);
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc((void **)&m->flags, kMailboxBytes); }
+    }
+    if (e == hipSuccess) e = hipMemset(m->flags, 0, kMailboxBytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    MeshDesc dsc;
+    memset(&dsc, 0, sizeof(dsc));
+    void *bQ = nullptr, *bG = nullptr;
+    size_t sz = 0;
+    if (e == hipSuccess) e = hipMemGetAddressRange((hipDeviceptr_t *)&bQ, &sz, (hipDeviceptr_t)Q);
+    if (e == hipSuccess) e = hipMemGetAddressRange((hipDeviceptr_t *)&bG, &sz, (hipDeviceptr_t)G);
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&dsc.hQ, bQ);
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&dsc.hG, bG);
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&dsc.hF, m->flags);
+    if (e != hipSuccess) {
+        const int rc = mesh_fail("rsx_mesh_local (hipIpcGetMemHandle needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this driver)", e);
+        rsx_mesh_destroy(m);
+        return rc;
+    }
+    dsc.offQ = (uint64_t)((char *)Q - (char *)bQ); dsc.offG = (uint64_t)((char *)G - (char *)bG);
+    dsc.baseQ = (uint64_t)(uintptr_t)bQ; dsc.baseG = (uint64_t)(uintptr_t)bG;
+    dsc.rows = rows; dsc.d = d; dsc.device = m->device; dsc.pid = (int64_t)getpid();
+    memset(desc_out, 0, RSX_MESH_DESC_BYTES);
+    memcpy(desc_out, &dsc, sizeof(dsc));
+    *out = m;
+    return RSX_OK;
+}
+
+RSX_API int rsx_mesh_connect(rsx_mesh *m, int rank, int world, const void *all_desc)
+{
+    RSX_CHECK_ARG(m != nullptr && all_desc != nullptr, "null pointer");
+    RSX_CHECK_ARG(world >= 1 && world <= kMaxWorld && rank >= 0 && rank < world, "rank / world out of range (at most 16 ranks)");
+    RSX_CHECK_ARG(!m->connected, "already connected");
+    m->rank = rank; m->world = world;
+    for (int q = 0; q < world; ++q) {
+        MeshDesc dsc;
+        memcpy(&dsc, (const char *)all_desc + (size_t)q * RSX_MESH_DESC_BYTES, sizeof(dsc));
+        RSX_CHECK_ARG(dsc.rows == m->rows && dsc.d == m->d, "the ranks' tables differ in shape");
+        if (q == rank) {
+            RSX_CHECK_ARG(dsc.pid == (int64_t)getpid(), "descriptor of this rank does not come from this process");
+            m->peers.Q[q] = m->Q; m->peers.G[q] = m->G; m->peers.flags[q] = m->flags;
+            continue;
+        }
+        RSX_CHECK_ARG(dsc.pid != (int64_t)getpid(), "two ranks in one process: hipIpcOpenMemHandle cannot open its own handle");
+        void *bQ = nullptr, *bG = nullptr, *bF = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&bQ, dsc.hQ, hipIpcMemLazyEnablePeerAccess);
+        if (e == hipSuccess) {
+            m->opened.push_back(bQ);
+            if (dsc.baseG == dsc.baseQ) bG = bQ;           // both tables in ONE allocation of the peer: opened once
+            else { e = hipIpcOpenMemHandle(&bG, dsc.hG, hipIpcMemLazyEnablePeerAccess); if (e == hipSuccess) m->opened.push_back(bG); }
+        }
+        if (e == hipSuccess) { e = hipIpcOpenMemHandle(&bF, dsc.hF, hipIpcMemLazyEnablePeerAccess); if (e == hipSuccess) m->opened.push_back(bF); }
+        if (e != hipSuccess) return mesh_fail("rsx_mesh_connect: hipIpcOpenMemHandle", e);
+        m->peers.Q[q] = (const float *)((char *)bQ + dsc.offQ);
+        m->peers.G[q] = (const float *)((char *)bG + dsc.offG);
+        m->peers.flags[q] = (uint32_t *)bF;
+    }
+    m->connected = true;
+    return RSX_OK;
+}
+
+RSX_API int rsx_mesh_exchange_apply(rsx_mesh *m, int64_t first_row, int64_t rows, float lr, rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(m != nullptr && m->connected, "mesh not connected");
+    RSX_CHECK_ARG(first_row >= 0 && rows > 0 && first_row + rows <= m->rows, "rows out of range");
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t seq = ++m->seq;
+    const int world = m->world, rank = m->rank;
+    const int64_t d4 = m->d / 4;
+    const int64_t slice = ceil_div64(rows, world);                       // rows per owner (the last slices may be short or empty)
+    const int64_t first4 = first_row * d4, end4 = (first_row + rows) * d4, slice4 = slice * d4;
+    int64_t lo4 = first4 + (int64_t)rank * slice4, hi4 = lo4 + slice4;
+    if (lo4 > end4) lo4 = end4;
+    if (hi4 > end4) hi4 = end4;
+    // few workgroups, like a collective's channels: the exchange runs beside the other ranges' step kernels
+    const int cus = rsx_num_cus();
+    auto grid = [&](int64_t n4) { int64_t g = ceil_div64(n4, (int64_t)kMeshBlock * 4); if (g > cus) g = cus; return (unsigned)(g < 1 ? 1 : g); };
+    if (world > 1) hipLaunchKernelGGL(mesh_signal_kernel, dim3(1), dim3(64), 0, st, m->peers, rank, world, kReady, seq);
+    hipLaunchKernelGGL(mesh_reduce_apply_kernel, dim3(grid(hi4 - lo4)), dim3(kMeshBlock), 0, st, m->peers, m->flags, rank, world, seq,
+                       m->limit_ticks, (float4 *)m->Q, (float4 *)m->G, lo4, hi4, lr);
+    if (world > 1) {
+        hipLaunchKernelGGL(mesh_signal_kernel, dim3(1), dim3(64), 0, st, m->peers, rank, world, kApplied, seq);
+        hipLaunchKernelGGL(mesh_gather_kernel, dim3(grid(end4 - first4)), dim3(kMeshBlock), 0, st, m->peers, m->flags, rank, world, seq,
+                           m->limit_ticks, (float4 *)m->Q, (float4 *)m->G, first4, slice4, end4);
+    }
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+}
+
+RSX_API int rsx_mesh_set_wait_limit(rsx_mesh *m, double seconds)
+{
+    RSX_CHECK_ARG(m != nullptr && seconds > 0.0 && seconds < 3600.0, "limit must be in (0, 3600) seconds");
+    m->limit_ticks = (uint64_t)(seconds * 1e8);
+    return RSX_OK;
+}
+
+RSX_API int rsx_mesh_info(const rsx_mesh *m, int *rank, int *world, int64_t *exchanges)
+{
+    RSX_CHECK_ARG(m != nullptr, "null mesh");
+    if (rank) *rank = m->rank;
+    if (world) *world = m->world;
+    if (exchanges) *exchanges = (int64_t)m->seq;
+    return RSX_OK;
+}
+
+RSX_API int rsx_mesh_check(rsx_mesh *m, rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(m != nullptr, "null mesh");
+    uint32_t h = 0;
+    hipError_t e = hipMemcpyAsync(&h, m->flags + kErrorWord, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return mesh_fail("rsx_mesh_check", e);
+    if (h != 0) {
+        rsx_set_error("rsx_mesh_check: rank %d gave up waiting for a peer's %s%s signal (a peer is stuck or gone): item rows of that exchange are wrong",
+                      m->rank, (h & 1u) ? "READY" : "", (h & 2u) ? " APPLIED" : "");
+        return RSX_E_INVALID;
+    }
+    return RSX_OK;
+}
+
+RSX_API void rsx_mesh_destroy(rsx_mesh *m)
+{
+    if (m == nullptr) return;
+    (void)hipDeviceSynchronize();
+    for (void *p : m->opened) (void)hipIpcCloseMemHandle(p);
+    if (m->flags) (void)hipFree(m->flags);
+    delete m;
+}

@@ -241,6 +241,10 @@ RSX_API int rsx_bpr_trainer_create(const rsx_bpr_trainer_config *cfg, rsx_bpr_tr
     RSX_CHECK_ARG(!(native && cfg->exchange_begin != nullptr), "give the exchange callbacks OR a communicator, not both");
     RSX_CHECK_ARG(!native || cfg->exchange_kind == RSX_EXCHANGE_ALLREDUCE || cfg->exchange_kind == RSX_EXCHANGE_SCATTER_GATHER,
                   "with comm: exchange_kind must be RSX_EXCHANGE_ALLREDUCE or RSX_EXCHANGE_SCATTER_GATHER");
+    const bool meshed = cfg->mesh != nullptr;
+    RSX_CHECK_ARG(!(meshed && (native || cfg->exchange_begin != nullptr || cfg->exchange_range != nullptr)),
+                  "give ONE exchange: the callbacks, a communicator, or a mesh");
+    RSX_CHECK_ARG(!(meshed && (cfg->two_pass || cfg->stale_exchange)), "a mesh exchanges and applies in one go: no two_pass / stale_exchange");
     const bool sg = native && cfg->exchange_kind == RSX_EXCHANGE_SCATTER_GATHER;
     if (sg) {
         int world = 1;
@@ -350,7 +354,8 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
     const float inv_batch = 1.0f / (float)global_batch;
     const bool native = c.comm != nullptr;                                     // the library issues the exchange itself (RCCL)
     const bool by_range = c.exchange_range != nullptr;                        // chunked: the caller's collective, range by range
-    const bool sharded = c.exchange_begin != nullptr || native || by_range;
+    const bool meshed = c.mesh != nullptr;                                     // the library's own exchange over xGMI (rsx_mesh.hip)
+    const bool sharded = c.exchange_begin != nullptr || native || by_range || meshed;
     const bool sg = native && c.exchange_kind == RSX_EXCHANGE_SCATTER_GATHER;
     const bool applies = sg || (!native && c.exchange_applies);                // the exchange leaves Q updated and G zero
     const bool hot = c.hot_slot != nullptr;
@@ -479,7 +484,13 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
                 hipStream_t ck = RSX_RANGE_STREAM(k);
                 const int64_t lo = (int64_t)k * g.Ic;
                 float *Gk = c.G + (size_t)lo * c.d, *Qk = c.Q + (size_t)lo * c.d;
-                if (native || by_range) {
+                if (meshed) {
+                    // the library's own exchange: reduce-scatter by direct reads of the peers' rows -> the own slice applied ->
+                    // all-gather of the updated rows from their owners (rsx_mesh.hip); it leaves Q updated and G zero
+                    RSX_HIP(hipStreamWaitEvent(t->aux, t->ev_k[k][par], 0));
+                    if (hot) RSX_TRY(rsx_fold_hot_grad_range(c.G, c.G_hot, c.hot_items, c.n_hot, c.hot_replicas, c.d, lo, lo + g.Ic, t->aux));
+                    RSX_TRY(rsx_mesh_exchange_apply(c.mesh, lo, g.Ic, c.lr, (rsx_stream_t)t->aux));
+                } else if (native || by_range) {
                     // one stream for every collective of the step, issued in range order on every rank: RCCL from here, or the
                     // caller's collective (exchange_range: it queues the all-reduce of the range's rows on that same stream)
                     RSX_HIP(hipStreamWaitEvent(t->aux, t->ev_k[k][par], 0));
@@ -538,6 +549,13 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
 #endif
         if (!sharded) {
             RSX_TRY(rsx_apply_item_grad_ex(c.Q, c.G, c.num_items, c.d, c.lr, c.hot_slot, c.G_hot, c.hot_replicas, batch >= c.num_items, st));
+        } else if (meshed) {
+            // one pass, the exchange exposed: the mesh sums, applies and redistributes the item rows (Q updated, G zero afterwards)
+            if (hot) RSX_TRY(rsx_fold_hot_grad(c.G, c.G_hot, c.hot_items, c.n_hot, c.hot_replicas, c.d, stream));
+            RSX_TRY(rsx_mesh_exchange_apply(c.mesh, 0, c.num_items, c.lr, stream));
+            RSX_HIP(hipEventRecord(t->fork, st));
+            RSX_HIP(hipStreamWaitEvent(t->side, t->fork, 0));
+            RSX_TRY(top_up());
         } else {
             // the one exchange of the step: the item gradients, summed over the ranks.  It needs the
             // folded G; with two passes it travels under the user pass and the next step's sampler.

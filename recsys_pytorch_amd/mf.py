@@ -75,10 +75,12 @@ def end_of_epoch(model, epoch, epoch_summary, scores, evaluator, early_stop, log
 
 
 def _pad_dim(d):
-    for p in (32, 64, 128):
+    """the kernels are instantiated for rows of 32, 64, 128 and 256 floats; any other hidden_dim (the reference takes any,
+    models/MF.py:19,23-24; conf/MF.yaml ships 50) is stored with zero columns behind it, which provably stay zero"""
+    for p in (32, 64, 128, 256):
         if d <= p:
             return p
-    raise ValueError(f"hidden_dim {d} > 128 is not supported by the HIP kernels")
+    raise ValueError(f"hidden_dim {d} > 256 is not supported by the HIP kernels")
 
 
 def _get(cfg, key, default=None):

@@ -28,9 +28,10 @@ RSX_MAX_CHUNKS = 8
 RSX_PROGRESS_WORDS = 16
 RSX_PROGRESS_VIOLATIONS = 8
 RSX_COMM_ID_BYTES = 128
+RSX_MESH_DESC_BYTES = 512
 RSX_EXCHANGE_ALLREDUCE = 1
 RSX_EXCHANGE_SCATTER_GATHER = 2
-SUPPORTED_DIMS = (32, 64, 128)
+SUPPORTED_DIMS = (32, 64, 128, 256)
 
 # symbol -> (restype, argtypes); mirrors include/rsx.h one to one
 _P, _I64, _I32, _F, _U, _U64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint, C.c_uint64
@@ -83,6 +84,13 @@ SIGNATURES = {
     "rsx_comm_destroy": (None, [_P]),
     "rsx_comm_info": (C.c_int, [_P, _P, _P]),
     "rsx_comm_all_reduce_f32": (C.c_int, [_P, _P, _I64, _P]),
+    "rsx_mesh_local": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "rsx_mesh_connect": (C.c_int, [_P, _I32, _I32, _P]),
+    "rsx_mesh_exchange_apply": (C.c_int, [_P, _I64, _I64, _F, _P]),
+    "rsx_mesh_set_wait_limit": (C.c_int, [_P, C.c_double]),
+    "rsx_mesh_info": (C.c_int, [_P, _P, _P, _P]),
+    "rsx_mesh_check": (C.c_int, [_P, _P]),
+    "rsx_mesh_destroy": (None, [_P]),
     "rsx_score": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P, _P, _P, _P]),
     "rsx_topk": (C.c_int, [_P, _I64, _I64, _I32, _P, _P, _P]),
     "rsx_score_topk_workspace": (_I64, [_I64, _I64]),
@@ -477,6 +485,70 @@ class Comm:
             pass
 
 
+class Mesh:
+    """The library's own exchange of the item gradients over xGMI (include/rsx.h: rsx_mesh_*): every rank maps the peers' Q, G and
+    a mailbox (HIP IPC), sums ITS slice of the rows by reading the peers directly, applies it, and the updated rows are copied
+    from their owners -- one process per GPU, the descriptors travel through torch.distributed (any backend: host bootstrap only).
+    Q and G [rows x d] must stay allocated on every rank until close(); close() is collective (a barrier first: no peer may still
+    be reading this rank's buffers)."""
+
+    def __init__(self, Q, G, group=None):
+        import torch.distributed as dist
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        assert Q.shape == G.shape and Q.dim() == 2
+        self._keep = (Q, G)
+        desc = C.create_string_buffer(RSX_MESH_DESC_BYTES)
+        self._h = C.c_void_p()
+        rc = lib().rsx_mesh_local(_dev(Q, torch.float32, "Q"), _dev(G, torch.float32, "G"), Q.shape[0], Q.shape[1], desc, C.byref(self._h))
+        err = None if rc == 0 else f"rsx_mesh_local failed ({rc}): {lib().rsx_last_error().decode()}"
+        box = [None] * self.world
+        dist.all_gather_object(box, (err, desc.raw), group=group)          # (a failed rank still takes part: nobody is left waiting)
+        bad = [f"rank {q}: {e}" for q, (e, _) in enumerate(box) if e is not None]
+        if not bad:
+            rc = lib().rsx_mesh_connect(self._h, self.rank, self.world, C.create_string_buffer(b"".join(raw for _, raw in box), RSX_MESH_DESC_BYTES * self.world))
+            err = None if rc == 0 else f"rsx_mesh_connect failed ({rc}): {lib().rsx_last_error().decode()}"
+            box = [None] * self.world
+            dist.all_gather_object(box, err, group=group)
+            bad = [f"rank {q}: {e}" for q, e in enumerate(box) if e is not None]
+        if bad:
+            self._destroy()
+            raise RsxError("; ".join(bad))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def exchange_apply(self, first_row, rows, lr):
+        """Q[first_row:first_row + rows] -= lr * (sum over the ranks of G[...]) on every rank, those rows of G zeroed; on torch's
+        current stream, behind whatever completed G there"""
+        _check(lib().rsx_mesh_exchange_apply(self._h, int(first_row), int(rows), float(lr), _stream()), "rsx_mesh_exchange_apply")
+
+    def set_wait_limit(self, seconds):
+        _check(lib().rsx_mesh_set_wait_limit(self._h, float(seconds)), "rsx_mesh_set_wait_limit")
+
+    def info(self):
+        r, w, n = C.c_int(-1), C.c_int(-1), C.c_int64(-1)
+        _check(lib().rsx_mesh_info(self._h, C.byref(r), C.byref(w), C.byref(n)), "rsx_mesh_info")
+        return int(r.value), int(w.value), int(n.value)
+
+    def check(self):
+        """synchronises; raises if a wait for a peer's signal gave up (the rows of that exchange are wrong)"""
+        _check(lib().rsx_mesh_check(self._h, _stream()), "rsx_mesh_check")
+
+    def _destroy(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().rsx_mesh_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            import torch.distributed as dist
+            torch.cuda.synchronize()
+            dist.barrier(group=self.group)             # every rank has finished every exchange: nobody reads my buffers any more
+            self._destroy()
+
+
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 EXCHANGE_RANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p)   # (ctx, range, G rows, n floats, stream)
 
@@ -492,7 +564,7 @@ class TrainerConfig(C.Structure):
                 ("exchange_applies", C.c_int32), ("sort_min_batch", C.c_int32), ("step0", _I64), ("epoch_pos0", _I64),
                 ("G_alt", _P), ("stale_exchange", C.c_int32), ("exchange_kind", C.c_int32), ("comm", _P),
                 ("item_rows_padded", _I64), ("chunks", C.c_int32), ("reserved0", C.c_int32), ("items_real", _I64),
-                ("chunk_pos", _P), ("progress", _P), ("exchange_range", EXCHANGE_RANGE_FN)]
+                ("chunk_pos", _P), ("progress", _P), ("exchange_range", EXCHANGE_RANGE_FN), ("mesh", _P)]
 
 
 class BPRTrainer:
@@ -502,7 +574,8 @@ class BPRTrainer:
 
     def __init__(self, P, Q, G, indptr, indices, lr, batch, seed, seed_key, neg_block=0, hot=None, user_sig=None,
                  item_cdf=None, loss_acc=None, exchange=None, two_pass=False, exchange_applies=False, sort_min_batch=0, step0=0, epoch_pos0=0,
-                 G_alt=None, comm=None, exchange_kind=0, item_rows_padded=0, chunks=0, items_real=0, num_items=None, exchange_range=None):
+                 G_alt=None, comm=None, exchange_kind=0, item_rows_padded=0, chunks=0, items_real=0, num_items=None, exchange_range=None,
+                 mesh=None):
         """exchange: (begin, end) callables (the collective stays with the caller) OR comm: an rsx.Comm (the library issues it).
         chunks > 1: P / Q / G / the CSR live in the caller's relabelled item space of chunks * chunk_rows ids; sharded without
         comm: exchange_range(k, first_row, rows, stream_handle) queues the caller's all-reduce of G[first_row:first_row + rows] on
@@ -519,7 +592,7 @@ class BPRTrainer:
         if neg_block or sort_min_batch or self.chunks > 1:
             self.sample_ws = torch.empty(bpr_sample_workspace(self.batch, int(num_items) if num_items is not None else Q.shape[0]),
                                          dtype=torch.uint8, device=dev)
-        self._keep = (P, Q, G, indptr, indices, hot, user_sig, item_cdf, loss_acc, G_alt, comm)
+        self._keep = (P, Q, G, indptr, indices, hot, user_sig, item_cdf, loss_acc, G_alt, comm, mesh)
         ptr = lambda t, dt, name: _dev(t, dt, name) if t is not None else None
         self._cb = (None, None)
         if exchange is not None:                       # (begin, end) callables; exceptions become error codes
@@ -567,7 +640,7 @@ class BPRTrainer:
             exchange_kind=int(exchange_kind), comm=comm.handle if comm is not None else None,
             item_rows_padded=int(item_rows_padded), chunks=self.chunks, reserved0=0, items_real=int(items_real),
             chunk_pos=ptr(self.chunk_pos, torch.int64, "chunk_pos"), progress=ptr(self.progress, torch.int32, "progress"),
-            exchange_range=self._cb_range or EXCHANGE_RANGE_FN())
+            exchange_range=self._cb_range or EXCHANGE_RANGE_FN(), mesh=mesh.handle if mesh is not None else None)
         self._h = C.c_void_p()
         _check(lib().rsx_bpr_trainer_create(C.byref(cfg), C.byref(self._h)), "rsx_bpr_trainer_create")
 

@@ -123,7 +123,7 @@ class BPREngine:
         # sharded + unique users: the exchange of G travels under the user pass of a two-pass step.  The split
         # costs 165 us per step at the headline shape (measured), less than 51 MB over xGMI can take at any N
         # 
-        self.overlap_exchange = self.sharded
+        self.overlap_exchange = self.sharded and exchange != "direct"      # (the mesh exchanges and applies in one go)
         self.user_begin = int(user_begin)
         self.seed = int(seed)
         self.step_count = 0
@@ -147,9 +147,14 @@ class BPREngine:
         #                    the updated Q rows.  Every item row is computed by exactly one rank and copied
         #                    to the others: the replicas are identical by construction, whatever order the
         #                    collective sums in, and the apply sweep shrinks to 1/W of the table per rank.
-        if exchange not in ("allreduce", "scatter_gather"):
+        #   "direct"         the library's own full mesh over xGMI (include/rsx.h: rsx_mesh_*): every rank sums ITS slice of the
+        #                    rows by reading the peers' G directly (all links at once), applies it, and copies the other slices'
+        #                    updated rows from their owners -- reduce-scatter + all-gather without RCCL, replicas identical by
+        #                    construction.  HIP kernels only; per step, or per item range with set_chunks.
+        if exchange not in ("allreduce", "scatter_gather", "direct"):
             raise ValueError(exchange)
         self.exchange = exchange if (self.sharded and optimizer == "sgd") else "allreduce"
+        self._mesh = None           # (rsx.Mesh, the tables it was built over)
         self._work = None
         # comm: an rsx.Comm (RCCL communicator owned by the library).  The native loop then issues the exchange ITSELF on its own
         # stream (include/rsx.h: rsx_bpr_trainer_config.comm) -- no callback into the interpreter inside a run; without it the
@@ -267,7 +272,7 @@ class BPREngine:
         of the range its sampled positive fell in (1/chunks of the catalog, another one after every redraw) instead of over the
         whole catalog."""
         chunks = int(chunks)
-        if chunks > 1 and (self.optimizer != "sgd" or self.exchange != "allreduce"):
+        if chunks > 1 and (self.optimizer != "sgd" or self.exchange not in ("allreduce", "direct")):
             raise ValueError("chunks > 1 needs SGD and exchange='allreduce' (sharded: the library's communicator `comm`, or without "
                              "one this engine's torch.distributed all-reduce handed in range by range)")
         if chunks != self.chunks:
@@ -398,11 +403,37 @@ class BPREngine:
                 self._G_alt = torch.zeros_like(self.G)
         return self._G_alt
 
+    def _mesh_over(self, Q, G):
+        """the rsx.Mesh over these two tables (collective: every rank builds it at the same point); one at a time -- a mesh over
+        other tables (the relabelled item space of another round) replaces it"""
+        m = self._mesh
+        if m is not None and m[1] is Q and m[2] is G:
+            return m[0]
+        self.close_mesh()
+        if not hasattr(self.k, "Mesh"):
+            raise ValueError("exchange='direct' needs the HIP library (rsx.Mesh)")
+        mesh = self.k.Mesh(Q, G, group=self.group)
+        self._mesh = (mesh, Q, G)
+        return mesh
+
+    def close_mesh(self):
+        """collective: checks and releases the mesh (a barrier first -- no peer may still read this rank's tables)"""
+        if self._mesh is not None:
+            mesh, self._mesh = self._mesh[0], None
+            try:
+                mesh.check()
+            finally:
+                mesh.close()
+
     def _exchange_begin(self):
         """the gradient buffer of this step (folded) is complete on the current stream: start the collective.
         Begun exchanges queue up (one deep normally, two with stale_exchange) and end oldest first."""
         alt = self.stale_exchange and (self._begin_step & 1)
         self._begin_step += 1
+        if self.exchange == "direct":       # sums, applies and redistributes in one go (Q updated, G zero afterwards)
+            self._mesh_over(self.Q, self.G).exchange_apply(0, self.Q.shape[0], self.lr)
+            self._pending.append((None, None))
+            return
         if self.exchange == "allreduce":
             G = self._G_alt if alt else self.G
             self._pending.append((dist.all_reduce(G, op=dist.ReduceOp.SUM, group=self.group, async_op=True), G))
@@ -418,6 +449,8 @@ class BPREngine:
         """the current stream waits for the OLDEST exchange in flight; with "scatter_gather" this also applies the
         own shard and gathers the updated item rows, so no apply sweep follows"""
         work, Gp = self._pending.pop(0)
+        if self.exchange == "direct":
+            return
         work.wait()
         if self.exchange == "allreduce":
             return
@@ -645,7 +678,7 @@ class BPREngine:
         if self.optimizer != "sgd":
             raise ValueError("the native loop runs the SGD step; optimizer='adam' steps through BPREngine.step")
         batch = min(int(batch), indptr.numel() - 1)
-        native = self.sharded and self.comm is not None       # the library issues the exchange itself (RCCL)
+        native = self.sharded and self.comm is not None and self.exchange != "direct"      # the library issues the exchange itself (RCCL)
         kind = {"allreduce": 1, "scatter_gather": 2}[self.exchange] if native else 0      # RSX_EXCHANGE_*
         stale = bool(self.stale_exchange) and self.sharded
         blocked = bool(self.neg_block) and batch >= 2 * self.Q.shape[0]
@@ -657,7 +690,10 @@ class BPREngine:
             r = self._build_relabel(indptr, indices)
             self._items_to_relabelled()
             self._relabel_step0 = self.step_count
-            by_range = {"exchange_range": self._exchange_range} if (self.sharded and not native) else {}
+            direct = self.sharded and self.exchange == "direct"
+            by_range = {"exchange_range": self._exchange_range} if (self.sharded and not native and not direct) else {}
+            if direct:       # the library's own mesh over the relabelled tables (collective; replaces the mesh of the round before)
+                by_range = {"mesh": self._mesh_over(r["Q"], r["G"])}
             return self.k.BPRTrainer(self.P, r["Q"], r["G"], indptr, r["indices"], self.lr, batch,
                                      seed=self.seed + 7919 * self.user_begin, seed_key=self.seed, neg_block=self.neg_block,
                                      hot=r["hot"], user_sig=r["sig"], item_cdf=r["cdf"], loss_acc=loss_acc,
@@ -666,12 +702,15 @@ class BPREngine:
         sort_min = int(self.sorted_min_batch) if (self.sorted_min_batch and not self.neg_block) else 0
         if self.neg_block or sort_min:
             self._bind_csr(indptr, indices)
-        exchange = (self._exchange_begin, self._exchange_end) if (self.sharded and not native) else None
+        direct = self.sharded and self.exchange == "direct"
+        exchange = (self._exchange_begin, self._exchange_end) if (self.sharded and not native and not direct) else None
         self._pending.clear()
         self._begin_step = 0                        # the trainer alternates G / G_alt, G first
         sg = self.exchange == "scatter_gather"
         extra = {}
-        if native:
+        if direct:
+            extra = {"mesh": self._mesh_over(self.Q, self.G)}
+        elif native:
             extra = {"comm": self.comm, "exchange_kind": kind, "item_rows_padded": self._Qp.shape[0] if sg else 0,
                      "num_items": self.Q.shape[0]}
         return self.k.BPRTrainer(self.P, self._Qp if (native and sg) else self.Q,
@@ -680,7 +719,7 @@ class BPREngine:
                                  hot=self.hot, user_sig=self._sig if self.neg_block else None,
                                  item_cdf=self._cdf if ((self.neg_block or sort_min) and self.use_item_cdf) else None,
                                  sort_min_batch=sort_min,
-                                 loss_acc=loss_acc, exchange=exchange, two_pass=self.overlap_exchange,
+                                 loss_acc=loss_acc, exchange=exchange, two_pass=self.overlap_exchange and not direct,
                                  exchange_applies=self.exchange == "scatter_gather",
                                  step0=self.step_count, epoch_pos0=self.epoch_pos, **extra,
                                  **({"G_alt": self._stale_buffers()} if stale else {}))
@@ -689,6 +728,8 @@ class BPREngine:
         """take over the step counter and permutation position a native run has reached (and, after a chunked run, the
         item rows it trained in the relabelled space)"""
         self.step_count, self.epoch_pos = trainer.state()
+        if self._mesh is not None:
+            self._mesh[0].check()                   # (synchronises) no wait for a peer's signal gave up
         if getattr(trainer, "chunks", 0) > 1:
             trainer.check()
             self.sync_items()

@@ -68,7 +68,7 @@ def test_bench_json_contract_small_shape():
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("two_pass,exchange,chunks", [("0", "allreduce", "0"), ("1", "allreduce", "0"), ("1", "scatter_gather", "0"),
-                                                      ("1", "allreduce", None), ("0", "allreduce", "3")])
+                                                      ("1", "allreduce", None), ("0", "allreduce", "3"), ("1", "direct", None), ("0", "direct", "0")])
 def test_bench_two_ranks_on_one_gpu(two_pass, exchange, chunks):
     """the N > 1 code path of bench.py (torch.distributed.run, native loop with the exchange callbacks) with two
     ranks sharing the box's GPU and gloo moving G: not a performance number, a does-it-run-and-agree check.  chunks = None:
@@ -80,13 +80,16 @@ def test_bench_two_ranks_on_one_gpu(two_pass, exchange, chunks):
            "--score-tiles", "1" if chunks is None else "0", "--no-legs", *(["--chunks", chunks] if chunks is not None else [])]
     d = run_bench(cmd, env={"RSX_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "RSX_TWO_PASS": two_pass,
                                 "RSX_EXCHANGE": exchange, "RSX_CHUNKS": "-1"})
-    assert ("reduce-scatter" in d["config"]["parallelism"]) == (exchange == "scatter_gather")
+    assert ("reduce-scatter" in d["config"]["parallelism"]) == (exchange in ("scatter_gather", "direct"))
+    assert d["config"]["exchange"] == exchange and ("rsx_mesh" in d["config"]["exchange_issued_by"]) == (exchange == "direct")
+    if exchange == "direct":       # every step's exchange (x item ranges) went through the library's own mesh: warm-up + 3 timed regions
+        assert d["config"]["mesh_exchanges"] == (1 + 3 * 4) * max(1, int(chunks) if chunks is not None else 2)
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 240000 and d["config"]["item_replicas_identical"] is True
     want_chunks = int(chunks) if chunks is not None else 2
     assert d["config"]["item_chunks"] == want_chunks
     assert ("negatives_with_item_ranges" in d["config"]) == (want_chunks > 1)
     assert ("range by range" in d["config"]["exchange_issued_by"]) == (want_chunks > 1)
-    assert ("two-pass" in d["config"]["parallelism"]) == (two_pass == "1" and want_chunks == 0)
+    assert ("two-pass" in d["config"]["parallelism"]) == (two_pass == "1" and want_chunks == 0 and exchange != "direct")
     assert d["roofline"]["kernel_launches_timed"] == 4
     assert abs(d["value"] - 240000 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     if chunks is None:           # scoring: every rank its own users, the job's rate = all ranks' scores / the slowest rank's time

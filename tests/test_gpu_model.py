@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import (DELTA_TOL_SMALL_LR, G1_SGD, G1_SGD_BIGLR, GOLDEN, assert_update, delta_err, golden, rel_err, resolvable_lr,
+from conftest import (DELTA_TOL_SMALL_LR, G1_PADDED, G1_SGD, G1_SGD_BIGLR, GOLDEN, assert_update, delta_err, golden, rel_err, resolvable_lr,
                       split_batches)
 
 pytestmark = pytest.mark.gpu
@@ -42,7 +42,7 @@ def test_model_replay_matches_reference_golden(ml100k):
     assert rel_err(m.user_embedding.weight.cpu().numpy(), g["P0"]) == 0.0   # nothing was updated
 
 
-@pytest.mark.parametrize("name", G1_SGD_BIGLR)
+@pytest.mark.parametrize("name", G1_SGD_BIGLR + G1_PADDED)
 def test_model_replay_large_lr_resolves_the_update_to_1e5(name):
     """the model class on the large-lr fixtures (duplicate users: general path): the 20-step update
     is 0.3-0.8 of the table, so the 1e-5 bar is a 1e-5 bar on the update itself"""
@@ -70,6 +70,50 @@ def test_model_adam_as_shipped_matches_reference_golden(ml100k):
         assert abs(float(m.train_step(u, i, j)) - g["loss"][t]) < 1e-5
     assert rel_err(m.user_embedding.weight.cpu().numpy(), g["PT"]) < 1e-5
     assert rel_err(m.item_embedding.weight.cpu().numpy(), g["QT"]) < 1e-5
+
+
+def test_device_reports_the_lds_the_step_kernel_reserves_against():
+    """the blocked step kernel holds its residency by LDS reservation against the CU's LDS as the DEVICE reports it
+    (csrc/rsx_bpr.hip: lds_for_residency; no 160 KB constant): MI355X = 160 KB, 256 CUs, 64-wide wavefronts"""
+    from recsys_pytorch_amd import rsx
+    info = rsx.device_info(0)
+    assert info["arch"].startswith("gfx950") and info["lds_bytes_per_cu"] == 160 * 1024, info
+    assert info["wavefront_size"] == 64 and info["compute_units"] == 256, info
+
+
+def test_hidden_dim_256_and_padding_d200_through_the_model(oracle_mod):
+    """the reference takes any hidden_dim (models/MF.py:19,23-24): 256 runs in the EPL = 8 kernels, 200 as 256 columns with a zero pad
+    -- SGD steps with repeated users, the sampled fit path, scores and top-k against the oracle"""
+    import recsys_pytorch_amd as pkg
+    rng = np.random.default_rng(5)
+    for d in (256, 200):
+        U, I, B = 3000, 900, 2500
+        ds = types.SimpleNamespace(num_users=U, num_items=I)
+        lr = resolvable_lr(B)
+        m = pkg.MF(ds, dict(HP, hidden_dim=d, lr=lr), "cuda")
+        assert m._P.shape[1] == 256
+        P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+        Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+        m.load_tables(P0, Q0)
+        orc = oracle_mod.MFOracle(P0, Q0, "sgd", lr)
+        for t in range(3):
+            u = rng.integers(0, U, B) if t else rng.permutation(U)[:B]          # unique users (in-place path), then repeats
+            i, j = rng.integers(0, I, B), rng.integers(0, I, B)
+            l = m.train_step(u, i, j, users_unique=(t == 0))
+            assert abs(float(l) - orc.step(u, i, j)) < 1e-5
+        assert_update(m.user_embedding.weight.cpu().numpy(), P0, orc.P, f"P (d={d})")
+        assert_update(m.item_embedding.weight.cpu().numpy(), Q0, orc.Q, f"Q (d={d})")
+        if d < 256:
+            assert float(m._P[:, d:].abs().max()) == 0.0 and float(m._Q[:, d:].abs().max()) == 0.0
+        users = np.arange(200)
+        S = m.predict_batch_users(users).cpu().numpy()
+        So = orc.score(users)
+        assert rel_err(S, So) < 2e-6
+        top = m.predict_topk(users, None, 20)
+        srt = -np.sort(-So, axis=1)
+        safe = srt[:, 19] - srt[:, 20] > 1e-5
+        want = oracle_mod.topk(So, 20)
+        assert safe.mean() > 0.9 and all(set(top[r]) == set(want[r]) for r in np.nonzero(safe)[0])
 
 
 def test_hidden_dim_padding_d50(oracle_mod):

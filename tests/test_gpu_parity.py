@@ -86,8 +86,11 @@ def test_adam_as_shipped_matches_reference_golden(rsx, name):
     assert float(GP.abs().max()) == 0.0 and float(GQ.abs().max()) == 0.0
     assert rel_err(P.cpu().numpy(), g["PT"]) < REL_TOL
     assert rel_err(Q.cpu().numpy(), g["QT"]) < REL_TOL
-    # Adam's update is 1.5-4 % of the table: asserted directly, to 1e-4 of the update
-    assert delta_err(P.cpu().numpy(), g["P0"], g["PT"]) < 1e-4 and delta_err(Q.cpu().numpy(), g["Q0"], g["QT"]) < 1e-4
+    # Adam's update is 1.5-4 % of the table: asserted directly, to 1e-4 of the update (the d = 256 fixture: 3e-4 -- there the C
+    # oracle itself, a sequential sum in the reference's own order, sits at 7e-5 of the reference's update: m / sqrt(v) at entries
+    # whose few gradient terms nearly cancel amplifies the last bit of g, and the kernel's atomics sum in yet another order)
+    bar = 3e-4 if P.shape[1] >= 256 else 1e-4
+    assert delta_err(P.cpu().numpy(), g["P0"], g["PT"]) < bar and delta_err(Q.cpu().numpy(), g["Q0"], g["QT"]) < bar
 
 
 @pytest.mark.parametrize("name", G8_POINTWISE)
@@ -132,7 +135,7 @@ def test_first_step_gradients(rsx):
     assert torch.equal(Q.cpu(), torch.from_numpy(g["Q0"])), "Q must not change before apply"
 
 
-@pytest.mark.parametrize("d", [32, 64, 128])
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
 @pytest.mark.parametrize("B", [1, 63, 257, 4096])
 def test_bpr_step_random_vs_oracle(rsx, oracle_mod, d, B):
     """ragged batch sizes (not multiples of 64), heavy duplicate users AND items"""
@@ -156,7 +159,7 @@ def test_step_kernels_on_random_shapes(rsx, oracle_mod):
     positions), three steps each, against the CPU oracle"""
     rng = np.random.default_rng(777)
     for trial in range(48):
-        d = int(rng.choice([32, 64, 128]))
+        d = int(rng.choice([32, 64, 128, 256]))
         U, I = int(rng.integers(1, 3000)), int(rng.integers(2, 2000))
         unique = trial % 3 != 0
         B = int(rng.integers(1, U + 1)) if unique else int(rng.integers(1, 4000))
@@ -418,7 +421,8 @@ def test_topk_ties_and_masked_rows(rsx, oracle_mod):
 
 @pytest.mark.parametrize("d,I,rows,K", [(64, 40_001, 300, 50), (128, 65_537, 1500, 10), (32, 33_000, 77, 200),
                                         (32, 33_000, 17_000, 20),    # > 8192 rows: passes on two streams
-                                        (64, 1_000_003, 200, 50)])   # BASELINE configs[3]'s catalog size (a prime)
+                                        (64, 1_000_003, 200, 50),    # BASELINE configs[3]'s catalog size (a prime)
+                                        (256, 50_021, 700, 50)])     # hidden_dim 256: eight K chunks of the product
 def test_fused_score_topk_equals_dense_path(rsx, oracle_mod, d, I, rows, K):
     """catalogs >= 32768 items take the fused path (sample threshold -> filtered MFMA epilogue ->
     merge); it must give exactly what dense scoring + row top-k gives, mask included"""
@@ -510,7 +514,7 @@ def test_fused_score_topk_on_random_shapes(rsx, oracle_mod):
     from recsys_pytorch_amd.data import synthetic_csr
     rng = np.random.default_rng(4242)
     for trial in range(16):
-        d = int(rng.choice([32, 64, 128]))
+        d = int(rng.choice([32, 64, 128, 256]))
         I = int(rng.choice([32_768, 32_769, 40_000, 50_011, 70_003]))
         rows = int(rng.choice([1, 63, 129, 1024, 3000, 8192, 8193, 9000]))
         K = int(rng.choice([1, 5, 50, 128, 512]))
@@ -578,10 +582,11 @@ def test_fused_score_topk_degenerate_ties_take_the_dense_redo(rsx, oracle_mod):
     assert list(idx[r]) == [x for x in range(K + len(seen)) if x not in seen][:K]
 
 
-def test_score_large_tile_vs_torch_fp64(rsx):
+@pytest.mark.parametrize("d", [128, 256])
+def test_score_large_tile_vs_torch_fp64(rsx, d):
     """ragged tile edges (rows, items not multiples of 128) against an fp64 product"""
     torch.manual_seed(1)
-    U, I, d = 1000, 10_007, 128
+    U, I = 1000, 10_007
     P = torch.randn(U, d, device="cuda") * 0.1
     Q = torch.randn(I, d, device="cuda") * 0.1
     users = torch.randperm(U, device="cuda")[:333].to(torch.int32)

@@ -98,7 +98,7 @@ def test_hip_spmm_long_rows_vs_oracle(oracle_mod, max_seg):
     A.eliminate_zeros()
     G = rsx.SpmmGraph(A, "cuda", max_seg=max_seg)
     seg = max_seg or 1024
-    for d in (32, 64, 128):
+    for d in (32, 64, 128, 256):
         X = rng.standard_normal((N, d)).astype(np.float32)
         Yo = np.empty_like(X)
         oracle_mod.lib().orc_spmm_csr(A.indptr.astype(np.int64), A.indices.astype(np.int32), A.data.astype(np.float32),

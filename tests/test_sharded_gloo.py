@@ -140,10 +140,10 @@ def test_two_ranks_agree_on_the_relabelled_item_space():
         assert np.array_equal(np.sort(ir0[ix].reshape(U, 12), axis=1), im.reshape(U, 12))
 
 
-def _ranges_worker(rank, world, port, gpu, U, I, d, B, deg, chunks, steps, one_run, out):
+def _ranges_worker(rank, world, port, gpu, U, I, d, B, deg, chunks, steps, one_run, out, exchange="allreduce"):
     """one rank of the chunked native loop with the per-range exchange handed in as a callback (include/rsx.h:
     exchange_range) over gloo: the CPU stand-in trainer (gpu = False) or the HIP library, both ranks on the box's one GPU"""
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from recsys_pytorch_amd.sharded import BPREngine
     dev = torch.device("cuda", 0) if gpu else torch.device("cpu")
@@ -159,8 +159,8 @@ def _ranges_worker(rank, world, port, gpu, U, I, d, B, deg, chunks, steps, one_r
     P = (torch.randn(U, d, generator=torch.Generator().manual_seed(100 + rank)) * 0.1).to(dev)
     Q = (torch.randn(I, d, generator=torch.Generator().manual_seed(7)) * 0.1).to(dev)
     P_init, Q_init = P.cpu().numpy().copy(), Q.cpu().numpy().copy()
-    eng = BPREngine(P, Q, resolvable_lr(world * B), kernels=kernels, user_begin=rank * U, seed=11)
-    assert eng.sharded and eng.comm is None
+    eng = BPREngine(P, Q, resolvable_lr(world * B), kernels=kernels, user_begin=rank * U, seed=11, exchange=exchange)
+    assert eng.sharded and eng.comm is None and eng.exchange == exchange
     if gpu:
         assert (eng.set_neg_block(B, 8) > 0) == (B >= 2 * I)
         if B < 2 * I:
@@ -193,19 +193,22 @@ def _ranges_worker(rank, world, port, gpu, U, I, d, B, deg, chunks, steps, one_r
     Qm = r["Q"].cpu().numpy().copy()                            # the relabelled replica, padding rows included
     eng.adopt(tr)                                               # checks the run (no triplet left its range), item rows back to the caller's ids
     tr.close()
+    if exchange == "direct":
+        assert eng._mesh[0].info() == (rank, world, steps * chunks)       # one exchange per item range and step went through the mesh
+    eng.close_mesh()                                            # (exchange = "direct": collective -- checks that no wait gave up, barrier, unmap)
     out[rank] = (P.cpu().numpy(), eng.Q.cpu().numpy(), Qm, trips, r["rank_item"].cpu().numpy(), float(acc.sum()), P_init, Q_init,
                  float(r["G"].abs().max()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _check_ranges(oracle_mod, world, port, gpu, U, I, d, B, deg, chunks, steps):
+def _check_ranges(oracle_mod, world, port, gpu, U, I, d, B, deg, chunks, steps, exchange="allreduce"):
     """two ranks on the chunked native loop == ONE process (the oracle) on the concatenation of what the ranks sampled"""
     mgr = mp.Manager()
     res = {}
     for one_run in (False, True):
         out = mgr.dict()
-        mp.spawn(_ranges_worker, args=(world, port + 3 * one_run, gpu, U, I, d, B, deg, chunks, steps, one_run, out), nprocs=world, join=True)
+        mp.spawn(_ranges_worker, args=(world, port + 3 * one_run, gpu, U, I, d, B, deg, chunks, steps, one_run, out, exchange), nprocs=world, join=True)
         res[one_run] = [out[r] for r in range(world)]
     for arm in res.values():
         assert np.array_equal(arm[0][2], arm[1][2]), "relabelled item replicas diverged (some range)"
@@ -253,8 +256,20 @@ def test_two_ranks_item_ranges_on_hip_kernels_equal_one_process(oracle_mod, I, c
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("I,chunks", [(2500, 2), (9001, 3)])
-def test_two_ranks_item_ranges_soak(I, chunks):
+@pytest.mark.parametrize("I,chunks,d", [(2500, 2, 64), (1999, 3, 128), (7001, 2, 128)])
+def test_two_ranks_item_ranges_over_the_direct_mesh_equal_one_process(oracle_mod, I, chunks, d):
+    """the same schedule with the library's OWN exchange (include/rsx.h: rsx_mesh_*, exchange = "direct"): two processes on the
+    box's GPU map each other's item table, gradient buffer and mailbox over HIP IPC; per item range every rank sums ITS slice by
+    reading the peer's rows directly, applies it, and copies the other slice from its owner -- no torch.distributed collective in
+    the step (gloo only carries the handles and the barriers around the run).  Step by step against the oracle on the concatenated
+    triplets and all steps queued by one call, replicas identical row by row, G zero, no wait gave up, steps x ranges exchanges"""
+    _check_ranges(oracle_mod, 2, 29500 + (os.getpid() + 83 + I) % 2000, True, 9000, I, d, 6000, 10, chunks, 4, exchange="direct")
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("I,chunks,exchange", [(2500, 2, "allreduce"), (9001, 3, "allreduce"), (2500, 2, "direct"), (9001, 3, "direct")])
+def test_two_ranks_item_ranges_soak(I, chunks, exchange):
     """sixty steps of the range schedule queued by ONE call on each of two ranks (HIP loop, two processes on the box's GPU, the
     exchange range by range over gloo): the pipelines of neighbouring steps interleave for a long stretch -- afterwards the item
     replicas are identical row by row (padding rows included), every gradient row is applied and cleared, no triplet left its
@@ -263,7 +278,7 @@ def test_two_ranks_item_ranges_soak(I, chunks):
     world, U, d, B, steps = 2, 9000, 64, 6000, 60
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_ranges_worker, args=(world, 29500 + (os.getpid() + 71 + I) % 2000, True, U, I, d, B, 10, chunks, steps, True, out),
+    mp.spawn(_ranges_worker, args=(world, 29500 + (os.getpid() + 71 + I + 7 * len(exchange)) % 2000, True, U, I, d, B, 10, chunks, steps, True, out, exchange),
              nprocs=world, join=True)
     a, b = out[0], out[1]
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[1], b[1]), "item replicas diverged"
@@ -276,7 +291,7 @@ def test_two_ranks_item_ranges_soak(I, chunks):
 
 
 def _gpu_worker(rank, world, port, P0, Q0, batches, lr, out, unique=False, exchange="allreduce"):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from recsys_pytorch_amd.sharded import BPREngine, user_block
     dev = torch.device("cuda", 0)                      # both ranks share the one GPU of the test box
@@ -296,6 +311,9 @@ def _gpu_worker(rank, world, port, P0, Q0, batches, lr, out, unique=False, excha
             acc = eng.step(ul, il, jl)
         losses.append(float(acc.sum()) / len(u))
     torch.cuda.synchronize()
+    if exchange == "direct":
+        assert eng._mesh[0].info() == (rank, world, len(batches))
+    eng.close_mesh()
     out[rank] = (lo, hi, P.cpu().numpy(), Q.cpu().numpy(), losses)
     dist.barrier()
     dist.destroy_process_group()
@@ -303,7 +321,7 @@ def _gpu_worker(rank, world, port, P0, Q0, batches, lr, out, unique=False, excha
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("exchange", ["allreduce", "scatter_gather"])
+@pytest.mark.parametrize("exchange", ["allreduce", "scatter_gather", "direct"])
 def test_two_ranks_on_hip_kernels_equal_one_process(oracle_mod, exchange):
     """same check with the real HIP kernels: two processes (sharing the box's GPU, gloo for the
     all-reduce) on their own triplets == one process on the concatenated batch"""
@@ -331,7 +349,7 @@ def test_two_ranks_on_hip_kernels_equal_one_process(oracle_mod, exchange):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("exchange", ["allreduce", "scatter_gather"])
+@pytest.mark.parametrize("exchange", ["allreduce", "scatter_gather", "direct"])      # ("direct": one pass, the mesh exposed)
 def test_two_ranks_on_hip_kernels_with_the_exchange_under_the_user_pass(oracle_mod, exchange):
     rng = np.random.default_rng(29)
     U, I, d, B, T = 4001, 1501, 128, 3000, 4
@@ -356,7 +374,7 @@ def test_two_ranks_on_hip_kernels_with_the_exchange_under_the_user_pass(oracle_m
 
 
 def _gpu_sampled_worker(rank, world, port, mode, U, I, d, B, steps, out, exchange="allreduce"):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from recsys_pytorch_amd.data import synthetic_csr
     from recsys_pytorch_amd.sharded import BPREngine
@@ -381,6 +399,7 @@ def _gpu_sampled_worker(rank, world, port, mode, U, I, d, B, steps, out, exchang
         eng.adopt(tr)
         tr.close()
     torch.cuda.synchronize()
+    eng.close_mesh()
     # (the Python-driven engine's epoch_pos already counts the batch it sampled ahead)
     pos = eng.epoch_pos if mode == "native" else eng._bufs[eng._cur]["pos_before"]
     out[(mode, rank)] = (P.cpu().numpy(), Q.cpu().numpy(), eng.step_count, pos, P_init, Q_init)
@@ -390,7 +409,8 @@ def _gpu_sampled_worker(rank, world, port, mode, U, I, d, B, steps, out, exchang
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("B,I,exchange", [(6000, 2500, "allreduce"), (3000, 4000, "allreduce"), (6000, 2501, "scatter_gather")])
+@pytest.mark.parametrize("B,I,exchange", [(6000, 2500, "allreduce"), (3000, 4000, "allreduce"), (6000, 2501, "scatter_gather"),
+                                          (6000, 2503, "direct")])
 def test_two_ranks_native_loop_with_exchange_callbacks_equals_python_driven(B, I, exchange):
     """user-sharded SAMPLED steps, two processes on the HIP kernels: the native loop (exchange handed
     in as callbacks, all-reduce of G under the user pass) against the Python-driven engine on the
