@@ -107,8 +107,9 @@ def test_hip_spmm_long_rows_vs_oracle(oracle_mod, max_seg):
         Y = torch.full_like(Xd, 7.0)
         S = Xd.clone()
         rsx.spmm(G, Xd, Y, S_acc=S)
-        assert rel_err(Y.cpu().numpy(), Yo) < 2e-6
-        assert rel_err(S.cpu().numpy(), X + Yo) < 2e-6
+        # (3000-term fp32 sums in another order than the oracle's sequential one: 2.2e-6 of the largest entry on the d = 256 draw)
+        assert rel_err(Y.cpu().numpy(), Yo) < 4e-6
+        assert rel_err(S.cpu().numpy(), X + Yo) < 4e-6
         assert float(Y[5].abs().max()) == 0.0
         # an X most of whose rows are zero, with its row flags: the flagged-off rows are not fetched, the result is BIT-identical
         # (single-segment rows; split rows add their partial sums atomically, whose order is free: to rounding)
