@@ -152,13 +152,15 @@ template <int D>
 __global__ __launch_bounds__(kBlock) void zero_split_rows_kernel(const int32_t *__restrict__ seg_row, const int64_t *__restrict__ seg_begin,
                                                                  const int32_t *__restrict__ seg_len, int64_t num_segs,
                                                                  const int64_t *__restrict__ indptr, float *__restrict__ Y,
-                                                                 float *__restrict__ S, const float *__restrict__ Sinit)
+                                                                 float *__restrict__ S, const float *__restrict__ Sinit,
+                                                                 const uint8_t *__restrict__ want)
 {
     // one thread per segment decides; the few that start a split row clear it (a thread per quad of every segment -- 35M threads
     // at the configs[4] shape -- took 99 us, more than the memset it had replaced)
     const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (s >= num_segs) return;
     const int32_t row = seg_row[s];
+    if (want != nullptr && want[row] == 0) return;       // rsx_spmm_csr_select_rows: an unwanted row is NOT written, split or not
     const int64_t lo = indptr[row], hi = indptr[row + 1];
     if (seg_begin[s] == lo && (int64_t)seg_len[s] < hi - lo) {
         float4 *y = reinterpret_cast<float4 *>(Y + (size_t)row * D);
@@ -218,10 +220,10 @@ static int spmm_launch(const int32_t *seg_row_dev, const int64_t *seg_begin_dev,
     {   // split rows add into zeros (whole rows are stored)
         const unsigned zb = (unsigned)((num_segs + kBlock - 1) / kBlock);
         switch (d) {
-        case 32: hipLaunchKernelGGL(zero_split_rows_kernel<32>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y, S_acc, S_init); break;
-        case 64: hipLaunchKernelGGL(zero_split_rows_kernel<64>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y, S_acc, S_init); break;
-        case 128: hipLaunchKernelGGL(zero_split_rows_kernel<128>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y, S_acc, S_init); break;
-        default: hipLaunchKernelGGL(zero_split_rows_kernel<256>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y, S_acc, S_init); break;
+        case 32: hipLaunchKernelGGL(zero_split_rows_kernel<32>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y, S_acc, S_init, want); break;
+        case 64: hipLaunchKernelGGL(zero_split_rows_kernel<64>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y, S_acc, S_init, want); break;
+        case 128: hipLaunchKernelGGL(zero_split_rows_kernel<128>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y, S_acc, S_init, want); break;
+        default: hipLaunchKernelGGL(zero_split_rows_kernel<256>, dim3(zb ? zb : 1), dim3(kBlock), 0, st, seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, Y, S_acc, S_init, want); break;
         }
     }
     const int gpw = 64 / (d / 4);

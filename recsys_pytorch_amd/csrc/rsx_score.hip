@@ -653,7 +653,9 @@ __global__ __launch_bounds__(256) void permute_items_kernel(const float4 *__rest
 }
 
 constexpr int MG_THREADS = 256;
-constexpr int MG_CAP = 4096;    // candidate list capacity per row
+constexpr int MG_CAP = 4096;    // candidate list capacity per row.  (Since round 4 the survivors enter the list RAW -- seen items included, they are
+                                // dropped after the histogram cut -- so a user whose seen items crowd the top of the catalog overflows, and takes
+                                // the dense re-do, a little earlier than when seen items were filtered on arrival: a cost, never a wrong row.)
 constexpr int MG_SEEN = 512;    // seen items of a user held in LDS for the mask test (longer rows: searched in the CSR)
 constexpr int MG_BATCH = 8;     // cells a thread requests together
 constexpr int MG_BIN_BITS = 10;
