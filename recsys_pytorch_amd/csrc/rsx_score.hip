@@ -55,6 +55,14 @@ constexpr int BM = 128, BN = 128, BK = 32;
 //  64 KB of LDS, so TWO workgroups per CU: bit-identical, 256.3 -> 280.5 us per 1024 users.  Four resident wavefronts per SIMD hide
 //  the chunk latency better than a prefetch inside two; with 16-wide chunks (four workgroups again) the 64-byte row pitch costs
 //  2-way LDS bank conflicts on every fragment read.  Round 3, profiles/r03_exp_scoring_variants.txt.)
+// RSX_SCORE_FRAG64 = 1 (round 5): the fragments of TWO MFMA steps come with one ds_read_b64 per tile row instead of two ds_read_b32 -- a
+// b64 read takes the same two LDS cycles as a b32 read (MI355X_MICROARCH.md, LDS table) and half the instructions.  The contraction index
+// is permuted for that (any order of k is the same sum as long as A and B use the same one): in the pair of steps that covers the k-quad q
+// the low half of the wavefront multiplies k = 4q, 4q + 1 and the high half k = 4q + 2, 4q + 3 (it used to be 2 kk / 2 kk + 1 per step).  The
+// tiles are swizzled by bits 1-3 of the row and padded by two dwords per 16 rows for it: the 32 lanes of a read then cover the 64 banks once.
+#ifndef RSX_SCORE_FRAG64
+#define RSX_SCORE_FRAG64 0
+#endif
 constexpr int kSlots = 2;     // private candidate slots per (64-item strip, row) of the filtered product
 constexpr int LDT = BM + 1;   // K-major tile leading dimension (odd -> conflict-free transpose)
 
@@ -78,7 +86,7 @@ __device__ __forceinline__ void score_tile_body(const float *__restrict__ P,
     // (GLDS + RSX_SCORE_LDS_PAD: one dword of padding behind every 8 rows -- the 8 rows one DMA instruction of a wavefront writes.  With
     //  the XOR swizzle alone the 32 lanes of a fragment read fall on 8 banks, 4 lanes each; the pad moves the four 8-row groups of
     //  those lanes to four different bank offsets: conflict-free.)
-    constexpr int PADA = (GLDS && RSX_SCORE_LDS_PAD) ? BM / 8 : 0;
+    constexpr int PADA = (GLDS && RSX_SCORE_FRAG64) ? 2 * (BM / 16) : (GLDS && RSX_SCORE_LDS_PAD) ? BM / 8 : 0;
     __shared__ __attribute__((aligned(16))) float As[GLDS ? BM * BK + PADA : BK * LDT];
     __shared__ __attribute__((aligned(16))) float Bs[GLDS ? BN * BK + PADA : BK * LDT];
     __shared__ __attribute__((aligned(16))) float tau_s[BM];
@@ -105,7 +113,8 @@ __device__ __forceinline__ void score_tile_body(const float *__restrict__ P,
         // computed and never stored, which keeps every staging load an unconditional dwordx4
         int64_t r = row0 + srow + 32 * n;
         r = (r < num_rows) ? r : num_rows - 1;
-        const int gq = GLDS ? (kq ^ (srow & 7)) : kq;      // GLDS: LDS slot kq of this row receives the row's k-quad kq ^ (row & 7)
+        // GLDS: LDS slot kq of this row receives the row's k-quad kq ^ (row & 7)  (FRAG64: kq ^ ((row >> 1) & 7))
+        const int gq = GLDS ? (kq ^ (RSX_SCORE_FRAG64 ? ((srow >> 1) & 7) : (srow & 7))) : kq;
         int64_t it = item0 + srow + 32 * n;
         it = (it < num_items) ? it : num_items - 1;
         a_src[n] = P + (size_t)user_ids[r] * D + 4 * gq;
@@ -126,7 +135,45 @@ __device__ __forceinline__ void score_tile_body(const float *__restrict__ P,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
-    if constexpr (GLDS) {
+    if constexpr (GLDS && RSX_SCORE_FRAG64) {
+    // lane's fragment rows: wr * 64 + l31 (+ 32) of A, wc * 64 + l31 (+ 32) of B.  Element (row, k) sits at dword
+    //   row * 32 + (((k >> 2) ^ ((row >> 1) & 7)) << 2) + (k & 3) + 2 * (row >> 4)
+    // and this lane reads the two floats k = 4 q + 2 hi, 4 q + 2 hi + 1 of the quad q: one ds_read_b64 per row and pair of steps
+    const int xq = (l31 >> 1) & 7;                      // the same for row and row + 32 (and for wr * 64 + ..., wc * 64 + ...)
+    const float *ap = As + (wr * 64 + l31) * BK + ((wr * 64 + l31) >> 4) * 2 + 2 * hi;
+    const float *bp = Bs + (wc * 64 + l31) * BK + ((wc * 64 + l31) >> 4) * 2 + 2 * hi;
+    constexpr int kRow32 = 32 * BK + 4;                 // rows r and r + 32: two 16-row pads apart
+    auto frag = [&](const float *base, int q) __attribute__((always_inline)) { return *reinterpret_cast<const float2 *>(base + ((q ^ xq) << 2)); };
+    for (int k0 = 0; k0 < k_end; k0 += BK) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const float *gb = reinterpret_cast<const float *>(reinterpret_cast<const char *>(Q) + (b_off[n] + (uint32_t)k0 * 4u));
+            __builtin_amdgcn_global_load_lds(a_src[n] + k0, As + (32 * n + 8 * wid) * BK + (2 * n + (wid >> 1)) * 2, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(gb, Bs + (32 * n + 8 * wid) * BK + (2 * n + (wid >> 1)) * 2, 16, 0, 0);
+        }
+        __syncthreads();          // (carries the vmcnt(0) of the DMA: the chunk has landed for every wavefront)
+        float2 a0 = frag(ap, 0), a1 = frag(ap + kRow32, 0), b0 = frag(bp, 0), b1 = frag(bp + kRow32, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int q = 0; q < BK / 4; ++q) {
+            float2 na0 = make_float2(0.f, 0.f), na1 = na0, nb0 = na0, nb1 = na0;
+            if (q + 1 < BK / 4) { na0 = frag(ap, q + 1); na1 = frag(ap + kRow32, q + 1); nb0 = frag(bp, q + 1); nb1 = frag(bp + kRow32, q + 1); }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[1][1], 0, 0, 0);
+            // the four reads of the NEXT pair of steps, then this pair's eight MFMAs (the reads are a whole pair ahead of their use)
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        }
+        __syncthreads();          // every wavefront is done reading before the next chunk overwrites the tiles
+    }
+    } else if constexpr (GLDS) {
     // lane's fragment rows: wr * 64 + l31 (+ 32) of A, wc * 64 + l31 (+ 32) of B; element (row, k) sits at row * 32 + (k ^ x),
     // x = (row & 7) << 2 = (l31 & 7) << 2 for all four rows; this lane reads k = kk + hi
     const int xs = (l31 & 7) << 2;
