@@ -579,3 +579,46 @@ def test_exchange_over_rccl_with_one_rank_equals_the_unsharded_step(B, I):
         assert scale > 1e-2
         assert np.abs(P - Pr).max() < 1e-5 * scale and np.abs(Q - Qr).max() < 1e-5 * scale, exchange
         assert np.abs(Q - Qs).max() > 1e-3 * scale, "the stale recurrence cannot be told from the synchronous step"
+
+
+def _mesh_timeout_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from recsys_pytorch_amd import rsx
+    dev = torch.device("cuda", 0)
+    Q = torch.ones(1000, 64, device=dev)
+    G = torch.full((1000, 64), float(rank + 1), device=dev)
+    mesh = rsx.Mesh(Q, G)
+    mesh.set_wait_limit(0.5)
+    # a healthy exchange first: Q -= 0.5 * (1 + 2) on both ranks, G cleared
+    mesh.exchange_apply(0, 1000, 0.5)
+    mesh.check()
+    ok = bool((Q == -0.5).all()) and float(G.abs().max()) == 0.0
+    dist.barrier()
+    err = None
+    if rank == 0:                # ... then rank 1 never shows up for the next one: rank 0's waits give up after 0.5 s, and say so
+        G.fill_(1.0)
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+        t0.record(); mesh.exchange_apply(0, 1000, 0.5); t1.record()
+        try:
+            mesh.check()
+        except rsx.RsxError as e:
+            err = str(e)
+        out["ms"] = t0.elapsed_time(t1)
+    out[rank] = (ok, err)
+    mesh.close()                 # (collective: barrier inside)
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_mesh_exchange_and_a_missing_peer_is_an_error_not_a_hang():
+    """rsx_mesh on its own (two processes on the box's GPU): one exchange sums both ranks' gradients into both replicas; when a peer never
+    queues its half of the next exchange, the waiting rank's kernels give up at the mesh's limit and rsx_mesh_check reports it -- wrong
+    rows, loudly, never a hung GPU"""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_mesh_timeout_worker, args=(2, 29500 + (os.getpid() + 97) % 2000, out), nprocs=2, join=True)
+    assert out[0][0] and out[1][0]                                   # the healthy exchange: both replicas updated, G zero
+    assert out[1][1] is None and out[0][1] is not None and "gave up waiting" in out[0][1]
+    assert 400.0 < out["ms"] < 5000.0                                # two waits of 0.5 s each, not a hang
