@@ -374,11 +374,9 @@ def cpu_baseline(args, U, I, d, batches):
             "legs": legs}
 
 
-def launch_ranks(n):
-    """`python bench.py --gpus N` with no WORLD_SIZE in the environment (the driver's plain command): start N fresh ranks of this
-    file -- one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous on a free port -- BEFORE this
-    process has touched the GPU (it never does: it only relays), pass rank 0's single JSON line on, and leave with the first
-    non-zero status of a rank.  Children, never a re-exec.  (The reference pins one device: main.py:24-27.)"""
+def run_ranks(n, argv, extra_env, limit):
+    """start N fresh ranks of this file (children: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous on a free port) and
+    wait for them: (status, rank 0's JSON lines, what went wrong).  A failing rank ends the others -- exactly the processes started here."""
     import socket
     import subprocess
     import threading
@@ -386,24 +384,18 @@ def launch_ranks(n):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    limit = float(os.environ.get("RSX_LAUNCH_LIMIT_S", "3000"))
     procs = []
     for r in range(n):
         env = {**os.environ, "RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0",
-               "RSX_LAUNCHED_BY": "bench.py"}
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env, cwd=ROOT,
+               "RSX_LAUNCHED_BY": "bench.py", **extra_env}
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
     lines = []
 
-    def relay():                      # rank 0's stdout: JSON lines are this process's output, anything else goes to stderr
+    def relay():                      # rank 0's stdout: JSON lines are collected, anything else goes to stderr
         for line in procs[0].stdout:
-            if line.startswith("{"):
-                lines.append(line)
-                sys.stdout.write(line)
-                sys.stdout.flush()
-            else:
-                sys.stderr.write(line)
+            (lines.append if line.startswith("{") else sys.stderr.write)(line)
     t = threading.Thread(target=relay, daemon=True)
     t.start()
     t0, rc, why = time.time(), 0, None
@@ -416,9 +408,9 @@ def launch_ranks(n):
                 if c != 0 and rc == 0:
                     rc, why = c, f"rank {r} left with status {c}"
         if time.time() - t0 > limit and live:
-            rc, why = 4, f"ranks {sorted(live)} still running after {limit:.0f} s (RSX_LAUNCH_LIMIT_S)"
+            rc, why = 4, f"ranks {sorted(live)} still running after {limit:.0f} s"
         time.sleep(0.2)
-    if rc != 0:                       # one rank failed: the others sit in a collective -- end exactly the processes started here
+    if rc != 0:                       # one rank failed: the others sit in a collective
         grace = time.time() + 10.0    # (their own watchdogs get a moment to print their error line)
         while time.time() < grace and any(p.poll() is None for p in procs):
             time.sleep(0.2)
@@ -428,10 +420,55 @@ def launch_ranks(n):
     for p in procs:
         p.wait()
     t.join(timeout=10)
-    if rc != 0 and not lines:
-        print(json.dumps({"metric": "bpr_triplet_updates_per_sec", "value": None, "unit": "triplets/s", "n_gpus": n,
-                          "error": f"bench.py launcher: {why}"}), flush=True)
-    return rc
+    return rc, lines, why
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment (the driver's plain command): start N fresh ranks of this
+    file BEFORE this process has touched the GPU (it never does: it only relays), pass rank 0's single JSON line on, and leave with
+    the first non-zero status of a rank.  Children, never a re-exec.  (The reference pins one device: main.py:24-27.)
+
+    The exchange of the measured job is the default one (RCCL issued by the library).  So that the FIRST multi-GPU run also says what
+    the library's own mesh over xGMI does (include/rsx.h: rsx_mesh_*; exact with two ranks on one GPU, never timed over real links),
+    a second, short job of N fresh ranks then runs the headline alone with RSX_EXCHANGE=direct, in processes of its own -- whatever
+    happens to it cannot touch the line of the first -- and its summary is merged into that line as `legs.exchange_direct_mesh`
+    (+ `config.mesh_value / mesh_ms_per_step`).  RSX_BENCH_MESH_LEG=0 skips it."""
+    limit = float(os.environ.get("RSX_LAUNCH_LIMIT_S", "3000"))
+    rc, lines, why = run_ranks(n, sys.argv[1:], {}, limit)
+    if rc != 0 or not lines:
+        for line in lines:
+            sys.stdout.write(line)
+        if not lines:
+            print(json.dumps({"metric": "bpr_triplet_updates_per_sec", "value": None, "unit": "triplets/s", "n_gpus": n,
+                              "error": f"bench.py launcher: {why or 'rank 0 printed no JSON line'}"}), flush=True)
+        sys.stdout.flush()
+        return rc or 5
+    out = lines[-1]
+    if os.environ.get("RSX_BENCH_MESH_LEG", "1") != "0" and os.environ.get("RSX_EXCHANGE", "allreduce") != "direct":
+        try:
+            d = json.loads(out)
+            argv = [a for a in sys.argv[1:]] + ["--no-legs", "--score-tiles", "0", "--no-cpu-baseline"]
+            rc2, lines2, why2 = run_ranks(n, argv, {"RSX_EXCHANGE": "direct", "RSX_WATCHDOG_S": os.environ.get("RSX_MESH_LEG_WATCHDOG_S", "240")},
+                                          float(os.environ.get("RSX_MESH_LEG_LIMIT_S", "600")))
+            m = json.loads(lines2[-1]) if lines2 else {}
+            if rc2 == 0 and m.get("value"):
+                leg = {"value": m["value"], "unit": m["unit"], "ms_per_step": m["ms_per_step"], "kernel_ms": m["roofline"]["kernel_ms"],
+                       "item_replicas_identical": m["config"].get("item_replicas_identical"), "item_chunks": m["config"].get("item_chunks"),
+                       "mesh_exchanges": m["config"].get("mesh_exchanges"), "exchange_issued_by": m["config"].get("exchange_issued_by"),
+                       "vs_default_exchange": m["value"] / d["value"] if d.get("value") else None}
+            else:
+                leg = {"value": None, "error": m.get("error") or why2 or f"status {rc2}"}
+            d.setdefault("legs", {})["exchange_direct_mesh"] = leg
+            d["config"]["mesh_value"] = leg.get("value")
+            d["config"]["mesh_ms_per_step"] = leg.get("ms_per_step")
+            d["config"]["mesh_note"] = ("the same headline in a second job of N fresh ranks with the library's own exchange over xGMI "
+                                        "(RSX_EXCHANGE=direct): " + ("replicas identical" if leg.get("item_replicas_identical") else str(leg.get("error"))[:80]))
+            out = json.dumps(d) + "\n"
+        except Exception as e:       # noqa: BLE001 -- the second job must never cost the first one its line
+            sys.stderr.write(f"bench.py launcher: mesh leg not merged: {e!r}\n")
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return 0
 
 
 class Watchdog:

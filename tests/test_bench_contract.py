@@ -117,6 +117,11 @@ def test_bench_plain_command_starts_its_own_ranks():
     assert d["config"]["launched_by"] == "bench.py" and d["config"]["dist_backend"] == "gloo"
     assert d["config"]["rccl_world"] is None            # gloo: the callbacks moved G; over "nccl" this is RCCL's own world size
     assert d["scoring"]["n_gpus"] == 2
+    # ... and the launcher's second, short job: the same headline over the library's own mesh (RSX_EXCHANGE=direct), merged into the line
+    mesh = d["legs"]["exchange_direct_mesh"]
+    assert mesh["value"] > 0 and mesh["item_replicas_identical"] is True and mesh["item_chunks"] == 2, mesh
+    assert "rsx_mesh" in mesh["exchange_issued_by"] and mesh["mesh_exchanges"] == (1 + 3 * 5) * 2
+    assert d["config"]["mesh_value"] == mesh["value"] and "replicas identical" in d["config"]["mesh_note"]
 
 
 def test_bench_launcher_reports_a_failed_rank():
