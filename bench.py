@@ -542,11 +542,15 @@ def main():
             fn2 = rsx.lib().rsx_debug_set_exchange_traffic
             fn2.restype, fn2.argtypes = ctypes.c_int, [ctypes.c_int]
             assert fn2(1) == 0
-    if os.environ.get("RSX_SAMPLER_REPLAY") == "1":  # DEVELOPMENT library only: the loop without a sampler beside it (3 batches replayed)
-        import ctypes
+    if os.environ.get("RSX_SAMPLER_REPLAY", "0") != "0":  # DEVELOPMENT library only: 1 = the loop without a sampler beside it (3 batches
+        import ctypes                                    # replayed), 2 = replayed steps with the sampler running into a shadow buffer
         fn = rsx.lib().rsx_debug_set_sampler_replay
         fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_int]
-        assert fn(1) == 0
+        assert fn(int(os.environ["RSX_SAMPLER_REPLAY"])) == 0
+        if os.environ.get("RSX_SAMPLE_ABLATION"):        # ... and parts of the sampler switched off (timing only: tools/sampler_parts.sh)
+            fn = rsx.lib().rsx_debug_set_sample_ablation
+            fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_int]
+            assert fn(int(os.environ["RSX_SAMPLE_ABLATION"])) == 0
     global COMM
     comm_note = None
     if SHARDED and os.environ.get("RSX_DIST_BACKEND", "nccl") == "nccl" and os.environ.get("RSX_NATIVE_RCCL", "1") == "1" \

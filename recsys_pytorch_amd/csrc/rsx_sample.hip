@@ -484,7 +484,7 @@ __device__ __forceinline__ void negatives_lockstep(
 #pragma unroll
     for (int g = 0; g < kNegGroup; ++g) {
         rec[g] = make_ulonglong2(~0ull, 0ull);
-        if (live[g] && use_sig) rec[g] = reinterpret_cast<const ulonglong2 *>(user_sig)[u[g]];
+        if (live[g] && use_sig) rec[g] = RSX_ABL(8) ? make_ulonglong2(0ull, 0ull) : reinterpret_cast<const ulonglong2 *>(user_sig)[u[g]];   // (8: every block "proven" negative)
     }
     bool any = false;
 #pragma unroll
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(kBlock, 5) void bucket_sort_kernel(
         }
         uint2 pr[kGather];
 #pragma unroll
-        for (int e = 0; e < kGather; ++e) pr[e] = (r0 + e * kBlock + tid < n) ? pairs[src[e]] : make_uint2(0u, 0u);
+        for (int e = 0; e < kGather; ++e) pr[e] = (r0 + e * kBlock + tid < n && !RSX_ABL(16)) ? pairs[src[e]] : make_uint2(0u, 0u);
 #pragma unroll
         for (int e = 0; e < kGather; ++e) {
             const int r = r0 + e * kBlock + tid;
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(kBlock, 5) void bucket_sort_kernel(
     __threadfence_block();
     __syncthreads();
     if (in_lds) {
-        bitonic_sort_lds(keys, n, tid);
+        if (!RSX_ABL(4)) bitonic_sort_lds(keys, n, tid);
     } else if (bk != nbm) {        // (the "no positive" bucket holds one key; its order is irrelevant)
         bitonic_sort(GlobalKeys{ug, ig}, n, tid);
     }
@@ -786,6 +786,18 @@ __global__ __launch_bounds__(kScanBlock) void item_cdf_kernel(const unsigned lon
     if (tid == 0) cdf[I] = 0xFFFFFFFFu;
 }
 
+#ifdef RSX_ABLATE
+// dev build only (librsx_dev.so), TIMING ONLY -- the triplets these switches leave behind are wrong: which part of the sampler disturbs the
+// step kernel it runs beside (tools/sampler_parts.sh; the loop steps on replayed batches meanwhile: rsx_debug_set_sampler_replay(2))
+//   1  no bucketing pass (the sort pass works on the chunks an earlier step left in the workspace)     2  no sort pass
+//   4  the sort pass without its LDS sort      8  ... without the rejection test (no signature, no row)   16  ... without the gather of its pairs
+int g_sample_ablate = 0;          // in force (host side)
+int g_sample_ablate_wanted = 0;
+#define RSX_SAMPLE_ABL_HOST(mask) ((g_sample_ablate & (mask)) != 0)
+#else
+#define RSX_SAMPLE_ABL_HOST(mask) false
+#endif
+
 unsigned grid_1d(int64_t n)
 {
     int64_t blocks = (n + kBlock - 1) / kBlock;
@@ -812,6 +824,19 @@ size_t sort_temp_bytes(int64_t batch, int bits)
 int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
 
 }  // namespace
+
+#ifdef RSX_ABLATE
+RSX_API int rsx_debug_set_sample_ablation(int mask) { g_sample_ablate_wanted = mask; return RSX_OK; }
+// armed by the native loop when its FIRST shadow sample is queued (the batches the loop replays were sampled whole); the caller has
+// drained the sampler's stream: no sampler kernel is in flight when the device-side switch flips
+int rsx_debug_sample_ablation_arm(bool on)
+{
+    const int mask = on ? g_sample_ablate_wanted : 0;
+    if (mask == g_sample_ablate) return RSX_OK;
+    g_sample_ablate = mask;
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_rsx_ablate), &mask, sizeof(int)) == hipSuccess ? RSX_OK : RSX_E_HIP;
+}
+#endif
 
 RSX_API int rsx_bpr_build_signature(const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users,
                                     int neg_block, uint64_t *sig_out, rsx_stream_t stream)
@@ -915,14 +940,16 @@ RSX_API int rsx_bpr_sample(const int64_t *indptr_dev, const int32_t *indices_dev
             const int nblk = (int)((n + kChunk - 1) / kChunk);
             const BucketWs w = bucket_carve(ws, n, NB);
             const ChunkArgs ca{1, 0, ChunkGeom{}, nullptr, false};
-            if (hipMemsetAsync(w.totals, 0, (size_t)NB * 4 * kTotalStride, st) != hipSuccess) {
+            if (!RSX_SAMPLE_ABL_HOST(1) && hipMemsetAsync(w.totals, 0, (size_t)NB * 4 * kTotalStride, st) != hipSuccess) {
                 rsx_set_error("rsx_bpr_sample: memset failed");
                 return RSX_E_HIP;
             }
             const size_t lds = ((size_t)((NB + 3) & ~3)) * 4 + (size_t)kChunk * sizeof(uint2);
+            if (!RSX_SAMPLE_ABL_HOST(1))
             hipLaunchKernelGGL(bucket_chunk_kernel, dim3(nblk), dim3(kChunkThreads), lds, st, indptr_dev, indices_dev,
                                item_cdf_dev, num_users, num_items, piece_lo, n, seed, step, epoch_pos, hb, nbm, nblk,
                                w.pairs, w.table, w.totals, ca);
+            if (!RSX_SAMPLE_ABL_HOST(2))
             hipLaunchKernelGGL(bucket_sort_kernel, dim3(NB), dim3(kBlock), 0, st, indptr_dev, indices_dev,
                                user_sig_dev, num_items, batch, piece_lo, seed, step, neg_block, neg_key, nbm, nblk,
                                lds_sort_cap(), w.pairs, w.table, w.totals, u_out, i_out, j_out, ca);

@@ -32,6 +32,10 @@
 #define RSX_RANGE_STREAM(k) (t->cs[k])
 #endif
 
+#ifdef RSX_ABLATE
+int rsx_debug_sample_ablation_arm(bool on);      // rsx_sample.hip (development build only)
+#endif
+
 struct rsx_bpr_trainer {
     rsx_bpr_trainer_config c;
     int device = 0;
@@ -168,7 +172,11 @@ static int rsx_debug_exchange_delay(hipStream_t st, int parts, float *buf = null
 // `rsx_debug_set_sampler_replay(1)`: once every slot of the ring holds a batch, the sampler kernels are no longer launched and
 // the loop steps on the three batches it has (with their own keys) -- the step WITHOUT a sampler beside it, to price what the
 // sampler costs the loop (not training: the same 3 batches again and again).
+// `rsx_debug_set_sampler_replay(2)`: the same replayed steps, but the sampler kernels DO run beside them, into a shadow buffer
+// nobody reads -- so that variants of the sampler (rsx_debug_set_sample_ablation) disturb an IDENTICAL step workload.
 static int g_sampler_replay = 0;
+static int32_t *g_shadow = nullptr;
+static int64_t g_shadow_n = 0;
 RSX_API int rsx_debug_set_sampler_replay(int on) { g_sampler_replay = on; return RSX_OK; }
 #else
 static inline int rsx_debug_exchange_delay(hipStream_t, int, float * = nullptr, int64_t = 0) { return RSX_OK; }
@@ -194,7 +202,25 @@ int launch_sample(rsx_bpr_trainer *t, int slot, int64_t step_index, int64_t batc
     const uint64_t key = nb ? neg_key_for(c.seed_key, step_index) : 0ull;
     if (t->freed_valid[slot]) RSX_HIP(hipStreamWaitEvent(t->side, t->freed[slot], 0));
 #ifdef RSX_ABLATE
-    if (g_sampler_replay && step_index >= rsx_bpr_trainer::S && t->slot_batch[slot] == batch) {
+    if (g_sampler_replay == 1 && step_index >= rsx_bpr_trainer::S && t->slot_batch[slot] == batch) {
+        RSX_HIP(hipEventRecord(t->ready[slot], t->side));
+        t->epoch_pos += batch;
+        return RSX_OK;
+    }
+    if (g_sampler_replay == 2 && step_index >= rsx_bpr_trainer::S && t->slot_batch[slot] == batch && !chunked(t)) {
+        if (g_shadow_n < 3 * batch) {
+            if (g_shadow) (void)hipFree(g_shadow);
+            RSX_HIP(hipMalloc((void **)&g_shadow, (size_t)3 * batch * sizeof(int32_t)));
+            g_shadow_n = 3 * batch;
+        }
+        if (step_index == rsx_bpr_trainer::S) {      // the first shadow sample of this trainer: the whole samples before it are done
+            RSX_HIP(hipStreamSynchronize(t->side));
+            RSX_TRY(rsx_debug_sample_ablation_arm(true));
+        }
+        RSX_TRY(rsx_bpr_sample(c.indptr, c.indices, c.num_users, c.num_items, batch, c.seed, (uint64_t)step_index,
+                               t->epoch_pos, nb, key, sorted ? RSX_SAMPLE_SORT_POS : 0u, sorted ? c.sample_ws : nullptr,
+                               sorted ? c.sample_ws_bytes : 0, nb ? c.user_sig : nullptr, sorted ? c.item_cdf : nullptr,
+                               g_shadow, g_shadow + batch, g_shadow + 2 * batch, (rsx_stream_t)t->side));
         RSX_HIP(hipEventRecord(t->ready[slot], t->side));
         t->epoch_pos += batch;
         return RSX_OK;
@@ -268,6 +294,10 @@ RSX_API int rsx_bpr_trainer_create(const rsx_bpr_trainer_config *cfg, rsx_bpr_tr
     } else {
         RSX_CHECK_ARG(cfg->exchange_range == nullptr, "exchange_range is the per-range exchange of a chunked trainer (chunks > 1)");
     }
+#ifdef RSX_ABLATE
+    (void)hipDeviceSynchronize();
+    (void)rsx_debug_sample_ablation_arm(false);      // a new trainer samples its first batches whole
+#endif
     rsx_bpr_trainer *t = new (std::nothrow) rsx_bpr_trainer();
     if (t == nullptr) { rsx_set_error("rsx_bpr_trainer_create: out of memory"); return RSX_E_INVALID; }
     t->c = *cfg;
