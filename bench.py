@@ -203,6 +203,8 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     tr = eng.native_trainer(indptr, indices, B, loss_acc=loss)
     gb = B * world
     tr.run(warmup, B, gb)
+    if eng._mesh is not None:        # RSX_EXCHANGE=direct: a broken signal path shows in the warm-up already (bounded waits): stop here, loudly
+        eng._mesh[0].check()
     loss.zero_()
     runs = []
     for _ in range(max(1, int(regions))):
@@ -448,8 +450,10 @@ def launch_ranks(n):
         try:
             d = json.loads(out)
             argv = [a for a in sys.argv[1:]] + ["--no-legs", "--score-tiles", "0", "--no-cpu-baseline"]
-            rc2, lines2, why2 = run_ranks(n, argv, {"RSX_EXCHANGE": "direct", "RSX_WATCHDOG_S": os.environ.get("RSX_MESH_LEG_WATCHDOG_S", "240")},
-                                          float(os.environ.get("RSX_MESH_LEG_LIMIT_S", "600")))
+            # (bounded on every level: a kernel's wait for a peer 2 s, a leg 120 s, the whole second job 300 s)
+            rc2, lines2, why2 = run_ranks(n, argv, {"RSX_EXCHANGE": "direct", "RSX_WATCHDOG_S": os.environ.get("RSX_MESH_LEG_WATCHDOG_S", "120"),
+                                                    "RSX_MESH_WAIT_S": os.environ.get("RSX_MESH_WAIT_S", "2")},
+                                          float(os.environ.get("RSX_MESH_LEG_LIMIT_S", "300")))
             m = json.loads(lines2[-1]) if lines2 else {}
             if rc2 == 0 and m.get("value"):
                 leg = {"value": m["value"], "unit": m["unit"], "ms_per_step": m["ms_per_step"], "kernel_ms": m["roofline"]["kernel_ms"],

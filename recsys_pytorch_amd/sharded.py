@@ -413,6 +413,9 @@ class BPREngine:
         if not hasattr(self.k, "Mesh"):
             raise ValueError("exchange='direct' needs the HIP library (rsx.Mesh)")
         mesh = self.k.Mesh(Q, G, group=self.group)
+        import os
+        if os.environ.get("RSX_MESH_WAIT_S"):       # how long a kernel waits for a peer's signal before it gives up (default 20 s)
+            mesh.set_wait_limit(float(os.environ["RSX_MESH_WAIT_S"]))
         self._mesh = (mesh, Q, G)
         return mesh
 
