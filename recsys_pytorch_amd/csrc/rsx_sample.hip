@@ -24,6 +24,9 @@
 namespace {
 
 constexpr int kBlock = 256;
+#ifdef RSX_ABLATE
+__device__ uint32_t *g_mock_neg = nullptr;       // [kPiece] scratch of the redesign mock (development build, see rsx_debug_set_sample_ablation)
+#endif
 constexpr uint64_t kSigStartMask = (1ull << 40) - 1, kSigLenClip = (1ull << 24) - 1;
 
 // rocPRIM's default policy (merge sort up to 1M pairs, ~195 us for 1M on MI355X) measured
@@ -287,6 +290,34 @@ __global__ __launch_bounds__(kChunkThreads) void bucket_chunk_kernel(
         ei[e] = (uint32_t)I;
         if (has) ei[e] = (uint32_t)indices[rlo[e] + (int64_t)(((uint64_t)xorshift32(s) * deg) >> 32)];
     }
+#ifdef RSX_ABLATE
+    if (RSX_ABL(32) && g_mock_neg != nullptr) {
+        for (int e0 = 0; e0 < kPerThread; e0 += 4) {             // four positions at a time: 96 registers of rows in flight
+            int32_t row[4][24];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int deg = (int)(rhi[e0 + g] - rlo[e0 + g]);
+#pragma unroll
+                for (int q = 0; q < 24; ++q) row[g][q] = (ok[e0 + g] && q < deg) ? indices[rlo[e0 + g] + q] : -1;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint32_t s2 = rng_seed(seed, step, (uint64_t)(piece_lo + (int64_t)blk * kChunk + (e0 + g) * kChunkThreads + tid), 0x5bd1e995ull);
+                const uint32_t blk2 = mulhi32((uint32_t)splitmix64(eu[e0 + g] ^ ei[e0 + g]), (uint32_t)(I / 2));
+                int32_t cand = 0;
+                for (int tries = 0; tries < 8; ++tries) {
+                    cand = (int32_t)(2u * (uint32_t)neg_block_of(blk2, I / 2, seed | 1ull) + (xorshift32(s2) & 1u));
+                    bool in = false;
+#pragma unroll
+                    for (int q = 0; q < 24; ++q) in |= row[g][q] == cand;
+                    if (!in) break;
+                }
+                const int64_t loc = (int64_t)blk * kChunk + (e0 + g) * kChunkThreads + tid;
+                if (ok[e0 + g]) g_mock_neg[loc] = (uint32_t)cand;
+            }
+        }
+    }
+#endif
     uint32_t c0[kPerThread], c1[kPerThread];
 #pragma unroll
     for (int e = 0; e < kPerThread; ++e) {
@@ -708,6 +739,9 @@ __global__ __launch_bounds__(kBlock, 5) void bucket_sort_kernel(
 #pragma unroll
         for (int e = 0; e < kGather; ++e) {
             const int r = r0 + e * kBlock + tid;
+#ifdef RSX_ABLATE
+            if (RSX_ABL(32) && g_mock_neg != nullptr && r < n) { const uint32_t w4 = g_mock_neg[src[e]]; asm volatile("" :: "v"(w4)); }      // (the mock's fourth word: gathered, not used)
+#endif
             const uint64_t kv = ((uint64_t)pr[e].y << 32) | pr[e].x;
             if (r < n) { if (in_lds) keys[r] = kv; else GlobalKeys{ug, ig}.set(r, kv); }
         }
@@ -787,6 +821,9 @@ __global__ __launch_bounds__(kScanBlock) void item_cdf_kernel(const unsigned lon
 }
 
 #ifdef RSX_ABLATE
+// (mask 32, a MOCK of the redesign sketched in DESIGN.md section 9: the bucketing pass also loads the user's row -- four positions at a time,
+//  24 registers each -- tests a candidate negative against it and writes a fourth word per pair; the sort pass gathers that word.  With 8:
+//  what a sampler that draws the negative where the row is would cost the step.  Wrong triplets: timing only.)
 // dev build only (librsx_dev.so), TIMING ONLY -- the triplets these switches leave behind are wrong: which part of the sampler disturbs the
 // step kernel it runs beside (tools/sampler_parts.sh; the loop steps on replayed batches meanwhile: rsx_debug_set_sampler_replay(2))
 //   1  no bucketing pass (the sort pass works on the chunks an earlier step left in the workspace)     2  no sort pass
@@ -834,6 +871,11 @@ int rsx_debug_sample_ablation_arm(bool on)
     const int mask = on ? g_sample_ablate_wanted : 0;
     if (mask == g_sample_ablate) return RSX_OK;
     g_sample_ablate = mask;
+    if (mask & 32) {
+        static uint32_t *scratch = nullptr;
+        if (scratch == nullptr && hipMalloc((void **)&scratch, (size_t)kPiece * 4) != hipSuccess) return RSX_E_HIP;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_mock_neg), &scratch, sizeof(scratch)) != hipSuccess) return RSX_E_HIP;
+    }
     return hipMemcpyToSymbol(HIP_SYMBOL(c_rsx_ablate), &mask, sizeof(int)) == hipSuccess ? RSX_OK : RSX_E_HIP;
 }
 #endif
