@@ -63,6 +63,14 @@ constexpr int BM = 128, BN = 128, BK = 32;
 #ifndef RSX_SCORE_FRAG64
 #define RSX_SCORE_FRAG64 0
 #endif
+// RSX_SCORE_TILES_PER_WG = T (round 5 experiment): a workgroup computes T consecutive item tiles of its row tile instead of one --
+// tools/mfma_peak.hip: the inner loop of this kernel alone sustains 154 TFLOP/s (0.98 of the peak) in long-running workgroups, 136 in
+// 50 000 workgroups of one tile each, 143.5 with two: starting and ending workgroups costs the matrix pipe a tenth of its time.
+// (PERSISTENT workgroups -- four per CU walking all tiles -- were measured first: 6-7 % SLOWER; they take the hardware's dynamic
+//  balancing away and leave the other lane's selection kernels no slot to run in.)
+#ifndef RSX_SCORE_TILES_PER_WG
+#define RSX_SCORE_TILES_PER_WG 1
+#endif
 constexpr int kSlots = 2;     // private candidate slots per (64-item strip, row) of the filtered product
 constexpr int LDT = BM + 1;   // K-major tile leading dimension (odd -> conflict-free transpose)
 
@@ -81,7 +89,8 @@ __device__ __forceinline__ void score_tile_body(const float *__restrict__ P,
                                                          float *__restrict__ cand_val,
                                                          int32_t *__restrict__ cand_idx,
                                                          int32_t *__restrict__ cand_cnt, int cand_cap,
-                                                         uint2 *__restrict__ slots, int64_t item_base)
+                                                         uint2 *__restrict__ slots, int64_t item_base,
+                                                         int64_t n_item_tiles, int64_t n_tiles)
 {
     // (GLDS + RSX_SCORE_LDS_PAD: one dword of padding behind every 8 rows -- the 8 rows one DMA instruction of a wavefront writes.  With
     //  the XOR swizzle alone the 32 lanes of a fragment read fall on 8 banks, 4 lanes each; the pad moves the four 8-row groups of
@@ -89,17 +98,28 @@ __device__ __forceinline__ void score_tile_body(const float *__restrict__ P,
     constexpr int PADA = (GLDS && RSX_SCORE_FRAG64) ? 2 * (BM / 16) : (GLDS && RSX_SCORE_LDS_PAD) ? BM / 8 : 0;
     __shared__ __attribute__((aligned(16))) float As[GLDS ? BM * BK + PADA : BK * LDT];
     __shared__ __attribute__((aligned(16))) float Bs[GLDS ? BN * BK + PADA : BK * LDT];
-    __shared__ __attribute__((aligned(16))) float tau_s[BM];
+    __shared__ __attribute__((aligned(16))) float tau_s2[2][BM];    // (two: a persistent workgroup's next tile writes its thresholds while slower wavefronts still read this tile's)
 
-    const int tid = threadIdx.x;
+    // item tile varies fastest: the 8 XCDs each stream different item tiles of
+    // the SAME user tile, and a user tile's A panel (128 x d) stays L2 resident.
+    // this workgroup's RSX_SCORE_TILES_PER_WG consecutive item tiles of one row tile (one pass, known at compile time, when that is 1)
+    const uint32_t n_it = (uint32_t)n_item_tiles;
+    int tile_par = 0;
+    uint32_t tile_x = blockIdx.x * RSX_SCORE_TILES_PER_WG;
+    const uint32_t tile_x_end = (tile_x + RSX_SCORE_TILES_PER_WG < n_it) ? tile_x + RSX_SCORE_TILES_PER_WG : n_it;
+    const uint32_t tile_y = blockIdx.y;
+    do {
+    float *const tau_s = tau_s2[tile_par];
+    // (a workgroup of several tiles recomputes its per-thread constants for every tile -- a dozen vector instructions -- instead of carrying
+    //  them, hoisted by the compiler, across the tile loop: carried, they cost the 128-register budget of four wavefronts per SIMD 47-89 spills)
+    int tid = threadIdx.x;
+    if (RSX_SCORE_TILES_PER_WG > 1) asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     const int hi = lane >> 5, l31 = lane & 31;
-    // item tile varies fastest: the 8 XCDs each stream different item tiles of
-    // the SAME user tile, and a user tile's A panel (128 x d) stays L2 resident.
-    const int64_t item0 = (int64_t)blockIdx.x * BN;
-    const int64_t row0 = (int64_t)blockIdx.y * BM;
+    const int64_t item0 = (int64_t)tile_x * BN;
+    const int64_t row0 = (int64_t)tile_y * BM;
 
     // staging assignment: thread -> (row = tid>>3 + 32 n, k-quad = tid&7)
     const int kq = tid & 7;
@@ -294,8 +314,8 @@ __device__ __forceinline__ void score_tile_body(const float *__restrict__ P,
         // the slot array is ROW-major [row][strip][kSlots] (the merge kernel reads one contiguous
         // run per row) and 0xFF-filled before the launch: an unused slot keeps item index -1, so
         // no per-cell count has to be written.  32-bit cell arithmetic, one base per wavefront.
-        const int n_strips = (int)gridDim.x * 2;
-        const int strip = (int)blockIdx.x * 2 + wc;                              // 64-column strip id
+        const int n_strips = (int)n_item_tiles * 2;
+        const int strip = (int)tile_x * 2 + wc;                                  // 64-column strip id
         // (round 3: the hit path in 32-bit arithmetic -- with ~29 survivors per wavefront and tile more than half of the 32 sites
         //  take it, which makes it the largest block of non-MFMA vector instructions of the kernel: ranks from mbcnt instead of
         //  two 64-bit and + popcount pairs, the slot addressed by a 32-bit byte offset from the array's base in SGPRs)
@@ -364,6 +384,8 @@ __device__ __forceinline__ void score_tile_body(const float *__restrict__ P,
             }
         }
     }
+    ++tile_x; tile_par ^= 1;
+    } while (RSX_SCORE_TILES_PER_WG > 1 && tile_x < tile_x_end);
 }
 
 // the two entry points: register staging (three wavefronts per SIMD) and LDS-DMA (four).  (One template with a launch bound that
@@ -371,8 +393,8 @@ __device__ __forceinline__ void score_tile_body(const float *__restrict__ P,
 #define RSX_SCORE_ARGS const float *__restrict__ P, const int32_t *__restrict__ user_ids, int64_t num_rows, const float *__restrict__ Q, \
                        int64_t num_items, int64_t item_stride, float *__restrict__ out, const float *__restrict__ tau,               \
                        float *__restrict__ cand_val, int32_t *__restrict__ cand_idx, int32_t *__restrict__ cand_cnt, int cand_cap,  \
-                       uint2 *__restrict__ slots, int64_t item_base
-#define RSX_SCORE_PASS P, user_ids, num_rows, Q, num_items, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, item_base
+                       uint2 *__restrict__ slots, int64_t item_base, int64_t n_item_tiles, int64_t n_tiles
+#define RSX_SCORE_PASS P, user_ids, num_rows, Q, num_items, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, item_base, n_item_tiles, n_tiles
 template <int D, bool FILTER>
 __global__ __launch_bounds__(256) void score_tile_kernel(RSX_SCORE_ARGS) { score_tile_body<D, FILTER, false>(RSX_SCORE_PASS); }
 template <int D, bool FILTER>
@@ -878,11 +900,13 @@ int launch_score(const float *P, const int32_t *users, int64_t rows, const float
                  int64_t item_stride, int d, float *out, const float *tau, float *cand_val,
                  int32_t *cand_idx, int32_t *cand_cnt, int cand_cap, uint2 *slots, hipStream_t st, int64_t item_base = 0)
 {
-    dim3 grid((unsigned)((cols + BN - 1) / BN), (unsigned)((rows + BM - 1) / BM));
+    const int64_t n_item_tiles = (cols + BN - 1) / BN;
+    const int64_t n_row_tiles = (rows + BM - 1) / BM, n_tiles = n_item_tiles * n_row_tiles;
+    dim3 grid((unsigned)((n_item_tiles + RSX_SCORE_TILES_PER_WG - 1) / RSX_SCORE_TILES_PER_WG), (unsigned)n_row_tiles);
     // the LDS-DMA form addresses item rows by 32-bit byte offsets: item tables below 4 GB (every BASELINE catalog: 1M x 128 = 512 MB)
     const bool glds = RSX_SCORE_GLDS != 0 && cols * item_stride * (int64_t)d * 4 < (1ll << 32);
-#define RSX_SCORE_LAUNCH(D_) do { if (glds) hipLaunchKernelGGL((score_tile_glds_kernel<D_, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, item_base); \
-                                  else hipLaunchKernelGGL((score_tile_kernel<D_, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, item_base); } while (0)
+#define RSX_SCORE_LAUNCH(D_) do { if (glds) hipLaunchKernelGGL((score_tile_glds_kernel<D_, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, item_base, n_item_tiles, n_tiles); \
+                                  else hipLaunchKernelGGL((score_tile_kernel<D_, FILTER>), grid, dim3(256), 0, st, P, users, rows, Q, cols, item_stride, out, tau, cand_val, cand_idx, cand_cnt, cand_cap, slots, item_base, n_item_tiles, n_tiles); } while (0)
     switch (d) {
     case 32: RSX_SCORE_LAUNCH(32); break;
     case 64: RSX_SCORE_LAUNCH(64); break;

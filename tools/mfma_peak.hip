@@ -1,0 +1,249 @@
+// tools/mfma_peak.hip : what v_mfma_f32_32x32x2_f32 delivers with NOTHING around it -- no memory, no LDS, no barriers: every wavefront
+// issues chains of independent MFMAs on register operands.  The ceiling of the scoring product (csrc/rsx_score.hip) on this part, next to
+// the nominal 157.3 TFLOP/s (256 CUs x 4 SIMDs x 256 flop / clk x 2.4 GHz).
+//   hipcc --offload-arch=gfx950 -O3 -o tools/mfma_peak tools/mfma_peak.hip && tools/mfma_peak
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int ACCS>
+__global__ __launch_bounds__(256) void mfma_chain(float *out, int iters, float a, float b)
+{
+    f32x16 acc[ACCS];
+#pragma unroll
+    for (int q = 0; q < ACCS; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int q = 0; q < ACCS; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < ACCS; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[q][r];
+    if (s == 12345.678f) out[threadIdx.x] = s;      // (never true: keeps the chain alive)
+}
+
+// the same chain on operands that CHANGE every step and differ from lane to lane (pseudo-random mantissas, like real embeddings): the
+// data path toggles, the power per MFMA is what a real product draws
+template <int ACCS>
+__global__ __launch_bounds__(256) void mfma_chain_data(float *out, int iters, const float *seed)
+{
+    f32x16 acc[ACCS];
+#pragma unroll
+    for (int q = 0; q < ACCS; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    float a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[k] = seed[(threadIdx.x * 8 + k) & 1023]; b[k] = seed[(threadIdx.x * 8 + 4 + k) & 1023]; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+#pragma unroll
+            for (int q = 0; q < ACCS; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(u + q) & 3], b[(u + 2 * q) & 3], acc[q], 0, 0, 0);
+            // (one cheap VALU op per step keeps the operands moving: sign flips and a mantissa rotation, magnitudes stay ~0.1)
+            a[u & 3] = __uint_as_float((__float_as_uint(a[u & 3]) ^ 0x80155555u) | 0x3D000000u);
+            b[u & 3] = __uint_as_float((__float_as_uint(b[u & 3]) ^ 0x802AAAAAu) | 0x3D000000u);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < ACCS; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[q][r];
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
+// the inner loop of the scoring product (csrc/rsx_score.hip) and nothing else: per step four fragment reads from LDS (one step ahead) and four
+// MFMAs into a 2 x 2 block of accumulators, 16 steps per "chunk" -- no global memory, no DMA, no barriers, no epilogue
+__global__ __launch_bounds__(256, 4) void mfma_lds_loop(float *out, int chunks, int random_data)
+{
+    __shared__ float As[128 * 32 + 16], Bs[128 * 32 + 16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1, hi = lane >> 5, l31 = lane & 31;
+    for (int q = tid; q < 128 * 32 + 16; q += 256) {
+        As[q] = 0.001f * (float)((q * 37) % 201 - 100); Bs[q] = 0.001f * (float)((q * 53) % 199 - 99);
+        if (random_data) {       // full-entropy mantissas and random signs, magnitudes ~0.1 like N(0, 0.1^2) embeddings
+            unsigned x = (unsigned)q * 2654435761u + blockIdx.x * 40503u; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+            unsigned y = x * 3266489917u; y ^= y >> 16;
+            As[q] = __uint_as_float((x & 0x807FFFFFu) | 0x3D800000u);      // +-[0.0625, 0.125)
+            Bs[q] = __uint_as_float((y & 0x807FFFFFu) | 0x3D800000u);
+        }
+    }
+    __syncthreads();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    const int xs = (l31 & 7) << 2;
+    const float *ap = As + (wr * 64 + l31) * 32 + ((wr * 64 + l31) >> 3) + hi;
+    const float *bp = Bs + (wc * 64 + l31) * 32 + ((wc * 64 + l31) >> 3) + hi;
+    for (int c = 0; c < chunks; ++c) {
+        float a0 = ap[xs], a1 = ap[32 * 32 + 4 + xs], b0 = bp[xs], b1 = bp[32 * 32 + 4 + xs];
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 2) {
+            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+            if (kk + 2 < 32) {
+                const int o = (kk + 2) ^ xs;
+                na0 = ap[o]; na1 = ap[32 * 32 + 4 + o]; nb0 = bp[o]; nb1 = bp[32 * 32 + 4 + o];
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        }
+        asm volatile("" ::: "memory");      // (the next chunk reads LDS again)
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[m][n][r];
+    if (s == 12345.678f) out[tid] = s;
+}
+
+template <int ACCS>
+void run(int waves_per_simd, int cus, int iters = 2000)
+{
+    float *out;
+    (void)hipMalloc(&out, 4096);
+    dim3 grid(cus * waves_per_simd), block(256);      // a 256-thread workgroup = one wavefront per SIMD
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    mfma_chain<ACCS><<<grid, block>>>(out, 10, 1.0f, 1.0f);
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; ++rep) {
+        hipEventRecord(e0);
+        mfma_chain<ACCS><<<grid, block>>>(out, iters, 1.0f, 1.0f);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double flop = (double)grid.x * 4 /*waves*/ * iters * 16.0 * ACCS * 4096.0;      // 32 x 32 x 2 x 2 flop per MFMA
+    printf("%d independent accumulators, %d wavefronts per SIMD: %8.3f ms  %7.1f TFLOP/s  (%.3f of 157.3)\n", ACCS, waves_per_simd, best,
+           flop / best / 1e9, flop / best / 1e9 / 157.3);
+    hipFree(out);
+}
+
+int main()
+{
+    hipDeviceProp_t p;
+    hipGetDeviceProperties(&p, 0);
+    printf("%s, %d CUs, clock %d MHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate / 1000);
+    for (int w : {1, 2, 4}) { run<1>(w, p.multiProcessorCount); run<2>(w, p.multiProcessorCount); run<4>(w, p.multiProcessorCount); }
+    // the shape of the scoring product is 4 accumulators x 4 wavefronts per SIMD: which of the two makes 0.80 of it?  (launches of equal length)
+    printf("--- equal work per launch (~3.4 ms at full rate)\n");
+    for (int w : {1, 2, 3, 4, 5, 6, 8}) {
+        run<1>(w, p.multiProcessorCount, 8000 / w); run<2>(w, p.multiProcessorCount, 4000 / w); run<3>(w, p.multiProcessorCount, 2667 / w);
+        run<4>(w, p.multiProcessorCount, 2000 / w);
+    }
+    // SUSTAINED: back-to-back launches of ~3.4 ms each for ~0.3 s, the rate of every tenth one -- does the part hold its clock under fp32 MFMA?
+    {
+        float *out;
+        (void)hipMalloc(&out, 4096);
+        dim3 grid(p.multiProcessorCount * 4), block(256);
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        const int iters = 2000;
+        const double flop = (double)grid.x * 4 * iters * 16.0 * 1 * 4096.0;
+        printf("sustained (1 accumulator, 4 wavefronts per SIMD, launches of ~3.4 ms back to back):");
+        for (int rep = 0; rep < 100; ++rep) {
+            (void)hipEventRecord(e0);
+            mfma_chain<1><<<grid, block>>>(out, iters, 1.0f, 1.0f);
+            (void)hipEventRecord(e1);
+            if (rep % 10 == 9) {
+                (void)hipEventSynchronize(e1);
+                float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+                printf(" %.1f", flop / ms / 1e9);
+            }
+        }
+        printf(" TFLOP/s\n");
+        // ... and with operands that toggle like real data
+        float h[1024];
+        unsigned x = 12345u;
+        for (int k = 0; k < 1024; ++k) { x = x * 1664525u + 1013904223u; h[k] = ((int)(x >> 8) % 2001 - 1000) * 1e-4f; }
+        float *seed;
+        (void)hipMalloc(&seed, sizeof(h));
+        (void)hipMemcpy(seed, h, sizeof(h), hipMemcpyHostToDevice);
+        for (int accs = 2; accs <= 3; ++accs) {
+            printf("sustained, operands changing every step (%d accumulators, 4 wavefronts per SIMD, ~3.4 ms launches back to back):", accs);
+            const double fl = (double)grid.x * 4 * (accs == 2 ? 1000 : 667) * 16.0 * accs * 4096.0;
+            for (int rep = 0; rep < 100; ++rep) {
+                (void)hipEventRecord(e0);
+                if (accs == 2) mfma_chain_data<2><<<grid, block>>>(out, 1000, seed); else mfma_chain_data<3><<<grid, block>>>(out, 667, seed);
+                (void)hipEventRecord(e1);
+                if (rep % 10 == 9) {
+                    (void)hipEventSynchronize(e1);
+                    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+                    printf(" %.1f", fl / ms / 1e9);
+                }
+            }
+            printf(" TFLOP/s\n");
+        }
+    }
+    // the scoring product's inner loop alone, four workgroups per CU like the real kernel
+    {
+        float *out;
+        (void)hipMalloc(&out, 4096);
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        for (int random_data : {0, 1})
+        for (int wg_per_cu : {1, 2, 4}) {
+            dim3 grid(p.multiProcessorCount * wg_per_cu), block(256);
+            const int chunks = 2000 / wg_per_cu;
+            const double flop = (double)grid.x * 4 * chunks * 16.0 * 4 * 4096.0;
+            printf("scoring inner loop only (LDS fragment reads + 2 x 2 MFMAs, %d workgroups per CU, %s):", wg_per_cu,
+                   random_data ? "RANDOM full-entropy operands" : "201 distinct operand values");
+            for (int rep = 0; rep < 60; ++rep) {
+                (void)hipEventRecord(e0);
+                mfma_lds_loop<<<grid, block>>>(out, chunks, random_data);
+                (void)hipEventRecord(e1);
+                if (rep % 10 == 9) {
+                    (void)hipEventSynchronize(e1);
+                    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+                    printf(" %.1f", flop / ms / 1e9);
+                }
+            }
+            printf(" TFLOP/s\n");
+        }
+    }
+    // ... and in workgroups as SHORT as the real kernel's: one 128 x 128 x 128 tile each (4 chunks), ~50 000 of them per launch
+    {
+        float *out;
+        (void)hipMalloc(&out, 4096);
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        for (int chunks : {4, 8, 16, 64}) {
+            dim3 grid(50048 * 4 / chunks), block(256);
+            const double flop = (double)grid.x * 4 * chunks * 16.0 * 4 * 4096.0;
+            printf("scoring inner loop in %d workgroups of %d chunks each:", (int)grid.x, chunks);
+            for (int rep = 0; rep < 40; ++rep) {
+                (void)hipEventRecord(e0);
+                mfma_lds_loop<<<grid, block>>>(out, chunks, 1);
+                (void)hipEventRecord(e1);
+                if (rep % 10 == 9) {
+                    (void)hipEventSynchronize(e1);
+                    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+                    printf(" %.1f", flop / ms / 1e9);
+                }
+            }
+            printf(" TFLOP/s\n");
+        }
+    }
+    return 0;
+}
