@@ -115,6 +115,161 @@ __global__ __launch_bounds__(256, 4) void mfma_lds_loop(float *out, int chunks, 
     if (s == 12345.678f) out[tid] = s;
 }
 
+// ... the same loop WITH the kernel's global -> LDS traffic: per chunk every wavefront issues its eight global_load_lds_dwordx4 (8 rows x 128 B
+// each, rows of a `rows`-row fp32 table picked like the kernel picks them), then the two barriers -- the scoring kernel minus prologue and epilogue
+template <int MODE>
+__device__ __forceinline__ void mfma_dma_body(float *out, int chunks, const float *table, int rows, int d)
+{
+    constexpr int NB = MODE == 3 ? 2 : 1;
+    constexpr int TS = 128 * 32 + 16;
+    __shared__ __attribute__((aligned(16))) float As[NB * TS], Bs[NB * TS];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1, hi = lane >> 5, l31 = lane & 31;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    const int xs = (l31 & 7) << 2;
+    const float *ap = As + (wr * 64 + l31) * 32 + ((wr * 64 + l31) >> 3) + hi;
+    const float *bp = Bs + (wc * 64 + l31) * 32 + ((wc * 64 + l31) >> 3) + hi;
+    const int kq = tid & 7, srow = tid >> 3, gq = kq ^ (srow & 7);
+    unsigned base = blockIdx.x * 2654435761u;
+    auto dma = [&](int c, int buf) __attribute__((always_inline)) {
+        const int k0 = (c * 32) % d;
+        if (k0 == 0) base = base * 1664525u + 1013904223u;      // a new pair of 128-row panels every d / 32 chunks
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const unsigned ra = (base + (unsigned)(srow + 32 * n)) % (unsigned)rows, rb = (base * 7u + (unsigned)(srow + 32 * n)) % (unsigned)rows;
+            __builtin_amdgcn_global_load_lds(table + (size_t)ra * d + k0 + 4 * gq, As + buf * TS + (32 * n + 8 * wid) * 32 + (4 * n + wid), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(table + (size_t)rb * d + k0 + 4 * gq, Bs + buf * TS + (32 * n + 8 * wid) * 32 + (4 * n + wid), 16, 0, 0);
+        }
+    };
+    if (MODE == 1 || MODE == 3) { dma(0, 0); }
+    if (MODE == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+    for (int c = 0; c < chunks; ++c) {
+        const int buf = MODE == 3 ? (c & 1) : 0;
+        if (MODE == 0 || MODE == 2) dma(c, 0);
+        if (MODE == 3) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (c + 1 < chunks) dma(c + 1, buf ^ 1); }
+        else if (MODE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else __syncthreads();
+        const float *apc = ap + buf * TS, *bpc = bp + buf * TS;
+        float a0 = apc[xs], a1 = apc[32 * 32 + 4 + xs], b0 = bpc[xs], b1 = bpc[32 * 32 + 4 + xs];
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 2) {
+            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+            if (kk + 2 < 32) {
+                const int o = (kk + 2) ^ xs;
+                na0 = apc[o]; na1 = apc[32 * 32 + 4 + o]; nb0 = bpc[o]; nb1 = bpc[32 * 32 + 4 + o];
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        }
+        if (MODE == 0 || MODE == 1) __syncthreads();
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[m][n][r];
+    if (s == 12345.678f) out[tid] = s;
+}
+// (one plain kernel per mode: a templated __global__ with this body loses its host stub at link time -- the same compiler quirk
+//  csrc/rsx_score.hip works around)
+__global__ __launch_bounds__(256, 4) void mfma_dma_loop0(float *o, int c, const float *t, int r, int d) { mfma_dma_body<0>(o, c, t, r, d); }
+__global__ __launch_bounds__(256, 4) void mfma_dma_loop1(float *o, int c, const float *t, int r, int d) { mfma_dma_body<1>(o, c, t, r, d); }
+__global__ __launch_bounds__(256, 4) void mfma_dma_loop2(float *o, int c, const float *t, int r, int d) { mfma_dma_body<2>(o, c, t, r, d); }
+__global__ __launch_bounds__(256, 4) void mfma_dma_loop3(float *o, int c, const float *t, int r, int d) { mfma_dma_body<3>(o, c, t, r, d); }
+
+
+// the same structure for other workgroup SHAPES: WR x WC wavefronts of 64 x 64 outputs each (tile 64 WR x 64 WC), every wavefront issuing its share
+// of the (64 WR + 64 WC) / 8 LDS-DMA instructions of a chunk; DB: two LDS buffers, the next chunk's DMA in flight, one barrier per chunk.
+// The DMA instruction count per MFMA falls with the tile: 2 x 2: 8 per wavefront and chunk, 4 x 2: 6, 4 x 4: 4.
+template <int WR, int WC, bool DB>
+__device__ __forceinline__ void shape_body(float *out, int chunks, const float *table, int rows, int d)
+{
+    constexpr int BMs = 64 * WR, BNs = 64 * WC, NW = WR * WC, NB = DB ? 2 : 1;
+    constexpr int TA = BMs * 32 + BMs / 8, TB = BNs * 32 + BNs / 8;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *As = lds, *Bs = lds + NB * TA;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid / WC, wc = wid % WC, hi = lane >> 5, l31 = lane & 31;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    const int xs = (l31 & 7) << 2;
+    const float *ap = As + (wr * 64 + l31) * 32 + ((wr * 64 + l31) >> 3) + hi;
+    const float *bp = Bs + (wc * 64 + l31) * 32 + ((wc * 64 + l31) >> 3) + hi;
+    const int kq = lane & 7, r8 = lane >> 3, gq = kq ^ r8;      // a DMA instruction: 8 rows x 8 quads; row & 7 = r8
+    unsigned base = blockIdx.x * 2654435761u;
+    constexpr int PIECES = (BMs + BNs) / 8, PER = PIECES / NW;      // 8-row pieces of both tiles, dealt to the wavefronts
+    static_assert(PIECES % NW == 0, "pieces must divide");
+    auto dma = [&](int c, int buf) __attribute__((always_inline)) {
+        const int k0 = (c * 32) % d;
+        if (k0 == 0) base = base * 1664525u + 1013904223u;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int piece = wid * PER + q;                         // < BMs / 8: a piece of A, else of B
+            const bool isA = piece < BMs / 8;
+            const int prow = (isA ? piece : piece - BMs / 8) * 8;
+            const unsigned gr = ((isA ? base : base * 7u) + (unsigned)(prow + r8)) % (unsigned)rows;
+            float *dst = (isA ? As + buf * TA : Bs + buf * TB) + prow * 32 + (prow >> 3);
+            __builtin_amdgcn_global_load_lds(table + (size_t)gr * d + k0 + 4 * gq, dst, 16, 0, 0);
+        }
+    };
+    if (DB) dma(0, 0);
+    for (int c = 0; c < chunks; ++c) {
+        const int buf = DB ? (c & 1) : 0;
+        if (!DB) dma(c, 0);
+        if (DB) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (c + 1 < chunks) dma(c + 1, buf ^ 1); }
+        else __syncthreads();
+        const float *apc = ap + buf * TA, *bpc = bp + buf * TB;
+        float a0 = apc[xs], a1 = apc[32 * 32 + 4 + xs], b0 = bpc[xs], b1 = bpc[32 * 32 + 4 + xs];
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 2) {
+            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+            if (kk + 2 < 32) {
+                const int o = (kk + 2) ^ xs;
+                na0 = apc[o]; na1 = apc[32 * 32 + 4 + o]; nb0 = bpc[o]; nb1 = bpc[32 * 32 + 4 + o];
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        }
+        if (!DB) __syncthreads();
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[m][n][r];
+    if (s == 12345.678f) out[tid] = s;
+}
+__global__ __launch_bounds__(256, 4) void shape_2x2(float *o, int c, const float *t, int r, int d) { shape_body<2, 2, false>(o, c, t, r, d); }
+__global__ __launch_bounds__(512, 2) void shape_4x2(float *o, int c, const float *t, int r, int d) { shape_body<4, 2, false>(o, c, t, r, d); }
+__global__ __launch_bounds__(512, 2) void shape_4x2db(float *o, int c, const float *t, int r, int d) { shape_body<4, 2, true>(o, c, t, r, d); }
+__global__ __launch_bounds__(1024, 1) void shape_4x4(float *o, int c, const float *t, int r, int d) { shape_body<4, 4, false>(o, c, t, r, d); }
+__global__ __launch_bounds__(1024, 1) void shape_4x4db(float *o, int c, const float *t, int r, int d) { shape_body<4, 4, true>(o, c, t, r, d); }
+
 template <int ACCS>
 void run(int waves_per_simd, int cus, int iters = 2000)
 {
@@ -243,6 +398,75 @@ int main()
                 }
             }
             printf(" TFLOP/s\n");
+        }
+    }
+    // ... and with the kernel's DMA traffic and barriers: long-running workgroups, then one tile per workgroup; tables of 12 MB (L2 / MALL) and 512 MB
+    {
+        float *out;
+        (void)hipMalloc(&out, 4096);
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        for (int rows : {24576, 1000000}) {
+            float *table;
+            (void)hipMalloc(&table, (size_t)rows * 128 * 4);
+            (void)hipMemset(table, 0x3d, (size_t)rows * 128 * 4);      // (0x3d3d3d3d = 0.046...)
+            const char *names[4] = {"DMA + two barriers per chunk (the kernel's structure)", "barriers only, no DMA", "DMA, no barriers (own vmcnt wait)",
+                                    "DOUBLE-BUFFERED: next chunk's DMA in flight, one barrier per chunk, 2 workgroups per CU"};
+            for (int mode = 0; mode < 4; ++mode) {
+                dim3 grid(p.multiProcessorCount * (mode == 3 ? 2 : 4)), block(256);
+                const int chunks = mode == 3 ? 1000 : 500;
+                const double flop = (double)grid.x * 4 * chunks * 16.0 * 4 * 4096.0;
+                printf("table of %d rows x 128, %s:", rows, names[mode]);
+                for (int rep = 0; rep < 8; ++rep) {
+                    (void)hipEventRecord(e0);
+                    if (mode == 0) mfma_dma_loop0<<<grid, block>>>(out, chunks, table, rows, 128);
+                    if (mode == 1) mfma_dma_loop1<<<grid, block>>>(out, chunks, table, rows, 128);
+                    if (mode == 2) mfma_dma_loop2<<<grid, block>>>(out, chunks, table, rows, 128);
+                    if (mode == 3) mfma_dma_loop3<<<grid, block>>>(out, chunks, table, rows, 128);
+                    (void)hipEventRecord(e1);
+                    if (rep % 2 == 1) {
+                        (void)hipEventSynchronize(e1);
+                        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+                        printf(" %.1f", flop / ms / 1e9);
+                    }
+                }
+                printf(" TFLOP/s\n");
+            }
+            (void)hipFree(table);
+        }
+    }
+    // workgroup shapes: fewer LDS-DMA instructions per MFMA with larger tiles
+    {
+        float *out, *table;
+        const int rows = 1000000;
+        (void)hipMalloc(&out, 4096);
+        (void)hipMalloc(&table, (size_t)rows * 128 * 4);
+        (void)hipMemset(table, 0x3d, (size_t)rows * 128 * 4);
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        struct { const char *name; void (*k)(float *, int, const float *, int, int); int threads, per_cu; size_t lds; } shapes[] = {
+            {"2 x 2 wavefronts (128 x 128), 4 workgroups per CU", shape_2x2, 256, 4, (size_t)(128 * 32 + 16) * 2 * 4},
+            {"4 x 2 wavefronts (256 x 128), 2 per CU", shape_4x2, 512, 2, (size_t)((256 * 32 + 32) + (128 * 32 + 16)) * 4},
+            {"4 x 2, double-buffered, 1-2 per CU", shape_4x2db, 512, 2, (size_t)((256 * 32 + 32) + (128 * 32 + 16)) * 2 * 4},
+            {"4 x 4 wavefronts (256 x 256), 1 per CU", shape_4x4, 1024, 1, (size_t)(256 * 32 + 32) * 2 * 4},
+            {"4 x 4, double-buffered, 1 per CU", shape_4x4db, 1024, 1, (size_t)(256 * 32 + 32) * 2 * 2 * 4}};
+        for (auto &sh : shapes) {
+            (void)hipFuncSetAttribute((const void *)sh.k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh.lds);
+            dim3 grid(p.multiProcessorCount * sh.per_cu), block(sh.threads);
+            const int chunks = 500;
+            const double flop = (double)grid.x * (sh.threads / 64) * chunks * 16.0 * 4 * 4096.0;
+            printf("shape %s (LDS %zu KB per workgroup):", sh.name, sh.lds / 1024);
+            for (int rep = 0; rep < 8; ++rep) {
+                (void)hipEventRecord(e0);
+                sh.k<<<grid, block, sh.lds>>>(out, chunks, table, rows, 128);
+                (void)hipEventRecord(e1);
+                if (rep % 2 == 1) {
+                    (void)hipEventSynchronize(e1);
+                    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+                    printf(" %.1f", flop / ms / 1e9);
+                }
+            }
+            printf(" TFLOP/s  [%s]\n", hipGetErrorString(hipGetLastError()));
         }
     }
     return 0;
