@@ -124,6 +124,25 @@ def test_bench_plain_command_starts_its_own_ranks():
     assert d["config"]["mesh_value"] == mesh["value"] and "replicas identical" in d["config"]["mesh_note"]
 
 
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_mesh_leg_that_fails_leaves_the_first_jobs_line_alone():
+    """the launcher's second job (the library's own mesh) is cut off after one second: the line of the FIRST job comes out whole, exit
+    status 0, and the leg says what happened"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--users", "120000", "--batch", "120000", "--items", "30000", "--score-tiles", "0", "--no-legs"],
+                         capture_output=True, text=True, timeout=800, cwd=ROOT,
+                         env={**env, "RSX_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "RSX_MESH_LEG_LIMIT_S": "1"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["item_replicas_identical"] is True
+    leg = d["legs"]["exchange_direct_mesh"]
+    assert leg["value"] is None and "still running" in leg["error"] and d["config"]["mesh_value"] is None
+
+
 def test_bench_launcher_reports_a_failed_rank():
     """a rank that cannot start (here: no GPU in this container; on a GPU box: a launcher limit of zero seconds) must give a
     non-zero status and ONE JSON error line, not silence"""
