@@ -622,3 +622,50 @@ def test_mesh_exchange_and_a_missing_peer_is_an_error_not_a_hang():
     assert out[0][0] and out[1][0]                                   # the healthy exchange: both replicas updated, G zero
     assert out[1][1] is None and out[0][1] is not None and "gave up waiting" in out[0][1]
     assert 400.0 < out["ms"] < 5000.0                                # two waits of 0.5 s each, not a hang
+
+
+def _mesh_shapes_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from recsys_pytorch_amd import rsx
+    dev = torch.device("cuda", 0)
+    res = []
+    for rows, d in ((1, 32), (5, 64), (257, 128), (1000, 256)):          # fewer rows than ranks, odd slices, every row width
+        gen = torch.Generator().manual_seed(1000 * rows + d)
+        Q0 = torch.randn(rows, d, generator=gen)
+        Gs = [torch.randn(rows, d, generator=gen) for _ in range(world)]      # every rank's partial sums (the same draws on both ranks)
+        Q, G = Q0.clone().to(dev), Gs[rank].clone().to(dev)
+        mesh = rsx.Mesh(Q, G)
+        # two exchanges over parts of the table, then the whole: rows [0, rows / 2), [rows / 2, rows) -- like item ranges -- and a second
+        # step over everything with fresh partial sums
+        half = rows // 2
+        if half > 0:
+            mesh.exchange_apply(0, half, 0.5)
+        mesh.exchange_apply(half, rows - half, 0.5)
+        mesh.check()
+        want = Q0 - 0.5 * sum(Gs)
+        ok1 = bool(torch.allclose(Q.cpu(), want, rtol=1e-6, atol=1e-6)) and float(G.abs().max()) == 0.0
+        G.copy_(Gs[1 - rank].to(dev))                                           # step 2: the partial sums swapped
+        mesh.exchange_apply(0, rows, 0.25)
+        mesh.check()
+        want2 = want - 0.25 * sum(Gs)
+        ok2 = bool(torch.allclose(Q.cpu(), want2, rtol=1e-6, atol=1e-6)) and float(G.abs().max()) == 0.0
+        res.append((rows, d, ok1, ok2, Q.cpu().numpy().copy(), mesh.info()[2]))
+        mesh.close()
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_mesh_exchange_on_small_and_odd_tables():
+    """rsx_mesh_exchange_apply on its own: tables with fewer rows than ranks, odd slice boundaries, every row width (32 .. 256), part of a
+    table and the whole of it: Q -= lr * (sum of the ranks' G) on both ranks, G zero afterwards, the two replicas bit-identical"""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_mesh_shapes_worker, args=(2, 29500 + (os.getpid() + 101) % 2000, out), nprocs=2, join=True)
+    for a, b in zip(out[0], out[1]):
+        assert a[:4] == b[:4] and a[2] and a[3], (a[:4], b[:4])
+        assert np.array_equal(a[4], b[4]), ("replicas differ", a[0], a[1])
+        assert a[5] == b[5] == (3 if a[0] > 1 else 2)
