@@ -211,10 +211,11 @@ def _check_ranges(oracle_mod, world, port, gpu, U, I, d, B, deg, chunks, steps, 
         mp.spawn(_ranges_worker, args=(world, port + 3 * one_run, gpu, U, I, d, B, deg, chunks, steps, one_run, out, exchange), nprocs=world, join=True)
         res[one_run] = [out[r] for r in range(world)]
     for arm in res.values():
-        assert np.array_equal(arm[0][2], arm[1][2]), "relabelled item replicas diverged (some range)"
-        assert np.array_equal(arm[0][1], arm[1][1]), "item replicas diverged"
-        assert np.array_equal(arm[0][4], arm[1][4])
-        assert arm[0][8] == 0.0 and arm[1][8] == 0.0              # every range's gradient rows were applied and cleared
+        for r in range(1, world):
+            assert np.array_equal(arm[0][2], arm[r][2]), f"relabelled item replicas diverged (some range), rank {r}"
+            assert np.array_equal(arm[0][1], arm[r][1]), f"item replicas diverged, rank {r}"
+            assert np.array_equal(arm[0][4], arm[r][4])
+        assert all(a[8] == 0.0 for a in arm)                      # every range's gradient rows were applied and cleared
     step_arm = res[False]
     rank_item, Q_init = step_arm[0][4], step_arm[0][7]
     P_init = np.concatenate([step_arm[r][6] for r in range(world)])
@@ -264,6 +265,21 @@ def test_two_ranks_item_ranges_over_the_direct_mesh_equal_one_process(oracle_mod
     the step (gloo only carries the handles and the barriers around the run).  Step by step against the oracle on the concatenated
     triplets and all steps queued by one call, replicas identical row by row, G zero, no wait gave up, steps x ranges exchanges"""
     _check_ranges(oracle_mod, 2, 29500 + (os.getpid() + 83 + I) % 2000, True, 9000, I, d, 6000, 10, chunks, 4, exchange="direct")
+
+
+@pytest.mark.timeout(600)
+def test_three_ranks_item_ranges_with_range_callbacks_equal_one_process(oracle_mod):
+    """... and with THREE ranks (1 / sum_r B_r over three batches, three user blocks, every replica against rank 0's)"""
+    _check_ranges(oracle_mod, 3, 29500 + (os.getpid() + 61) % 2000, False, 400, 171, 32, 360, 6, 2, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,I,chunks,d", [(3, 1999, 3, 128), (4, 2500, 2, 64)])
+def test_more_ranks_item_ranges_over_the_direct_mesh_equal_one_process(oracle_mod, world, I, chunks, d):
+    """the direct mesh with three and four ranks (processes on the box's GPU): every rank reads two / three peers' rows for its slice and
+    gathers from two / three owners; slices with a remainder.  Same checks as with two ranks"""
+    _check_ranges(oracle_mod, world, 29500 + (os.getpid() + 89 + I) % 2000, True, 6000, I, d, 4000, 10, chunks, 3, exchange="direct")
 
 
 @pytest.mark.gpu
@@ -633,9 +649,10 @@ def _mesh_shapes_worker(rank, world, port, out):
     for rows, d in ((1, 32), (5, 64), (257, 128), (1000, 256)):          # fewer rows than ranks, odd slices, every row width
         gen = torch.Generator().manual_seed(1000 * rows + d)
         Q0 = torch.randn(rows, d, generator=gen)
-        Gs = [torch.randn(rows, d, generator=gen) for _ in range(world)]      # every rank's partial sums (the same draws on both ranks)
+        Gs = [torch.randn(rows, d, generator=gen) for _ in range(world)]      # every rank's partial sums (the same draws on all ranks)
         Q, G = Q0.clone().to(dev), Gs[rank].clone().to(dev)
         mesh = rsx.Mesh(Q, G)
+        mesh.set_wait_limit(20.0)                                               # (a lost peer fails the test, it does not hang the box)
         # two exchanges over parts of the table, then the whole: rows [0, rows / 2), [rows / 2, rows) -- like item ranges -- and a second
         # step over everything with fresh partial sums
         half = rows // 2
@@ -644,12 +661,12 @@ def _mesh_shapes_worker(rank, world, port, out):
         mesh.exchange_apply(half, rows - half, 0.5)
         mesh.check()
         want = Q0 - 0.5 * sum(Gs)
-        ok1 = bool(torch.allclose(Q.cpu(), want, rtol=1e-6, atol=1e-6)) and float(G.abs().max()) == 0.0
-        G.copy_(Gs[1 - rank].to(dev))                                           # step 2: the partial sums swapped
+        ok1 = bool(torch.allclose(Q.cpu(), want, rtol=1e-5, atol=1e-5)) and float(G.abs().max()) == 0.0
+        G.copy_(Gs[(rank + 1) % world].to(dev))                                 # step 2: the partial sums handed round
         mesh.exchange_apply(0, rows, 0.25)
         mesh.check()
         want2 = want - 0.25 * sum(Gs)
-        ok2 = bool(torch.allclose(Q.cpu(), want2, rtol=1e-6, atol=1e-6)) and float(G.abs().max()) == 0.0
+        ok2 = bool(torch.allclose(Q.cpu(), want2, rtol=1e-5, atol=1e-5)) and float(G.abs().max()) == 0.0
         res.append((rows, d, ok1, ok2, Q.cpu().numpy().copy(), mesh.info()[2]))
         mesh.close()
     out[rank] = res
@@ -658,14 +675,17 @@ def _mesh_shapes_worker(rank, world, port, out):
 
 
 @pytest.mark.gpu
-@pytest.mark.timeout(300)
-def test_mesh_exchange_on_small_and_odd_tables():
-    """rsx_mesh_exchange_apply on its own: tables with fewer rows than ranks, odd slice boundaries, every row width (32 .. 256), part of a
-    table and the whole of it: Q -= lr * (sum of the ranks' G) on both ranks, G zero afterwards, the two replicas bit-identical"""
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_mesh_exchange_on_small_and_odd_tables(world):
+    """rsx_mesh_exchange_apply on its own, with two, three and four ranks (processes on the box's GPU -- more than one peer to read, slices
+    with a remainder): tables with fewer rows than ranks, odd slice boundaries, every row width (32 .. 256), part of a table and the whole
+    of it: Q -= lr * (sum of the ranks' G) on every rank, G zero afterwards, the replicas bit-identical"""
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_mesh_shapes_worker, args=(2, 29500 + (os.getpid() + 101) % 2000, out), nprocs=2, join=True)
-    for a, b in zip(out[0], out[1]):
-        assert a[:4] == b[:4] and a[2] and a[3], (a[:4], b[:4])
-        assert np.array_equal(a[4], b[4]), ("replicas differ", a[0], a[1])
-        assert a[5] == b[5] == (3 if a[0] > 1 else 2)
+    mp.spawn(_mesh_shapes_worker, args=(world, 29500 + (os.getpid() + 101 + 13 * world) % 2000, out), nprocs=world, join=True)
+    for r in range(1, world):
+        for a, b in zip(out[0], out[r]):
+            assert a[:4] == b[:4] and a[2] and a[3], (r, a[:4], b[:4])
+            assert np.array_equal(a[4], b[4]), ("replicas differ", r, a[0], a[1])
+            assert a[5] == b[5] == (3 if a[0] > 1 else 2)
