@@ -354,6 +354,9 @@ int rsx_comm_all_reduce_f32(rsx_comm *c, float *buf_dev, int64_t n, rsx_stream_t
  *   rsx_mesh_exchange_apply(first_row, rows, lr)   collective in the sense that every rank must queue the same sequence
  *                      of calls: afterwards (stream order) Q[first_row .. +rows) -= lr * sum over the ranks of G[...] on
  *                      every rank, and those rows of G are zero.  What precedes it on `stream` must have completed G.
+ *                      The exchanges of ONE mesh must execute in the order they were queued -- one stream, or streams
+ *                      ordered by events: a flag holds the LATEST sequence number, so an exchange overtaking an earlier
+ *                      one would release the peers' waits for both.
  *   rsx_mesh_check     synchronises `stream`; fails if a wait for a peer's signal gave up (rsx_mesh_set_wait_limit, default
  *                      20 s): such an exchange leaves wrong rows and says so -- it never hangs the GPU.
  *   rsx_mesh_destroy   the caller makes sure (host barrier) that no peer still reads this rank's buffers.

@@ -788,6 +788,10 @@ __global__ __launch_bounds__(kBlock) void apply_item_grad_kernel(float4 *__restr
             g[c] = make_float4(0.f, 0.f, 0.f, 0.f); q[c] = g[c];
             if (n < n4) { g[c] = G[n]; if constexpr (DENSE) q[c] = Q[n]; }
         }
+        // (a replicated row whose G quad and replicas cancel EXACTLY -- a triplet with i == j, which the reference's generator can
+        //  draw, data/generators.py:169-190: +g p in the replica, -g p in G -- has nothing to apply, but its G quad must still be
+        //  cleared: the replicas are.  Found by tools/fuzz_campaign.sh, round 5)
+        bool cancel[kQuads] = {false, false, false, false};
         if (hot.slot != nullptr) {
 #pragma unroll
             for (int c = 0; c < kQuads; ++c) {
@@ -796,6 +800,7 @@ __global__ __launch_bounds__(kBlock) void apply_item_grad_kernel(float4 *__restr
                 const int64_t row = n / d4;
                 const int32_t hs = hot.slot[row];
                 if (hs >= 0) {
+                    cancel[c] = g[c].x != 0.f || g[c].y != 0.f || g[c].z != 0.f || g[c].w != 0.f;
                     float4 *src = reinterpret_cast<float4 *>(hot.ghot) + ((size_t)hs * hot.replicas) * d4 + (n - row * d4);
                     for (int r = 0; r < hot.replicas; ++r) {
                         const float4 v = src[(size_t)r * d4];
@@ -820,6 +825,8 @@ __global__ __launch_bounds__(kBlock) void apply_item_grad_kernel(float4 *__restr
                 w.x = fmaf(-lr, g[c].x, w.x); w.y = fmaf(-lr, g[c].y, w.y);
                 w.z = fmaf(-lr, g[c].z, w.z); w.w = fmaf(-lr, g[c].w, w.w);
                 Q[n] = w;
+                G[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else if (cancel[c]) {
                 G[n] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }

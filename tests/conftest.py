@@ -81,6 +81,14 @@ G8_POINTWISE = ["g8_pointwise_ce_sgd_300x200_d32", "g8_pointwise_mse_sgd_200x150
                 "g8_pointwise_ce_adam_generator_120x90_d32"]
 
 
+def fuzz(seed, trials):
+    """(rng, number of trials) of a random-shapes test.  The committed suite runs the seed and count given here; a campaign sets
+    RSX_FUZZ_SEED (added to the seed) and RSX_FUZZ_TRIALS (a multiplier) -- tools/fuzz_campaign.sh, results under profiles/"""
+    extra = int(os.environ.get("RSX_FUZZ_SEED", "0"))
+    mult = float(os.environ.get("RSX_FUZZ_TRIALS", "1"))
+    return np.random.default_rng(seed + 7919 * extra), max(1, int(round(trials * mult)))
+
+
 def split_pointwise(g):
     """yield (u, i, y) batches from a g8* fixture."""
     off = 0

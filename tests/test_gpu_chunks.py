@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import UPDATE_TOL, assert_update, resolvable_lr
+from conftest import UPDATE_TOL, assert_update, fuzz, resolvable_lr
 
 pytestmark = pytest.mark.gpu
 
@@ -233,8 +233,8 @@ def test_chunked_sampler_on_random_shapes():
     positions of the ranges consistent, positives true, negatives true / real / in the positive's range, a user owning its whole
     range skipped, twice the same call gives the same bits"""
     from recsys_pytorch_amd import rsx
-    rng = np.random.default_rng(321)
-    for trial in range(30):
+    rng, trials = fuzz(321, 30)
+    for trial in range(trials):
         C = int(rng.integers(2, 9))
         c = int(rng.integers(0, 17)) if trial % 5 else 0        # 0: no blocks -- negatives over the real items of the positive's range
         I = int(rng.integers(max(2 * C, 8), 3000))

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import (DELTA_TOL_SMALL_LR, G1_PADDED, G1_SGD, G1_SGD_BIGLR, GOLDEN, assert_update, delta_err, golden, rel_err, resolvable_lr,
+from conftest import (DELTA_TOL_SMALL_LR, fuzz, G1_PADDED, G1_SGD, G1_SGD_BIGLR, GOLDEN, assert_update, delta_err, golden, rel_err, resolvable_lr,
                       split_batches)
 
 pytestmark = pytest.mark.gpu
@@ -428,9 +428,9 @@ def test_item_cdf_buckets_on_random_shapes():
     import scipy.sparse as sp
     from recsys_pytorch_amd import rsx
     from recsys_pytorch_amd.data import csr_to_device
-    rng = np.random.default_rng(123)
+    rng, trials = fuzz(123, 40)
     try:
-        for trial in range(40):
+        for trial in range(trials):
             U = int(rng.integers(1, 4000))
             I = int(rng.integers(2, 3000))
             kind = trial % 4
@@ -474,14 +474,19 @@ def test_item_cdf_buckets_on_random_shapes():
             for p in np.flatnonzero(live)[:: max(1, B // 300)]:
                 row = indices[indptr[ua[p]]:indptr[ua[p] + 1]]
                 assert ia[p] in row and ja[p] not in row and 0 <= ja[p] < I, ctx
-            # negatives of one position range share one item block (unless the user owns that block)
+            # negatives of one position range share ONE item block E; a position whose negative lies elsewhere belongs to a user who owns
+            # (nearly) all of E (rsx_sample.hip draw_negative: 64 rejected draws, then the whole catalog -- owning 3/4 of E or less, that
+            # has probability (3/4)^64 = 1e-8).  Per range: some block E explains every position.  (Until round 5 this was a 20 % allowance -- tools/fuzz_campaign.sh found small catalogs with long rows
+            # where more users than that own their block)
+            owns = np.zeros((U, I), dtype=bool)
+            owns[np.repeat(np.arange(U), np.diff(indptr)), indices] = True
             w = (np.arange(B, dtype=np.int64) * I // B) // c
             blocks = ja // c
-            bad = 0
             for ww in np.unique(w[live]):
-                vals, cnt = np.unique(blocks[live & (w == ww)], return_counts=True)
-                bad += cnt.sum() - cnt.max()
-            assert bad <= max(2, 0.2 * live.sum()) or kind == 2, ctx
+                pos = np.flatnonzero(live & (w == ww))
+                seen = np.unique(blocks[pos])
+                explains = lambda E: all(blocks[q] == E or owns[ua[q], E * c:min(I, (E + 1) * c)].mean() > 0.75 for q in pos)
+                assert any(explains(E) for E in seen) or any(explains(E) for E in range(nb)), (ctx, int(ww), seen[:8])
             assert nb >= 1
     finally:
         rsx.set_option("sample_sort_cap", 0)
