@@ -105,6 +105,81 @@ def test_chunked_native_steps_follow_the_range_rule_and_replay_through_the_oracl
     tr.close()
 
 
+def test_native_loop_on_random_shapes(oracle_mod):
+    """16 random (users, items, d, batch, popularity, row lengths, item ranges or none, replicated rows or none, ordered layout or
+    not) engines through the native loop, three steps each: what every step consumed (rsx_bpr_trainer_last_batch) is a batch of unique
+    users with true positives and true negatives, and replayed on the CPU oracle it gives the same loss and the same update"""
+    from recsys_pytorch_amd import rsx
+    from recsys_pytorch_amd.sharded import BPREngine
+    rng, trials = fuzz(555, 16)
+    failures = []
+    for trial in range(trials):
+        chunks = int(rng.choice([0, 0, 2, 3, 5]))
+        d = int(rng.choice([32, 64, 128, 256]))
+        I = int(rng.integers(16 * max(chunks, 1), 5000))
+        U = int(rng.integers(50, 8000))
+        B = U if trial % 3 == 0 else int(rng.integers(max(1, U // 8), U + 1))
+        maxdeg = max(1, min(12, I // (2 * max(chunks, 1)) - 1))          # (no user owns half a range: every pair finds a negative)
+        pop = 1.0 / (1.0 + np.arange(I)) ** float(rng.choice([0.0, 0.7, 1.0]))
+        draws = rng.choice(I, size=(U, maxdeg), p=pop / pop.sum())
+        keep = rng.random((U, maxdeg)) < 0.6
+        keep[:, 0] = True
+        rows = [np.unique(draws[uu][keep[uu]]) for uu in range(U)]
+        indptr = np.concatenate([[0], np.cumsum([len(r_) for r_ in rows])]).astype(np.int64)
+        indices = np.concatenate(rows).astype(np.int32)
+        ip, ix = torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda()
+        P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+        Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+        P, Q = torch.from_numpy(P0).cuda(), torch.from_numpy(Q0).cuda()
+        lr = resolvable_lr(B)
+        eng = BPREngine(P, Q, lr, seed=int(rng.integers(1, 1 << 30)))
+        nb = eng.set_neg_block(B, int(rng.integers(1, 17)))
+        ordered = nb > 0
+        if nb == 0 and (chunks > 1 or trial % 2):
+            eng.sorted_min_batch = 1                                     # the ordered layout without blocks
+            ordered = True
+        hot = int(rng.choice([0, 8, 32]))
+        if hot:
+            eng.set_hot_items(torch.bincount(ix.long(), minlength=I), min(hot, I), int(rng.choice([1, 4])))
+        if chunks > 1:
+            eng.set_chunks(chunks)
+        acc = torch.zeros(rsx.RSX_LOSS_SLOTS, device="cuda")
+        tr = eng.native_trainer(ip, ix, B, loss_acc=acc)
+        ranged = tr.chunks > 1
+        ctx = f"trial {trial}: U={U} I={I} d={d} B={B} chunks={chunks} (ran {tr.chunks}) nb={nb} ordered={ordered} hot={hot} maxdeg={maxdeg}"
+        try:
+            assert ranged == (chunks > 1), ctx
+            if ranged:
+                r = eng._relabel
+                Pn, Qn, ixn = P0, r["Q"].cpu().numpy(), r["indices"].cpu().numpy()
+                table = r["Q"]
+            else:
+                Pn, Qn, ixn, table = P0, Q0, indices, Q
+            orc = oracle_mod.MFOracle(Pn, Qn, "sgd", lr)
+            for step in range(3):
+                acc.zero_()
+                tr.run(1)
+                torch.cuda.synchronize()
+                u, i, j = (x.cpu().numpy() for x in tr.last_batch()[:3])
+                assert len(np.unique(u)) == B and i.min() >= 0 and j.min() >= 0, ctx
+                assert not ordered or np.all(np.diff(i) >= 0), ctx
+                for a, b_, c_ in list(zip(u, i, j))[::max(1, B // 200)]:
+                    row = ixn[indptr[a]:indptr[a + 1]]
+                    assert b_ in row and c_ not in row, ctx
+                want = orc.step(u, i, j)
+                assert abs(float(acc.sum()) / B - want) < 1e-5 * max(1.0, abs(want)), ctx
+            tr.check()
+            assert_update(P.cpu().numpy(), P0, orc.P, "P, " + ctx)
+            assert_update(table.cpu().numpy(), Qn, orc.Q, "Q, " + ctx)
+            eng.adopt(tr)
+            assert float(eng.G.abs().max()) == 0.0 or ranged, ctx
+        except AssertionError as e:
+            failures.append(str(e).splitlines()[0])
+        finally:
+            tr.close()
+    assert not failures, "\n".join(failures)
+
+
 @pytest.mark.parametrize("nb", [6, 0])
 def test_chunked_step_counts_triplets_outside_their_range(nb):
     """the contract check: the same kernel on triplets that do NOT follow the range rule still sums them, but counts every

@@ -470,6 +470,49 @@ def test_topk_vs_oracle_shapes(rsx, oracle_mod, rows, I, K):
     assert np.array_equal(idx.cpu().numpy()[uniq], ref[uniq])
 
 
+def test_score_mask_topk_on_random_shapes(rsx, oracle_mod):
+    """24 random (users, items, d, rows, K, seen-item rows incl. empty and full ones, ties) problems through the dense path: the score tile
+    (predict_batch_users, MF.py:109-112) against the oracle's product, -inf exactly at the seen positions (MF.py:130), the row Top-K
+    (func.h:12-31) equal to the oracle's partial sort of the DEVICE scores -- values always, indices wherever a row has no equal
+    scores -- and rows with fewer than K candidates"""
+    rng, trials = fuzz(99, 24)
+    for trial in range(trials):
+        d = int(rng.choice([32, 64, 128, 256]))
+        U, I = int(rng.integers(1, 600)), int(rng.integers(1, 5000))
+        rows = int(rng.integers(1, 700))
+        K = int(rng.integers(1, min(I, 1024) + 1))
+        scale = float(rng.choice([0.01, 0.3, 5.0]))
+        P = (rng.standard_normal((U, d)) * scale).astype(np.float32)
+        Q = (rng.standard_normal((I, d)) * scale).astype(np.float32)
+        if trial % 5 == 1:
+            Q[rng.integers(0, I, max(1, I // 3))] = Q[0]                     # exact ties between items
+        users = rng.integers(0, U, rows).astype(np.int32)
+        kind = trial % 4
+        degs = (np.zeros(U, np.int64) if kind == 0 else rng.integers(0, min(I, 40) + 1, U) if kind == 1
+                else np.where(rng.random(U) < 0.1, I, rng.integers(0, min(I, 5) + 1, U)) if kind == 2
+                else np.minimum(I, (rng.pareto(1.0, U) * 3).astype(np.int64)))
+        seen = [np.sort(rng.choice(I, int(g), replace=False)) for g in degs]
+        mp = np.concatenate([[0], np.cumsum([len(r) for r in seen])]).astype(np.int64)
+        mi = (np.concatenate(seen) if mp[-1] else np.zeros(0)).astype(np.int32)
+        ctx = f"trial {trial}: U={U} I={I} d={d} rows={rows} K={K} kind={kind} scale={scale}"
+        mask = (dev(mp), dev(mi if len(mi) else np.zeros(1, np.int32))) if kind else None
+        S = rsx.score(dev(P), dev(Q), dev(users), mask=mask).cpu().numpy()
+        ref = oracle_mod.score(P, Q, users)
+        if kind:
+            ref = oracle_mod.mask_seen(ref, users, mp, mi)
+        assert np.array_equal(np.isneginf(S), np.isneginf(ref)), ctx
+        fin = np.isfinite(ref)
+        assert not fin.any() or np.abs(S[fin] - ref[fin]).max() <= 2e-6 * max(np.abs(ref[fin]).max(), 1e-30), ctx
+        idx, val = rsx.topk(dev(S), K, want_values=True)
+        idx, val = idx.cpu().numpy(), val.cpu().numpy()
+        want = oracle_mod.topk(S, K)
+        assert np.array_equal(val, np.take_along_axis(S, want.astype(np.int64), 1)), ctx
+        assert np.array_equal(np.take_along_axis(S, idx.astype(np.int64), 1), val), ctx
+        uniq = np.array([len(np.unique(r)) == len(r) for r in S])
+        assert np.array_equal(idx[uniq], want[uniq]), ctx
+        assert all(len(set(r)) == K for r in idx), ctx                      # K different items in every row, ties or not
+
+
 def test_topk_ties_and_masked_rows(rsx, oracle_mod):
     """exact ties (oracle rule: lower index first), all-equal rows, rows mostly -inf"""
     S = np.zeros((4, 5000), np.float32)

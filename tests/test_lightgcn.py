@@ -157,6 +157,58 @@ def test_hip_spmm_long_rows_vs_oracle(oracle_mod, max_seg):
 
 
 @pytest.mark.gpu
+def test_hip_spmm_on_random_graphs():
+    """20 random square sparse matrices (empty rows, rows of one entry, heavy tails, rows holding every column; any segment length from 1
+    up; every row width) through every form of the product -- plain, with the running sum, started from S_init, with row flags on X,
+    with only some rows wanted -- against scipy in fp64"""
+    from conftest import fuzz
+    from recsys_pytorch_amd import rsx
+    rng, trials = fuzz(2024, 20)
+    for trial in range(trials):
+        N = int(rng.integers(1, 4000))
+        d = int(rng.choice([32, 64, 128, 256]))
+        kind = trial % 4
+        degs = (rng.integers(0, min(N, 4) + 1, N) if kind == 0 else rng.integers(0, min(N, 60) + 1, N) if kind == 1
+                else np.where(rng.random(N) < 0.01, N, rng.integers(0, min(N, 8) + 1, N)) if kind == 2
+                else np.minimum(N, (rng.pareto(0.8, N) * 2).astype(np.int64)))
+        cols = [np.sort(rng.choice(N, int(g), replace=False)) for g in degs]
+        indptr = np.concatenate([[0], np.cumsum([len(c) for c in cols])]).astype(np.int64)
+        indices = (np.concatenate(cols) if indptr[-1] else np.zeros(0)).astype(np.int32)
+        vals = rng.standard_normal(len(indices)).astype(np.float32)
+        A = sp.csr_matrix((vals, indices, indptr), shape=(N, N))
+        max_seg = [None, 1, 3, 64, 1000][int(rng.integers(0, 5))]
+        ctx = f"trial {trial}: N={N} d={d} kind={kind} nnz={len(indices)} max_seg={max_seg}"
+        G = rsx.SpmmGraph(A, "cuda", max_seg=max_seg)
+        X = rng.standard_normal((N, d)).astype(np.float32)
+        A64 = A.astype(np.float64)
+        Y64 = A64 @ X.astype(np.float64)
+        # the bound: fp32 sums of up to N terms in some order -- a few ulp of the sum of the magnitudes
+        bound = 4e-6 * np.maximum((abs(A64) @ np.abs(X).astype(np.float64)), 1e-30).max()
+        Xd = torch.from_numpy(X).cuda()
+        Y, S = torch.full_like(Xd, 7.0), Xd.clone()
+        rsx.spmm(G, Xd, Y, S_acc=S)
+        assert np.abs(Y.cpu().numpy() - Y64).max() <= bound, ctx
+        assert np.abs(S.cpu().numpy() - (X + Y64)).max() <= bound + 1e-6 * np.abs(X).max(), ctx
+        empty = torch.from_numpy(np.diff(indptr) == 0).cuda()
+        assert not bool(empty.any()) or float(Y[empty].abs().max()) == 0.0, ctx
+        Yi, Si = torch.full_like(Xd, -1.0), torch.full_like(Xd, 123.0)
+        rsx.spmm(G, Xd, Yi, S_acc=Si, S_init=Xd)
+        assert np.abs(Yi.cpu().numpy() - Y64).max() <= bound and np.abs(Si.cpu().numpy() - (X + Y64)).max() <= bound + 1e-6 * np.abs(X).max(), ctx
+        dead = rng.random(N) < 0.7
+        Xs = X.copy(); Xs[dead] = 0.0
+        Ys64 = A64 @ Xs.astype(np.float64)
+        Yb = torch.full_like(Xd, 5.0)
+        rsx.spmm(G, torch.from_numpy(Xs).cuda(), Yb, x_nonzero=torch.from_numpy((~dead).astype(np.uint8)).cuda())
+        assert np.abs(Yb.cpu().numpy() - Ys64).max() <= bound, ctx
+        want = rng.random(N) < 0.3
+        Yw, Sw = torch.full_like(Xd, 7.0), torch.full_like(Xd, -3.0)
+        rsx.spmm(G, Xd, Yw, S_acc=Sw, y_wanted=torch.from_numpy(want.astype(np.uint8)).cuda())
+        Yw, Sw = Yw.cpu().numpy(), Sw.cpu().numpy()
+        assert not want.any() or (np.abs(Yw[want] - Y64[want]).max() <= bound and np.abs(Sw[want] - (Y64[want] - 3.0)).max() <= bound + 3e-6), ctx
+        assert want.all() or (bool((Yw[~want] == 7.0).all()) and bool((Sw[~want] == -3.0).all())), ctx
+
+
+@pytest.mark.gpu
 def test_hip_lightgcn_fit_and_topk_end_to_end():
     """fit() on ml-100k with the evaluator: loss goes down, predict and predict_topk agree"""
     import recsys_pytorch_amd as pkg

@@ -10,6 +10,8 @@ for seed in $(seq ${1:-1} ${2:-4}); do
     RSX_FUZZ_SEED=$seed RSX_FUZZ_TRIALS=${3:-4} timeout 1500 python -m pytest -q -m gpu -p no:cacheprovider --no-header --tb=short -s \
         "tests/test_gpu_parity.py::test_step_kernels_on_random_shapes" "tests/test_gpu_parity.py::test_fused_score_topk_on_random_shapes" \
         "tests/test_gpu_chunks.py::test_chunked_sampler_on_random_shapes" "tests/test_gpu_model.py::test_item_cdf_buckets_on_random_shapes" \
+        "tests/test_gpu_parity.py::test_score_mask_topk_on_random_shapes" "tests/test_lightgcn.py::test_hip_spmm_on_random_graphs" \
+        "tests/test_gpu_chunks.py::test_native_loop_on_random_shapes" \
         2>&1 | grep -v "amdgpu.ids" | tail -40 >> $out
 done
 grep -c passed $out
