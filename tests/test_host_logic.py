@@ -54,6 +54,34 @@ def test_eval_loo_matches_reference_golden(oracle_mod):
         rsx.eval_loo(np.zeros((2, 5), np.int32), [6], np.zeros(2, np.int32))
 
 
+def test_eval_metrics_on_random_shapes_match_reference_native(oracle_mod):
+    """60 random (users, items, ranking length, cut-offs in any order, holdout rows of any length incl. EMPTY ones -- NaN like the
+    reference's 0 / 0) problems: rsx_eval_holdout / rsx_eval_loo == the reference's holdout.h / loo.h compiled in oracle/_ref == the
+    oracle's restatement"""
+    from conftest import fuzz
+    from recsys_pytorch_amd import rsx
+    use_ref = oracle_mod.ref_lib() is not None
+    rng, trials = fuzz(31, 60)
+    for trial in range(trials):
+        n, I = int(rng.integers(1, 300)), int(rng.integers(2, 800))
+        mk = int(rng.integers(1, min(I, 60) + 1))
+        rk = np.stack([rng.permutation(I)[:mk] for _ in range(n)]).astype(np.int32)
+        lens = rng.integers(0 if trial % 3 == 0 else 1, min(I, 50) + 1, n)
+        ip = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        ix = (np.concatenate([rng.permutation(I)[:l] for l in lens]) if ip[-1] else np.zeros(1)).astype(np.int32)
+        ks = sorted({int(x) for x in rng.integers(1, mk + 1, int(rng.integers(1, 5)))}, reverse=trial % 5 == 0)
+        ctx = f"trial {trial}: n={n} I={I} mk={mk} ks={ks} shortest row {lens.min()}"
+        a = rsx.eval_holdout(rk, ks, ip, ix)
+        assert np.allclose(a, oracle_mod.holdout(rk, ks, ip, ix), atol=1e-6, equal_nan=True), ctx
+        t = rng.integers(0, I, n).astype(np.int32)
+        b = rsx.eval_loo(rk, ks, t)
+        assert np.allclose(b, oracle_mod.loo(rk, ks, t), atol=1e-6), ctx
+        if use_ref:
+            assert np.allclose(a, oracle_mod.holdout(rk, ks, ip, ix, use_ref=True), atol=1e-6, equal_nan=True), ctx
+            if hasattr(oracle_mod.ref_lib(), "ref_evaluate_loo"):
+                assert np.allclose(b, oracle_mod.loo(rk, ks, t, use_ref=True), atol=1e-6), ctx
+
+
 def test_eval_holdout_rejects_bad_k():
     from recsys_pytorch_amd import rsx
     with pytest.raises(rsx.RsxError):

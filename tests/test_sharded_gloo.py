@@ -267,6 +267,20 @@ def test_two_ranks_item_ranges_over_the_direct_mesh_equal_one_process(oracle_mod
     _check_ranges(oracle_mod, 2, 29500 + (os.getpid() + 83 + I) % 2000, True, 9000, I, d, 6000, 10, chunks, 4, exchange="direct")
 
 
+@pytest.mark.timeout(900)
+def test_ranks_item_ranges_on_random_shapes(oracle_mod):
+    """three random (ranks, users, items, ranges, batch) problems through the same check (the CPU stand-in trainer over gloo)"""
+    from conftest import fuzz
+    rng, trials = fuzz(77, 3)
+    for trial in range(trials):
+        world = int(rng.integers(2, 4))
+        chunks = int(rng.integers(2, 5))
+        I = int(rng.integers(8 * chunks, 260))
+        B = int(rng.integers(2 * I, 3 * I + 40))                     # (the blocked layout: B >= 2 I on every rank)
+        U = B + int(rng.integers(0, 200))
+        _check_ranges(oracle_mod, world, 29500 + (os.getpid() + 151 + 17 * trial) % 2000, False, U, I, int(rng.choice([8, 32])), B, 5, chunks, 2)
+
+
 @pytest.mark.timeout(600)
 def test_three_ranks_item_ranges_with_range_callbacks_equal_one_process(oracle_mod):
     """... and with THREE ranks (1 / sum_r B_r over three batches, three user blocks, every replica against rank 0's)"""
