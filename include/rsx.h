@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RSX_ABI_VERSION 6
+#define RSX_ABI_VERSION 7
 
 #define RSX_OK 0
 #define RSX_E_INVALID (-1)   /* bad argument (null pointer, unsupported d, K ...) */
@@ -182,12 +182,15 @@ int rsx_apply_item_grad(float *Q, float *G, int64_t num_items, int d, float lr,
  * between steps.  rsx_adam_apply then is torch.optim.Adam's single-tensor update over ALL n
  * elements of one table (rows with a zero gradient move too once their moments are non-zero):
  *   m += (1-b1)(g-m);  v = b2 v + (1-b2) g^2;  w -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
- * and zeroes G.  t = 1 for the first step.  Call it once per table per step.             */
+ * and zeroes G.  t = 1 for the first step.  Call it once per table per step.
+ * lr, the betas and eps are DOUBLES, as torch holds them (Python floats): the reference's kernel receives 1 - beta2 = 0.001
+ * rounded ONCE to fp32 (ABI 7; with float arguments the library could only form 1.0f - 0.999f = 0.00099998713, 1.3e-5 off:
+ * found by the round-5 fuzz campaign, which checks the step against torch's formula on the device's own p, m, v, g).    */
 int rsx_bpr_grad(const float *P, const float *Q, float *GP, float *GQ, int64_t num_users,
                  int64_t num_items, const int32_t *u_dev, const int32_t *i_dev, const int32_t *j_dev,
                  int64_t batch, int d, float inv_batch, float *loss_acc, rsx_stream_t stream);
-int rsx_adam_apply(float *W, float *M, float *V, float *G, int64_t n, float lr, float beta1,
-                   float beta2, float eps, int64_t t, rsx_stream_t stream);
+int rsx_adam_apply(float *W, float *M, float *V, float *G, int64_t n, double lr, double beta1,
+                   double beta2, double eps, int64_t t, rsx_stream_t stream);
 
 /* rsx_pointwise_grad: the POINTWISE branch of the reference model (models/MF.py:99-102 with hparams['pointwise'] = True;
  * "widening" row beyond SURVEY section 8f).  Batch of n (user, item, rating) entries -- users and items repeat, as in the

@@ -50,8 +50,8 @@ def lib():
                                        C.POINTER(C.c_double)]
         L.orc_bpr_step_adam.restype = None
         L.orc_bpr_step_adam.argtypes = [_f32p, _f32p, C.c_int64, C.c_int64, _i64p, _i64p, _i64p,
-                                        C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float,
-                                        C.c_float, C.c_int64, _f32p, _f32p, _f32p, _f32p,
+                                        C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double,
+                                        C.c_double, C.c_int64, _f32p, _f32p, _f32p, _f32p,
                                         _f32p, _f32p, C.POINTER(C.c_double)]
         L.orc_score.restype = None
         L.orc_score.argtypes = [_f32p, _i64p, C.c_int64, _f32p, C.c_int64, C.c_int, _f32p]
@@ -70,8 +70,8 @@ def lib():
                                              C.c_int, C.c_int]
         L.orc_lightgcn_step_adam.restype = None
         L.orc_lightgcn_step_adam.argtypes = [_f32p, _f32p, _f32p, C.c_int64, C.c_int64, _i64p, _i32p, _f32p,
-                                             C.c_int, _i64p, _i64p, _i64p, C.c_int64, C.c_int, C.c_float,
-                                             C.c_float, C.c_float, C.c_float, C.c_int64, _f32p, _f32p, _f32p,
+                                             C.c_int, _i64p, _i64p, _i64p, C.c_int64, C.c_int, C.c_double,
+                                             C.c_double, C.c_double, C.c_double, C.c_int64, _f32p, _f32p, _f32p,
                                              _f32p, _f32p, C.POINTER(C.c_double)]
         L.orc_pointwise_grad.restype = None
         L.orc_pointwise_grad.argtypes = [_f32p, _f32p, _i64p, _i64p, _f32p, C.c_int64, C.c_int, C.c_int, _f32p, _f32p,
@@ -81,7 +81,7 @@ def lib():
                                              C.c_int, C.c_float, _f32p, _f32p, C.POINTER(C.c_double)]
         L.orc_pointwise_step_adam.restype = None
         L.orc_pointwise_step_adam.argtypes = [_f32p, _f32p, C.c_int64, C.c_int64, _i64p, _i64p, _f32p, C.c_int64, C.c_int,
-                                              C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64,
+                                              C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64,
                                               _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.POINTER(C.c_double)]
         _LIB = L
     return _LIB

@@ -109,23 +109,26 @@ ORC_EXPORT void orc_bpr_step_sgd(float *P, float *Q, int64_t U, int64_t I,
  *   step = lr / (1 - b1^t);  denom = sqrt(v)/sqrt(1 - b2^t) + eps
  *   theta -= step * m / denom                                               */
 static void orc_adam_apply(float *w, float *m, float *v, const float *g, int64_t n,
-                           float lr, float b1, float b2, float eps, int64_t t)
+                           double lr, double b1, double b2, double eps, int64_t t)
 {
-    double bc1 = 1.0 - pow((double)b1, (double)t);
-    double bc2 = 1.0 - pow((double)b2, (double)t);
-    float step_size = (float)((double)lr / bc1);
+    /* the hyper-parameters are Python floats (doubles) in torch; its kernels receive each scalar rounded ONCE to the tensor's
+     * type: lerp_'s weight 1 - b1, mul_'s b2, addcmul_'s value 1 - b2 = 0.001 (not 1.0f - 0.999f = 0.00099998713: round 5) */
+    double bc1 = 1.0 - pow(b1, (double)t);
+    double bc2 = 1.0 - pow(b2, (double)t);
+    float step_size = (float)(lr / bc1);
     float bc2_sqrt = (float)sqrt(bc2);
+    const float w1 = (float)(1.0 - b1), b2f = (float)b2, w2 = (float)(1.0 - b2), epsf = (float)eps;
     for (int64_t k = 0; k < n; ++k) {
-        m[k] = m[k] + (1.0f - b1) * (g[k] - m[k]);            /* lerp_         */
-        v[k] = b2 * v[k] + (1.0f - b2) * g[k] * g[k];          /* addcmul_      */
-        float denom = sqrtf(v[k]) / bc2_sqrt + eps;
+        m[k] = m[k] + w1 * (g[k] - m[k]);                      /* lerp_         */
+        v[k] = b2f * v[k] + w2 * g[k] * g[k];                  /* addcmul_      */
+        float denom = sqrtf(v[k]) / bc2_sqrt + epsf;
         w[k] = w[k] - step_size * (m[k] / denom);              /* addcdiv_      */
     }
 }
 
 ORC_EXPORT void orc_bpr_step_adam(float *P, float *Q, int64_t U, int64_t I,
                                   const int64_t *u, const int64_t *i, const int64_t *j,
-                                  int64_t B, int d, float lr, float b1, float b2, float eps,
+                                  int64_t B, int d, double lr, double b1, double b2, double eps,
                                   int64_t t,
                                   float *mP, float *vP, float *mQ, float *vQ,
                                   float *gP, float *gQ, double *loss_out)
@@ -185,8 +188,8 @@ ORC_EXPORT void orc_pointwise_step_sgd(float *P, float *Q, int64_t U, int64_t I,
 }
 
 ORC_EXPORT void orc_pointwise_step_adam(float *P, float *Q, int64_t U, int64_t I, const int64_t *u, const int64_t *i,
-                                        const float *y, int64_t n, int d, int loss_kind, float lr, float b1, float b2,
-                                        float eps, int64_t t, float *mP, float *vP, float *mQ, float *vQ,
+                                        const float *y, int64_t n, int d, int loss_kind, double lr, double b1, double b2,
+                                        double eps, int64_t t, float *mP, float *vP, float *mQ, float *vQ,
                                         float *gP, float *gQ, double *loss_out)
 {
     memset(gP, 0, sizeof(float) * (size_t)U * d);
@@ -372,7 +375,7 @@ ORC_EXPORT void orc_lightgcn_propagate(const int64_t *indptr, const int32_t *ind
 ORC_EXPORT void orc_lightgcn_step_adam(float *E0, float *mE, float *vE, int64_t U, int64_t I,
                                        const int64_t *indptr, const int32_t *indices, const float *vals,
                                        int L, const int64_t *u, const int64_t *i, const int64_t *j,
-                                       int64_t B, int d, float lr, float b1, float b2, float eps, int64_t t,
+                                       int64_t B, int d, double lr, double b1, double b2, double eps, int64_t t,
                                        float *out, float *dout, float *tA, float *tB, float *g,
                                        double *loss_out)
 {

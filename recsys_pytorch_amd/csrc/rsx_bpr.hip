@@ -720,17 +720,18 @@ __global__ __launch_bounds__(kBlock) void bpr_release_kernel(const int32_t *__re
 
 // dense Adam sweep as torch's single-tensor Adam does it (models/MF.py:30: lr 1e-3, betas
 // (0.9, 0.999), eps 1e-8, no weight decay), then G = 0.  Every element moves, also where g == 0.
+// The scalars arrive as torch's kernels receive them: 1 - beta formed in double on the host and rounded once.
 __global__ __launch_bounds__(kBlock) void adam_apply_kernel(float4 *__restrict__ W, float4 *__restrict__ M,
                                                             float4 *__restrict__ V, float4 *__restrict__ G,
-                                                            int64_t n4, float beta1, float beta2, float eps,
-                                                            float step_size, float bc2_sqrt)
+                                                            int64_t n4, float one_minus_beta1, float beta2, float one_minus_beta2,
+                                                            float eps, float step_size, float bc2_sqrt)
 {
     for (int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x; n < n4; n += (int64_t)gridDim.x * kBlock) {
         const float4 g = G[n];
         float4 m = M[n], v = V[n], w = W[n];
 #define RSX_ADAM1(c)                                             \
-        m.c = m.c + (1.0f - beta1) * (g.c - m.c);                \
-        v.c = beta2 * v.c + (1.0f - beta2) * g.c * g.c;          \
+        m.c = m.c + one_minus_beta1 * (g.c - m.c);               \
+        v.c = beta2 * v.c + one_minus_beta2 * g.c * g.c;         \
         w.c = w.c - step_size * (m.c / (sqrtf(v.c) / bc2_sqrt + eps));
         RSX_ADAM1(x) RSX_ADAM1(y) RSX_ADAM1(z) RSX_ADAM1(w)
 #undef RSX_ADAM1
@@ -1131,18 +1132,19 @@ RSX_API int rsx_pointwise_grad(const float *P, const float *Q, float *GP, float 
     return RSX_OK;
 }
 
-RSX_API int rsx_adam_apply(float *W, float *M, float *V, float *G, int64_t n, float lr, float beta1,
-                           float beta2, float eps, int64_t t, rsx_stream_t stream)
+RSX_API int rsx_adam_apply(float *W, float *M, float *V, float *G, int64_t n, double lr, double beta1,
+                           double beta2, double eps, int64_t t, rsx_stream_t stream)
 {
     RSX_CHECK_ARG(W && M && V && G, "null pointer");
     RSX_CHECK_ARG(n >= 0 && n % 4 == 0 && t >= 1, "n must be a multiple of 4 and t >= 1");
+    RSX_CHECK_ARG(lr >= 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0, "bad Adam hyper-parameters");
     if (n == 0) return RSX_OK;
     const double tb = (double)t + (RSX_ABL_HOST(512) ? 1.0 : 0.0);      // (dev build only: a planted error, tests/test_mutation.py)
-    const double bc1 = 1.0 - pow((double)beta1, tb);
-    const double bc2 = 1.0 - pow((double)beta2, tb);
+    const double bc1 = 1.0 - pow(beta1, tb);
+    const double bc2 = 1.0 - pow(beta2, tb);
     hipLaunchKernelGGL(adam_apply_kernel, dim3((unsigned)grid_1d(n / 4)), dim3(kBlock), 0, (hipStream_t)stream,
-                       (float4 *)W, (float4 *)M, (float4 *)V, (float4 *)G, n / 4, beta1, beta2, eps,
-                       (float)((double)lr / bc1), (float)sqrt(bc2));
+                       (float4 *)W, (float4 *)M, (float4 *)V, (float4 *)G, n / 4, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                       (float)eps, (float)(lr / bc1), (float)sqrt(bc2));
     RSX_CHECK_LAUNCH();
     return RSX_OK;
 }

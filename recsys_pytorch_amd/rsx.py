@@ -34,7 +34,7 @@ RSX_EXCHANGE_SCATTER_GATHER = 2
 SUPPORTED_DIMS = (32, 64, 128, 256)
 
 # symbol -> (restype, argtypes); mirrors include/rsx.h one to one
-_P, _I64, _I32, _F, _U, _U64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint, C.c_uint64
+_P, _I64, _I32, _F, _U, _U64, _D = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint, C.c_uint64, C.c_double
 SIGNATURES = {
     "rsx_version": (C.c_int, []),
     "rsx_last_error": (C.c_char_p, []),
@@ -48,7 +48,7 @@ SIGNATURES = {
     "rsx_apply_item_grad": (C.c_int, [_P, _P, _I64, _I32, _F, _P, _P, _I32, _P]),
     "rsx_bpr_grad": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _I64, _I32, _F, _P, _P]),
     "rsx_pointwise_grad": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _I64, _I32, _F, _I32, _P, _P]),
-    "rsx_adam_apply": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I64, _P]),
+    "rsx_adam_apply": (C.c_int, [_P, _P, _P, _P, _I64, _D, _D, _D, _D, _I64, _P]),
     "rsx_spmm_plan": (_I64, [_P, _I64, _I32, _P, _P, _P]),
     "rsx_spmm_csr": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
     "rsx_spmm_csr_sparse_rows": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),

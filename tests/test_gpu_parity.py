@@ -121,6 +121,77 @@ def test_pointwise_branch_matches_reference_golden(rsx, name):
     assert delta_err(P.cpu().numpy(), g["P0"], g["PT"]) < 1e-4 and delta_err(Q.cpu().numpy(), g["Q0"], g["QT"]) < 1e-4
 
 
+def _adam_reference(p, m, v, g, lr, t, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam's update (what models/MF.py:30 constructs: betas (0.9, 0.999), eps 1e-8, no weight decay) in fp64"""
+    p, m, v, g = (x.double() for x in (p, m, v, g))
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    p = p - (lr / (1 - b1 ** t)) * m / (v.sqrt() / (1 - b2 ** t) ** 0.5 + eps)
+    return p, m, v
+
+
+def test_dense_gradient_paths_on_random_shapes(rsx, oracle_mod):
+    """24 random problems through the paths with DENSE gradients (users and items repeat inside a batch): the pairwise gradients
+    (rsx_bpr_grad, MF.py:67) and the pointwise branch (rsx_pointwise_grad, ce / mse, MF.py:99-102), followed by the as-shipped Adam
+    (MF.py:30) or the SGD sweep, three steps each.  Every step: the gradients and the loss against the oracle's AT THE DEVICE'S TABLES
+    (2e-5 of the largest entry), and the optimizer's step from those gradients -- SGD through the oracle, Adam against
+    torch.optim.Adam's formula in fp64 on the device's own (p, m, v, g): an Adam step is +-lr wherever a gradient entry is not
+    zero, whatever its size, so two runs whose gradients differ in the last bit drift apart by 2 lr at nearly cancelling entries --
+    the step is checked from the same inputs instead (the goldens G1b pin whole trajectories)"""
+    rng, trials = fuzz(4711, 24)
+    failures = []
+    for trial in range(trials):
+        d = int(rng.choice([32, 64, 128, 256]))
+        U, I = int(rng.integers(1, 2500)), int(rng.integers(2, 2000))
+        B = int(rng.integers(1, 5000))
+        kind = ["bpr_adam", "ce_adam", "mse_sgd", "ce_sgd", "mse_adam", "bpr_adam"][trial % 6]
+        opt = kind.split("_")[1]
+        cut = 0.2
+        lr = 1e-3 * float(rng.choice([1.0, 10.0])) if opt == "adam" else resolvable_lr(B) * cut
+        P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+        Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+        P, Q = dev(P0), dev(Q0)
+        GP, GQ = torch.zeros_like(P), torch.zeros_like(Q)
+        mP, vP, mQ, vQ = (torch.zeros_like(t) for t in (P, P, Q, Q))
+        ctx = f"trial {trial}: {kind} U={U} I={I} d={d} B={B} lr={lr}"
+        try:
+            for t in range(3):
+                u = rng.integers(0, U, B)
+                i = np.minimum(I - 1, (rng.pareto(1.0, B) * 2).astype(np.int64)) if trial % 2 else rng.integers(0, I, B)
+                acc = torch.zeros(rsx.RSX_LOSS_SLOTS, dtype=torch.float32, device="cuda")
+                Pn, Qn = P.cpu().numpy(), Q.cpu().numpy()
+                orc = oracle_mod.MFOracle(Pn, Qn, "sgd", lr)                       # the oracle at the device's tables
+                if kind.startswith("bpr"):
+                    j = rng.integers(0, I, B)
+                    gP, gQ, want = orc.grad(u, i, j)
+                    rsx.bpr_grad(P, Q, GP, GQ, dev(u, torch.int32), dev(i, torch.int32), dev(j, torch.int32), 1.0 / B, loss_acc=acc)
+                    orc.step(u, i, j)
+                else:
+                    lf = kind.split("_")[0]
+                    y = (rng.integers(0, 2, B) if lf == "ce" else rng.integers(1, 6, B)).astype(np.float32)
+                    gP, gQ, want = orc.pointwise_grad(u, i, y, lf)
+                    rsx.pointwise_grad(P, Q, GP, GQ, dev(u, torch.int32), dev(i, torch.int32), dev(y, torch.float32), 1.0 / B, loss_func=lf, loss_acc=acc)
+                    orc.pointwise_step(u, i, y, lf)
+                assert rel_err(GP.cpu().numpy(), gP) < 2e-5 and rel_err(GQ.cpu().numpy(), gQ) < 2e-5, (ctx, t, "gradients")
+                assert abs(float(acc.sum()) / B - want) < 2e-5 * max(1.0, abs(want)), (ctx, t, "loss")
+                if opt == "adam":
+                    for X, m, v, Gx, name in ((Q, mQ, vQ, GQ, "Q"), (P, mP, vP, GP, "P")):
+                        pw, mw, vw = _adam_reference(X, m, v, Gx, lr, t + 1)
+                        rsx.adam_apply(X, m, v, Gx, lr, t + 1)
+                        assert float((X.double() - pw).abs().max()) <= 1e-5 * lr + 2e-7 * float(pw.abs().max()), (ctx, t, name)
+                        assert float((m.double() - mw).abs().max()) <= 1e-6 * float(mw.abs().max()) + 1e-30, (ctx, t, "m" + name)
+                        assert float((v.double() - vw).abs().max()) <= 1e-6 * float(vw.abs().max()) + 1e-30, (ctx, t, "v" + name)
+                else:
+                    rsx.apply_item_grad(Q, GQ, lr)
+                    rsx.apply_item_grad(P, GP, lr)
+                    eP, eQ = delta_err(P.cpu().numpy(), Pn, orc.P), delta_err(Q.cpu().numpy(), Qn, orc.Q)
+                    assert eP < UPDATE_TOL / cut and eQ < UPDATE_TOL / cut, (ctx, t, eP, eQ)
+                assert float(GP.abs().max()) == 0.0 and float(GQ.abs().max()) == 0.0, (ctx, t, "gradients not cleared")
+        except AssertionError as e:
+            failures.append(str(e).splitlines()[0][:400])
+    assert not failures, "\n".join(failures)
+
+
 def test_first_step_gradients(rsx):
     """dense grads of step 1 (MF.py:67): G holds dQ; dP recovered from the P update."""
     g = golden(G1_SGD[3])
