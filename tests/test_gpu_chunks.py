@@ -353,8 +353,10 @@ def test_chunked_sampler_on_random_shapes():
         n_live = int(live.sum())
         assert np.array_equal(cpa, cpb) and np.array_equal(ia, ib) and np.array_equal(ja, jb) and np.array_equal(ua[live], ub[live]), ctx
         assert len(np.unique(ua)) == B and np.all(ja[~live] == -1), ctx
-        for p in np.flatnonzero(~live & (np.arange(B) >= cpa[-1])):                       # pairs without a positive come last
-            assert len(rows[ua[p]]) == 0, ctx
+        for p in np.flatnonzero(~live & (np.arange(B) >= cpa[-1])):                       # pairs without a positive come last --
+            assert len(rows[ua[p]]) in (0, I), ctx                                        # an empty row, or one that owns the whole
+            #                                                                               catalog (no negative exists: the plain sampler's
+            #                                                                               rule too; found by the campaign at I = 21, 30)
         # cp counts the pairs that HAD a positive; a pair skipped for want of a negative keeps its place (i = -1 inside a range)
         assert cpa[0] == 0 and np.all(np.diff(cpa) >= 0) and cpa[-1] >= n_live, ctx
         inside = ia[:cpa[-1]]

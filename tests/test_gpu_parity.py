@@ -393,6 +393,45 @@ def test_deterministic_step_is_bit_reproducible_and_matches_the_oracle(rsx, orac
         rsx.bpr_step(P, Q, G, ut, it, jt, lr, 1.0, users_unique=True, deterministic=True)
 
 
+def test_deterministic_step_on_random_shapes(rsx, oracle_mod):
+    """the unique-user problems of 24 random draws (random_step_problems: any d, tiny and ragged sizes, skipped triplets, ordered or
+    shuffled batches) through RSX_DETERMINISTIC: two runs agree bit for bit, three steps equal the oracle's"""
+    rng, trials = fuzz(1313, 24)
+    failures = []
+    for pb in random_step_problems(rng, trials):
+        if not pb["unique"]:
+            continue
+        ctx = f"trial {pb['trial']}: U={pb['U']} I={pb['I']} d={pb['d']} B={pb['B']}"
+        try:
+            orc = oracle_mod.MFOracle(pb["P0"], pb["Q0"], "sgd", pb["lr"])
+            ws = torch.empty(rsx.bpr_step_det_workspace(pb["B"], pb["I"]), dtype=torch.uint8, device="cuda")
+            state = []
+            for rep in range(2):
+                P, Q = torch.from_numpy(pb["P0"]).cuda(), torch.from_numpy(pb["Q0"]).cuda()
+                G = torch.zeros_like(Q)
+                losses = []
+                for u, i, j, i_dev in pb["steps"]:
+                    live = i_dev >= 0
+                    ut, it, jt = (torch.from_numpy(x.astype(np.int32)).cuda() for x in (u, i_dev, j))
+                    loss = torch.zeros(rsx.RSX_LOSS_SLOTS, device="cuda")
+                    rsx.bpr_step(P, Q, G, ut, it, jt, pb["lr"], 1.0 / max(int(live.sum()), 1), loss_acc=loss, users_unique=True,
+                                 deterministic=True, ws=ws, wide_offsets=pb["wide"])
+                    rsx.apply_item_grad(Q, G, pb["lr"])
+                    losses.append(loss.clone())
+                    if rep == 0 and live.any():
+                        want = orc.step(u[live], i[live], j[live])
+                        assert abs(float(loss.sum()) / int(live.sum()) - want) < 2e-5 * max(1.0, abs(want)), ctx
+                state.append((P, Q, losses))
+            assert torch.equal(state[0][0], state[1][0]) and torch.equal(state[0][1], state[1][1]), ctx + ": two runs differ"
+            assert all(torch.equal(a, b) for a, b in zip(state[0][2], state[1][2])), ctx + ": the loss differs between two runs"
+            tol = UPDATE_TOL / pb["lr_cut"]
+            assert_update(state[0][0].cpu().numpy(), pb["P0"], orc.P, "P, " + ctx, tol=tol)
+            assert_update(state[0][1].cpu().numpy(), pb["Q0"], orc.Q, "Q, " + ctx, tol=tol)
+        except AssertionError as e:
+            failures.append(str(e).splitlines()[0][:400])
+    assert not failures, "\n".join(failures)
+
+
 def test_bpr_step_unique_users_fast_path_equals_general_path(rsx, oracle_mod):
     rng = np.random.default_rng(5)
     U, I, d, B = 5000, 700, 128, 3001

@@ -297,6 +297,25 @@ def test_more_ranks_item_ranges_over_the_direct_mesh_equal_one_process(oracle_mo
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(1500)
+def test_ranks_item_ranges_on_hip_kernels_on_random_shapes(oracle_mod):
+    """three random (ranks, exchange, items, ranges, row width, batch above or below two triplets per item) problems through the same
+    check on the HIP kernels (processes on the box's GPU)"""
+    from conftest import fuzz
+    rng, trials = fuzz(88, 3)
+    for trial in range(trials):
+        world = int(rng.integers(2, 4))
+        exchange = ["direct", "allreduce", "direct"][trial % 3]
+        chunks = int(rng.integers(2, 5))
+        d = int(rng.choice([32, 64, 128, 256]))
+        I = int(rng.integers(200, 6000))
+        B = int(rng.integers(I // 2 + 200, 3 * I + 500))
+        U = B + int(rng.integers(0, 2000))
+        _check_ranges(oracle_mod, world, 29500 + (os.getpid() + 163 + 19 * trial) % 2000, True, U, I, d, B, int(rng.integers(4, 12)), chunks, 3,
+                      exchange=exchange)
+
+
+@pytest.mark.gpu
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("I,chunks,exchange", [(2500, 2, "allreduce"), (9001, 3, "allreduce"), (2500, 2, "direct"), (9001, 3, "direct")])
 def test_two_ranks_item_ranges_soak(I, chunks, exchange):
