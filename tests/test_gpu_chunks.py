@@ -1,6 +1,8 @@
 """GPU: the step as a pipeline over item ranges (include/rsx.h: "item chunks") -- the chunked sampler's rules, the chunked
 step kernel against the CPU oracle on the dumped triplets, the range-by-range apply on the trainer's own stream, the
 contract check, and the full-size step through the native loop.  Run with `-m gpu` on an MI355X."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -178,6 +180,44 @@ def test_native_loop_on_random_shapes(oracle_mod):
         finally:
             tr.close()
     assert not failures, "\n".join(failures)
+
+
+_REPRO_CHILD = """
+import hashlib, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from recsys_pytorch_amd.sharded import BPREngine
+from recsys_pytorch_amd.data import synthetic_csr
+U, I, d, B = 2400, 782, 64, 1000
+ip, ix = synthetic_csr(U, I, 7, "cuda", seed=3)
+torch.manual_seed(1)
+P, Q = torch.randn(U, d, device="cuda") * 0.1, torch.randn(I, d, device="cuda") * 0.1
+eng = BPREngine(P, Q, 0.05 * B, seed=11)
+eng.set_neg_block(B, 8)
+eng.sorted_min_batch = 1
+eng.set_chunks(3)
+tr = eng.native_trainer(ip, ix, B)
+tr.run(1)
+torch.cuda.synchronize()
+h = lambda t: hashlib.md5(t.cpu().numpy().tobytes()).hexdigest()
+print("HASH", h(eng._relabel["rank_item"]), *(h(x) for x in tr.last_batch()[:3]))
+"""
+
+
+def test_item_ranges_of_a_seeded_engine_are_the_same_in_every_process():
+    """the relabelling into item ranges is a function of the seed and the data: two PROCESSES deal the items alike and sample the
+    same first batch.  (Until round 5 the items' sampling masses were float64 sums added atomically on the device: their last bits,
+    and with them the dealing of items that tie, changed from launch to launch -- found by the random-shape test of
+    tests/test_sharded_gloo.py, whose two arms are two launches; the masses are fixed-point integers now)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for _ in range(3):
+        r = subprocess.run([sys.executable, "-c", _REPRO_CHILD % root], capture_output=True, text=True, timeout=600)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("HASH")]
+        assert r.returncode == 0 and lines, r.stderr[-2000:]
+        outs.append(lines[0])
+    assert outs[0] == outs[1] == outs[2], outs
 
 
 @pytest.mark.parametrize("nb", [6, 0])

@@ -190,6 +190,8 @@ def _ranges_worker(rank, world, port, gpu, U, I, d, B, deg, chunks, steps, one_r
             trips.append((u[live] + rank * U, i[live], j[live]))
     if gpu:
         torch.cuda.synchronize()
+    lu, li, lj = (t.cpu().numpy().astype(np.int64) for t in tr.last_batch()[:3])       # what the LAST step consumed (either arm)
+    last = (lu[li >= 0] + rank * U, li[li >= 0], lj[li >= 0])
     Qm = r["Q"].cpu().numpy().copy()                            # the relabelled replica, padding rows included
     eng.adopt(tr)                                               # checks the run (no triplet left its range), item rows back to the caller's ids
     tr.close()
@@ -197,7 +199,7 @@ def _ranges_worker(rank, world, port, gpu, U, I, d, B, deg, chunks, steps, one_r
         assert eng._mesh[0].info() == (rank, world, steps * chunks)       # one exchange per item range and step went through the mesh
     eng.close_mesh()                                            # (exchange = "direct": collective -- checks that no wait gave up, barrier, unmap)
     out[rank] = (P.cpu().numpy(), eng.Q.cpu().numpy(), Qm, trips, r["rank_item"].cpu().numpy(), float(acc.sum()), P_init, Q_init,
-                 float(r["G"].abs().max()))
+                 float(r["G"].abs().max()), last)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -231,6 +233,9 @@ def _check_ranges(oracle_mod, world, port, gpu, U, I, d, B, deg, chunks, steps, 
     assert_update(P, P_init, orc.P, "P (step by step)")
     assert_update(step_arm[0][1], Q_init, orc.Q, "Q (step by step)")
     # the same steps queued by one call (same seeds, same triplets): the same tables
+    for rr in range(world):
+        for x, y, what in zip(res[True][rr][9], step_arm[rr][3][-1], "uij"):
+            assert np.array_equal(x, y), f"rank {rr}: the last step of the single call consumed other triplets ({what}) than the same step run alone"
     assert_update(np.concatenate([a[0] for a in res[True]]), P_init, P, "P (one run vs step by step)")
     assert_update(res[True][0][1], Q_init, step_arm[0][1], "Q (one run vs step by step)")
 
