@@ -175,7 +175,13 @@ class HotItems:
     def __init__(self, item_counts, num_hot, replicas, d, device):
         counts = torch.as_tensor(item_counts).to(device)
         num_hot = int(min(num_hot, counts.numel()))
-        self.items = torch.topk(counts, num_hot).indices.to(torch.int32).contiguous()
+        if not counts.dtype.is_floating_point and counts.numel() and int(counts.max()) < (1 << 31) and int(counts.min()) >= 0:
+            # (integer counts tie often: the lower item id wins, so that the same rows are replicated in every launch)
+            n = counts.numel()
+            key = counts.to(torch.int64) * n + (n - 1 - torch.arange(n, device=counts.device))
+            self.items = torch.topk(key, num_hot).indices.to(torch.int32).contiguous()
+        else:
+            self.items = torch.topk(counts, num_hot).indices.to(torch.int32).contiguous()
         self.slot = torch.full((counts.numel(),), -1, dtype=torch.int32, device=device)
         self.slot[self.items.long()] = torch.arange(num_hot, dtype=torch.int32, device=device)
         self.replicas = int(replicas)
