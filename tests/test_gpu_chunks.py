@@ -187,25 +187,36 @@ import hashlib, sys, numpy as np, torch
 sys.path.insert(0, %r)
 from recsys_pytorch_amd.sharded import BPREngine
 from recsys_pytorch_amd.data import synthetic_csr
-U, I, d, B = 2400, 782, 64, 1000
-ip, ix = synthetic_csr(U, I, 7, "cuda", seed=3)
-torch.manual_seed(1)
-P, Q = torch.randn(U, d, device="cuda") * 0.1, torch.randn(I, d, device="cuda") * 0.1
-eng = BPREngine(P, Q, 0.05 * B, seed=11)
-eng.set_neg_block(B, 8)
-eng.sorted_min_batch = 1
-eng.set_chunks(3)
-tr = eng.native_trainer(ip, ix, B)
-tr.run(1)
-torch.cuda.synchronize()
-h = lambda t: hashlib.md5(t.cpu().numpy().tobytes()).hexdigest()
-print("HASH", h(eng._relabel["rank_item"]), *(h(x) for x in tr.last_batch()[:3]))
+h = lambda t: hashlib.md5(t.cpu().numpy().tobytes()).hexdigest()[:8]
+out = []
+for name, U, I, B, chunks, ordered, hot in (("blocked", 2400, 400, 1000, 0, False, 16), ("ordered", 2400, 782, 1000, 0, True, 0),
+                                            ("plain", 2400, 782, 1000, 0, False, 8), ("ranges+blocks", 2400, 300, 1000, 3, False, 16),
+                                            ("ranges", 2400, 782, 1000, 3, True, 0)):
+    ip, ix = synthetic_csr(U, I, 7, "cuda", seed=3)
+    torch.manual_seed(1)
+    P, Q = torch.randn(U, 64, device="cuda") * 0.1, torch.randn(I, 64, device="cuda") * 0.1
+    eng = BPREngine(P, Q, 0.05 * B, seed=11)
+    eng.set_neg_block(B, 8)
+    if ordered:
+        eng.sorted_min_batch = 1
+    if hot:
+        eng.set_hot_items(torch.bincount(ix.long(), minlength=I), hot, 4)
+    if chunks:
+        eng.set_chunks(chunks)
+    tr = eng.native_trainer(ip, ix, B)
+    hs = [h(eng._relabel["rank_item"])] if chunks else []
+    for _ in range(2):
+        tr.run(1); torch.cuda.synchronize()
+        hs += [h(x) for x in tr.last_batch()[:3]]
+    out.append(name + ":" + "".join(hs))
+    tr.close()
+print("HASH", " ".join(out))
 """
 
 
 def test_item_ranges_of_a_seeded_engine_are_the_same_in_every_process():
-    """the relabelling into item ranges is a function of the seed and the data: two PROCESSES deal the items alike and sample the
-    same first batch.  (Until round 5 the items' sampling masses were float64 sums added atomically on the device: their last bits,
+    """what a seeded engine samples is a function of the seed and the data in every layout (blocked, ordered, plain, item ranges with
+    and without blocks): three PROCESSES deal the items to the ranges alike and sample the same first two batches.  (Until round 5 the items' sampling masses were float64 sums added atomically on the device: their last bits,
     and with them the dealing of items that tie, changed from launch to launch -- found by the random-shape test of
     tests/test_sharded_gloo.py, whose two arms are two launches; the masses are fixed-point integers now)"""
     import subprocess
