@@ -116,6 +116,63 @@ def test_hidden_dim_256_and_padding_d200_through_the_model(oracle_mod):
         assert safe.mean() > 0.9 and all(set(top[r]) == set(want[r]) for r in np.nonzero(safe)[0])
 
 
+def test_model_on_random_shapes(oracle_mod):
+    """12 random (users, items, ANY hidden_dim in 1 .. 256, batch, pairwise or pointwise / ce or mse, seen-item matrix) models through the
+    class a user of the reference holds: replayed batches (train_step) against the oracle at the model's own width, the zero pad still zero,
+    predict_batch_users, predict (the dense matrix with -inf at eval_pos, MF.py:114-132) and predict_topk against the oracle's scores /
+    mask / partial sort"""
+    import scipy.sparse as sp
+    import recsys_pytorch_amd as pkg
+    rng, trials = fuzz(2718, 12)
+    for trial in range(trials):
+        d = int(rng.integers(1, 257)) if trial % 3 else int(rng.choice([1, 31, 33, 64, 129, 255, 256]))
+        U, I, B = int(rng.integers(2, 1500)), int(rng.integers(2, 1200)), int(rng.integers(1, 2000))
+        pointwise = trial % 4 == 3
+        lf = "mse" if (pointwise and trial % 8 == 7) else "ce"
+        lr = resolvable_lr(B) * 0.2
+        ctx = f"trial {trial}: U={U} I={I} hidden_dim={d} B={B} pointwise={pointwise} {lf}"
+        ds = types.SimpleNamespace(num_users=U, num_items=I)
+        m = pkg.MF(ds, dict(HP, hidden_dim=d, lr=lr, pointwise=pointwise, loss_func=lf), "cuda")
+        P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+        Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+        m.load_tables(P0, Q0)
+        orc = oracle_mod.MFOracle(P0, Q0, "sgd", lr)
+        for t in range(3):
+            u, i = rng.integers(0, U, B), rng.integers(0, I, B)
+            if pointwise:
+                y = (rng.integers(0, 2, B) if lf == "ce" else rng.integers(1, 6, B)).astype(np.float32)
+                want = orc.pointwise_step(u, i, y, lf)
+                got = float(m.train_step(u, i, y))
+            else:
+                j = rng.integers(0, I, B)
+                want = orc.step(u, i, j)
+                got = float(m.train_step(u, i, j))
+            assert abs(got - want) < 2e-5 * max(1.0, abs(want)), (ctx, t)
+        assert_update(m.user_embedding.weight.cpu().numpy(), P0, orc.P, "P, " + ctx, tol=5e-5)
+        assert_update(m.item_embedding.weight.cpu().numpy(), Q0, orc.Q, "Q, " + ctx, tol=5e-5)
+        if d < m._P.shape[1]:
+            assert float(m._P[:, d:].abs().max()) == 0.0 and float(m._Q[:, d:].abs().max()) == 0.0, ctx
+        users = rng.permutation(U)[:min(U, 150)]
+        S = m.predict_batch_users(users).cpu().numpy()
+        So = orc.score(users)
+        assert np.abs(S - So).max() <= 2e-6 * max(np.abs(So).max(), 1e-30), ctx
+        seen = sp.random(U, I, density=min(1.0, 8.0 / I), format="csr", random_state=np.random.default_rng(trial), dtype=np.float32)
+        seen.data[:] = 1.0
+        full = m.predict(users, seen, 64)
+        ref = oracle_mod.mask_seen(orc.score(np.arange(U)), np.arange(U), seen.indptr.astype(np.int64), seen.indices.astype(np.int32))
+        assert np.array_equal(np.isneginf(full[users]), np.isneginf(ref[users])), ctx
+        fin = np.isfinite(ref[users])
+        assert not fin.any() or np.abs(full[users][fin] - ref[users][fin]).max() <= 2e-6 * max(np.abs(So).max(), 1e-30), ctx
+        K = int(rng.integers(1, min(I, 50) + 1))
+        top = m.predict_topk(users, seen, K)
+        for r, uu in enumerate(users):
+            row = ref[uu]
+            kth = np.sort(row)[-K]
+            assert len(set(top[r])) == K, ctx
+            if np.isfinite(kth):                                # (fewer than K unseen items: the tail is arbitrary among -inf)
+                assert all(row[x] >= kth - (1e-5 + 2e-6 * np.abs(So).max()) for x in top[r]), (ctx, r)
+
+
 def test_hidden_dim_padding_d50(oracle_mod):
     """conf/MF.yaml ships hidden_dim 50: stored as 64 columns, the pad stays zero"""
     import recsys_pytorch_amd as pkg
