@@ -209,6 +209,50 @@ def test_hip_spmm_on_random_graphs():
 
 
 @pytest.mark.gpu
+def test_hip_lightgcn_on_random_graphs(oracle_mod):
+    """10 random interaction matrices (users and items WITHOUT any interaction -- isolated nodes, zero rows of the adjacency -- short
+    and long rows; any emb_dim in 1 .. 256; 1-4 layers) through the model class: the propagated embeddings (LightGCN.py:174-202)
+    against the oracle's to 2e-6, the loss of the first two steps to 1e-5, and after them the base tables within two Adam steps
+    of the oracle's (|delta| <= 2 lr everywhere and the mean far below: an Adam step is +-lr at any non-zero gradient entry,
+    so entries whose gradient nearly cancels may differ by a step -- the goldens G6 pin whole trajectories)"""
+    import recsys_pytorch_amd as pkg
+    from conftest import fuzz
+    rng, trials = fuzz(606, 10)
+    for trial in range(trials):
+        U, I = int(rng.integers(2, 900)), int(rng.integers(2, 700))
+        d = int(rng.integers(1, 257)) if trial % 2 else int(rng.choice([32, 64, 128, 256]))
+        L = int(rng.integers(1, 5))
+        dens = float(rng.choice([0.002, 0.02, 0.2]))
+        R = sp.random(U, I, density=dens, format="csr", random_state=np.random.default_rng(1000 + trial), dtype=np.float32)
+        R.data[:] = 1.0
+        if R.nnz == 0:
+            R = sp.csr_matrix(([1.0], ([0], [0])), shape=(U, I), dtype=np.float32)
+        B = int(rng.integers(1, 600))
+        ctx = f"trial {trial}: U={U} I={I} emb_dim={d} L={L} nnz={R.nnz} B={B}"
+        P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+        Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+        ds = types.SimpleNamespace(num_users=U, num_items=I, dataname="t")
+        m = pkg.LightGCN(ds, {"emb_dim": d, "num_layers": L, "node_dropout": 0.0, "split": False, "num_folds": 100, "reg": 1e-4,
+                              "graph_dir": "graph"}, "cuda")
+        m.load_tables(P0, Q0)
+        m.getSparseGraph(R)
+        orc = oracle_mod.LightGCNOracle(P0, Q0, oracle_mod.normalized_adjacency(R), L)
+        m.update_lightgcn_embedding()
+        ou, oi = orc.propagate()
+        scale = max(np.abs(ou).max(), np.abs(oi).max(), 1e-30)
+        assert np.abs(m.user_embeddings[:, :d].cpu().numpy() - ou).max() <= 2e-6 * scale, ctx
+        assert np.abs(m.item_embeddings[:, :d].cpu().numpy() - oi).max() <= 2e-6 * scale, ctx
+        for t in range(2):
+            u, i, j = rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)
+            want = orc.step(u, i, j)
+            got = float(m.train_step(u, i, j))
+            assert abs(got - want) < 1e-5 * max(1.0, abs(want)), (ctx, t)
+        E = np.concatenate([m.user_embedding.weight.cpu().numpy(), m.item_embedding.weight.cpu().numpy()])
+        diff = np.abs(E - orc.E0)
+        assert diff.max() <= 2.0 * orc.lr * 1.001 + 1e-7 and diff.mean() <= 0.02 * orc.lr, (ctx, float(diff.max()), float(diff.mean()))
+
+
+@pytest.mark.gpu
 def test_hip_lightgcn_fit_and_topk_end_to_end():
     """fit() on ml-100k with the evaluator: loss goes down, predict and predict_topk agree"""
     import recsys_pytorch_amd as pkg

@@ -13,6 +13,7 @@ for seed in $(seq ${1:-1} ${2:-4}); do
         "tests/test_gpu_parity.py::test_score_mask_topk_on_random_shapes" "tests/test_lightgcn.py::test_hip_spmm_on_random_graphs" \
         "tests/test_gpu_chunks.py::test_native_loop_on_random_shapes" "tests/test_gpu_parity.py::test_dense_gradient_paths_on_random_shapes" \
         "tests/test_gpu_parity.py::test_deterministic_step_on_random_shapes" "tests/test_gpu_model.py::test_model_on_random_shapes" \
+        "tests/test_lightgcn.py::test_hip_lightgcn_on_random_graphs" \
         2>&1 | grep -v "amdgpu.ids" | tail -40 >> $out
 done
 grep -c passed $out
