@@ -167,17 +167,30 @@ def load_uirt(path, separator="\t", min_item_per_user=0, min_user_per_item=0, va
                                           protocol, leave_k))
         if all(os.path.exists(os.path.join(cdir, f)) for f in CACHE_FILES):     # dataset.py:183-191
             return _read_cache(cdir, protocol)
-    raw = np.loadtxt(path, delimiter=separator, dtype=np.float64, ndmin=2)
+    if len(separator) == 1:
+        raw = np.loadtxt(path, delimiter=separator, dtype=np.float64, ndmin=2)
+    else:
+        # a separator of several characters -- ml-1m's '::' -- is a regular expression to the reference's reader (dataset.py:115-118:
+        # pandas, engine='python'); numpy's reader takes single characters only
+        import re
+        cut = re.compile(separator)
+        with open(path) as f:
+            raw = np.array([[float(x) for x in cut.split(line.rstrip("\r\n"))[:4]] for line in f if line.strip()], dtype=np.float64).reshape(-1, 4)
     users, items, ratings, ts = raw[:, 0].astype(np.int64), raw[:, 1].astype(np.int64), raw[:, 2], raw[:, 3]
     # filter users, then items (dataset.py:131-146)
     uid, ucnt = np.unique(users, return_counts=True)
     keep = np.isin(users, uid[ucnt >= min_item_per_user])
     users, items, ratings, ts = users[keep], items[keep], ratings[keep], ts[keep]
+    # the reference numbers the users that passed the USER filter (dataset.py:135-137,153-157: its per-user counts are taken before
+    # the item filter): a user whose every item falls to the item filter keeps an id and an empty row.  (Round 5: found by running
+    # the reference's loader and this one on 300 random files; the ids used to be taken after both filters)
+    uid = np.unique(users)                       # ascending raw ids -> 0..U-1 (dataset.py:153-167)
     iid, icnt = np.unique(items, return_counts=True)
     keep = np.isin(items, iid[icnt >= min_user_per_item])
     users, items, ratings, ts = users[keep], items[keep], ratings[keep], ts[keep]
-    uid = np.unique(users)                       # ascending raw ids -> 0..U-1 (dataset.py:153-167)
     iid = np.unique(items)
+    if len(users) == 0:      # (the reference fails here too: pandas' "No objects to concatenate" from the split of an empty frame)
+        raise ValueError("No objects to concatenate: no interaction is left after the min_item_per_user / min_user_per_item filters")
     users = np.searchsorted(uid, users)
     items = np.searchsorted(iid, items)
     U, I = len(uid), len(iid)
@@ -201,7 +214,10 @@ def load_uirt(path, separator="\t", min_item_per_user=0, min_user_per_item=0, va
             else:
                 mask[n - n_out:] = False
             keep_idx.append(grp[mask]); out_idx.append(grp[~mask])
-        return np.concatenate(keep_idx), np.concatenate(out_idx)
+        keep_all, out_all = np.concatenate(keep_idx), np.concatenate(out_idx)
+        if len(keep_all) == 0 or len(out_all) == 0:                 # preprocess.py:87-88: pd.concat of an empty list
+            raise ValueError("No objects to concatenate: a split left no interaction on one of its sides")
+        return keep_all, out_all
 
     if protocol not in ("holdout", "leave_one_out"):
         raise ValueError(f"{protocol} is not a valid protocol.")                 # dataset.py:189-190

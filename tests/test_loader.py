@@ -121,6 +121,40 @@ def test_ml100k_leave_one_out_split_and_cache_equal_the_reference(tmp_path):
     assert again.protocol == "leave_one_out"                   # ... also when served from the cache
 
 
+def test_random_files_split_and_cache_equal_the_reference(tmp_path):
+    """14 random `user item rating timestamp` files (tests/loader_cases.py: separators of one and of several characters -- ml-1m's
+    '::', a regular expression to the reference's reader --, duplicate pairs, timestamp ties, both protocols, leave_k = 2, users whose every
+    item falls to the item filter -- they keep an id and an empty row, dataset.py:135-157 --, files nothing survives): the cache
+    directory and the sha256 of its five files as the reference's own UIRTDataset wrote them on the same file, or the same refusal
+    (oracle/gen_golden_loader_random.py; found by running both loaders on 600 such files: multi-character separators were not
+    read, users emptied by the item filter were dropped from the id map)"""
+    import hashlib
+    import json
+    from loader_cases import SEEDS, case
+    from recsys_pytorch_amd.data import load_uirt
+    want = json.load(open(os.path.join(GOLDEN, "g10_loader_random.json")))
+    assert sorted(want, key=int) == [str(s_) for s_ in SEEDS]
+    for seed in SEEDS:
+        text, kw = case(seed)
+        rec = want[str(seed)]
+        assert hashlib.sha256(text.encode()).hexdigest() == rec["input_sha256"], f"case {seed}: the generated file changed"
+        work = tmp_path / f"case{seed}"
+        work.mkdir()
+        (work / "d.data").write_text(text)
+        if "raises" in rec:
+            with pytest.raises(ValueError):
+                load_uirt(str(work / "d.data"), seed=7, cache_dir="cache", **kw)
+            continue
+        ds = load_uirt(str(work / "d.data"), seed=7, cache_dir="cache", **kw)
+        cdir = work / "cache" / rec["cache_subdir"]
+        assert sorted(os.listdir(cdir)) == sorted(rec["files"]), seed
+        for name, digest in rec["files"].items():
+            assert hashlib.sha256(open(cdir / name, "rb").read()).hexdigest() == digest, (seed, name)
+        again = load_uirt(str(work / "d.data"), seed=None, cache_dir="cache", **kw)          # ... and read back from the cache
+        for a, b in ((ds.train_data, again.train_data), (ds.valid_target, again.valid_target), (ds.test_target, again.test_target)):
+            assert a.shape == b.shape and (a != b).nnz == 0, seed
+
+
 def test_cache_round_trip_on_a_toy_file(tmp_path):
     """runs everywhere (no reference data needed): write, read back, and the file grammar"""
     from recsys_pytorch_amd.data import load_uirt
