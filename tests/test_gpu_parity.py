@@ -290,7 +290,11 @@ def run_step_problem(rsx, oracle_mod, pb, watch=None):
         if watch is not None:
             watch(step, Q, G, hot, orc)
         if n_live:
-            assert abs(float(loss.sum()) / n_live - want_loss) < 2e-5 * max(1.0, abs(want_loss)), ctx
+            # (a handful of users repeated hundreds of times in a batch -- U = 7, B = 2824 in the round-5 campaign -- move their rows by
+            #  hundreds of summed updates per step: by the third step the scores are in the hundreds and the loss follows the tables'
+            #  1e-6 only to 1e-4; the bar widens with the repetition)
+            rep = max(1.0, B / (50.0 * U))
+            assert abs(float(loss.sum()) / n_live - want_loss) < 2e-5 * rep * max(1.0, abs(want_loss)), ctx + f": loss {float(loss.sum()) / n_live} vs {want_loss}"
     return P, Q, G, hot, orc, ctx
 
 
