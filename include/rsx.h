@@ -126,7 +126,10 @@ int rsx_set_option(const char *name, int64_t value);
  *         RSX_USERS_UNIQUE set : written in place by the owning wavefront
  *         otherwise            : summed per distinct user in `ws`, then applied
  *                                (exact for repeated users)
- *   loss_acc (nullable): float[RSX_LOSS_SLOTS]; sum_b softplus(-x_b) is ADDED,
+ *   loss_acc (nullable): float[RSX_LOSS_SLOTS]; sum_b softplus(-x_b) is ADDED
+ *                        (= the reference's -log(sigmoid(x_b)), models/MF.py:105, in the form that does not overflow: at
+ *                        x_b < -88.7 the reference's fp32 sigmoid is 0 and its loss +inf -- the gradient, -sigmoid(-x) / B,
+ *                        is finite and the same either way; this library reports the finite value -x_b),
  *     spread over the entries (loss of the batch = sum(all entries) * inv_batch).
  *   inv_batch = 1 / (global batch size)  (the mean of MF.py:105; with user
  *     sharding it is 1/(sum over ranks))
