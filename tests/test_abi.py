@@ -88,6 +88,41 @@ def test_argument_errors_use_the_error_channel(libpath):
     assert rc == -1
 
 
+_NULL_SWEEP = """
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from recsys_pytorch_amd import rsx
+L = rsx.lib()
+sizing = {"rsx_bpr_item_cdf_workspace", "rsx_bpr_sample_workspace", "rsx_bpr_step_det_workspace", "rsx_bpr_step_workspace", "rsx_chunk_rows",
+          "rsx_score_topk_workspace"}
+bad = []
+for name, (res, args) in sorted(rsx.SIGNATURES.items()):
+    if name in ("rsx_last_error", "rsx_version"):
+        continue
+    for pat in (0, -1, 7):
+        a = [None if t in (C.c_void_p, C.c_char_p) else 0.0 if t in (C.c_float, C.c_double) else (abs(pat) if t in (C.c_uint, C.c_uint64) else pat)
+             for t in args]
+        print("CALL", name, pat, flush=True)
+        rc = getattr(L, name)(*a)
+        if res is C.c_int and rc >= 0 and name not in sizing:
+            bad.append((name, pat, rc))
+print("DONE", bad)
+"""
+
+
+def test_every_entry_point_refuses_null_pointers_and_garbage_sizes(libpath):
+    """every function of include/rsx.h called with ALL pointers null and every size 0, -1 and 7 (in a child process: a crash would be
+    reported, not fatal): an error code through the error channel -- only the sizing functions may answer -- and no crash.  Runs
+    without a GPU: the argument checks come before anything touches the device"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", _NULL_SWEEP % ROOT], capture_output=True, text=True, timeout=300)
+    last = [ln for ln in r.stdout.splitlines() if ln.startswith("CALL")][-1:] or ["(none)"]
+    assert r.returncode == 0, f"crashed in / after {last[0]}: {r.stderr[-1500:]}"
+    done = [ln for ln in r.stdout.splitlines() if ln.startswith("DONE")]
+    assert done and done[0] == "DONE []", done
+
+
 def test_trainer_config_binding_mirrors_the_header_struct(libpath, tmp_path):
     """recsys_pytorch_amd/rsx.py:TrainerConfig against include/rsx.h:rsx_bpr_trainer_config: same fields in the same
     order, and the same size and offsets as the C compiler lays them out (a probe compiled from the header)"""
