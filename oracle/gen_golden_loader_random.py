@@ -37,7 +37,13 @@ def main():
         random.seed(7); np.random.seed(7)          # utils/general.py:31-38 via main.py:30
         rec = {"params": {k: v for k, v in kw.items()}, "input_sha256": hashlib.sha256(text.encode()).hexdigest()}
         try:
-            UIRTDataset(data_path=path, generalization="weak", **kw)
+            ds = UIRTDataset(data_path=path, generalization="weak", **kw)
+            rec["shape"] = [int(ds.num_users), int(ds.num_items)]
+            rec["matrices"] = {}
+            for part, m in (("train", ds.train_data), ("valid", ds.valid_target), ("test", ds.test_target)):
+                m = m.tocsr().copy(); m.sum_duplicates(); m.sort_indices()
+                rec["matrices"][part] = hashlib.sha256(m.indptr.astype(np.int64).tobytes() + m.indices.astype(np.int64).tobytes()
+                                                       + m.data.astype(np.float64).tobytes()).hexdigest()
             (sub,) = os.listdir(os.path.join(work, "cache"))
             rec["cache_subdir"] = sub
             rec["files"] = {name: hashlib.sha256(open(os.path.join(work, "cache", sub, name), "rb").read()).hexdigest()

@@ -126,8 +126,9 @@ def _read_cache(cdir, protocol="holdout"):
     for name in ("train", "valid", "test"):
         raw = np.loadtxt(os.path.join(cdir, name + ".csv"), delimiter=",", dtype=np.float64, ndmin=2)
         m = sp.csr_matrix((np.ones(len(raw)), (raw[:, 0].astype(np.int64), raw[:, 1].astype(np.int64))), shape=(U, I))
-        m.sum_duplicates()
-        m.data[:] = 1.0                                         # implicit=True: ratings binarised at load
+        m.sum_duplicates()                                      # implicit=True: every rating becomes 1 at load (dataset.py:46-51); a pair
+        #                                                         listed twice in the file then holds 2, as in the reference's
+        #                                                         csr_matrix((ones, (users, items))) (utils/types.py:5-11)
         mats.append(m)
     return InteractionData(*mats, protocol=protocol)
 
@@ -227,8 +228,7 @@ def load_uirt(path, separator="\t", min_item_per_user=0, min_user_per_item=0, va
 
     def csr(idx):
         m = sp.csr_matrix((np.ones(len(idx)), (users[idx], items[idx])), shape=(U, I))
-        m.sum_duplicates()
-        m.data[:] = 1.0
+        m.sum_duplicates()                                      # (a pair listed twice holds 2, as in the reference: see _read_cache)
         return m
     if cdir is not None:
         _write_cache(cdir, {n: (users[ix], items[ix], ratings[ix], ts[ix]) for n, ix in

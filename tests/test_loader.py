@@ -150,6 +150,13 @@ def test_random_files_split_and_cache_equal_the_reference(tmp_path):
         assert sorted(os.listdir(cdir)) == sorted(rec["files"]), seed
         for name, digest in rec["files"].items():
             assert hashlib.sha256(open(cdir / name, "rb").read()).hexdigest() == digest, (seed, name)
+        # the matrices the reference holds in memory after loading (a pair listed twice in the file holds 2: utils/types.py:5-11)
+        assert list(ds.train_data.shape) == rec["shape"], seed
+        for part, m in (("train", ds.train_data), ("valid", ds.valid_target), ("test", ds.test_target)):
+            m = m.tocsr().copy(); m.sum_duplicates(); m.sort_indices()
+            digest = hashlib.sha256(m.indptr.astype(np.int64).tobytes() + m.indices.astype(np.int64).tobytes()
+                                    + m.data.astype(np.float64).tobytes()).hexdigest()
+            assert digest == rec["matrices"][part], (seed, part)
         again = load_uirt(str(work / "d.data"), seed=None, cache_dir="cache", **kw)          # ... and read back from the cache
         for a, b in ((ds.train_data, again.train_data), (ds.valid_target, again.valid_target), (ds.test_target, again.test_target)):
             assert a.shape == b.shape and (a != b).nnz == 0, seed
