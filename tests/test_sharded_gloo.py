@@ -402,6 +402,42 @@ def test_two_ranks_on_hip_kernels_equal_one_process(oracle_mod, exchange):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(1500)
+def test_ranks_routed_steps_on_random_shapes(oracle_mod):
+    """four random (ranks 2-4, exchange, users, items -- fewer than ranks too --, row width, batch, unique users or repeats) problems: every
+    rank steps on the triplets routed to its user block (BPREngine.route / step), the ranks together equal ONE process on the whole
+    batch, the item replicas are identical"""
+    from conftest import fuzz
+    rng, trials = fuzz(4040, 4)
+    for trial in range(trials):
+        world = int(rng.integers(2, 5))
+        exchange = ["allreduce", "scatter_gather", "direct"][trial % 3]
+        unique = bool(trial % 2)
+        d = int(rng.choice([32, 64, 128, 256]))
+        U, I = int(rng.integers(world, 3000)), int(rng.integers(2, 2500))
+        B = int(rng.integers(1, U + 1)) if unique else int(rng.integers(1, 3000))
+        T = 3
+        lr = resolvable_lr(B)
+        P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+        Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+        batches = [((rng.permutation(U)[:B] if unique else rng.integers(0, U, B)), rng.integers(0, I, B), rng.integers(0, I, B)) for _ in range(T)]
+        ctx = f"trial {trial}: world={world} {exchange} unique={unique} U={U} I={I} d={d} B={B}"
+        single = oracle_mod.MFOracle(P0, Q0, "sgd", lr)
+        ref_losses = [single.step(*b) for b in batches]
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_gpu_worker, args=(world, 29500 + (os.getpid() + 173 + 23 * trial) % 2000, P0, Q0, batches, lr, out, unique, exchange), nprocs=world, join=True)
+        P = np.zeros_like(P0)
+        for r in range(world):
+            lo, hi, Pr, Qr, losses = out[r]
+            P[lo:hi] = Pr
+            assert np.allclose(losses, ref_losses, rtol=2e-5, atol=1e-6), ctx
+            assert np.array_equal(out[0][3], Qr), ctx + f": item replica of rank {r} diverged"
+        assert_update(P, P0, single.P, "P, " + ctx)
+        assert_update(out[0][3], Q0, single.Q, "Q, " + ctx)
+
+
+@pytest.mark.gpu
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("exchange", ["allreduce", "scatter_gather", "direct"])      # ("direct": one pass, the mesh exposed)
 def test_two_ranks_on_hip_kernels_with_the_exchange_under_the_user_pass(oracle_mod, exchange):
