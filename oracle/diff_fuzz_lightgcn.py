@@ -17,7 +17,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     d, L = int(rng.integers(1, 130)), int(rng.integers(1, 5))
     dens = float(rng.choice([0.005, 0.05, 0.3]))
     R = sp.random(U, I, density=dens, format="csr", random_state=np.random.default_rng(seed + 1), dtype=np.float32)
-    R.data[:] = 1.0
+    R.data[:] = 1.0 if seed % 2 else rng.choice([1.0, 1.0, 2.0, 3.0], R.nnz)     # (a pair listed twice in the raw file holds 2 in the train matrix)
     if R.nnz == 0:
         continue
     gdir = "/tmp/rsx_diff_fuzz/graph"; shutil.rmtree(gdir, ignore_errors=True); os.makedirs(gdir)
