@@ -19,12 +19,18 @@ class InteractionData:
     """Duck type of the reference's UIRTDataset for the MF path (weak generalisation:
     eval input == train matrix, data/dataset.py:229-248)."""
 
-    def __init__(self, train_data, valid_target=None, test_target=None, protocol="holdout"):
+    def __init__(self, train_data, valid_target=None, test_target=None, protocol="holdout", dataname=None, user2id=None, item2id=None):
         self.train_data = sp.csr_matrix(train_data)
         self.num_users, self.num_items = self.train_data.shape
         self.valid_target = valid_target
         self.test_target = test_target
         self.protocol = protocol
+        # what else a caller of the reference's UIRTDataset reads (data/dataset.py:19,55-56,67): the name LightGCN files its graph
+        # under, the raw-id -> id maps, the users that have a train row (weak generalisation: the same list three times)
+        self.dataname = dataname
+        self.user2id, self.item2id = user2id, item2id
+        users = np.flatnonzero(np.diff(self.train_data.indptr)).tolist()
+        self.train_users = self.valid_users = self.test_users = users
 
     @property
     def valid_input(self):
@@ -117,11 +123,11 @@ def _write_cache(cdir, parts, user_raw, item_raw):
 
 def _read_cache(cdir, protocol="holdout"):
     """data/dataset.py:43-66,209-212: id maps give the table sizes, the three csv files the matrices"""
-    sizes = []
+    maps = []
     for name in ("user_map", "item_map"):
-        with open(os.path.join(cdir, name), "rt") as f:
-            sizes.append(sum(1 for line in f if line.strip()))
-    U, I = sizes
+        with open(os.path.join(cdir, name), "rt") as f:              # dataset.py:229-235
+            maps.append({int(a): int(b) for a, b in (line.strip().split(", ") for line in f if line.strip())})
+    U, I = len(maps[0]), len(maps[1])
     mats = []
     for name in ("train", "valid", "test"):
         raw = np.loadtxt(os.path.join(cdir, name + ".csv"), delimiter=",", dtype=np.float64, ndmin=2)
@@ -130,7 +136,7 @@ def _read_cache(cdir, protocol="holdout"):
         #                                                         listed twice in the file then holds 2, as in the reference's
         #                                                         csr_matrix((ones, (users, items))) (utils/types.py:5-11)
         mats.append(m)
-    return InteractionData(*mats, protocol=protocol)
+    return InteractionData(*mats, protocol=protocol, dataname=os.path.basename(os.path.dirname(os.path.dirname(cdir))), user2id=maps[0], item2id=maps[1])
 
 
 def load_uirt(path, separator="\t", min_item_per_user=0, min_user_per_item=0, valid_ratio=0.1,
@@ -233,4 +239,5 @@ def load_uirt(path, separator="\t", min_item_per_user=0, min_user_per_item=0, va
     if cdir is not None:
         _write_cache(cdir, {n: (users[ix], items[ix], ratings[ix], ts[ix]) for n, ix in
                             (("train", train), ("valid", valid), ("test", test))}, uid, iid)
-    return InteractionData(csr(train), csr(valid), csr(test), protocol=protocol)
+    return InteractionData(csr(train), csr(valid), csr(test), protocol=protocol, dataname=os.path.basename(os.path.dirname(os.path.abspath(path))),
+                           user2id={int(old): new for new, old in enumerate(uid)}, item2id={int(old): new for new, old in enumerate(iid)})

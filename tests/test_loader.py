@@ -160,6 +160,13 @@ def test_random_files_split_and_cache_equal_the_reference(tmp_path):
         again = load_uirt(str(work / "d.data"), seed=None, cache_dir="cache", **kw)          # ... and read back from the cache
         for a, b in ((ds.train_data, again.train_data), (ds.valid_target, again.valid_target), (ds.test_target, again.test_target)):
             assert a.shape == b.shape and (a != b).nnz == 0, seed
+        # what else a caller of the reference's dataset object reads (dataset.py:19,55-56,67; checked against the reference's own
+        # object in the build container): the directory's name, the raw-id maps in ascending raw id, the users with a train row
+        for d_ in (ds, again):
+            assert d_.dataname == f"case{seed}" and len(d_.user2id) == d_.num_users and len(d_.item2id) == d_.num_items
+            assert list(d_.user2id.values()) == list(range(d_.num_users)) and sorted(d_.user2id) == list(d_.user2id)
+            assert d_.train_users == np.flatnonzero(np.diff(d_.train_data.indptr)).tolist() and d_.valid_users is d_.train_users
+        assert ds.user2id == again.user2id and ds.item2id == again.item2id
 
 
 def test_cache_round_trip_on_a_toy_file(tmp_path):
