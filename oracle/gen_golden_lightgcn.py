@@ -111,6 +111,13 @@ def main():
     R5 = sp.csr_matrix((np.ones(U5 * 12), np.concatenate(rows), np.arange(U5 + 1) * 12), shape=(U5, I5))
     mk5 = lambda B, T: [(rng5.integers(0, U5, B), rng5.integers(0, I5, B), rng5.integers(0, I5, B)) for _ in range(T)]
     run("g6_lightgcn_200x150_d128_L3", R5, 128, 3, mk5(128, 6), 41)
+    # (round 5) an emb_dim the kernels store padded (50 -> 64 columns), isolated users and items (rows / columns without interactions),
+    # four layers
+    rng7 = np.random.default_rng(77)
+    R7 = sp.random(120, 90, density=0.03, format="csr", random_state=np.random.default_rng(7))
+    R7.data[:] = 1.0
+    mk7 = lambda B, T: [(rng7.integers(0, 120, B), rng7.integers(0, 90, B), rng7.integers(0, 90, B)) for _ in range(T)]
+    run("g6_lightgcn_120x90_d50_L4_isolated", R7, 50, 4, mk7(64, 6), 51)
 
 
 if __name__ == "__main__":

@@ -11,7 +11,8 @@ import torch
 from conftest import GOLDEN, golden, rel_err, split_batches
 
 G6 = ["g6_lightgcn_50x40_d32_L1", "g6_lightgcn_50x40_d32_L2", "g6_lightgcn_50x40_d32_L3",
-      "g6_lightgcn_ml100k_d64_L2", "g6_lightgcn_200x150_d128_L3"]    # the last: BASELINE configs[4] model shape
+      "g6_lightgcn_ml100k_d64_L2", "g6_lightgcn_200x150_d128_L3",     # BASELINE configs[4] model shape
+      "g6_lightgcn_120x90_d50_L4_isolated"]                             # (round 5) emb_dim 50 (stored as 64), isolated nodes, 4 layers
 
 
 def graph_of(g):
