@@ -75,6 +75,9 @@ G1_SGD = ["g1_sgd_200x100_d32_b64", "g1_sgd_ml100k_d32_b256",
           "g1_sgd_500x300_d64_b257", "g1_sgd_400x250_d128_b512", "g1_sgd_300x180_d256_b300"]
 G1_ADAM = ["g1b_adam_200x100_d32_b64", "g1b_adam_ml100k_d32_b256", "g1b_adam_150x90_d256_b64"]
 G1_PADDED = ["g1c_sgd_biglr_260x140_d200_b200", "g1c_sgd_biglr_150x90_d1_b64", "g1c_sgd_biglr_220x130_d77_b128"]    # (d 1, 77: oracle/gen_golden_odd_dims.py)
+# the reference exactly as it ships (BASELINE configs[0]): hidden_dim 50 (stored as 64 columns), Adam, its own generator's ml-100k batches
+# (oracle/gen_golden_shipped_config.py) -- replayed by the oracle test and, through the model class, on the GPU
+G1_ADAM_PADDED = ["g1b_adam_ml100k_d50_b256"]
 G23 = [n.replace("g1_sgd", "g23") for n in G1_SGD]
 # G8: the pointwise branch (models/MF.py:99-102), oracle/gen_golden_pointwise.py
 G8_POINTWISE = ["g8_pointwise_ce_sgd_300x200_d32", "g8_pointwise_mse_sgd_200x150_d64", "g8_pointwise_ce_adam_250x120_d128",

@@ -72,6 +72,22 @@ def test_model_adam_as_shipped_matches_reference_golden(ml100k):
     assert rel_err(m.item_embedding.weight.cpu().numpy(), g["QT"]) < 1e-5
 
 
+def test_model_as_the_reference_ships_it(ml100k):
+    """BASELINE configs[0] to the letter: conf/MF.yaml's hidden_dim 50 (stored as 64 columns), optimizer = the shipped Adam, ml-100k, the
+    first 12 batches of the reference's own generator -- losses and tables against the reference's (oracle/gen_golden_shipped_config.py)"""
+    import recsys_pytorch_amd as pkg
+    g = golden("g1b_adam_ml100k_d50_b256")
+    m = pkg.MF(ml100k, dict(HP, hidden_dim=50, optimizer="adam"), "cuda")
+    assert m.lr == 1e-3 and m._P.shape[1] == 64
+    m.load_tables(g["P0"], g["Q0"])
+    for t, (u, i, j) in enumerate(split_batches(g)):
+        assert abs(float(m.train_step(u, i, j)) - g["loss"][t]) < 1e-5
+    P, Q = m.user_embedding.weight.cpu().numpy(), m.item_embedding.weight.cpu().numpy()
+    assert P.shape[1] == 50 and rel_err(P, g["PT"]) < 1e-5 and rel_err(Q, g["QT"]) < 1e-5
+    assert delta_err(P, g["P0"], g["PT"]) < 1e-4 and delta_err(Q, g["Q0"], g["QT"]) < 1e-4       # (Adam's bar on the update, as in G1b)
+    assert float(m._P[:, 50:].abs().max()) == 0.0 and float(m._Q[:, 50:].abs().max()) == 0.0    # the pad stays zero under Adam too
+
+
 def test_device_reports_the_lds_the_step_kernel_reserves_against():
     """the blocked step kernel holds its residency by LDS reservation against the CU's LDS as the DEVICE reports it
     (csrc/rsx_bpr.hip: lds_for_residency; no 160 KB constant): MI355X = 160 KB, 256 CUs, 64-wide wavefronts"""

@@ -3,11 +3,11 @@ vectors captured from the imported reference (oracle/gen_golden.py).  CPU only."
 import numpy as np
 import pytest
 
-from conftest import (DELTA_TOL_SMALL_LR, G1_ADAM, G1_PADDED, G1_SGD, G1_SGD_BIGLR, G23, G8_POINTWISE, delta_err, golden, rel_err,
+from conftest import (DELTA_TOL_SMALL_LR, G1_ADAM, G1_ADAM_PADDED, G1_PADDED, G1_SGD, G1_SGD_BIGLR, G23, G8_POINTWISE, delta_err, golden, rel_err,
                       split_batches, split_pointwise)
 
 
-@pytest.mark.parametrize("name", G1_SGD + G1_SGD_BIGLR + G1_ADAM + G1_PADDED)
+@pytest.mark.parametrize("name", G1_SGD + G1_SGD_BIGLR + G1_ADAM + G1_PADDED + G1_ADAM_PADDED)
 def test_c_oracle_step_matches_reference(oracle_mod, name):
     g = golden(name)
     m = oracle_mod.MFOracle(g["P0"], g["Q0"], optimizer=str(g["optimizer"]), lr=float(g["lr"]))
