@@ -86,6 +86,16 @@ def test_model_as_the_reference_ships_it(ml100k):
     assert P.shape[1] == 50 and rel_err(P, g["PT"]) < 1e-5 and rel_err(Q, g["QT"]) < 1e-5
     assert delta_err(P, g["P0"], g["PT"]) < 1e-4 and delta_err(Q, g["Q0"], g["QT"]) < 1e-4       # (Adam's bar on the update, as in G1b)
     assert float(m._P[:, 50:].abs().max()) == 0.0 and float(m._Q[:, 50:].abs().max()) == 0.0    # the pad stays zero under Adam too
+    # ... and the reference's evaluation of that model (main.py:62-63): its Evaluator's score dictionary on the valid split, and its top-10
+    e = golden("g4_eval_ml100k_d50")
+    top = m.predict_topk(np.arange(ml100k.num_users), ml100k.valid_input, 10)
+    safe = e["gap_10"] > 1e-5
+    assert safe.mean() > 0.95 and all(set(top[r]) == set(e["topk10"][r]) for r in np.nonzero(safe)[0])
+    scores = pkg.Evaluator(ml100k.valid_input, ml100k.valid_target, "holdout", [5, 10]).evaluate(m)
+    assert sorted(scores) == sorted(str(n) for n in e["names"])
+    for n, want in zip(e["names"], e["scores_py"]):
+        # (a user whose 10th and 11th scores tie to 1e-5 may swap them between two summation orders: 1 / 943 of a metric per such user)
+        assert abs(float(scores[str(n)]) - float(want)) <= 1e-6 + (~safe).sum() / ml100k.num_users * 0.2, (n, float(scores[str(n)]), float(want))
 
 
 def test_device_reports_the_lds_the_step_kernel_reserves_against():
