@@ -85,6 +85,7 @@ def run(name, R, d, L, batches, seed):
                         R_indptr=sp.csr_matrix(R).indptr.astype(np.int64), R_indices=sp.csr_matrix(R).indices.astype(np.int32),
                         u=cat(0), i=cat(1), j=cat(2), batch_len=np.array([len(b[0]) for b in batches], np.int32),
                         loss=np.array(losses), num_layers=np.int32(L), lr=np.float32(1e-3))
+    return m
 
 
 def main():
@@ -102,7 +103,25 @@ def main():
     c = np.load(os.path.join(OUT, "ml100k_csr.npz"))
     U, I = int(c["num_users"]), int(c["num_items"])
     Rm = sp.csr_matrix((np.ones(len(c["train_indices"])), c["train_indices"].astype(np.int32), c["train_indptr"]), shape=(U, I))
-    run("g6_lightgcn_ml100k_d64_L2", Rm, 64, 2, mk(U, I, 256, 6), 31)       # conf/LightGCN.yaml shape
+    m = run("g6_lightgcn_ml100k_d64_L2", Rm, 64, 2, mk(U, I, 256, 6), 31)       # conf/LightGCN.yaml shape
+    if m is not None:
+        # (round 5) the reference's evaluation of that model (main.py:62-63): its Evaluator's dictionary on the valid split, its top-10
+        from evaluation.evaluator import Evaluator  # noqa: E402  (reference)
+        valid = sp.csr_matrix((np.ones(len(c["valid_indices"]), np.float32), c["valid_indices"].astype(np.int32), c["valid_indptr"]), shape=(U, I))
+        ks = [5, 10]
+        m.eval()
+        scores = {k: float(v) for k, v in Evaluator(Rm, valid, protocol="holdout", ks=ks).evaluate(m).items()}
+        pred32 = m.predict(np.arange(U), Rm, 1024).astype(np.float32)
+        top = oracle.ref_topk(pred32, 10)
+        per_user = oracle.holdout(top, ks, valid.indptr.astype(np.int64), valid.indices.astype(np.int32), use_ref=True)
+        srt = -np.sort(-pred32, axis=1)
+        names = [f"{mt}@{k}" for mt in ("Prec", "Recall", "NDCG") for k in ks]
+        for col, n in enumerate(names):
+            assert abs(float(np.mean(per_user[:, col], dtype=np.float32)) - scores[n]) < 1e-6, n
+        np.savez_compressed(os.path.join(OUT, "g4_eval_lightgcn_ml100k.npz"), names=np.array(names), scores_py=np.array([scores[n] for n in names]),
+                            topk10=top, per_user=per_user, gap_10=(srt[:, 9] - srt[:, 10]).astype(np.float32),
+                            score_max=np.float32(np.abs(pred32[np.isfinite(pred32)]).max()))
+        print("G4 LightGCN:", scores)
     # BASELINE configs[4] model shape (d=128, 3 layers) at fixture size, Zipf-ish item degrees
     rng5 = np.random.default_rng(55)
     U5, I5 = 200, 150

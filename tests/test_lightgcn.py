@@ -84,6 +84,33 @@ def test_hip_lightgcn_matches_reference_golden(name):
 
 
 @pytest.mark.gpu
+def test_hip_lightgcn_evaluation_equals_the_reference(oracle_mod):
+    """conf/LightGCN.yaml's shape on ml-100k: after the golden's six steps the reference evaluated its model (main.py:62-63, its Evaluator on the
+    valid split; oracle/gen_golden_lightgcn.py) -- the package's model + Evaluator give the same top-10 wherever the 10th / 11th scores
+    are apart, and the same score dictionary"""
+    import recsys_pytorch_amd as pkg
+    g, e, c = golden("g6_lightgcn_ml100k_d64_L2"), golden("g4_eval_lightgcn_ml100k"), golden("ml100k_csr")
+    U, I, d = g["P0"].shape[0], g["Q0"].shape[0], g["P0"].shape[1]
+    ds = types.SimpleNamespace(num_users=U, num_items=I, dataname="t")
+    m = pkg.LightGCN(ds, {"emb_dim": d, "num_layers": int(g["num_layers"]), "node_dropout": 0.0, "split": False, "num_folds": 100, "reg": 1e-4,
+                          "graph_dir": "graph"}, "cuda")
+    m.load_tables(g["P0"], g["Q0"])
+    R = ratings_of(g)
+    m.getSparseGraph(R)
+    for u, i, j in split_batches(g):
+        m.train_step(u, i, j)
+    valid = sp.csr_matrix((np.ones(len(c["valid_indices"]), np.float32), c["valid_indices"].astype(np.int32), c["valid_indptr"]), shape=(U, I))
+    top = m.predict_topk(np.arange(U), R, 10)
+    # (six Adam steps at lr 1e-3 from the reference's small initial tables: the scores are of order 1e-3 and the 10th / 11th of a row
+    #  often closer than two fp32 summation orders resolve -- "apart" is relative to the largest score)
+    safe = e["gap_10"] > 2e-5 * float(e["score_max"])
+    assert safe.mean() > 0.5 and all(set(top[r]) == set(e["topk10"][r]) for r in np.nonzero(safe)[0])
+    scores = pkg.Evaluator(R, valid, "holdout", [5, 10]).evaluate(m)
+    for n, want in zip(e["names"], e["scores_py"]):
+        assert abs(float(scores[str(n)]) - float(want)) <= 1e-6 + (~safe).sum() / U * 0.2, (str(n), float(scores[str(n)]), float(want))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("max_seg", [None, 128, 7])
 def test_hip_spmm_long_rows_vs_oracle(oracle_mod, max_seg):
     """rows far longer than a segment (split + atomics into rows the product clears itself), empty rows, d = 32/64/128; the
