@@ -168,6 +168,56 @@ def fence(world):
 COMM = None         # rsx.Comm: the library's own RCCL communicator (N > 1 over the "nccl" backend, unless RSX_NATIVE_RCCL=0)
 
 
+def mesh_selfcheck(eng, world, rank):
+    """RSX_EXCHANGE=direct, N > 1: one exchange of the library's own mesh on known data, checked against the sum a torch.distributed
+    all-reduce gives, before the leg is timed -- the mesh's ordering between GPUs (flags in uncached memory, system-scope fences,
+    peer reads over xGMI) has only ever run between processes that share one GPU.  Leaves the tables as it found them.  Every rank
+    learns every rank's verdict before anyone raises."""
+    mesh, Qm, Gm = eng._mesh
+    host = dist.get_backend() == "gloo"                  # (the one-GPU smoke runs: gloo reduces host tensors)
+
+    def all_reduce(t, op=dist.ReduceOp.SUM):
+        if host:
+            c = t.cpu()
+            dist.all_reduce(c, op=op)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=op)
+    keep_Q = Qm.clone()
+    rows = Qm.shape[0]
+    gen = torch.Generator(device=Qm.device).manual_seed(777 + rank)
+    err = None
+    for rnd in range(3):                                 # three rounds: a stale line of round r would show in round r + 1
+        Gm.copy_(torch.randn(Gm.shape, device=Gm.device, generator=gen) * (rnd + 1))
+        want = Gm.clone()
+        all_reduce(want)
+        before = Qm.clone()
+        torch.cuda.synchronize()
+        dist.barrier()
+        mesh.exchange_apply(0, rows, 0.5)
+        try:
+            mesh.check()
+        except Exception as e:       # noqa: BLE001
+            err = repr(e)
+        ref = before - 0.5 * want
+        bad = float((Qm - ref).abs().max()) if err is None else float("inf")
+        if err is None and not (bad <= 1e-4 * float(want.abs().max()) and float(Gm.abs().max()) == 0.0):
+            err = f"round {rnd}: |Q - (Q0 - lr * all_reduce(G))| max {bad:.3e}, |G| max {float(Gm.abs().max()):.3e} after the exchange"
+        h = Qm.double().sum(1)                              # (collectives are unconditional: a rank with an error still takes part)
+        cs = torch.stack([h, -h])
+        all_reduce(cs, dist.ReduceOp.MAX)
+        if err is None and not bool((cs[0] + cs[1] == 0.0).all()):
+            err = f"round {rnd}: the ranks' item rows differ after the exchange"
+        box = [None] * world
+        dist.all_gather_object(box, err)
+        if any(box):
+            raise RuntimeError("mesh self-check failed before timing: " + "; ".join(f"rank {q}: {e}" for q, e in enumerate(box) if e))
+    Qm.copy_(keep_Q)
+    Gm.zero_()
+    torch.cuda.synchronize()
+    dist.barrier()
+
+
 def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, warmup, world, rank, popularity, two_pass=None,
              chunks=0, regions=1):
     """`regions` back-to-back timed regions of `steps` native steps each (the MEDIAN region is the leg's figure); returns the
@@ -183,6 +233,8 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     eng = BPREngine(P, Q, lr, user_begin=rank * U, seed=2020, exchange=os.environ.get("RSX_EXCHANGE", "allreduce"),
                     force_sharded=SHARDED, comm=COMM)
     Q = eng.Q                                            # (scatter_gather may re-home the item table)
+    if os.environ.get("RSX_CSC_SAMPLER", "1") == "0":    # A/B: the bucket passes also for whole-pass batches
+        eng.use_csc = False
     if two_pass is not None:
         eng.overlap_exchange = bool(two_pass) and SHARDED and eng.exchange != "direct"      # (the mesh sums and applies in one go)
     # OPT-IN, never the default: RSX_STALE_EXCHANGE=1 lets a step's exchange travel under the NEXT step kernel (item
@@ -202,6 +254,8 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     loss = torch.zeros(rsx.RSX_LOSS_SLOTS, dtype=torch.float32, device=dev)
     tr = eng.native_trainer(indptr, indices, B, loss_acc=loss)
     gb = B * world
+    if eng._mesh is not None and world > 1:
+        mesh_selfcheck(eng, world, rank)                 # the library's own exchange against a torch.distributed all-reduce, BEFORE anything is timed
     tr.run(warmup, B, gb)
     if eng._mesh is not None:        # RSX_EXCHANGE=direct: a broken signal path shows in the warm-up already (bounded waits): stop here, loudly
         eng._mesh[0].check()
@@ -243,6 +297,8 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     kernel = "bpr_step_blocked_kernel" if nb else ("bpr_step_blocked_kernel<TILE=false>" if eng._sorts(B) else "bpr_step_kernel")
     key = f"U{U}_I{I}_d{d}_B{B}_{popularity}_nb{nb}" + (f"_c{ran_chunks}" if ran_chunks > 1 else "")
     return {"batch_per_gpu": B, "chunks": ran_chunks, "mesh_exchanges": mesh_exchanges,
+            "sampler": ("CSC walk (whole-pass batch: one streaming pass over the transposed interactions, no buckets, no sort)"
+                        if eng._csc is not None else "bucket passes (item-CDF buckets + LDS sort)" if eng._sorts(B, nb) else "plain"),
             "exchange_issued_by": (("library (own full mesh over HIP IPC / xGMI: rsx_mesh)" if eng.exchange == "direct" else
                                     "library (RCCL from librsx)" if COMM is not None else "torch.distributed callbacks")
                                    + (", range by range" if ran_chunks > 1 else "")) if SHARDED else None, "global_batch": gb, "value": gb * steps / elapsed, "unit": "triplets/s",
@@ -450,9 +506,10 @@ def launch_ranks(n):
         try:
             d = json.loads(out)
             argv = [a for a in sys.argv[1:]] + ["--no-legs", "--score-tiles", "0", "--no-cpu-baseline"]
-            # (bounded on every level: a kernel's wait for a peer 2 s, a leg 120 s, the whole second job 300 s)
+            # (bounded on every level: a kernel's wait for a peer 10 s, a leg 120 s, the whole second job 300 s; the job checks the
+            #  mesh against a torch.distributed all-reduce on known data BEFORE it times anything: bench.py mesh_selfcheck)
             rc2, lines2, why2 = run_ranks(n, argv, {"RSX_EXCHANGE": "direct", "RSX_WATCHDOG_S": os.environ.get("RSX_MESH_LEG_WATCHDOG_S", "120"),
-                                                    "RSX_MESH_WAIT_S": os.environ.get("RSX_MESH_WAIT_S", "2")},
+                                                    "RSX_MESH_WAIT_S": os.environ.get("RSX_MESH_WAIT_S", "10")},
                                           float(os.environ.get("RSX_MESH_LEG_LIMIT_S", "300")))
             m = json.loads(lines2[-1]) if lines2 else {}
             if rc2 == 0 and m.get("value"):
@@ -720,7 +777,7 @@ def main():
                        "users_per_gpu": U, "items": I, "d": d, "batch_per_gpu": B, "global_batch": head["global_batch"],
                        "positives_per_user": args.degree, "item_popularity": args.popularity, "lr": args.lr,
                        "negatives": f"stratified by item block of {nb}, batch sorted by positive item" if nb else "independent uniform",
-                       "sampler": "on device, two steps ahead on a lowest-priority side stream",
+                       "sampler": "on device, two steps ahead on a lowest-priority side stream: " + head["sampler"],
                        "loop": "native (rsx_bpr_trainer_run): no interpreter between the kernels of the timed region",
                        "item_chunks": head["chunks"], "exchange_issued_by": head["exchange_issued_by"],
                        # what RCCL's own communicator says (rsx_comm_info), not what the environment asked for

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RSX_ABI_VERSION 7
+#define RSX_ABI_VERSION 8
 
 #define RSX_OK 0
 #define RSX_E_INVALID (-1)   /* bad argument (null pointer, unsupported d, K ...) */
@@ -331,6 +331,37 @@ int rsx_bpr_step_chunked(float *P, const float *Q, float *G, int64_t num_users, 
                          uint64_t neg_key, const int64_t *chunk_pos_dev, uint32_t *progress_dev,
                          int first_range, int num_ranges, rsx_stream_t stream);
 
+/* ---- whole-pass batches: the CSC walk -------------------------------------------------------------
+ * Replaces data/generators.py:151-224 for a batch that holds EVERY user once (batch == num_users -- the reference's epoch: one
+ * triplet per user, generators.py:206-210; the shape of every BASELINE config's bench step).  Such a batch needs no user
+ * permutation, and its order by positive item is the order of the TRANSPOSED interaction matrix: rsx_bpr_build_csc writes, once per
+ * CSR, the entries item by item (users ascending) as (user uint32, rank of the item in the user's row | row length) -- 6 bytes per
+ * interaction, 8 when a row is longer than 255 (rows up to 65535) -- and rsx_bpr_sample_csc streams them once per step:
+ *   pos i : entry e is kept iff  floor(h(seed, step, u) * deg(u) / 2^32) == rank(e): one positive per user, uniform in its row
+ *           (h: a keyed 32-bit integer hash of the user id; users with an empty row or deg >= num_items get no triplet);
+ *   order : the kept (user, item) pairs are compacted IN ORDER (wavefront ballots, a workgroup scan, decoupled look-back between
+ *           the tiles): the batch comes out ordered by (item, user) without bucketing or sorting;
+ *   neg j : per ordered position exactly as rsx_bpr_sample(RSX_SAMPLE_SORT_POS) / rsx_bpr_sample_chunked draw it (neg_block,
+ *           neg_key, user_sig, the item ranges with chunks > 1 and chunk_pos_out): same rule, same rejection test.
+ * Positions [n_live, num_users) (users without a triplet) carry i = j = -1.  The triplet DISTRIBUTION is that of the bucket path; the
+ * draws differ (the positive is keyed by the user id instead of by the batch position).
+ *   rsx_bpr_csc_bytes / _workspace   device bytes of the blob (the caller's, kept alive as long as the handle) / of the build scratch
+ *   rsx_bpr_build_csc                a set-up call: it waits for `stream` once (the longest row decides the entry format)
+ *   rsx_csc_destroy                  frees the host-side handle only
+ *   rsx_bpr_sample_csc_workspace     scratch of one sampling call (tile states of the look-back; cleared by the call itself)     */
+typedef struct rsx_csc rsx_csc;
+int64_t rsx_bpr_csc_bytes(int64_t nnz, int64_t num_items);
+int64_t rsx_bpr_csc_workspace(int64_t nnz, int64_t num_items);
+int rsx_bpr_build_csc(const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users, int64_t num_items, int64_t nnz,
+                      void *blob_dev, int64_t blob_bytes, void *ws, int64_t ws_bytes, rsx_stream_t stream, rsx_csc **out);
+void rsx_csc_destroy(rsx_csc *c);
+int rsx_csc_info(const rsx_csc *c, int64_t *nnz, int64_t *num_items, int *entry_bytes, int64_t *tiles);
+int64_t rsx_bpr_sample_csc_workspace(int64_t nnz);
+int rsx_bpr_sample_csc(const rsx_csc *csc, const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users,
+                       int64_t num_items, int64_t items_real, int chunks, uint64_t seed, uint64_t step, int neg_block,
+                       uint64_t neg_key, void *ws, int64_t ws_bytes, const uint64_t *user_sig_dev, int32_t *u_out,
+                       int32_t *i_out, int32_t *j_out, int64_t *chunk_pos_out, rsx_stream_t stream);
+
 /* ---- RCCL from the library --------------------------------------------------------------------
  * One process per GPU, one communicator per process (created on the current device).  RCCL is bound at run time
  * (dlopen librccl.so.1: the copy torch.distributed already loaded, else ROCm's).  rank 0 calls rsx_comm_unique_id and
@@ -354,7 +385,14 @@ int rsx_comm_all_reduce_f32(rsx_comm *c, float *buf_dev, int64_t n, rsx_stream_t
  * replicas identical by construction.  Ordering between the ranks is device side (sequence-numbered flags, system-scope
  * release / acquire); no host thread takes part once the launches are queued.
  *   rsx_mesh_local     allocates the rank's mailbox, describes its tables -> desc_out (RSX_MESH_DESC_BYTES).  Q and G
- *                      [rows x d] are BORROWED and must stay allocated until rsx_mesh_destroy on EVERY rank.
+ *                      [rows x d] are BORROWED and must stay allocated until rsx_mesh_destroy on EVERY rank.  What is exported
+ *                      is VALIDATED first: each table must be plain device memory of the current device lying inside ONE
+ *                      allocation (hipPointerGetAttributes, hipMemGetAddressRange); an allocation that holds both tables is
+ *                      exported once.  Every HIP call that can refuse reports itself with its arguments (which table, base,
+ *                      size, offset).  hipIpcGetMemHandle is retried a bounded number of times (the runtime may refuse while
+ *                      peers still detach from an EARLIER export of the same allocation -- which the caller's barrier after
+ *                      rsx_mesh_destroy rules out); rsx_mesh_export_retries says how many calls failed before the
+ *                      exports succeeded (0 normally).
  *   rsx_mesh_connect   after the caller has gathered all ranks' descriptors in rank order (host bootstrap, e.g.
  *                      torch.distributed.all_gather_object): opens the peers' buffers.  world <= 16.
  *   rsx_mesh_exchange_apply(first_row, rows, lr)   collective in the sense that every rank must queue the same sequence
@@ -365,7 +403,9 @@ int rsx_comm_all_reduce_f32(rsx_comm *c, float *buf_dev, int64_t n, rsx_stream_t
  *                      one would release the peers' waits for both.
  *   rsx_mesh_check     synchronises `stream`; fails if a wait for a peer's signal gave up (rsx_mesh_set_wait_limit, default
  *                      20 s): such an exchange leaves wrong rows and says so -- it never hangs the GPU.
- *   rsx_mesh_destroy   the caller makes sure (host barrier) that no peer still reads this rank's buffers.
+ *   rsx_mesh_destroy   the caller makes sure (host barrier) that no peer still reads this rank's buffers, and -- before any
+ *                      rank exports the same allocations again -- that every rank has returned from rsx_mesh_destroy
+ *                      (a second host barrier: recsys_pytorch_amd/rsx.py Mesh.close).
  * Handed to rsx_bpr_trainer_create as config.mesh, the native loop issues it per step or per item range.            */
 #define RSX_MESH_DESC_BYTES 512
 typedef struct rsx_mesh rsx_mesh;
@@ -374,6 +414,7 @@ int rsx_mesh_connect(rsx_mesh *m, int rank, int world, const void *all_desc);
 int rsx_mesh_exchange_apply(rsx_mesh *m, int64_t first_row, int64_t rows, float lr, rsx_stream_t stream);
 int rsx_mesh_set_wait_limit(rsx_mesh *m, double seconds);
 int rsx_mesh_info(const rsx_mesh *m, int *rank, int *world, int64_t *exchanges);
+int rsx_mesh_export_retries(const rsx_mesh *m);                        /* -1 for NULL */
 int rsx_mesh_check(rsx_mesh *m, rsx_stream_t stream);
 void rsx_mesh_destroy(rsx_mesh *m);
 
@@ -450,6 +491,10 @@ void rsx_mesh_destroy(rsx_mesh *m);
  *                        one rsx_mesh_exchange_apply per step, or per item range with chunks > 1 (on the trainer's collective
  *                        stream, under the other ranges' kernels); it applies the summed gradient itself.  Not with two_pass /
  *                        stale_exchange.
+ *   csc                  (optional) built by rsx_bpr_build_csc from THIS config's indptr / indices: steps whose batch holds every
+ *                        user once (batch == num_users, starting a pass) and take an ordered layout (neg_block engaged, sort_min_batch,
+ *                        or chunks > 1) are sampled by rsx_bpr_sample_csc instead of the bucket passes; sample_ws must also hold
+ *                        rsx_bpr_sample_csc_workspace(nnz) bytes.  Other steps (short batches) sample as without it.
  *   stale_exchange / G_alt   OPT-IN, needs an exchange (callbacks or comm) and a second zeroed [num_items x d] buffer.
  *                        != 0: the exchange of step t's item gradients travels under the step kernel of
  *                        step t+1, which therefore reads an item table that lacks step t's update (ONE STEP
@@ -519,6 +564,7 @@ typedef struct rsx_bpr_trainer_config {
     uint32_t *progress;
     rsx_exchange_range_fn exchange_range;   /* chunks > 1 without comm: the caller's all-reduce of one item range  */
     rsx_mesh *mesh;                         /* the library's own exchange over xGMI (see rsx_mesh_*), or NULL        */
+    const rsx_csc *csc;                     /* the CSC walk for whole-pass batches (see rsx_bpr_sample_csc), or NULL  */
 } rsx_bpr_trainer_config;
 
 #define RSX_EXCHANGE_ALLREDUCE 1

@@ -137,6 +137,12 @@ int rsx_comm_all_reduce(rsx_comm *c, float *buf, int64_t n, hipStream_t st);
 int rsx_comm_reduce_scatter(rsx_comm *c, float *buf, int64_t n_per_rank, hipStream_t st);
 int rsx_comm_all_gather(rsx_comm *c, float *buf, int64_t n_per_rank, hipStream_t st);
 
+// rsx_sample.hip: was this CSC built from exactly this CSR?
+bool rsx_csc_matches(const rsx_csc *c, const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users, int64_t num_items);
+
+// rsx_mesh.hip: the tables a mesh was built over
+void rsx_mesh_tables(const rsx_mesh *m, const float **Q, const float **G, int64_t *rows, int *d);
+
 // rsx_bpr.hip: rsx_apply_item_grad with a hint (dense: nearly every row has a gradient; the result is the same either way)
 int rsx_apply_item_grad_ex(float *Q, float *G, int64_t num_items, int d, float lr, const int32_t *hot_slot_dev, float *G_hot,
                            int hot_replicas, bool dense, hipStream_t stream);

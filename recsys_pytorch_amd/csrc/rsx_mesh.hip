@@ -27,6 +27,7 @@
 //     waits for every peer's READY of that exchange -- signalled by a peer only after its own phase 2 of this one (stream order).
 // A wait that lasts longer than the mesh's limit (default 20 s) gives up, raises the mesh's error word and lets the kernel
 // finish -- wrong rows, loudly reported by rsx_mesh_check, never a hung GPU.
+#include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
 
@@ -69,6 +70,7 @@ struct rsx_mesh {
     PeerPtrs peers{};
     std::vector<void *> opened;       // what hipIpcOpenMemHandle returned (closed by rsx_mesh_destroy)
     bool connected = false;
+    int export_retries = 0;           // hipIpcGetMemHandle calls that failed before the one that succeeded (0 = every export at the first try)
 };
 
 namespace {
@@ -147,6 +149,61 @@ __global__ __launch_bounds__(kMeshBlock) void mesh_gather_kernel(PeerPtrs p, uin
 int mesh_fail(const char *what, hipError_t e)
 {
     rsx_set_error("%s: %s", what, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return RSX_E_HIP;
+}
+
+// What a rank exports must be memory the library can vouch for: a device allocation of the CURRENT device, whole (the handle names
+// the allocation, the table is an offset into it).  Every HIP call that can refuse has its own message with its arguments.
+struct Exported {
+    void *base = nullptr;
+    size_t size = 0;
+    hipIpcMemHandle_t handle;
+    int attempts = 0;
+};
+
+constexpr int kExportAttempts = 4;
+
+int export_allocation(const char *what, const void *ptr, size_t bytes_needed, int device, Exported *x)
+{
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    hipError_t e = hipPointerGetAttributes(&at, ptr);
+    if (e != hipSuccess) {
+        rsx_set_error("rsx_mesh_local: hipPointerGetAttributes(%s = %p) failed: %s -- not a pointer this process allocated on a GPU", what,
+                      ptr, hipGetErrorString(e));
+        (void)hipGetLastError();
+        return RSX_E_HIP;
+    }
+    if (at.type != hipMemoryTypeDevice || at.device != device) {
+        rsx_set_error("rsx_mesh_local: %s = %p is not plain device memory of the current device %d (memory type %d, device %d): only "
+                      "hipMalloc'ed memory of this GPU can be mapped by the peers", what, ptr, device, (int)at.type, at.device);
+        return RSX_E_INVALID;
+    }
+    e = hipMemGetAddressRange((hipDeviceptr_t *)&x->base, &x->size, (hipDeviceptr_t)ptr);
+    if (e != hipSuccess || x->base == nullptr) {
+        rsx_set_error("rsx_mesh_local: hipMemGetAddressRange(%s = %p) failed: %s", what, ptr, hipGetErrorString(e));
+        (void)hipGetLastError();
+        return RSX_E_HIP;
+    }
+    const size_t off = (size_t)((const char *)ptr - (const char *)x->base);
+    if (off + bytes_needed > x->size) {
+        rsx_set_error("rsx_mesh_local: %s = %p (+%zu bytes) does not lie inside ONE allocation (base %p, %zu bytes): a table stitched from "
+                      "several mappings cannot be exported by one handle", what, ptr, bytes_needed, x->base, x->size);
+        return RSX_E_INVALID;
+    }
+    // (the runtime has been seen to refuse an export while peers were still detaching from an earlier export of the same allocation:
+    //  bounded retries; how many failed first is reported by rsx_mesh_export_retries)
+    for (x->attempts = 1;; ++x->attempts) {
+        e = hipIpcGetMemHandle(&x->handle, x->base);
+        if (e == hipSuccess) return RSX_OK;
+        (void)hipGetLastError();
+        if (x->attempts >= kExportAttempts) break;
+        usleep(50000 * x->attempts);
+    }
+    rsx_set_error("rsx_mesh_local: hipIpcGetMemHandle(allocation of %s: base %p, %zu bytes; table at offset %zu, %zu bytes) failed %d "
+                  "times: %s (HSA_ENABLE_IPC_MODE_LEGACY=%s)", what, x->base, x->size, off, bytes_needed, x->attempts, hipGetErrorString(e),
+                  getenv("HSA_ENABLE_IPC_MODE_LEGACY") ? getenv("HSA_ENABLE_IPC_MODE_LEGACY") : "unset");
     return RSX_E_HIP;
 }
 
@@ -156,33 +213,51 @@ RSX_API int rsx_mesh_local(float *Q, float *G, int64_t rows, int d, void *desc_o
 {
     RSX_CHECK_ARG(Q && G && desc_out && out, "null pointer");
     RSX_CHECK_ARG(rows > 0 && rsx_dim_ok(d), "bad shape");
+    RSX_CHECK_ARG(Q != G, "Q and G are the same buffer");
     rsx_mesh *m = new (std::nothrow) rsx_mesh();
     if (m == nullptr) { rsx_set_error("rsx_mesh_local: out of memory"); return RSX_E_INVALID; }
     m->Q = Q; m->G = G; m->rows = rows; m->d = d;
     hipError_t e = hipGetDevice(&m->device);
+    if (e != hipSuccess) { const int rc = mesh_fail("rsx_mesh_local: hipGetDevice", e); rsx_mesh_destroy(m); return rc; }
     // the mailbox: polled by this rank's kernels while the peers store into it -- uncached device memory where the runtime has it
-    if (e == hipSuccess) {
-        e = hipExtMallocWithFlags((void **)&m->flags, kMailboxBytes, hipDeviceMallocUncached);
-        if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc((void **)&m->flags, kMailboxBytes); }
+    e = hipExtMallocWithFlags((void **)&m->flags, kMailboxBytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        m->flags = nullptr;
+        e = hipMalloc((void **)&m->flags, kMailboxBytes);
+        if (e != hipSuccess) { m->flags = nullptr; const int rc = mesh_fail("rsx_mesh_local: hipMalloc(mailbox)", e); rsx_mesh_destroy(m); return rc; }
     }
-    if (e == hipSuccess) e = hipMemset(m->flags, 0, kMailboxBytes);
+    e = hipMemset(m->flags, 0, kMailboxBytes);
     if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { const int rc = mesh_fail("rsx_mesh_local: clearing the mailbox (hipMemset + hipDeviceSynchronize)", e); rsx_mesh_destroy(m); return rc; }
+    const size_t table_bytes = (size_t)rows * (size_t)d * sizeof(float);
+    Exported xQ, xG, xF;
+    int rc = export_allocation("Q", Q, table_bytes, m->device, &xQ);
+    if (rc == RSX_OK) {
+        // both tables inside ONE allocation (a pooled segment of the caller's allocator): exported once
+        hipDeviceptr_t bG = nullptr;
+        size_t szG = 0;
+        if (hipMemGetAddressRange(&bG, &szG, (hipDeviceptr_t)G) == hipSuccess && (void *)bG == xQ.base &&
+            (size_t)((char *)G - (char *)bG) + table_bytes <= szG) {
+            xG = xQ; xG.attempts = 1;
+        } else {
+            (void)hipGetLastError();
+            rc = export_allocation("G", G, table_bytes, m->device, &xG);
+        }
+    }
+    if (rc == RSX_OK) rc = export_allocation("the mailbox", m->flags, kMailboxBytes, m->device, &xF);
+    if (rc != RSX_OK) { rsx_mesh_destroy(m); return rc; }
+    if (xF.base != (void *)m->flags) {
+        rsx_set_error("rsx_mesh_local: the mailbox %p is not at the start of its allocation (base %p)", (void *)m->flags, xF.base);
+        rsx_mesh_destroy(m);
+        return RSX_E_INVALID;
+    }
+    m->export_retries = (xQ.attempts - 1) + (xG.attempts - 1) + (xF.attempts - 1);
     MeshDesc dsc;
     memset(&dsc, 0, sizeof(dsc));
-    void *bQ = nullptr, *bG = nullptr;
-    size_t sz = 0;
-    if (e == hipSuccess) e = hipMemGetAddressRange((hipDeviceptr_t *)&bQ, &sz, (hipDeviceptr_t)Q);
-    if (e == hipSuccess) e = hipMemGetAddressRange((hipDeviceptr_t *)&bG, &sz, (hipDeviceptr_t)G);
-    if (e == hipSuccess) e = hipIpcGetMemHandle(&dsc.hQ, bQ);
-    if (e == hipSuccess) e = hipIpcGetMemHandle(&dsc.hG, bG);
-    if (e == hipSuccess) e = hipIpcGetMemHandle(&dsc.hF, m->flags);
-    if (e != hipSuccess) {
-        const int rc = mesh_fail("rsx_mesh_local (hipIpcGetMemHandle needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this driver)", e);
-        rsx_mesh_destroy(m);
-        return rc;
-    }
-    dsc.offQ = (uint64_t)((char *)Q - (char *)bQ); dsc.offG = (uint64_t)((char *)G - (char *)bG);
-    dsc.baseQ = (uint64_t)(uintptr_t)bQ; dsc.baseG = (uint64_t)(uintptr_t)bG;
+    dsc.hQ = xQ.handle; dsc.hG = xG.handle; dsc.hF = xF.handle;
+    dsc.offQ = (uint64_t)((char *)Q - (char *)xQ.base); dsc.offG = (uint64_t)((char *)G - (char *)xG.base);
+    dsc.baseQ = (uint64_t)(uintptr_t)xQ.base; dsc.baseG = (uint64_t)(uintptr_t)xG.base;
     dsc.rows = rows; dsc.d = d; dsc.device = m->device; dsc.pid = (int64_t)getpid();
     memset(desc_out, 0, RSX_MESH_DESC_BYTES);
     memcpy(desc_out, &dsc, sizeof(dsc));
@@ -207,14 +282,20 @@ RSX_API int rsx_mesh_connect(rsx_mesh *m, int rank, int world, const void *all_d
         }
         RSX_CHECK_ARG(dsc.pid != (int64_t)getpid(), "two ranks in one process: hipIpcOpenMemHandle cannot open its own handle");
         void *bQ = nullptr, *bG = nullptr, *bF = nullptr;
+        const char *which = "Q";
         hipError_t e = hipIpcOpenMemHandle(&bQ, dsc.hQ, hipIpcMemLazyEnablePeerAccess);
         if (e == hipSuccess) {
             m->opened.push_back(bQ);
             if (dsc.baseG == dsc.baseQ) bG = bQ;           // both tables in ONE allocation of the peer: opened once
-            else { e = hipIpcOpenMemHandle(&bG, dsc.hG, hipIpcMemLazyEnablePeerAccess); if (e == hipSuccess) m->opened.push_back(bG); }
+            else { which = "G"; e = hipIpcOpenMemHandle(&bG, dsc.hG, hipIpcMemLazyEnablePeerAccess); if (e == hipSuccess) m->opened.push_back(bG); }
         }
-        if (e == hipSuccess) { e = hipIpcOpenMemHandle(&bF, dsc.hF, hipIpcMemLazyEnablePeerAccess); if (e == hipSuccess) m->opened.push_back(bF); }
-        if (e != hipSuccess) return mesh_fail("rsx_mesh_connect: hipIpcOpenMemHandle", e);
+        if (e == hipSuccess) { which = "mailbox"; e = hipIpcOpenMemHandle(&bF, dsc.hF, hipIpcMemLazyEnablePeerAccess); if (e == hipSuccess) m->opened.push_back(bF); }
+        if (e != hipSuccess) {
+            rsx_set_error("rsx_mesh_connect: rank %d: hipIpcOpenMemHandle(rank %d's %s allocation; its pid %lld, device %d) failed: %s", rank, q,
+                          which, (long long)dsc.pid, dsc.device, hipGetErrorString(e));
+            (void)hipGetLastError();
+            return RSX_E_HIP;
+        }
         m->peers.Q[q] = (const float *)((char *)bQ + dsc.offQ);
         m->peers.G[q] = (const float *)((char *)bG + dsc.offG);
         m->peers.flags[q] = (uint32_t *)bF;
@@ -265,6 +346,17 @@ RSX_API int rsx_mesh_info(const rsx_mesh *m, int *rank, int *world, int64_t *exc
     if (world) *world = m->world;
     if (exchanges) *exchanges = (int64_t)m->seq;
     return RSX_OK;
+}
+
+RSX_API int rsx_mesh_export_retries(const rsx_mesh *m)
+{
+    return m == nullptr ? -1 : m->export_retries;
+}
+
+// (internal, rsx_common.h) what the mesh was built over: the native loop refuses a mesh over other tables than its own
+void rsx_mesh_tables(const rsx_mesh *m, const float **Q, const float **G, int64_t *rows, int *d)
+{
+    *Q = m->Q; *G = m->G; *rows = m->rows; *d = m->d;
 }
 
 RSX_API int rsx_mesh_check(rsx_mesh *m, rsx_stream_t stream)

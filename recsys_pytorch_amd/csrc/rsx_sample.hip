@@ -777,6 +777,338 @@ __global__ __launch_bounds__(kBlock, 5) void bucket_sort_kernel(
     }
 }
 
+// ---- whole-pass batches without bucketing or sorting: the CSC walk -------------------------------
+// A batch that holds EVERY user once (batch == num_users: the reference's epoch, data/generators.py:206-210, and the shape of
+// every BASELINE config's bench step) needs no permutation, no buckets and no sort to come out ordered by positive item: the
+// transposed interaction matrix (CSC: item -> its users, ascending) IS that order.  Per entry e = (user u, rank of the item inside
+// u's row, deg(u)) the blob built by rsx_bpr_build_csc holds 6 bytes (8 when a row is longer than 255); one streaming pass keeps
+// entry e iff  pick(seed, step, u) == rank  -- exactly one positive per user, uniform in its row -- and compacts the kept
+// (user, item) pairs IN ORDER (ballots inside a wavefront, a 32-entry LDS scan inside the workgroup, decoupled look-back between
+// the tiles), so the output is ordered by (item, user) with no sort at all.  A second kernel draws the negatives per ordered
+// position exactly like the bucket path (negatives_lockstep: signature first, rejection against the row).
+// Against the bucket path (two latency-bound passes, 0.34 GB, 105 us alone / 300 us beside the step kernel at the headline shape)
+// this is one streaming read of 6 bytes per interaction (120 MB) plus the negatives.
+constexpr int kCscThreads = 256;
+// rounds of one uint4 of users per thread: 8 -> 8192 entries per workgroup, 110 VGPRs; 4 -> 4096 entries, fewer registers -- the
+// kernel runs in what the step kernel's wavefronts leave free of a SIMD's registers (development A/B: -DRSX_CSC_ROUNDS=2 / 4 / 8)
+#ifndef RSX_CSC_ROUNDS
+#define RSX_CSC_ROUNDS 4
+#endif
+constexpr int kCscRounds = RSX_CSC_ROUNDS;
+constexpr int kCscTile = kCscThreads * 4 * kCscRounds;         // entries per workgroup
+constexpr int kCscCounts = kCscRounds * (kCscThreads / 64);    // (round, wavefront) counts of a tile
+constexpr int kCscItemsLds = 2048;                             // item borders of a tile kept in LDS (more: searched in memory)
+constexpr int kCscNegBlock = kBlock * kNegGroup;               // positions per workgroup of the negatives pass
+static_assert(kCscThreads == 256 && kCscCounts <= 32 && kCscTile <= 65535, "the tile's (round, wavefront) counts are scanned by half a wavefront; borders are uint16");
+
+// the positive of user u in this step: rank in [0, deg).  Keyed per (seed, step); two multiplies -- 20M entries per step run it
+__host__ __device__ __forceinline__ uint32_t csc_hash(uint32_t u, uint32_t k0, uint32_t k1)
+{
+    uint32_t x = u ^ k0;
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x ^ k1;
+}
+__host__ __device__ __forceinline__ uint64_t csc_step_key(uint64_t seed, uint64_t step) { return splitmix64(seed ^ (step * 0x9E3779B97F4A7C15ull) ^ 0xC5C0DE5A3D1E7ull); }
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+template <typename RD> struct RdBits;
+template <> struct RdBits<uint16_t> { static constexpr int shift = 8; static constexpr uint32_t mask = 0xFFu; };
+template <> struct RdBits<uint32_t> { static constexpr int shift = 16; static constexpr uint32_t mask = 0xFFFFu; };
+
+constexpr uint64_t kStatusAggregate = 1ull << 62, kStatusPrefix = 2ull << 62, kStatusValue = (1ull << 62) - 1;
+
+struct CscArgs {
+    const int64_t *ptr;          // [I + 1] first entry of every item
+    const int32_t *tile_item;    // [ntiles + 1] the item that holds the first entry of every tile (last: I - 1)
+    const uint32_t *users;       // [ntiles * kCscTile]
+    const void *rd;              // rank | deg << shift per entry
+    int64_t nnz, I;
+    int ntiles;
+};
+
+template <typename RD>
+__global__ __launch_bounds__(kCscThreads) void csc_select_kernel(CscArgs a, uint32_t k0, uint32_t k1, uint64_t *__restrict__ status,
+                                                                 uint32_t *__restrict__ ticket, int32_t *__restrict__ u_out,
+                                                                 int32_t *__restrict__ i_out, int64_t *__restrict__ n_live_out,
+                                                                 int C, int64_t Ic, int64_t *__restrict__ chunk_pos_out)
+{
+    __shared__ uint32_t s_tile;
+    __shared__ uint32_t s_cnt[kCscCounts], s_ex[kCscCounts + 1];
+    __shared__ int64_t s_base;
+    __shared__ uint16_t s_border[kCscItemsLds];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // tiles are numbered in the order their workgroups START: a tile only ever waits for tiles that are already running
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int tile = (int)s_tile;
+    const int64_t e0 = (int64_t)tile * kCscTile;
+    // (non-temporal: 120 MB stream through once per step and must not push the item table out of the memory-side cache)
+    const u32x4 *up = reinterpret_cast<const u32x4 *>(a.users) + e0 / 4;
+    u32x4 us[kCscRounds];
+    uint32_t rdv[kCscRounds][4];
+#pragma unroll
+    for (int k = 0; k < kCscRounds; ++k) us[k] = __builtin_nontemporal_load(up + k * kCscThreads + tid);
+    if constexpr (sizeof(RD) == 2) {
+        const u32x2 *rp = reinterpret_cast<const u32x2 *>(a.rd) + e0 / 4;
+#pragma unroll
+        for (int k = 0; k < kCscRounds; ++k) {
+            const u32x2 v = __builtin_nontemporal_load(rp + k * kCscThreads + tid);
+            rdv[k][0] = v.x & 0xFFFFu; rdv[k][1] = v.x >> 16; rdv[k][2] = v.y & 0xFFFFu; rdv[k][3] = v.y >> 16;
+        }
+    } else {
+        const u32x4 *rp = reinterpret_cast<const u32x4 *>(a.rd) + e0 / 4;
+#pragma unroll
+        for (int k = 0; k < kCscRounds; ++k) {
+            const u32x4 v = __builtin_nontemporal_load(rp + k * kCscThreads + tid);
+            rdv[k][0] = v.x; rdv[k][1] = v.y; rdv[k][2] = v.z; rdv[k][3] = v.w;
+        }
+    }
+    // the item borders inside this tile (while the loads above travel): item(x) = first + #{borders <= x}
+    const int first = a.tile_item[tile], nb = a.tile_item[tile + 1] - first;
+    const bool borders_in_lds = nb <= kCscItemsLds;
+    if (borders_in_lds)
+        for (int q = tid; q < nb; q += kCscThreads) {
+            const int64_t b = a.ptr[first + 1 + q] - e0;
+            s_border[q] = (uint16_t)(b < kCscTile ? b : kCscTile);      // (a border at or beyond the tile's end is never <= x)
+        }
+    // keep flags, in entry order: round k, thread tid, element j  <->  entry e0 + (k * 256 + tid) * 4 + j
+    const uint64_t lanes_below = (1ull << lane) - 1ull;
+    uint32_t keep = 0u;                                            // bit k * 4 + j
+    uint32_t before[kCscRounds];                                   // kept entries of this round in the lanes below me (this wavefront)
+#pragma unroll
+    for (int k = 0; k < kCscRounds; ++k) {
+        const uint32_t uu[4] = {us[k].x, us[k].y, us[k].z, us[k].w};
+        const int64_t e = e0 + (int64_t)(k * kCscThreads + tid) * 4;
+        uint32_t bef = 0, tot = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t rank = rdv[k][j] & RdBits<RD>::mask, deg = rdv[k][j] >> RdBits<RD>::shift;
+            const bool kp = e + j < a.nnz && (int64_t)deg < a.I && mulhi32(csc_hash(uu[j], k0, k1), deg) == rank;
+            const uint64_t m = __ballot(kp);
+            bef += (uint32_t)__popcll(m & lanes_below);
+            tot += (uint32_t)__popcll(m);
+            keep |= (kp ? 1u : 0u) << (k * 4 + j);
+        }
+        before[k] = bef;
+        if (lane == 0) s_cnt[k * 4 + wave] = tot;
+    }
+    __syncthreads();
+    if (tid < kCscCounts) {                                        // exclusive scan of the (round, wavefront) counts
+        const uint32_t mine = s_cnt[tid];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < kCscCounts; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off);
+            if (tid >= off) incl += v;
+        }
+        s_ex[tid] = incl - mine;
+        if (tid == kCscCounts - 1) s_ex[kCscCounts] = incl;
+    }
+    __syncthreads();
+    const uint32_t total = s_ex[kCscCounts];
+    // decoupled look-back: publish this tile's count, add up the tiles before it (the first wavefront, 64 tiles per trip)
+    if (wave == 0) {
+        int64_t excl = 0;
+        if (tile > 0) {
+            if (lane == 0) __hip_atomic_store(status + tile, kStatusAggregate | (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int look = tile - 1;;) {
+                const int idx = look - lane;
+                uint64_t v = kStatusPrefix;                        // (in front of tile 0: the prefix 0)
+                if (idx >= 0) v = __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint64_t m_prefix = __ballot((v >> 62) == 2ull), m_invalid = __ballot((v >> 62) == 0ull);
+                const int pl = m_prefix ? __builtin_ctzll(m_prefix) : 63;                   // nearest tile with a full prefix
+                const uint64_t span = pl == 63 ? ~0ull : ((2ull << pl) - 1ull);
+                if (m_invalid & span) { __builtin_amdgcn_s_sleep(8); continue; }            // a tile in between has not published yet
+                uint64_t part = lane <= pl ? (v & kStatusValue) : 0ull;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+                excl += (int64_t)part;
+                if (m_prefix) break;
+                look -= 64;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(status + tile, kStatusPrefix | (uint64_t)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_base = excl;
+        }
+    }
+    __syncthreads();
+    const int64_t base = s_base;
+    // rank (inside the tile) of the entry (k, j) of this thread
+    auto rank_of = [&](int k, int j) -> uint32_t {
+        return s_ex[k * 4 + wave] + before[k] + (uint32_t)__popc(keep & (((1u << j) - 1u) << (k * 4)));
+    };
+    if (keep) {
+#pragma unroll
+        for (int k = 0; k < kCscRounds; ++k) {
+            if (!((keep >> (k * 4)) & 0xFu)) continue;
+            const uint32_t uu[4] = {us[k].x, us[k].y, us[k].z, us[k].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!((keep >> (k * 4 + j)) & 1u)) continue;
+                const int x = (k * kCscThreads + tid) * 4 + j;
+                int item;
+                if (borders_in_lds) {
+                    int lo = 0, hi = nb;                           // #{q : border[q] <= x}
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)s_border[mid] <= x) lo = mid + 1; else hi = mid; }
+                    item = first + lo;
+                } else {
+                    int lo = first, hi = first + nb;               // last item whose first entry is <= e0 + x
+                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.ptr[mid] <= e0 + x) lo = mid; else hi = mid - 1; }
+                    item = lo;
+                }
+                const int64_t pos = base + rank_of(k, j);
+                u_out[pos] = (int32_t)uu[j];
+                i_out[pos] = item;
+            }
+        }
+    }
+    // where the item ranges start in the ordered batch (chunked layout) and how many positions are live
+    if (tile == 0 && tid == 0 && chunk_pos_out != nullptr) chunk_pos_out[0] = 0;
+    const bool last_tile = tile == a.ntiles - 1;
+    for (int ch = 1; ch < C; ++ch) {
+        const int64_t eb = a.ptr[ch * Ic];
+        if (eb >= a.nnz) { if (last_tile && tid == 0) chunk_pos_out[ch] = base + total; continue; }
+        if (eb < e0 || eb >= e0 + kCscTile) continue;
+        const int x = (int)(eb - e0), k = x / (kCscThreads * 4), t = (x / 4) % kCscThreads, j = x % 4;
+        if (t == tid) {
+            uint32_t r = 0;
+#pragma unroll
+            for (int kk = 0; kk < kCscRounds; ++kk) if (kk == k) r = rank_of(kk, j);
+            chunk_pos_out[ch] = base + r;
+        }
+    }
+    if (last_tile && tid == 0) {
+        *n_live_out = base + total;
+        if (chunk_pos_out != nullptr) chunk_pos_out[C] = base + total;
+    }
+}
+
+// negatives of the ordered positions (the second half of bucket_sort_kernel on pairs that are already in place): a workgroup
+// takes kCscNegBlock consecutive positions of ONE item range, or of the dead tail [n_live, B)
+__global__ __launch_bounds__(kBlock, 5) void csc_neg_kernel(
+    const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices, const uint64_t *__restrict__ user_sig,
+    int64_t I, int64_t B, uint64_t seed, uint64_t step, int neg_block, uint64_t neg_key, const int64_t *__restrict__ n_live_dev,
+    int32_t *u_out, int32_t *i_out, int32_t *__restrict__ j_out, ChunkArgs ca)
+{
+    __shared__ int64_t wstart[kRangeCap];
+    __shared__ int32_t wlo[kRangeCap];
+    __shared__ uint8_t wn[kRangeCap];
+    const int tid = threadIdx.x;
+    const bool chunked = ca.C > 1;
+    const int64_t n_live = *n_live_dev;
+    // which range this workgroup works in: ranges 0 .. C - 1 (the whole live batch when not chunked), then the dead tail
+    int64_t blocks_before = 0, lo_pos = 0, hi_pos = 0;
+    int ch = -1;
+    const int R = chunked ? ca.C : 1;
+    for (int k = 0; k <= R; ++k) {
+        const int64_t a = k < R ? (chunked ? ca.chunk_pos_out[k] : 0) : n_live;
+        const int64_t z = k < R ? (chunked ? ca.chunk_pos_out[k + 1] : n_live) : B;
+        const int64_t nblk = ceil_div64(z - a, kCscNegBlock);
+        if ((int64_t)blockIdx.x < blocks_before + nblk) { ch = k; lo_pos = a; hi_pos = z; break; }
+        blocks_before += nblk;
+    }
+    if (ch < 0) return;
+    const int64_t p0 = lo_pos + ((int64_t)blockIdx.x - blocks_before) * kCscNegBlock;
+    const int n = (int)((hi_pos - p0 < kCscNegBlock) ? hi_pos - p0 : kCscNegBlock);
+    if (ch == R) {                                                 // users without a usable row: no triplet (the step skips i < 0)
+        for (int r = tid; r < n; r += kBlock) { u_out[p0 + r] = 0; i_out[p0 + r] = -1; j_out[p0 + r] = -1; }
+        return;
+    }
+    NegCtx cx{ca.C, ch, ca.g, lo_pos, hi_pos - lo_pos, wn, ca.whole};
+    int m = 0;
+    if (chunked && ca.whole) {
+    } else if (chunked) {
+        const ChunkGeom &g = ca.g;
+        const int64_t w_first = (((p0 - cx.pc) * g.Ic) / cx.nc) / g.c, w_last = (((p0 + n - 1 - cx.pc) * g.Ic) / cx.nc) / g.c;
+        if (w_last - w_first < kRangeCap) {
+            m = (int)(w_last - w_first) + 1;
+            const uint64_t key = chunk_key(neg_key, ch);
+            for (int q = tid; q < m; q += kBlock) {
+                const int64_t blk = neg_block_of(w_first + q, g.nbc, key);
+                wstart[q] = cx.pc + ceil_div64((w_first + q) * g.c * cx.nc, g.Ic);
+                wlo[q] = (int32_t)((int64_t)ch * g.Ic + blk * g.c);
+                const int64_t left = g.real(ch) - blk * g.c;
+                wn[q] = (uint8_t)(left <= 0 ? 0 : (left < g.c ? left : g.c));
+            }
+        }
+    } else if (neg_block > 0) {
+        const int64_t w_first = ((p0 * I) / B) / neg_block, w_last = (((p0 + n - 1) * I) / B) / neg_block;
+        if (w_last - w_first < kRangeCap) {
+            m = (int)(w_last - w_first) + 1;
+            const int64_t nblocks = ceil_div64(I, neg_block);
+            for (int q = tid; q < m; q += kBlock) {
+                wstart[q] = ceil_div64((w_first + q) * neg_block * B, I);
+                wlo[q] = (int32_t)(neg_block_of(w_first + q, nblocks, neg_key) * neg_block);
+            }
+        }
+    }
+    __syncthreads();
+    bool live[kNegGroup];
+    int64_t p[kNegGroup];
+    uint32_t u[kNegGroup];
+    int32_t nj[kNegGroup];
+#pragma unroll
+    for (int g = 0; g < kNegGroup; ++g) {
+        const int r = g * kBlock + tid;
+        live[g] = r < n;
+        p[g] = p0 + r;
+        u[g] = live[g] ? (uint32_t)u_out[p[g]] : 0u;
+    }
+    negatives_lockstep(indptr, indices, user_sig, I, B, seed, step, neg_block, neg_key, wstart, wlo, m, live, p, u, nj, cx);
+#pragma unroll
+    for (int g = 0; g < kNegGroup; ++g)
+        if (live[g]) {
+            j_out[p[g]] = nj[g];
+            if (nj[g] < 0) i_out[p[g]] = -1;                       // (chunked layout: the user owns its whole range -- no triplet)
+        }
+}
+
+// ---- building the CSC blob (once per CSR) -----------------------------------------------------
+__global__ __launch_bounds__(kBlock) void csc_entries_kernel(const int64_t *__restrict__ indptr, int64_t U, int shift,
+                                                             uint64_t *__restrict__ vals, unsigned long long *__restrict__ max_deg)
+{
+    unsigned long long mx = 0;
+    for (int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x; u < U; u += (int64_t)gridDim.x * kBlock) {
+        const int64_t lo = indptr[u], hi = indptr[u + 1];
+        const uint64_t deg = (uint64_t)(hi - lo);
+        if (deg > mx) mx = deg;
+        if (vals != nullptr)
+            for (int64_t q = lo; q < hi; ++q) vals[q] = (uint64_t)(uint32_t)u | ((((uint64_t)(q - lo)) | (deg << shift)) << 32);
+    }
+    if (vals == nullptr) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
+        if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(max_deg, mx);
+    }
+}
+
+template <typename RD>
+__global__ __launch_bounds__(kBlock) void csc_split_kernel(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals, int64_t nnz,
+                                                           int64_t nnz_pad, int64_t I, uint32_t *__restrict__ users, RD *__restrict__ rd,
+                                                           int64_t *__restrict__ ptr, int32_t *__restrict__ tile_item, int ntiles)
+{
+    for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < nnz_pad; s += (int64_t)gridDim.x * kBlock) {
+        if (s >= nnz) { users[s] = 0u; rd[s] = (RD)(RdBits<RD>::mask | (1u << RdBits<RD>::shift)); continue; }   // padding: rank >= deg, never kept
+        const uint64_t v = vals[s];
+        users[s] = (uint32_t)v;
+        rd[s] = (RD)(v >> 32);
+        const int64_t k = (int64_t)keys[s];
+        if (s % kCscTile == 0) tile_item[s / kCscTile] = (int32_t)k;
+        const int64_t kprev = s == 0 ? -1 : (int64_t)keys[s - 1];
+        for (int64_t it = kprev + 1; it <= k; ++it) ptr[it] = s;    // first entry of item k and of the empty items in front of it
+        if (s == nnz - 1) for (int64_t it = k + 1; it <= I; ++it) ptr[it] = nnz;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        tile_item[ntiles] = (int32_t)(I - 1);
+        if (nnz == 0) { for (int64_t it = 0; it <= I; ++it) ptr[it] = 0; tile_item[0] = 0; }
+    }
+}
+
 // ---- item CDF of the positive-sampling distribution (static per CSR) -------------------------
 // mass[i] = sum over users holding i of floor(2^32 / deg(u)) (64-bit integer atomics: exact and
 // order-independent), cdf[i] = floor(2^32 * prefix(mass)[i] / total), cdf[I] = 2^32 - 1
@@ -1067,6 +1399,177 @@ RSX_API int rsx_bpr_sample_chunked(const int64_t *indptr_dev, const int32_t *ind
     hipLaunchKernelGGL(bucket_sort_kernel, dim3(NB), dim3(kBlock), 0, st, indptr_dev, indices_dev, user_sig_dev, num_items,
                        batch, (int64_t)0, seed, step, neg_block, neg_key, nbm, nblk, lds_sort_cap(), w.pairs, w.table, w.totals,
                        u_out, i_out, j_out, ca);
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+}
+
+// ---- the CSC walk: host side ----------------------------------------------------------------------
+struct rsx_csc {
+    CscArgs a{};
+    int rd_bits = 16;
+    int64_t num_users = 0;
+    const int64_t *indptr = nullptr;       // the CSR it was built from (identity check only)
+    const int32_t *indices = nullptr;
+};
+
+namespace {
+struct CscLayout { int64_t ntiles, nnz_pad, off_ptr, off_tile, off_users, off_rd, bytes; };
+CscLayout csc_layout(int64_t nnz, int64_t num_items)
+{
+    CscLayout L;
+    L.ntiles = nnz > 0 ? (nnz + kCscTile - 1) / kCscTile : 1;
+    L.nnz_pad = L.ntiles * kCscTile;
+    L.off_ptr = 0;
+    L.off_tile = L.off_ptr + align256((num_items + 1) * 8);
+    L.off_users = L.off_tile + align256((L.ntiles + 1) * 4);
+    L.off_rd = L.off_users + align256(L.nnz_pad * 4);
+    L.bytes = L.off_rd + align256(L.nnz_pad * 4);                 // (room for the 32-bit form; the 16-bit form uses half)
+    return L;
+}
+size_t csc_sort_temp_bytes(int64_t nnz, int bits)
+{
+    size_t n = 0;
+    uint32_t *k = nullptr;
+    uint64_t *v = nullptr;
+    (void)rocprim::radix_sort_pairs<sort_config>(nullptr, n, k, k, v, v, (size_t)(nnz > 0 ? nnz : 1), 0, (unsigned)bits, (hipStream_t)0);
+    return n;
+}
+}  // namespace
+
+RSX_API int64_t rsx_bpr_csc_bytes(int64_t nnz, int64_t num_items)
+{
+    if (nnz < 0 || nnz >= (1ll << 32) || num_items <= 0 || num_items >= (1ll << 31)) return RSX_E_INVALID;
+    return csc_layout(nnz, num_items).bytes;
+}
+
+RSX_API int64_t rsx_bpr_csc_workspace(int64_t nnz, int64_t num_items)
+{
+    if (nnz < 0 || nnz >= (1ll << 32) || num_items <= 0 || num_items >= (1ll << 31)) return RSX_E_INVALID;
+    const int64_t n = nnz > 0 ? nnz : 1;
+    return 256 + align256(n * 4) + 2 * align256(n * 8) + align256((int64_t)csc_sort_temp_bytes(nnz, key_bits(num_items)));
+}
+
+RSX_API int rsx_bpr_build_csc(const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users, int64_t num_items, int64_t nnz,
+                              void *blob, int64_t blob_bytes, void *ws, int64_t ws_bytes, rsx_stream_t stream, rsx_csc **out)
+{
+    RSX_CHECK_ARG(indptr_dev && indices_dev && blob && ws && out, "null pointer");
+    RSX_CHECK_ARG(num_users > 0 && num_users < (1ll << 31) && num_items > 0 && num_items < (1ll << 31) && nnz >= 0 && nnz < (1ll << 32),
+                  "table sizes must fit int32 (nnz: uint32)");
+    RSX_CHECK_ARG(blob_bytes >= rsx_bpr_csc_bytes(nnz, num_items), "blob smaller than rsx_bpr_csc_bytes(nnz, num_items)");
+    RSX_CHECK_ARG(ws_bytes >= rsx_bpr_csc_workspace(nnz, num_items), "workspace smaller than rsx_bpr_csc_workspace(nnz, num_items)");
+    hipStream_t st = (hipStream_t)stream;
+    const CscLayout L = csc_layout(nnz, num_items);
+    const int64_t n = nnz > 0 ? nnz : 1;
+    char *w = (char *)ws;
+    unsigned long long *max_deg = (unsigned long long *)w;          w += 256;
+    uint32_t *keys_out = (uint32_t *)w;                             w += align256(n * 4);
+    uint64_t *vals_in = (uint64_t *)w;                              w += align256(n * 8);
+    uint64_t *vals_out = (uint64_t *)w;                             w += align256(n * 8);
+    void *temp = w;
+    // the longest row decides the entry format (this is a set-up call: it waits for the device once)
+    unsigned long long mx = 0;
+    if (hipMemsetAsync(max_deg, 0, 8, st) != hipSuccess) { rsx_set_error("rsx_bpr_build_csc: memset failed"); return RSX_E_HIP; }
+    hipLaunchKernelGGL(csc_entries_kernel, dim3(grid_1d(num_users)), dim3(kBlock), 0, st, indptr_dev, num_users, 0, (uint64_t *)nullptr, max_deg);
+    hipError_t e = hipMemcpyAsync(&mx, max_deg, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { rsx_set_error("rsx_bpr_build_csc: reading the longest row failed: %s", hipGetErrorString(e)); return RSX_E_HIP; }
+    if (mx > 65535ull) {
+        rsx_set_error("rsx_bpr_build_csc: a user holds %llu items; the CSC walk takes rows of at most 65535 (use the bucket sampler)", mx);
+        return RSX_E_INVALID;
+    }
+    const int rd_bits = mx <= 255ull ? 16 : 32;
+    const int shift = rd_bits == 16 ? 8 : 16;
+    int64_t *ptr = (int64_t *)((char *)blob + L.off_ptr);
+    int32_t *tile_item = (int32_t *)((char *)blob + L.off_tile);
+    uint32_t *users = (uint32_t *)((char *)blob + L.off_users);
+    void *rd = (char *)blob + L.off_rd;
+    if (nnz > 0) {
+        hipLaunchKernelGGL(csc_entries_kernel, dim3(grid_1d(num_users)), dim3(kBlock), 0, st, indptr_dev, num_users, shift, vals_in, max_deg);
+        size_t temp_bytes = csc_sort_temp_bytes(nnz, key_bits(num_items));
+        // stable: inside an item the users stay ascending (the CSR is walked user by user)
+        e = rocprim::radix_sort_pairs<sort_config>(temp, temp_bytes, reinterpret_cast<const uint32_t *>(indices_dev), keys_out, vals_in, vals_out,
+                                                   (size_t)nnz, 0, (unsigned)key_bits(num_items), st);
+        if (e != hipSuccess) { rsx_set_error("rsx_bpr_build_csc: radix sort failed: %s", hipGetErrorString(e)); return RSX_E_HIP; }
+    }
+    if (rd_bits == 16)
+        hipLaunchKernelGGL(csc_split_kernel<uint16_t>, dim3(grid_1d(L.nnz_pad)), dim3(kBlock), 0, st, keys_out, vals_out, nnz, L.nnz_pad, num_items,
+                           users, (uint16_t *)rd, ptr, tile_item, (int)L.ntiles);
+    else
+        hipLaunchKernelGGL(csc_split_kernel<uint32_t>, dim3(grid_1d(L.nnz_pad)), dim3(kBlock), 0, st, keys_out, vals_out, nnz, L.nnz_pad, num_items,
+                           users, (uint32_t *)rd, ptr, tile_item, (int)L.ntiles);
+    RSX_CHECK_LAUNCH();
+    rsx_csc *c = new (std::nothrow) rsx_csc();
+    if (c == nullptr) { rsx_set_error("rsx_bpr_build_csc: out of memory"); return RSX_E_INVALID; }
+    c->a = CscArgs{ptr, tile_item, users, rd, nnz, num_items, (int)L.ntiles};
+    c->rd_bits = rd_bits; c->num_users = num_users; c->indptr = indptr_dev; c->indices = indices_dev;
+    *out = c;
+    return RSX_OK;
+}
+
+RSX_API void rsx_csc_destroy(rsx_csc *c) { delete c; }
+
+RSX_API int rsx_csc_info(const rsx_csc *c, int64_t *nnz, int64_t *num_items, int *entry_bytes, int64_t *tiles)
+{
+    RSX_CHECK_ARG(c != nullptr, "null csc");
+    if (nnz) *nnz = c->a.nnz;
+    if (num_items) *num_items = c->a.I;
+    if (entry_bytes) *entry_bytes = 4 + c->rd_bits / 8;
+    if (tiles) *tiles = c->a.ntiles;
+    return RSX_OK;
+}
+
+RSX_API int64_t rsx_bpr_sample_csc_workspace(int64_t nnz)
+{
+    if (nnz < 0 || nnz >= (1ll << 32)) return RSX_E_INVALID;
+    return 256 + align256(((nnz > 0 ? (nnz + kCscTile - 1) / kCscTile : 1)) * 8);
+}
+
+// (internal, rsx_common.h) the native loop asks before it takes the CSC walk
+bool rsx_csc_matches(const rsx_csc *c, const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users, int64_t num_items)
+{
+    return c != nullptr && c->indptr == indptr_dev && c->indices == indices_dev && c->num_users == num_users && c->a.I == num_items;
+}
+
+RSX_API int rsx_bpr_sample_csc(const rsx_csc *csc, const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users,
+                               int64_t num_items, int64_t items_real, int chunks, uint64_t seed, uint64_t step, int neg_block,
+                               uint64_t neg_key, void *ws, int64_t ws_bytes, const uint64_t *user_sig_dev, int32_t *u_out,
+                               int32_t *i_out, int32_t *j_out, int64_t *chunk_pos_out, rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(csc && indptr_dev && indices_dev && u_out && i_out && j_out && ws, "null pointer");
+    RSX_CHECK_ARG(rsx_csc_matches(csc, indptr_dev, indices_dev, num_users, num_items),
+                  "the CSC was built from another CSR (rsx_bpr_build_csc takes the SAME indptr, indices, num_users, num_items)");
+    RSX_CHECK_ARG(neg_block >= 0 && neg_block <= kMaxNegBlock, "neg_block must be in [0, 16]");
+    RSX_CHECK_ARG(chunks >= 0 && chunks <= RSX_MAX_CHUNKS && (chunks <= 1 || chunk_pos_out != nullptr), "chunks must be in [0, RSX_MAX_CHUNKS]; chunks > 1 needs chunk_pos_out");
+    RSX_CHECK_ARG(ws_bytes >= rsx_bpr_sample_csc_workspace(csc->a.nnz), "workspace smaller than rsx_bpr_sample_csc_workspace(nnz)");
+    const bool chunked_layout = chunks > 1;
+    const bool whole = chunked_layout && neg_block == 0;
+    ChunkGeom g{};
+    if (chunked_layout) {
+        RSX_CHECK_ARG(items_real > 0, "chunks > 1 needs items_real");
+        g = chunk_geom(items_real, chunks, whole ? 1 : neg_block);
+        RSX_CHECK_ARG(num_items == g.Ic * chunks, "num_items must be chunks * rsx_chunk_rows(items_real, chunks, neg_block)");
+    }
+    const int64_t B = num_users;                                   // the batch IS one pass over the users
+    hipStream_t st = (hipStream_t)stream;
+    int64_t *n_live = (int64_t *)ws;
+    uint32_t *ticket = (uint32_t *)((char *)ws + 64);
+    uint64_t *status = (uint64_t *)((char *)ws + 256);
+    if (hipMemsetAsync(ws, 0, (size_t)rsx_bpr_sample_csc_workspace(csc->a.nnz), st) != hipSuccess) {
+        rsx_set_error("rsx_bpr_sample_csc: memset failed");
+        return RSX_E_HIP;
+    }
+    const uint64_t k = csc_step_key(seed, step);
+    const uint32_t k0 = (uint32_t)k, k1 = (uint32_t)(k >> 32);
+    const ChunkArgs ca{chunked_layout ? chunks : 1, 0, g, chunked_layout ? chunk_pos_out : nullptr, whole};
+    if (csc->rd_bits == 16)
+        hipLaunchKernelGGL(csc_select_kernel<uint16_t>, dim3(csc->a.ntiles), dim3(kCscThreads), 0, st, csc->a, k0, k1, status, ticket, u_out, i_out,
+                           n_live, ca.C, g.Ic, ca.chunk_pos_out);
+    else
+        hipLaunchKernelGGL(csc_select_kernel<uint32_t>, dim3(csc->a.ntiles), dim3(kCscThreads), 0, st, csc->a, k0, k1, status, ticket, u_out, i_out,
+                           n_live, ca.C, g.Ic, ca.chunk_pos_out);
+    const int64_t blocks = ceil_div64(B, kCscNegBlock) + ca.C + 1;
+    hipLaunchKernelGGL(csc_neg_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, indptr_dev, indices_dev, user_sig_dev, num_items, B, seed, step,
+                       neg_block, neg_key, n_live, u_out, i_out, j_out, ca);
     RSX_CHECK_LAUNCH();
     return RSX_OK;
 }

@@ -226,7 +226,13 @@ int launch_sample(rsx_bpr_trainer *t, int slot, int64_t step_index, int64_t batc
         return RSX_OK;
     }
 #endif
-    if (chunked(t))
+    // a batch that holds every user once and wants an ordered layout: the CSC walk (no buckets, no sort; rsx_sample.hip)
+    if (c.csc != nullptr && batch == c.num_users && t->epoch_pos % c.num_users == 0 && (chunked(t) || sorted))
+        RSX_TRY(rsx_bpr_sample_csc(c.csc, c.indptr, c.indices, c.num_users, c.num_items, chunked(t) ? c.items_real : c.num_items,
+                                   chunked(t) ? c.chunks : 1, c.seed, (uint64_t)step_index, nb, key, c.sample_ws, c.sample_ws_bytes,
+                                   nb ? c.user_sig : nullptr, slot_ptr(t, slot, 0), slot_ptr(t, slot, 1), slot_ptr(t, slot, 2),
+                                   chunked(t) ? chunk_pos_ptr(t, slot) : nullptr, (rsx_stream_t)t->side));
+    else if (chunked(t))
         RSX_TRY(rsx_bpr_sample_chunked(c.indptr, c.indices, c.num_users, c.num_items, c.items_real, c.chunks, batch, c.seed,
                                        (uint64_t)step_index, t->epoch_pos, nb, key, c.sample_ws, c.sample_ws_bytes, c.user_sig,
                                        c.item_cdf, slot_ptr(t, slot, 0), slot_ptr(t, slot, 1), slot_ptr(t, slot, 2),
@@ -271,6 +277,22 @@ RSX_API int rsx_bpr_trainer_create(const rsx_bpr_trainer_config *cfg, rsx_bpr_tr
     RSX_CHECK_ARG(!(meshed && (native || cfg->exchange_begin != nullptr || cfg->exchange_range != nullptr)),
                   "give ONE exchange: the callbacks, a communicator, or a mesh");
     RSX_CHECK_ARG(!(meshed && (cfg->two_pass || cfg->stale_exchange)), "a mesh exchanges and applies in one go: no two_pass / stale_exchange");
+    if (cfg->csc != nullptr) {
+        int64_t cnnz = 0;
+        RSX_CHECK_ARG(rsx_csc_matches(cfg->csc, cfg->indptr, cfg->indices, cfg->num_users, cfg->num_items),
+                      "csc was built from another CSR than this config's indptr / indices / num_users / num_items");
+        RSX_TRY(rsx_csc_info(cfg->csc, &cnnz, nullptr, nullptr, nullptr));
+        RSX_CHECK_ARG(cfg->sample_ws != nullptr && cfg->sample_ws_bytes >= rsx_bpr_sample_csc_workspace(cnnz),
+                      "csc needs a sampler workspace of at least rsx_bpr_sample_csc_workspace(nnz) bytes");
+    }
+    if (meshed) {       // the mesh exchanges ITS OWN tables: they must be this trainer's
+        const float *mQ = nullptr, *mG = nullptr;
+        int64_t mrows = 0;
+        int md = 0;
+        rsx_mesh_tables(cfg->mesh, &mQ, &mG, &mrows, &md);
+        RSX_CHECK_ARG(mQ == cfg->Q && mG == cfg->G && mrows >= cfg->num_items && md == cfg->d,
+                      "the mesh was built over other tables than this trainer's Q / G (rsx_mesh_local takes the SAME Q, G, d and at least num_items rows)");
+    }
     const bool sg = native && cfg->exchange_kind == RSX_EXCHANGE_SCATTER_GATHER;
     if (sg) {
         int world = 1;

@@ -75,6 +75,13 @@ SIGNATURES = {
     "rsx_bpr_trainer_kernel_ms": (C.c_int, [_P, _P, _P]),
     "rsx_bpr_trainer_check": (C.c_int, [_P, _P]),
     "rsx_chunk_rows": (_I64, [_I64, _I32, _I32]),
+    "rsx_bpr_csc_bytes": (_I64, [_I64, _I64]),
+    "rsx_bpr_csc_workspace": (_I64, [_I64, _I64]),
+    "rsx_bpr_build_csc": (C.c_int, [_P, _P, _I64, _I64, _I64, _P, _I64, _P, _I64, _P, _P]),
+    "rsx_csc_destroy": (None, [_P]),
+    "rsx_csc_info": (C.c_int, [_P, _P, _P, _P, _P]),
+    "rsx_bpr_sample_csc_workspace": (_I64, [_I64]),
+    "rsx_bpr_sample_csc": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I32, _U64, _U64, _I32, _U64, _P, _I64, _P, _P, _P, _P, _P, _P]),
     "rsx_bpr_sample_chunked": (C.c_int, [_P, _P, _I64, _I64, _I64, _I32, _I64, _U64, _U64, _I64, _I32, _U64, _P, _I64,
                                          _P, _P, _P, _P, _P, _P, _P]),
     "rsx_bpr_step_chunked": (C.c_int, [_P, _P, _P, _I64, _I64, _I64, _I32, _P, _P, _P, _I64, _I32, _F, _F, _P, _P, _P, _I32,
@@ -90,6 +97,7 @@ SIGNATURES = {
     "rsx_mesh_set_wait_limit": (C.c_int, [_P, C.c_double]),
     "rsx_mesh_info": (C.c_int, [_P, _P, _P, _P]),
     "rsx_mesh_check": (C.c_int, [_P, _P]),
+    "rsx_mesh_export_retries": (C.c_int, [_P]),
     "rsx_mesh_destroy": (None, [_P]),
     "rsx_score": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P, _P, _P, _P]),
     "rsx_topk": (C.c_int, [_P, _I64, _I64, _I32, _P, _P, _P]),
@@ -408,6 +416,105 @@ def bpr_sample(indptr, indices, num_items, batch, seed, step, epoch_pos, u_out, 
         _dev(j_out, torch.int32, "j_out"), _stream()), "rsx_bpr_sample")
 
 
+class Csc:
+    """The transposed interaction matrix of one CSR for the whole-pass sampler (include/rsx.h: rsx_bpr_build_csc /
+    rsx_bpr_sample_csc): entries item by item, users ascending, 6 (or 8) bytes each.  Keeps the CSR tensors it was built from and
+    its own device blob alive."""
+
+    def __init__(self, indptr, indices, num_items):
+        U, nnz = indptr.numel() - 1, indices.numel()
+        nb, nw = lib().rsx_bpr_csc_bytes(nnz, int(num_items)), lib().rsx_bpr_csc_workspace(nnz, int(num_items))
+        if nb < 0 or nw < 0:
+            raise RsxError("rsx_bpr_csc_bytes: invalid shape")
+        self.blob = torch.empty(nb, dtype=torch.uint8, device=indptr.device)
+        ws = torch.empty(nw, dtype=torch.uint8, device=indptr.device)
+        self._keep = (indptr, indices)
+        self.num_items, self.nnz = int(num_items), nnz
+        self._h = C.c_void_p()
+        _check(lib().rsx_bpr_build_csc(_dev(indptr, torch.int64, "indptr"), _dev(indices, torch.int32, "indices"), U, int(num_items), nnz,
+                                       C.c_void_p(self.blob.data_ptr()), nb, C.c_void_p(ws.data_ptr()), nw, _stream(), C.byref(self._h)),
+               "rsx_bpr_build_csc")
+        torch.cuda.current_stream().synchronize()       # (the build scratch is released below)
+        self.sample_ws_bytes = int(lib().rsx_bpr_sample_csc_workspace(nnz))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self):
+        """{nnz, num_items, entry_bytes, tiles}"""
+        nnz, ni, eb, tiles = C.c_int64(), C.c_int64(), C.c_int(), C.c_int64()
+        _check(lib().rsx_csc_info(self._h, C.byref(nnz), C.byref(ni), C.byref(eb), C.byref(tiles)), "rsx_csc_info")
+        return {"nnz": nnz.value, "num_items": ni.value, "entry_bytes": eb.value, "tiles": tiles.value}
+
+    def arrays(self):
+        """{ptr int64 [I + 1], tile_item int32 [tiles + 1], users uint32 [nnz], rank, deg, tile: entries per tile} on the host -- tests"""
+        import numpy as np
+        inf = self.info()
+        a256 = lambda x: (x + 255) // 256 * 256
+        tiles, I = inf["tiles"], inf["num_items"]
+        # (the layout mirrors csc_layout in csrc/rsx_sample.hip)
+        raw = self.blob.cpu().numpy()
+        off_tile = a256((I + 1) * 8)
+        off_users = off_tile + a256((tiles + 1) * 4)
+        nnz_pad = (self.blob.numel() - off_users) // 8
+        off_rd = off_users + a256(nnz_pad * 4)
+        ptr = raw[:(I + 1) * 8].view(np.int64)
+        tile_item = raw[off_tile:off_tile + (tiles + 1) * 4].view(np.int32)
+        users = raw[off_users:off_users + self.nnz * 4].view(np.uint32)
+        if inf["entry_bytes"] == 6:
+            rd = raw[off_rd:off_rd + self.nnz * 2].view(np.uint16).astype(np.uint32)
+            rank, deg = rd & 0xFF, rd >> 8
+        else:
+            rd = raw[off_rd:off_rd + self.nnz * 4].view(np.uint32)
+            rank, deg = rd & 0xFFFF, rd >> 16
+        return {"ptr": ptr.copy(), "tile_item": tile_item.copy(), "users": users.copy(), "rank": rank, "deg": deg, "tile": nnz_pad // tiles}
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().rsx_csc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                              # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+def bpr_sample_csc(csc, indptr, indices, num_items, seed, step, u_out, i_out, j_out, neg_block=0, neg_key=0, ws=None, user_sig=None,
+                   chunks=1, items_real=None, chunk_pos=None):
+    """include/rsx.h:rsx_bpr_sample_csc -- a batch of EVERY user once, ordered by positive item by one walk over the CSC"""
+    _check(lib().rsx_bpr_sample_csc(
+        csc.handle, _dev(indptr, torch.int64, "indptr"), _dev(indices, torch.int32, "indices"), indptr.numel() - 1, int(num_items),
+        int(items_real if items_real is not None else num_items), int(chunks), seed & (2**64 - 1), step, int(neg_block),
+        int(neg_key) & (2**64 - 1), C.c_void_p(ws.data_ptr()), ws.numel() * ws.element_size(),
+        _dev(user_sig, torch.int64, "user_sig") if user_sig is not None else None,
+        _dev(u_out, torch.int32, "u_out"), _dev(i_out, torch.int32, "i_out"), _dev(j_out, torch.int32, "j_out"),
+        _dev(chunk_pos, torch.int64, "chunk_pos") if chunk_pos is not None else None, _stream()), "rsx_bpr_sample_csc")
+
+
+def csc_positive_rank(users, deg, seed, step):
+    """host restatement (numpy) of the walk's choice of the positive: rank in [0, deg) of every user's sampled item
+    (csrc/rsx_sample.hip: csc_step_key / csc_hash) -- tests compare the device pairs against it"""
+    import numpy as np
+    M = (1 << 64) - 1
+
+    def splitmix64(z):
+        z = (z + 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+    k = splitmix64((int(seed) & M) ^ ((int(step) * 0x9E3779B97F4A7C15) & M) ^ 0xC5C0DE5A3D1E7)
+    k0, k1 = np.uint32(k & 0xFFFFFFFF), np.uint32(k >> 32)
+    x = np.asarray(users).astype(np.uint32) ^ k0
+    x ^= x >> np.uint32(16); x *= np.uint32(0x7feb352d)
+    x ^= x >> np.uint32(15); x *= np.uint32(0x846ca68b)
+    x ^= x >> np.uint32(16)
+    x ^= k1
+    return ((x.astype(np.uint64) * np.asarray(deg).astype(np.uint64)) >> np.uint64(32)).astype(np.int64)
+
+
 def chunk_rows(items_real, chunks, neg_block):
     """rows per item range of the chunked step (include/rsx.h: "item chunks")"""
     n = lib().rsx_chunk_rows(int(items_real), int(chunks), int(neg_block))
@@ -517,8 +624,9 @@ class Mesh:
             box = [None] * self.world
             dist.all_gather_object(box, err, group=group)
             bad = [f"rank {q}: {e}" for q, e in enumerate(box) if e is not None]
-        if bad:
+        if bad:                                        # (the same list on every rank: all of them leave, together)
             self._destroy()
+            dist.barrier(group=group)                  # nobody exports again while a peer still detaches
             raise RsxError("; ".join(bad))
 
     @property
@@ -538,9 +646,28 @@ class Mesh:
         _check(lib().rsx_mesh_info(self._h, C.byref(r), C.byref(w), C.byref(n)), "rsx_mesh_info")
         return int(r.value), int(w.value), int(n.value)
 
+    def export_retries(self):
+        """hipIpcGetMemHandle calls that failed before rsx_mesh_local's exports succeeded (0 normally)"""
+        return int(lib().rsx_mesh_export_retries(self._h))
+
     def check(self):
         """synchronises; raises if a wait for a peer's signal gave up (the rows of that exchange are wrong)"""
         _check(lib().rsx_mesh_check(self._h, _stream()), "rsx_mesh_check")
+
+    def check_all(self):
+        """collective form of check(): every rank learns every rank's result BEFORE anyone raises, so a rank whose wait gave up
+        does not leave the others inside the next collective"""
+        import torch.distributed as dist
+        try:
+            self.check()
+            err = None
+        except RsxError as e:
+            err = str(e)
+        box = [None] * self.world
+        dist.all_gather_object(box, err, group=self.group)
+        bad = [f"rank {q}: {e}" for q, e in enumerate(box) if e is not None]
+        if bad:
+            raise RsxError("; ".join(bad))
 
     def _destroy(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -548,11 +675,21 @@ class Mesh:
             self._h = C.c_void_p()
 
     def close(self):
+        """collective.  Barrier, unmap + free, barrier: nobody reads my buffers any more when I unmap, and nobody exports the same
+        allocations again (a later Mesh over the same pooled segment) while a peer is still detaching from this export."""
         if getattr(self, "_h", None) is not None and self._h.value:
             import torch.distributed as dist
             torch.cuda.synchronize()
             dist.barrier(group=self.group)             # every rank has finished every exchange: nobody reads my buffers any more
             self._destroy()
+            dist.barrier(group=self.group)             # every rank has closed every mapping
+            self._keep = None
+
+    def __del__(self):
+        try:                                           # best effort (not collective): a dropped mesh must not leak mappings + mailbox
+            self._destroy()
+        except Exception:                              # noqa: BLE001 -- interpreter shutdown
+            pass
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
@@ -570,7 +707,7 @@ class TrainerConfig(C.Structure):
                 ("exchange_applies", C.c_int32), ("sort_min_batch", C.c_int32), ("step0", _I64), ("epoch_pos0", _I64),
                 ("G_alt", _P), ("stale_exchange", C.c_int32), ("exchange_kind", C.c_int32), ("comm", _P),
                 ("item_rows_padded", _I64), ("chunks", C.c_int32), ("reserved0", C.c_int32), ("items_real", _I64),
-                ("chunk_pos", _P), ("progress", _P), ("exchange_range", EXCHANGE_RANGE_FN), ("mesh", _P)]
+                ("chunk_pos", _P), ("progress", _P), ("exchange_range", EXCHANGE_RANGE_FN), ("mesh", _P), ("csc", _P)]
 
 
 class BPRTrainer:
@@ -581,8 +718,9 @@ class BPRTrainer:
     def __init__(self, P, Q, G, indptr, indices, lr, batch, seed, seed_key, neg_block=0, hot=None, user_sig=None,
                  item_cdf=None, loss_acc=None, exchange=None, two_pass=False, exchange_applies=False, sort_min_batch=0, step0=0, epoch_pos0=0,
                  G_alt=None, comm=None, exchange_kind=0, item_rows_padded=0, chunks=0, items_real=0, num_items=None, exchange_range=None,
-                 mesh=None):
+                 mesh=None, csc=None):
         """exchange: (begin, end) callables (the collective stays with the caller) OR comm: an rsx.Comm (the library issues it).
+        csc: an rsx.Csc over this CSR -- whole-pass batches of an ordered layout are then sampled by the CSC walk.
         chunks > 1: P / Q / G / the CSR live in the caller's relabelled item space of chunks * chunk_rows ids; sharded without
         comm: exchange_range(k, first_row, rows, stream_handle) queues the caller's all-reduce of G[first_row:first_row + rows] on
         the given HIP stream (include/rsx.h: exchange_range)."""
@@ -596,9 +734,11 @@ class BPRTrainer:
         self.triplets = torch.empty(RSX_TRAINER_SLOTS * 3 * self.batch, dtype=torch.int32, device=dev)
         self.sample_ws = None
         if neg_block or sort_min_batch or self.chunks > 1:
-            self.sample_ws = torch.empty(bpr_sample_workspace(self.batch, int(num_items) if num_items is not None else Q.shape[0]),
-                                         dtype=torch.uint8, device=dev)
-        self._keep = (P, Q, G, indptr, indices, hot, user_sig, item_cdf, loss_acc, G_alt, comm, mesh)
+            self.sample_ws = torch.empty(max(bpr_sample_workspace(self.batch, int(num_items) if num_items is not None else Q.shape[0]),
+                                             csc.sample_ws_bytes if csc is not None else 0), dtype=torch.uint8, device=dev)
+        else:
+            csc = None                                 # (the plain layout never takes the walk)
+        self._keep = (P, Q, G, indptr, indices, hot, user_sig, item_cdf, loss_acc, G_alt, comm, mesh, csc)
         ptr = lambda t, dt, name: _dev(t, dt, name) if t is not None else None
         self._cb = (None, None)
         if exchange is not None:                       # (begin, end) callables; exceptions become error codes
@@ -646,7 +786,8 @@ class BPRTrainer:
             exchange_kind=int(exchange_kind), comm=comm.handle if comm is not None else None,
             item_rows_padded=int(item_rows_padded), chunks=self.chunks, reserved0=0, items_real=int(items_real),
             chunk_pos=ptr(self.chunk_pos, torch.int64, "chunk_pos"), progress=ptr(self.progress, torch.int32, "progress"),
-            exchange_range=self._cb_range or EXCHANGE_RANGE_FN(), mesh=mesh.handle if mesh is not None else None)
+            exchange_range=self._cb_range or EXCHANGE_RANGE_FN(), mesh=mesh.handle if mesh is not None else None,
+            csc=csc.handle if csc is not None else None)
         self._h = C.c_void_p()
         _check(lib().rsx_bpr_trainer_create(C.byref(cfg), C.byref(self._h)), "rsx_bpr_trainer_create")
 

@@ -198,6 +198,10 @@ class BPREngine:
         self._sample_ws = {}        # sampler scratch, one per stream role ("main" / "side"): never shared
         self._csr = None            # the CSR tensors the static sampler tables below were built from
         self._sig = self._cdf = None
+        # whole-pass batches (batch == this rank's users) of an ordered layout are sampled by ONE walk over the transposed
+        # interaction matrix instead of the bucket passes (include/rsx.h: rsx_bpr_sample_csc); built on first use, per CSR
+        self.use_csc = True
+        self._csc = None            # (rsx.Csc, indptr, indices)
         self._bufs = None           # double-buffered triplets for the overlapped sampler
         self._side = None           # ONE side stream for the engine's lifetime
 
@@ -232,6 +236,19 @@ class BPREngine:
                      if (self.neg_block and hasattr(self.k, "build_signature")) else None)
         self._cdf = self.k.build_item_cdf(indptr, indices, self.Q.shape[0]) if hasattr(self.k, "build_item_cdf") else None
         self._csr = (indptr, indices, self.neg_block)
+
+    def _csc_for(self, indptr, indices, num_items, batch):
+        """the rsx.Csc of this CSR when `batch` is a whole pass over this rank's users and the kernels have the walk, else None"""
+        if not (self.use_csc and hasattr(self.k, "Csc")) or batch != indptr.numel() - 1:
+            return None
+        c = self._csc
+        if c is None or c[1] is not indptr or c[2] is not indices or c[0].num_items != num_items:
+            self._csc = c = (self.k.Csc(indptr, indices, num_items), indptr, indices)
+        return c[0]
+
+    def _csc_kw(self, indptr, indices, num_items, batch):
+        c = self._csc_for(indptr, indices, num_items, batch)
+        return {"csc": c} if c is not None else {}
 
     def _eff_neg_block(self, batch):
         """the block size a SAMPLED step of this batch size runs with: blocked negatives engage from two triplets per
@@ -428,7 +445,7 @@ class BPREngine:
         if self._mesh is not None:
             mesh, self._mesh = self._mesh[0], None
             try:
-                mesh.check()
+                mesh.check_all()                    # (every rank learns every rank's result before anyone raises)
             finally:
                 mesh.close()
 
@@ -602,8 +619,15 @@ class BPREngine:
                 kw["user_sig"] = self._sig
             if self._cdf is not None and self.use_item_cdf:
                 kw["item_cdf"] = self._cdf
-        self.k.bpr_sample(indptr, indices, self.Q.shape[0], batch, self.seed + 7919 * self.user_begin,
-                          step, self.epoch_pos, u, i, j, **kw)
+        csc = self._csc_for(indptr, indices, self.Q.shape[0], batch) if (kw and self.epoch_pos % U == 0) else None
+        if csc is not None:          # the same rule as the native loop (csrc/rsx_train.hip: launch_sample)
+            if kw["ws"].numel() < csc.sample_ws_bytes:
+                kw["ws"] = self._sample_ws[role] = torch.empty(csc.sample_ws_bytes, dtype=torch.uint8, device=self.Q.device)
+            self.k.bpr_sample_csc(csc, indptr, indices, self.Q.shape[0], self.seed + 7919 * self.user_begin, step, u, i, j,
+                                  neg_block=nb, neg_key=key, ws=kw["ws"], user_sig=kw.get("user_sig"))
+        else:
+            self.k.bpr_sample(indptr, indices, self.Q.shape[0], batch, self.seed + 7919 * self.user_begin,
+                              step, self.epoch_pos, u, i, j, **kw)
         self.epoch_pos += batch
         return key
 
@@ -705,7 +729,8 @@ class BPREngine:
                                      seed=self.seed + 7919 * self.user_begin, seed_key=self.seed, neg_block=self.neg_block,
                                      hot=r["hot"], user_sig=r["sig"], item_cdf=r["cdf"], loss_acc=loss_acc,
                                      comm=self.comm if native else None, exchange_kind=kind, chunks=self.chunks,
-                                     items_real=self.Q.shape[0], step0=self.step_count, epoch_pos0=self.epoch_pos, **by_range)
+                                     items_real=self.Q.shape[0], step0=self.step_count, epoch_pos0=self.epoch_pos,
+                                     **self._csc_kw(indptr, r["indices"], r["Q"].shape[0], batch), **by_range)
         sort_min = int(self.sorted_min_batch) if (self.sorted_min_batch and not self.neg_block) else 0
         if self.neg_block or sort_min:
             self._bind_csr(indptr, indices)
@@ -729,6 +754,7 @@ class BPREngine:
                                  loss_acc=loss_acc, exchange=exchange, two_pass=self.overlap_exchange and not direct,
                                  exchange_applies=self.exchange == "scatter_gather",
                                  step0=self.step_count, epoch_pos0=self.epoch_pos, **extra,
+                                 **(self._csc_kw(indptr, indices, self.Q.shape[0], batch) if (self.neg_block or sort_min) else {}),
                                  **({"G_alt": self._stale_buffers()} if stale else {}))
 
     def adopt(self, trainer):

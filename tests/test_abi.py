@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(libpath):
     for name in declared_functions():
         assert hasattr(L, name), f"{name} declared in include/rsx.h but not exported"
     L.rsx_version.restype = ctypes.c_int
-    assert L.rsx_version() == 7
+    assert L.rsx_version() == 8
 
 
 def test_library_exports_nothing_the_header_does_not_declare(libpath):
@@ -57,7 +57,7 @@ def test_options_are_validated(libpath):
 def test_binding_covers_every_declared_symbol(libpath):
     from recsys_pytorch_amd import rsx
     assert sorted(rsx.SIGNATURES) == declared_functions()
-    assert rsx.version() == 7
+    assert rsx.version() == 8
 
 
 def test_no_cpu_fallback():

@@ -1,0 +1,330 @@
+"""GPU: the whole-pass sampler (include/rsx.h: rsx_bpr_build_csc / rsx_bpr_sample_csc -- the CSC walk that replaces the bucket
+passes when a batch holds every user once; reference: data/generators.py:151-224, one triplet per user per epoch).  The blob
+against scipy's transpose, the sampled pairs against a numpy restatement of the walk's rule, order / negatives / item ranges by
+their properties, and the native loop through it against hand-driven steps and the oracle.  Run with `-m gpu` on an MI355X."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import assert_update, fuzz, resolvable_lr
+
+pytestmark = pytest.mark.gpu
+
+M64 = (1 << 64) - 1
+
+
+def _splitmix64(z):
+    z = (z + 0x9E3779B97F4A7C15) & M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+    return z ^ (z >> 31)
+
+
+def _half_bits_for(n):
+    bits = 1
+    while (1 << bits) < n:
+        bits += 1
+    return (bits + 1) // 2
+
+
+def _feistel(x, n, key):
+    """csrc/rsx_common.h: feistel_perm"""
+    hb = _half_bits_for(n)
+    mask = (1 << hb) - 1
+    while True:
+        l, r = x >> hb, x & mask
+        for rnd in range(4):
+            f = _splitmix64(key ^ (r << 8) ^ rnd) & mask
+            l, r = r, l ^ f
+        x = (l << hb) | r
+        if x < n:
+            return x
+
+
+def _neg_block_of(w, nblocks, key):
+    return w if key == 0 else _feistel(w, nblocks, key)
+
+
+def _random_csr(rng, U, I, kind, ids=None):
+    ids = np.arange(I) if ids is None else ids
+    n = len(ids)
+    if kind == 0:
+        degs = rng.integers(0, min(n, 6), U)
+    elif kind == 1:
+        degs = rng.integers(0, min(n, 120), U)
+    elif kind == 2:
+        degs = rng.integers(1, min(n, 30) + 1, U)
+    elif kind == 3:
+        degs = np.minimum(n - 1, (rng.pareto(1.0, U) * 3).astype(np.int64))
+    else:                                   # long rows: more than 255 items -> the 8-byte entries
+        degs = np.minimum(n - 1, rng.integers(0, 700, U))
+    if kind == 2 and U > 3:
+        degs[rng.integers(0, U, max(1, U // 50))] = n          # users who own EVERYTHING: never sampled
+    rows = [np.sort(rng.choice(ids, int(g), replace=False)) for g in degs]
+    indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    indices = (np.concatenate(rows) if indptr[-1] else np.zeros(0)).astype(np.int32)
+    return rows, indptr, indices
+
+
+def _dev_csr(indptr, indices):
+    ip = torch.from_numpy(indptr).cuda()
+    ix = torch.from_numpy(indices if len(indices) else np.zeros(1, np.int32)).cuda()
+    if len(indices) == 0:
+        ix = ix[:0]
+    return ip, ix
+
+
+def test_csc_blob_is_the_transposed_matrix():
+    """rsx_bpr_build_csc against scipy: first entry of every item (empty items too), users ascending inside an item, the rank of
+    the item inside its user's row and the row's length per entry; rows above 255 items switch to the 8-byte entries"""
+    from recsys_pytorch_amd import rsx
+    rng, trials = fuzz(77, 14)
+    for trial in range(trials):
+        U, I = int(rng.integers(1, 3000)), int(rng.integers(4, 2500))
+        kind = trial % 5
+        rows, indptr, indices = _random_csr(rng, U, I, kind)
+        if trial == 5:                                                     # no interaction at all
+            indptr[:] = 0; indices = indices[:0]; rows = [np.zeros(0, np.int64)] * U
+        ip, ix = _dev_csr(indptr, indices)
+        csc = rsx.Csc(ip, ix, I)
+        arr = csc.arrays()
+        ptr, tile_item, users, rank, deg = (arr[k] for k in ("ptr", "tile_item", "users", "rank", "deg"))
+        nnz = len(indices)
+        ctx = f"trial {trial}: U={U} I={I} kind={kind} nnz={nnz}"
+        A = sp.csr_matrix((np.ones(nnz, np.int8), indices, indptr), shape=(U, I)).tocsc()
+        A.sort_indices()
+        assert np.array_equal(ptr, A.indptr.astype(np.int64)), ctx
+        assert np.array_equal(users.astype(np.int64), A.indices.astype(np.int64)), ctx
+        row_len = np.diff(indptr)
+        assert np.array_equal(deg.astype(np.int64), row_len[A.indices]), ctx
+        item_of_entry = np.repeat(np.arange(I), np.diff(A.indptr))
+        for e in rng.integers(0, max(nnz, 1), 200) if nnz else []:
+            assert rows[users[e]][rank[e]] == item_of_entry[e], ctx
+        inf = csc.info()
+        assert inf["entry_bytes"] == (8 if row_len.max(initial=0) > 255 else 6) and inf["nnz"] == nnz, ctx
+        for t in range(inf["tiles"]):                                      # the item that holds the first entry of every tile
+            if t * arr["tile"] < nnz:
+                assert tile_item[t] == item_of_entry[t * arr["tile"]], ctx
+        assert tile_item[-1] == I - 1, ctx
+
+
+def _check_batch(rows, indptr, I, B, u, i, j, seed, step, c, key, ctx, chunk=None):
+    """properties of one sampled whole-pass batch.  chunk = (C, Ic, n_real, cp) for the item-range layout"""
+    from recsys_pytorch_amd import rsx
+    U = B
+    deg = np.diff(indptr)
+    I_all = I if chunk is None else chunk[0] * chunk[1]
+    usable = (deg > 0) & (deg < I_all)
+    n_pos = int(usable.sum())
+    had = np.arange(B) < n_pos                                   # positions that had a positive
+    live = i >= 0
+    assert not live[~had].any() and np.all(j[~live] == -1), ctx
+    if chunk is None:
+        assert live[had].all(), ctx                              # (without ranges nobody is skipped for want of a negative)
+    # every usable user exactly once, with the positive the rule picks
+    uu = u[:n_pos].astype(np.int64)
+    assert np.array_equal(np.sort(uu), np.flatnonzero(usable)), ctx
+    want_rank = rsx.csc_positive_rank(uu, deg[uu], seed, step)
+    want_item = np.array([rows[a][r] for a, r in zip(uu, want_rank)], np.int64) if n_pos else np.zeros(0, np.int64)
+    got_item = i[:n_pos].astype(np.int64)
+    assert np.array_equal(got_item[live[:n_pos]], want_item[live[:n_pos]]), ctx
+    # ordered by (item, user) -- by the item the rule picked, also where the pair was skipped afterwards
+    order_key = want_item * (U + 1) + uu
+    assert np.all(np.diff(order_key) > 0), ctx
+    # negatives
+    pick = np.flatnonzero(live)
+    pick = pick[:: max(1, len(pick) // 400)]
+    for p in pick:
+        row = rows[u[p]]
+        assert j[p] not in row and 0 <= j[p] < I_all, ctx
+    if chunk is None and c > 0:
+        nblocks = -(-I // c)
+        inblock = 0
+        for p in pick:
+            w = ((int(p) * I) // B) // c
+            blk = _neg_block_of(w, nblocks, key)
+            inblock += int(j[p] // c == blk)
+        assert inblock >= 0.9 * len(pick), ctx                   # (a user who owns its whole block draws from the catalog after 64 tries)
+    if chunk is not None:
+        C, Ic, n_real, cp = chunk
+        assert cp[0] == 0 and cp[-1] == n_pos and np.all(np.diff(cp) >= 0), ctx
+        assert np.array_equal(cp, np.searchsorted(want_item, np.arange(C + 1) * Ic)), ctx
+        for k in range(C):
+            sl = slice(cp[k], cp[k + 1])
+            ok = i[sl] >= 0
+            assert np.all(i[sl][ok] // Ic == k) and np.all(j[sl][ok] // Ic == k), ctx
+            assert np.all(j[sl][ok] - k * Ic < n_real[k]), ctx
+        for p in np.flatnonzero(~live & had):                    # skipped: the user owns (nearly) the whole range of its positive
+            row = rows[u[p]]
+            k = int(want_item[p] // Ic)
+            assert np.isin(k * Ic + np.arange(n_real[k]), row).mean() > 0.9, ctx
+
+
+def test_csc_sampler_on_random_shapes():
+    """random CSRs (empty rows, rows owning everything, heavy tails, long rows, tiny sizes; several tiles) through
+    rsx_bpr_sample_csc without item ranges: every usable user once with the positive the rule picks (numpy restatement), ordered
+    by (item, user), negatives true and from the position's item block, the dead tail marked, the same call twice the same bits"""
+    from recsys_pytorch_amd import rsx
+    rng, trials = fuzz(4242, 24)
+    for trial in range(trials):
+        kind = trial % 5
+        U = int(rng.integers(1, 6000)) if trial % 4 else int(rng.integers(20000, 60000))
+        I = int(rng.integers(8, 3000))
+        c = [0, 2, 3, 5, 16][trial % 5] if trial % 3 else 0
+        rows, indptr, indices = _random_csr(rng, U, I, kind)
+        ip, ix = _dev_csr(indptr, indices)
+        csc = rsx.Csc(ip, ix, I)
+        sig = rsx.build_signature(ip, ix, c) if (c and trial % 2) else None
+        ws = torch.empty(csc.sample_ws_bytes, dtype=torch.uint8, device="cuda")
+        key = (2 * trial + 1) if c else 0
+        outs = []
+        for rep in range(2):
+            u, i, j = (torch.full((U,), -7, dtype=torch.int32, device="cuda") for _ in range(3))
+            rsx.bpr_sample_csc(csc, ip, ix, I, 11, trial, u, i, j, neg_block=c, neg_key=key, ws=ws, user_sig=sig)
+            torch.cuda.synchronize()
+            outs.append([x.cpu().numpy() for x in (u, i, j)])
+        ctx = f"trial {trial}: U={U} I={I} c={c} kind={kind} nnz={len(indices)} entry_bytes={csc.info()['entry_bytes']} tiles={csc.info()['tiles']}"
+        assert all(np.array_equal(a, b) for a, b in zip(*outs)), ctx
+        _check_batch(rows, indptr, I, U, *outs[0], 11, trial, c, key, ctx)
+
+
+def test_csc_sampler_with_item_ranges_on_random_shapes():
+    """the same walk in the relabelled item space of 2..8 item ranges (padding rows behind every range), with and without
+    blocks: first positions of the ranges, positives and negatives of range k only, real rows only, a user owning its whole
+    range skipped in place"""
+    from recsys_pytorch_amd import rsx
+    rng, trials = fuzz(555, 20)
+    for trial in range(trials):
+        C = int(rng.integers(2, 9))
+        c = int(rng.integers(1, 17)) if trial % 4 else 0
+        I = int(rng.integers(max(2 * C, 8), 3000))
+        U = int(rng.integers(1, 5000)) if trial % 5 else int(rng.integers(20000, 40000))
+        Ic = rsx.chunk_rows(I, C, c)
+        base, rem = divmod(I, C)
+        n_real = np.array([base + (k < rem) for k in range(C)])
+        real_ids = np.concatenate([k * Ic + np.arange(n_real[k]) for k in range(C)])
+        kind = trial % 4
+        rows, indptr, indices = _random_csr(rng, U, I, kind, ids=real_ids)
+        if kind == 2:                                                      # users owning ALL items of range 0 (+ a few more)
+            for a in np.flatnonzero(rng.random(U) < 0.05):
+                rows[a] = np.unique(np.concatenate([np.arange(n_real[0]), rows[a]]))
+            indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+            indices = (np.concatenate(rows) if indptr[-1] else np.zeros(0)).astype(np.int32)
+        ip, ix = _dev_csr(indptr, indices)
+        csc = rsx.Csc(ip, ix, C * Ic)
+        sig = rsx.build_signature(ip, ix, c) if (c and trial % 2) else None
+        ws = torch.empty(csc.sample_ws_bytes, dtype=torch.uint8, device="cuda")
+        outs = []
+        for rep in range(2):
+            u, i, j = (torch.full((U,), -7, dtype=torch.int32, device="cuda") for _ in range(3))
+            cp = torch.full((C + 1,), -1, dtype=torch.int64, device="cuda")
+            rsx.bpr_sample_csc(csc, ip, ix, C * Ic, 11, trial, u, i, j, neg_block=c, neg_key=2 * trial + 1, ws=ws, user_sig=sig, chunks=C,
+                               items_real=I, chunk_pos=cp)
+            torch.cuda.synchronize()
+            outs.append([x.cpu().numpy() for x in (u, i, j, cp)])
+        ctx = f"trial {trial}: U={U} I={I} C={C} c={c} kind={kind} nnz={len(indices)}"
+        assert all(np.array_equal(a, b) for a, b in zip(*outs)), ctx
+        u, i, j, cp = outs[0]
+        _check_batch(rows, indptr, I, U, u, i, j, 11, trial, c, 2 * trial + 1, ctx, chunk=(C, Ic, n_real, cp))
+
+
+def test_csc_positives_are_uniform_in_the_row():
+    """over many steps every item of a row is the sampled positive equally often (chi-square per row length)"""
+    from recsys_pytorch_amd import rsx
+    rng = np.random.default_rng(5)
+    U, I, steps = 4000, 600, 300
+    rows, indptr, indices = _random_csr(rng, U, I, 2)
+    ip, ix = _dev_csr(indptr, indices)
+    csc = rsx.Csc(ip, ix, I)
+    ws = torch.empty(csc.sample_ws_bytes, dtype=torch.uint8, device="cuda")
+    deg = np.diff(indptr)
+    counts = np.zeros(len(indices), np.int64)
+    u, i, j = (torch.empty(U, dtype=torch.int32, device="cuda") for _ in range(3))
+    for step in range(steps):
+        rsx.bpr_sample_csc(csc, ip, ix, I, 99, step, u, i, j, ws=ws)
+        uu, ii = u.cpu().numpy().astype(np.int64), i.cpu().numpy().astype(np.int64)
+        ok = ii >= 0
+        # entry index of (user, item) in the CSR
+        e = np.array([indptr[a] + np.searchsorted(rows[a], b) for a, b in zip(uu[ok], ii[ok])])
+        np.add.at(counts, e, 1)
+    usable = (deg > 0) & (deg < I)
+    chi, dof = 0.0, 0
+    for a in np.flatnonzero(usable):
+        cnt = counts[indptr[a]:indptr[a + 1]]
+        assert cnt.sum() == steps
+        exp = steps / deg[a]
+        chi += float(((cnt - exp) ** 2 / exp).sum()); dof += int(deg[a]) - 1
+    z = (chi - dof) / np.sqrt(2.0 * dof)
+    assert abs(z) < 5.0, (chi, dof, z)
+
+
+@pytest.mark.parametrize("d,I,c_max,chunks", [(128, 3000, 8, 0), (64, 20000, 8, 0), (128, 3000, 8, 2), (32, 15000, 8, 3)])
+def test_native_loop_through_the_walk_replays_through_the_oracle(oracle_mod, d, I, c_max, chunks):
+    """whole-pass batches through rsx_bpr_trainer_run with the CSC walk engaged (blocked layout at 3 000 items, the ordered layout
+    without blocks at 15 000 / 20 000; plain and as item ranges): the triplets every step consumed replay through the CPU oracle --
+    loss 1e-5, the update of P and Q to 1e-5 of its size -- and the batches ARE the walk's (every usable user once, ordered)"""
+    from recsys_pytorch_amd import rsx
+    from recsys_pytorch_amd.data import synthetic_csr
+    from recsys_pytorch_amd.sharded import BPREngine
+    U, deg, steps = 24000, 9, 3
+    lr = resolvable_lr(U)
+    ip, ix = synthetic_csr(U, I, deg, "cuda", seed=5, popularity="zipf")
+    torch.manual_seed(1)
+    P = torch.randn(U, d, device="cuda") * 0.1
+    Q = torch.randn(I, d, device="cuda") * 0.1
+    eng = BPREngine(P, Q, lr)
+    nb = eng.set_neg_block(U, c_max)
+    if nb == 0:
+        eng.sorted_min_batch = 1
+    if chunks:
+        eng.set_chunks(chunks)
+    P0, Q0 = P.cpu().numpy().copy(), Q.cpu().numpy().copy()
+    orc = oracle_mod.MFOracle(P0, Q0, "sgd", lr)
+    loss_acc = torch.zeros(rsx.RSX_LOSS_SLOTS, device="cuda")
+    tr = eng.native_trainer(ip, ix, U, loss_acc=loss_acc)
+    assert eng._csc is not None, "the engine did not build the CSC for a whole-pass batch"
+    want_loss = 0.0
+    for step in range(steps):
+        tr.run(1)
+        torch.cuda.synchronize()
+        u, i, j = (x.cpu().numpy().astype(np.int64) for x in tr.last_batch()[:3])
+        live = i >= 0
+        assert live.sum() == U and np.array_equal(np.sort(u[live]), np.arange(U))
+        assert np.all(np.diff(i[live]) >= 0)
+        if chunks:
+            r = eng._relabel
+            back = r["rank_item"].cpu().numpy()
+            i, j = back[i[live]], back[j[live]]
+            u = u[live]
+        want_loss += orc.step(u, i, j) * len(u)
+    eng.adopt(tr)
+    torch.cuda.synchronize()
+    assert abs(float(loss_acc.sum()) / (steps * U) - want_loss / (steps * U)) < 1e-5
+    assert_update(P.cpu().numpy(), P0, orc.P, "P")
+    assert_update(eng.Q.cpu().numpy(), Q0, orc.Q, "Q")
+
+
+def test_hand_driven_steps_take_the_walk_too():
+    """n native steps equal n hand-driven steps (include/rsx.h) also where the walk samples: same triplets, same tables"""
+    from recsys_pytorch_amd.data import synthetic_csr
+    from recsys_pytorch_amd.sharded import BPREngine
+    U, I, d, deg = 20000, 2500, 64, 8
+    ip, ix = synthetic_csr(U, I, deg, "cuda", seed=9, popularity="zipf")
+    outs = []
+    for native in (False, True):
+        torch.manual_seed(2)
+        P = torch.randn(U, d, device="cuda") * 0.1
+        Q = torch.randn(I, d, device="cuda") * 0.1
+        eng = BPREngine(P, Q, resolvable_lr(U))
+        eng.set_neg_block(U, 8)
+        if native:
+            tr = eng.native_trainer(ip, ix, U)
+            tr.run(3)
+            eng.adopt(tr)
+        else:
+            for _ in range(3):
+                eng.sampled_step(ip, ix, U, want_loss=False)
+        torch.cuda.synchronize()
+        outs.append((P.cpu().numpy(), Q.cpu().numpy()))
+    assert np.allclose(outs[0][0], outs[1][0], rtol=0, atol=1e-6) and np.allclose(outs[0][1], outs[1][1], rtol=0, atol=1e-6)
