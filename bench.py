@@ -150,6 +150,13 @@ def roofline(kernel, kern_ms, n_timed, B, I, d, key, two_pass=False):
             "traffic_over_compulsory": hbm / compulsory if hbm else None,
             "algorithmic_bytes_per_launch": alg, "algorithmic_GBs": per_s(alg),
             "algorithmic_rate_over_peak": per_s(alg) / HBM_PEAK_GBS,
+            # SURVEY section 8d's formula is a FRACTION only while the kernel really moves 24 d bytes per triplet
+            "algorithmic_valid": per_s(alg) / HBM_PEAK_GBS <= 1.0,
+            **({"algorithmic_invalid_reason": "the batch holds several triplets per item and the kernel sums item-side gradients on chip "
+                                              "(positive runs in registers, negatives in a wave-private LDS tile): fewer than 24 d bytes per "
+                                              "triplet reach HBM, so bytes/time exceeds the peak -- use frac (PMC bytes) or the "
+                                              "independent-negatives leg (iid_*), where the formula holds"}
+               if per_s(alg) / HBM_PEAK_GBS > 1.0 else {}),
             "note": "achieved / frac are physical (HBM bytes the launch moved, PMC).  algorithmic_* is SURVEY section 8d's "
                     "24 d bytes per triplet over the kernel time: where item sums stay on chip those bytes are not moved and "
                     "the ratio to the peak is not a fraction (it can exceed 1)"}
@@ -371,8 +378,11 @@ def lightgcn_leg(U, I, d, indptr, indices, dev, layers=3, batch=65_536):
                          **({} if hbm else {"frac_null_reason": f"no PMC profile of this leg in profiles/traffic.json (key {key})"}),
                          "traffic_key": key,
                          "compulsory_bytes": compulsory, "frac_compulsory": per_s(compulsory) / HBM_PEAK_GBS,
+                         # waste: what the product moves at the fabric side over what it must move (re-reads of neighbour rows)
+                         "traffic_over_compulsory": hbm / compulsory if hbm else None,
                          "algorithmic_bytes_per_launch": alg, "algorithmic_GBs": per_s(alg),
                          "algorithmic_rate_over_peak": per_s(alg) / HBM_PEAK_GBS,
+                         "algorithmic_valid": per_s(alg) / HBM_PEAK_GBS <= 1.0,
                          "gathered_bytes_served_on_chip": (alg - hbm) if hbm else None,
                          "note": "the algorithmic figure counts every gathered neighbour row (nnz rows of 4 d bytes); rows that are "
                                  "re-read are served by L2 / MALL (gathered_bytes_served_on_chip), the HBM side moves `traffic`"}}
@@ -603,6 +613,11 @@ def main():
             fn2 = rsx.lib().rsx_debug_set_exchange_traffic
             fn2.restype, fn2.argtypes = ctypes.c_int, [ctypes.c_int]
             assert fn2(1) == 0
+    if os.environ.get("RSX_MESH_MODEL_WORLD"):       # DEVELOPMENT library only: a one-rank mesh moves what rank 0 of W ranks would move through
+        import ctypes                                 # HBM, with a per-phase wire time (tools/exchange_model_schedules.sh)
+        fn = rsx.lib().rsx_debug_set_mesh_model
+        fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_int, ctypes.c_int]
+        assert fn(int(os.environ["RSX_MESH_MODEL_WORLD"]), int(os.environ.get("RSX_MESH_MODEL_DELAY_US", "0"))) == 0
     if os.environ.get("RSX_SAMPLER_REPLAY", "0") != "0":  # DEVELOPMENT library only: 1 = the loop without a sampler beside it (3 batches
         import ctypes                                    # replayed), 2 = replayed steps with the sampler running into a shadow buffer
         fn = rsx.lib().rsx_debug_set_sampler_replay
@@ -835,7 +850,14 @@ def main():
                              f"{pre}_frac": cfgs[name]["frac"], f"{pre}_frac_e2e": cfgs[name]["frac_end_to_end"]})
         if "config4_lightgcn" in cfgs:
             flat.update({"lightgcn_ms_per_step": cfgs["config4_lightgcn"]["ms_per_step"], "lightgcn_value": cfgs["config4_lightgcn"]["value"],
-                         "lightgcn_product_ms": cfgs["config4_lightgcn"]["kernel_ms"], "lightgcn_product_frac": cfgs["config4_lightgcn"]["frac"]})
+                         "lightgcn_product_ms": cfgs["config4_lightgcn"]["kernel_ms"], "lightgcn_product_frac": cfgs["config4_lightgcn"]["frac"],
+                         # WASTE, named: fabric-side bytes of one product over its compulsory bytes (every row, the CSR, the output once)
+                         "lightgcn_traffic_over_compulsory": sig(legs["config4_lightgcn"]["roofline"].get("traffic_over_compulsory"))})
+        if "independent_uniform_negatives" in legs:      # the one leg where SURVEY 8d's 24 d bytes per triplet ARE moved: its algorithmic figure is a fraction
+            g = legs["independent_uniform_negatives"]
+            flat.update({"iid_value": sig(g["value"]), "iid_ms_per_step": sig(g["ms_per_step"]), "iid_kernel_ms": sig(g["roofline"]["kernel_ms"]),
+                         "iid_frac": sig(g["roofline"]["frac"]), "iid_algorithmic_frac": sig(g["roofline"]["algorithmic_rate_over_peak"]),
+                         "iid_algorithmic_frac_e2e": sig(g["algorithmic_end_to_end_over_peak"])})
         if scoring is not None:
             flat.update({"scoring_value": cfgs["scoring"]["value"], "scoring_frac": cfgs["scoring"]["frac"],
                          "scoring_ms_per_1024_users": cfgs["scoring"]["ms_per_step"]})

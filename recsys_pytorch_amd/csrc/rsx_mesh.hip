@@ -93,7 +93,7 @@ __global__ void mesh_signal_kernel(PeerPtrs p, int rank, int world, int kind, ui
 __device__ __forceinline__ void mesh_wait(uint32_t *flags, int rank, int world, int kind, uint32_t seq, uint64_t limit)
 {
     const int q = threadIdx.x;
-    if (q < world && q != rank) {
+    if (limit != 0 && q < world && q != rank) {      // (limit 0: the development build's one-GPU traffic model -- there are no peers to wait for)
         const uint64_t t0 = wall_clock64();
         // (seq is monotonic and compared as a signed distance: it may wrap)
         while ((int32_t)(__hip_atomic_load(flags + flag_slot(q, kind), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
@@ -304,13 +304,48 @@ RSX_API int rsx_mesh_connect(rsx_mesh *m, int rank, int world, const void *all_d
     return RSX_OK;
 }
 
+#ifdef RSX_ABLATE
+// DEVELOPMENT BUILD ONLY: the HBM side of a world-W exchange on ONE GPU (tools/exchange_model_schedules.sh).  A mesh of one
+// rank then behaves as rank 0 of W: it sums ITS 1/W of the rows from W "peers" (all of them its own G: W reads of the slice, as when the
+// rank reads 7 peers and serves 7), applies that slice, and copies the other (W - 1)/W of the rows of Q onto themselves (the all-gather's
+// writes) while clearing G -- with `delay_us` of idle time in front of either phase for the wire.  TIMING ONLY: the sums are W times too
+// large (lr is divided by W to keep the tables finite).
+static int g_mesh_model_world = 0, g_mesh_model_delay_us = 0;
+RSX_API int rsx_debug_set_mesh_model(int world, int delay_us_per_phase)
+{
+    g_mesh_model_world = (world >= 2 && world <= kMaxWorld) ? world : 0;
+    g_mesh_model_delay_us = delay_us_per_phase > 0 ? delay_us_per_phase : 0;
+    return RSX_OK;
+}
+__global__ void mesh_model_delay_kernel(uint64_t ticks)
+{
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+#endif
+
 RSX_API int rsx_mesh_exchange_apply(rsx_mesh *m, int64_t first_row, int64_t rows, float lr, rsx_stream_t stream)
 {
     RSX_CHECK_ARG(m != nullptr && m->connected, "mesh not connected");
     RSX_CHECK_ARG(first_row >= 0 && rows > 0 && first_row + rows <= m->rows, "rows out of range");
     hipStream_t st = (hipStream_t)stream;
     const uint32_t seq = ++m->seq;
-    const int world = m->world, rank = m->rank;
+    int world = m->world, rank = m->rank;
+    PeerPtrs peers = m->peers;
+    uint64_t limit = m->limit_ticks;
+#ifdef RSX_ABLATE
+    const bool model = g_mesh_model_world > 1 && m->world == 1;
+    if (model) {
+        world = g_mesh_model_world; rank = 0; limit = 0; lr /= (float)world;
+        for (int q = 0; q < world; ++q) { peers.Q[q] = m->Q; peers.G[q] = m->G; peers.flags[q] = m->flags; }
+    }
+    auto wire = [&]() {
+        if (model && g_mesh_model_delay_us > 0)
+            hipLaunchKernelGGL(mesh_model_delay_kernel, dim3(1), dim3(64), 0, st, (uint64_t)g_mesh_model_delay_us * 100ull * (uint64_t)rows / (uint64_t)m->rows);
+    };
+#else
+    auto wire = []() {};
+#endif
     const int64_t d4 = m->d / 4;
     const int64_t slice = ceil_div64(rows, world);                       // rows per owner (the last slices may be short or empty)
     const int64_t first4 = first_row * d4, end4 = (first_row + rows) * d4, slice4 = slice * d4;
@@ -320,13 +355,15 @@ RSX_API int rsx_mesh_exchange_apply(rsx_mesh *m, int64_t first_row, int64_t rows
     // few workgroups, like a collective's channels: the exchange runs beside the other ranges' step kernels
     const int cus = rsx_num_cus();
     auto grid = [&](int64_t n4) { int64_t g = ceil_div64(n4, (int64_t)kMeshBlock * 4); if (g > cus) g = cus; return (unsigned)(g < 1 ? 1 : g); };
-    if (world > 1) hipLaunchKernelGGL(mesh_signal_kernel, dim3(1), dim3(64), 0, st, m->peers, rank, world, kReady, seq);
-    hipLaunchKernelGGL(mesh_reduce_apply_kernel, dim3(grid(hi4 - lo4)), dim3(kMeshBlock), 0, st, m->peers, m->flags, rank, world, seq,
-                       m->limit_ticks, (float4 *)m->Q, (float4 *)m->G, lo4, hi4, lr);
+    if (world > 1) hipLaunchKernelGGL(mesh_signal_kernel, dim3(1), dim3(64), 0, st, peers, rank, world, kReady, seq);
+    wire();
+    hipLaunchKernelGGL(mesh_reduce_apply_kernel, dim3(grid(hi4 - lo4)), dim3(kMeshBlock), 0, st, peers, m->flags, rank, world, seq,
+                       limit, (float4 *)m->Q, (float4 *)m->G, lo4, hi4, lr);
     if (world > 1) {
-        hipLaunchKernelGGL(mesh_signal_kernel, dim3(1), dim3(64), 0, st, m->peers, rank, world, kApplied, seq);
-        hipLaunchKernelGGL(mesh_gather_kernel, dim3(grid(end4 - first4)), dim3(kMeshBlock), 0, st, m->peers, m->flags, rank, world, seq,
-                           m->limit_ticks, (float4 *)m->Q, (float4 *)m->G, first4, slice4, end4);
+        hipLaunchKernelGGL(mesh_signal_kernel, dim3(1), dim3(64), 0, st, peers, rank, world, kApplied, seq);
+        wire();
+        hipLaunchKernelGGL(mesh_gather_kernel, dim3(grid(end4 - first4)), dim3(kMeshBlock), 0, st, peers, m->flags, rank, world, seq,
+                           limit, (float4 *)m->Q, (float4 *)m->G, first4, slice4, end4);
     }
     RSX_CHECK_LAUNCH();
     return RSX_OK;
@@ -336,6 +373,7 @@ RSX_API int rsx_mesh_set_wait_limit(rsx_mesh *m, double seconds)
 {
     RSX_CHECK_ARG(m != nullptr && seconds > 0.0 && seconds < 3600.0, "limit must be in (0, 3600) seconds");
     m->limit_ticks = (uint64_t)(seconds * 1e8);
+    if (m->limit_ticks == 0) m->limit_ticks = 1;      // (0 is the development build's "no peers" marker)
     return RSX_OK;
 }
 

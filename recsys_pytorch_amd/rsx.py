@@ -613,13 +613,19 @@ class Mesh:
         self._keep = (Q, G)
         desc = C.create_string_buffer(RSX_MESH_DESC_BYTES)
         self._h = C.c_void_p()
+        import time
+        self.timings = {}                              # seconds per phase of set-up / teardown (tools/mesh_stress.py reports them)
+        t0 = time.perf_counter()
         rc = lib().rsx_mesh_local(_dev(Q, torch.float32, "Q"), _dev(G, torch.float32, "G"), Q.shape[0], Q.shape[1], desc, C.byref(self._h))
         err = None if rc == 0 else f"rsx_mesh_local failed ({rc}): {lib().rsx_last_error().decode()}"
+        self.timings["export"] = time.perf_counter() - t0
         box = [None] * self.world
         dist.all_gather_object(box, (err, desc.raw), group=group)          # (a failed rank still takes part: nobody is left waiting)
         bad = [f"rank {q}: {e}" for q, (e, _) in enumerate(box) if e is not None]
         if not bad:
+            t0 = time.perf_counter()
             rc = lib().rsx_mesh_connect(self._h, self.rank, self.world, C.create_string_buffer(b"".join(raw for _, raw in box), RSX_MESH_DESC_BYTES * self.world))
+            self.timings["open"] = time.perf_counter() - t0
             err = None if rc == 0 else f"rsx_mesh_connect failed ({rc}): {lib().rsx_last_error().decode()}"
             box = [None] * self.world
             dist.all_gather_object(box, err, group=group)
@@ -678,11 +684,16 @@ class Mesh:
         """collective.  Barrier, unmap + free, barrier: nobody reads my buffers any more when I unmap, and nobody exports the same
         allocations again (a later Mesh over the same pooled segment) while a peer is still detaching from this export."""
         if getattr(self, "_h", None) is not None and self._h.value:
+            import time
             import torch.distributed as dist
             torch.cuda.synchronize()
+            t0 = time.perf_counter()
             dist.barrier(group=self.group)             # every rank has finished every exchange: nobody reads my buffers any more
+            t1 = time.perf_counter()
             self._destroy()
+            t2 = time.perf_counter()
             dist.barrier(group=self.group)             # every rank has closed every mapping
+            self.timings.update(barrier_before=t1 - t0, destroy=t2 - t1, barrier_after=time.perf_counter() - t2)
             self._keep = None
 
     def __del__(self):

@@ -37,7 +37,7 @@ ORACLE = ["tests/test_gpu_model.py::test_sorted_blocked_sampled_path_replays_thr
 def run_child(tests, mask, var="RSX_ABLATION"):
     env = dict(os.environ, RSX_LIB=DEV_LIB, COLUMNS="2000", **{var: str(mask)})     # (wide: -rf lines are not truncated)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider", "--no-header", "--tb=line", "-rf",
-                        *tests], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+                        *tests], cwd=ROOT, env=env, capture_output=True, text=True, timeout=550)
     return r.returncode, r.stdout[-20000:] + r.stderr[-2000:]
 
 
@@ -66,7 +66,7 @@ def test_dev_library_without_a_planted_error_passes(dev_lib):
     assert rc == 0, text
 
 
-@pytest.mark.timeout(1800)
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("mask,what", [(128, "user rows"), (256, "item gradients")])
 def test_one_percent_error_is_caught_by_every_selected_parity_test(dev_lib, mask, what):
     tests = FULL_SIZE + ORACLE
@@ -119,7 +119,7 @@ def outcomes_by_prefix(text, tests):
     return got, passed
 
 
-@pytest.mark.timeout(1800)
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("var,mask,what,tests", OTHER, ids=[f"{o[0][4:-9].lower() or 'step'}{o[1]}" for o in OTHER])
 def test_planted_faults_in_the_other_kernels_are_caught(dev_lib, var, mask, what, tests):
     rc, text = run_child(tests, mask, var)

@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from conftest import UPDATE_TOL, assert_update, resolvable_lr  # noqa: E402  (lr = 0.05 * B: the update itself is compared)
+from conftest import UPDATE_TOL, assert_update, resolvable_lr  # noqa: E402
+from rankpool import spawn  # noqa: E402  (persistent rank processes instead of a fresh interpreter per rank and test)  (lr = 0.05 * B: the update itself is compared)
 
 
 def _worker(rank, world, port, P0, Q0, batches, lr, out, unique=False, exchange="allreduce"):
@@ -56,7 +57,7 @@ def test_two_ranks_equal_one_process(oracle_mod, exchange):
     mgr = mp.Manager()
     out = mgr.dict()
     port = 29500 + os.getpid() % 2000
-    mp.spawn(_worker, args=(world, port, P0, Q0, batches, lr, out, False, exchange), nprocs=world, join=True)
+    spawn(_worker, args=(world, port, P0, Q0, batches, lr, out, False, exchange), nprocs=world, join=True)
     P = np.zeros_like(P0)
     for r in range(world):
         lo, hi, Pr, Qr, losses, sums = out[r]
@@ -85,7 +86,7 @@ def test_two_ranks_with_the_exchange_under_the_user_pass_equal_one_process(oracl
     mgr = mp.Manager()
     out = mgr.dict()
     port = 29500 + (os.getpid() + 3) % 2000
-    mp.spawn(_worker, args=(2, port, P0, Q0, batches, lr, out, True, exchange), nprocs=2, join=True)
+    spawn(_worker, args=(2, port, P0, Q0, batches, lr, out, True, exchange), nprocs=2, join=True)
     P = np.zeros_like(P0)
     for r in range(2):
         lo, hi, Pr, Qr, losses, sums = out[r]
@@ -129,7 +130,7 @@ def test_two_ranks_agree_on_the_relabelled_item_space():
     mgr = mp.Manager()
     out = mgr.dict()
     port = 29500 + (os.getpid() + 41) % 2000
-    mp.spawn(_relabel_worker, args=(world, port, U, I, d, out), nprocs=world, join=True)
+    spawn(_relabel_worker, args=(world, port, U, I, d, out), nprocs=world, join=True)
     (ri0, ir0, Ic, m0, im0, ix0), (ri1, ir1, _, m1, im1, ix1) = out[0], out[1]
     assert np.array_equal(ri0, ri1) and np.array_equal(ir0, ir1)
     assert np.array_equal(ri0[ir0], np.arange(I)) and (ri0 >= 0).sum() == I
@@ -210,7 +211,7 @@ def _check_ranges(oracle_mod, world, port, gpu, U, I, d, B, deg, chunks, steps, 
     res = {}
     for one_run in (False, True):
         out = mgr.dict()
-        mp.spawn(_ranges_worker, args=(world, port + 3 * one_run, gpu, U, I, d, B, deg, chunks, steps, one_run, out, exchange), nprocs=world, join=True)
+        spawn(_ranges_worker, args=(world, port + 3 * one_run, gpu, U, I, d, B, deg, chunks, steps, one_run, out, exchange), nprocs=world, join=True)
         res[one_run] = [out[r] for r in range(world)]
     for arm in res.values():
         for r in range(1, world):
@@ -249,7 +250,7 @@ def test_two_ranks_item_ranges_with_range_callbacks_equal_one_process(oracle_mod
 
 
 @pytest.mark.gpu
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("I,chunks,d", [(2500, 2, 64), (1999, 3, 128), (7001, 2, 128)])
 def test_two_ranks_item_ranges_on_hip_kernels_equal_one_process(oracle_mod, I, chunks, d):
     """the same through csrc/rsx_train.hip's chunked loop and the HIP kernels, two processes sharing the box's GPU: per-range
@@ -261,7 +262,7 @@ def test_two_ranks_item_ranges_on_hip_kernels_equal_one_process(oracle_mod, I, c
 
 
 @pytest.mark.gpu
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("I,chunks,d", [(2500, 2, 64), (1999, 3, 128), (7001, 2, 128)])
 def test_two_ranks_item_ranges_over_the_direct_mesh_equal_one_process(oracle_mod, I, chunks, d):
     """the same schedule with the library's OWN exchange (include/rsx.h: rsx_mesh_*, exchange = "direct"): two processes on the
@@ -272,7 +273,7 @@ def test_two_ranks_item_ranges_over_the_direct_mesh_equal_one_process(oracle_mod
     _check_ranges(oracle_mod, 2, 29500 + (os.getpid() + 83 + I) % 2000, True, 9000, I, d, 6000, 10, chunks, 4, exchange="direct")
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(600)
 def test_ranks_item_ranges_on_random_shapes(oracle_mod):
     """three random (ranks, users, items, ranges, batch) problems through the same check (the CPU stand-in trainer over gloo)"""
     from conftest import fuzz
@@ -293,7 +294,7 @@ def test_three_ranks_item_ranges_with_range_callbacks_equal_one_process(oracle_m
 
 
 @pytest.mark.gpu
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("world,I,chunks,d", [(3, 1999, 3, 128), (4, 2500, 2, 64)])
 def test_more_ranks_item_ranges_over_the_direct_mesh_equal_one_process(oracle_mod, world, I, chunks, d):
     """the direct mesh with three and four ranks (processes on the box's GPU): every rank reads two / three peers' rows for its slice and
@@ -302,7 +303,7 @@ def test_more_ranks_item_ranges_over_the_direct_mesh_equal_one_process(oracle_mo
 
 
 @pytest.mark.gpu
-@pytest.mark.timeout(1500)
+@pytest.mark.timeout(600)
 def test_ranks_item_ranges_on_hip_kernels_on_random_shapes(oracle_mod):
     """three random (ranks, exchange, items, ranges, row width, batch above or below two triplets per item) problems through the same
     check on the HIP kernels (processes on the box's GPU)"""
@@ -321,7 +322,7 @@ def test_ranks_item_ranges_on_hip_kernels_on_random_shapes(oracle_mod):
 
 
 @pytest.mark.gpu
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("I,chunks,exchange", [(2500, 2, "allreduce"), (9001, 3, "allreduce"), (2500, 2, "direct"), (9001, 3, "direct")])
 def test_two_ranks_item_ranges_soak(I, chunks, exchange):
     """sixty steps of the range schedule queued by ONE call on each of two ranks (HIP loop, two processes on the box's GPU, the
@@ -332,7 +333,7 @@ def test_two_ranks_item_ranges_soak(I, chunks, exchange):
     world, U, d, B, steps = 2, 9000, 64, 6000, 60
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_ranges_worker, args=(world, 29500 + (os.getpid() + 71 + I + 7 * len(exchange)) % 2000, True, U, I, d, B, 10, chunks, steps, True, out, exchange),
+    spawn(_ranges_worker, args=(world, 29500 + (os.getpid() + 71 + I + 7 * len(exchange)) % 2000, True, U, I, d, B, 10, chunks, steps, True, out, exchange),
              nprocs=world, join=True)
     a, b = out[0], out[1]
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[1], b[1]), "item replicas diverged"
@@ -390,7 +391,7 @@ def test_two_ranks_on_hip_kernels_equal_one_process(oracle_mod, exchange):
     mgr = mp.Manager()
     out = mgr.dict()
     port = 29500 + (os.getpid() + 7) % 2000
-    mp.spawn(_gpu_worker, args=(2, port, P0, Q0, batches, lr, out, False, exchange), nprocs=2, join=True)
+    spawn(_gpu_worker, args=(2, port, P0, Q0, batches, lr, out, False, exchange), nprocs=2, join=True)
     P = np.zeros_like(P0)
     for r in range(2):
         lo, hi, Pr, Qr, losses = out[r]
@@ -402,7 +403,7 @@ def test_two_ranks_on_hip_kernels_equal_one_process(oracle_mod, exchange):
 
 
 @pytest.mark.gpu
-@pytest.mark.timeout(1500)
+@pytest.mark.timeout(600)
 def test_ranks_routed_steps_on_random_shapes(oracle_mod):
     """four random (ranks 2-4, exchange, users, items -- fewer than ranks too --, row width, batch, unique users or repeats) problems: every
     rank steps on the triplets routed to its user block (BPREngine.route / step), the ranks together equal ONE process on the whole
@@ -426,7 +427,7 @@ def test_ranks_routed_steps_on_random_shapes(oracle_mod):
         ref_losses = [single.step(*b) for b in batches]
         mgr = mp.Manager()
         out = mgr.dict()
-        mp.spawn(_gpu_worker, args=(world, 29500 + (os.getpid() + 173 + 23 * trial) % 2000, P0, Q0, batches, lr, out, unique, exchange), nprocs=world, join=True)
+        spawn(_gpu_worker, args=(world, 29500 + (os.getpid() + 173 + 23 * trial) % 2000, P0, Q0, batches, lr, out, unique, exchange), nprocs=world, join=True)
         P = np.zeros_like(P0)
         for r in range(world):
             lo, hi, Pr, Qr, losses = out[r]
@@ -452,7 +453,7 @@ def test_two_ranks_on_hip_kernels_with_the_exchange_under_the_user_pass(oracle_m
     mgr = mp.Manager()
     out = mgr.dict()
     port = 29500 + (os.getpid() + 11) % 2000
-    mp.spawn(_gpu_worker, args=(2, port, P0, Q0, batches, lr, out, True, exchange), nprocs=2, join=True)
+    spawn(_gpu_worker, args=(2, port, P0, Q0, batches, lr, out, True, exchange), nprocs=2, join=True)
     P = np.zeros_like(P0)
     for r in range(2):
         lo, hi, Pr, Qr, losses = out[r]
@@ -498,7 +499,7 @@ def _gpu_sampled_worker(rank, world, port, mode, U, I, d, B, steps, out, exchang
 
 
 @pytest.mark.gpu
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("B,I,exchange", [(6000, 2500, "allreduce"), (3000, 4000, "allreduce"), (6000, 2501, "scatter_gather"),
                                           (6000, 2503, "direct")])
 def test_two_ranks_native_loop_with_exchange_callbacks_equals_python_driven(B, I, exchange):
@@ -510,7 +511,7 @@ def test_two_ranks_native_loop_with_exchange_callbacks_equals_python_driven(B, I
     out = mgr.dict()
     for k, mode in enumerate(("python", "native")):
         port = 29500 + (os.getpid() + 13 + 17 * k + B) % 2000
-        mp.spawn(_gpu_sampled_worker, args=(2, port, mode, U, I, d, B, steps, out, exchange), nprocs=2, join=True)
+        spawn(_gpu_sampled_worker, args=(2, port, mode, U, I, d, B, steps, out, exchange), nprocs=2, join=True)
     for mode in ("python", "native"):
         assert np.array_equal(out[(mode, 0)][1], out[(mode, 1)][1]), f"item replicas diverged ({mode})"
     for r in range(2):
@@ -628,7 +629,7 @@ def _rccl_one_rank_worker(rank, port, U, I, d, B, steps, out):
 
 
 @pytest.mark.gpu
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("B,I", [(6000, 2500), (3000, 4001)])
 def test_exchange_over_rccl_with_one_rank_equals_the_unsharded_step(B, I):
     """the exchange path on the REAL collective library: a process group of one rank over RCCL (all a
@@ -641,7 +642,7 @@ def test_exchange_over_rccl_with_one_rank_equals_the_unsharded_step(B, I):
     mgr = mp.Manager()
     out = mgr.dict()
     port = 29500 + (os.getpid() + 29 + B) % 2000
-    mp.spawn(_rccl_one_rank_worker, args=(port, U, I, d, B, steps, out), nprocs=1, join=True)
+    spawn(_rccl_one_rank_worker, args=(port, U, I, d, B, steps, out), nprocs=1, join=True)
     P0, Q0 = out["plain"]
     P_init, Q_init = out["init"]
     assert len(out) == 23
@@ -708,7 +709,7 @@ def test_mesh_exchange_and_a_missing_peer_is_an_error_not_a_hang():
     rows, loudly, never a hung GPU"""
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_mesh_timeout_worker, args=(2, 29500 + (os.getpid() + 97) % 2000, out), nprocs=2, join=True)
+    spawn(_mesh_timeout_worker, args=(2, 29500 + (os.getpid() + 97) % 2000, out), nprocs=2, join=True)
     assert out[0][0] and out[1][0]                                   # the healthy exchange: both replicas updated, G zero
     assert out[1][1] is None and out[0][1] is not None and "gave up waiting" in out[0][1]
     assert 400.0 < out["ms"] < 5000.0                                # two waits of 0.5 s each, not a hang
@@ -750,14 +751,14 @@ def _mesh_shapes_worker(rank, world, port, out):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_mesh_exchange_on_small_and_odd_tables(world):
     """rsx_mesh_exchange_apply on its own, with two, three and four ranks (processes on the box's GPU -- more than one peer to read, slices
     with a remainder): tables with fewer rows than ranks, odd slice boundaries, every row width (32 .. 256), part of a table and the whole
     of it: Q -= lr * (sum of the ranks' G) on every rank, G zero afterwards, the replicas bit-identical"""
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_mesh_shapes_worker, args=(world, 29500 + (os.getpid() + 101 + 13 * world) % 2000, out), nprocs=world, join=True)
+    spawn(_mesh_shapes_worker, args=(world, 29500 + (os.getpid() + 101 + 13 * world) % 2000, out), nprocs=world, join=True)
     for r in range(1, world):
         for a, b in zip(out[0], out[r]):
             assert a[:4] == b[:4] and a[2] and a[3], (r, a[:4], b[:4])

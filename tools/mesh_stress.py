@@ -34,6 +34,7 @@ def worker(rank, world, port, loops, post_barrier, own_memory, out):
     from recsys_pytorch_amd import rsx
     dev = torch.device("cuda", 0)
     fails, retries, meshes = [], 0, 0
+    phases = {}
     t0 = time.time()
     for loop in range(loops):
         for rows, d in SHAPES:
@@ -85,9 +86,15 @@ def worker(rank, world, port, loops, post_barrier, own_memory, out):
                 mesh.close()
             else:                                # round 5's teardown
                 torch.cuda.synchronize()
+                tb = time.time()
                 dist.barrier()
+                td = time.time()
                 mesh._destroy()
-    out[rank] = {"fails": fails, "retries": retries, "meshes": meshes, "seconds": round(time.time() - t0, 2)}
+                mesh.timings.update(barrier_before=td - tb, destroy=time.time() - td)
+            for k, v in mesh.timings.items():
+                phases[k] = phases.get(k, 0.0) + v
+    out[rank] = {"fails": fails, "retries": retries, "meshes": meshes, "seconds": round(time.time() - t0, 2),
+                 "phase_seconds": {k: round(v, 3) for k, v in phases.items()}}
     dist.barrier()
     dist.destroy_process_group()
 
