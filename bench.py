@@ -749,7 +749,7 @@ def main():
         arm("scoring")
         tiles, K = args.score_tiles, args.topk
         users = torch.arange(1024 * tiles, device=dev, dtype=torch.int32) % U
-        ws = torch.empty(rsx.lib().rsx_score_topk_workspace(users.numel(), I) // 4 + 64, dtype=torch.float32, device=dev)
+        ws = torch.empty(rsx.lib().rsx_score_topk_workspace_d(users.numel(), I, d) // 4 + 64, dtype=torch.float32, device=dev)
         mask = (indptr, indices)
         rsx.score_topk(P, Q, users, K, mask=mask, ws=ws)        # warm-up pass (untimed)
         torch.cuda.synchronize()

@@ -617,7 +617,10 @@ int rsx_score(const float *P, const int32_t *user_ids_dev, int64_t num_rows, con
 int rsx_topk(const float *scores_dev, int64_t num_rows, int64_t num_items, int K,
              int32_t *topk_idx_out, float *topk_val_out, rsx_stream_t stream);
 
+/* workspace of rsx_score_topk: _d for the row width d it will be called with (the fused path keeps a permuted copy of the item table:
+ * num_items * d * 4 bytes of it); the form without d is the bound for d = 256 (at 1M items 512 MB more than d = 128 needs).        */
 int64_t rsx_score_topk_workspace(int64_t num_rows, int64_t num_items);
+int64_t rsx_score_topk_workspace_d(int64_t num_rows, int64_t num_items, int d);
 
 int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t num_rows, const float *Q,
                    int64_t num_items, int d, const int64_t *mask_indptr_dev,

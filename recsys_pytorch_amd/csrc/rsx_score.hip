@@ -1060,17 +1060,23 @@ FusedWs carve(void *ws, int64_t tile_rows, int64_t all_rows, int64_t num_items, 
 
 }  // namespace
 
-RSX_API int64_t rsx_score_topk_workspace(int64_t num_rows, int64_t num_items)
+RSX_API int64_t rsx_score_topk_workspace_d(int64_t num_rows, int64_t num_items, int d)
 {
-    if (num_rows < 0 || num_items <= 0) return RSX_E_INVALID;
+    if (num_rows < 0 || num_items <= 0 || !rsx_dim_ok(d)) return RSX_E_INVALID;
     const int64_t rows = num_rows < kRowTile ? num_rows : kRowTile;
     const int64_t dense = rows * num_items * 4;
     if (num_items < kFusedMinItems) return dense;
     const int64_t frows = num_rows < kFusedRows ? num_rows : kFusedRows;
     const int64_t passes = (num_rows + kFusedRows - 1) / kFusedRows;
     const int64_t lanes = passes < kMaxLanes ? passes : kMaxLanes;   // passes in flight (one stream each)
-    const int64_t fused = lanes * carve(nullptr, frows, num_rows, num_items, 512).bytes + a256(num_items * 256 * 4);   // + Qp (d <= 256)
+    const int64_t fused = lanes * carve(nullptr, frows, num_rows, num_items, 512).bytes + a256(num_items * (int64_t)d * 4);   // + Qp, the permuted item table
     return fused > dense ? fused : dense;   // (K > 512 still takes the dense path)
+}
+
+// the bound for any row width (d = 256): what a caller that does not know d yet reserves
+RSX_API int64_t rsx_score_topk_workspace(int64_t num_rows, int64_t num_items)
+{
+    return rsx_score_topk_workspace_d(num_rows, num_items, 256);
 }
 
 RSX_API int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t num_rows,
@@ -1079,7 +1085,7 @@ RSX_API int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t 
                            float *topk_val_out, void *ws, int64_t ws_bytes, rsx_stream_t stream)
 {
     RSX_CHECK_ARG(topk_idx_out != nullptr, "null output");
-    const int64_t need = rsx_score_topk_workspace(num_rows, num_items);
+    const int64_t need = rsx_score_topk_workspace_d(num_rows, num_items, rsx_dim_ok(d) ? d : 256);
     if (need < 0) { rsx_set_error("rsx_score_topk: bad shape"); return RSX_E_INVALID; }
     if (num_rows == 0) return RSX_OK;
     if (ws == nullptr || ws_bytes < need) {

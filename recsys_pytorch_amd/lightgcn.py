@@ -229,7 +229,7 @@ class LightGCN(BaseModel):
         for s in range(0, len(eval_users), chunk):
             users = self._idx(eval_users[s:s + chunk])
             if ws is None and hasattr(self._k, "lib"):
-                need = self._k.lib().rsx_score_topk_workspace(users.numel(), self.num_items)
+                need = self._k.lib().rsx_score_topk_workspace_d(users.numel(), self.num_items, self._dpad)
                 ws = torch.empty(max(need, 4) // 4 + 64, dtype=torch.float32, device=self.device)
             r = self._k.score_topk(self._out[:U], self._out[U:], users, K, mask=mask, want_values=False, ws=ws)
             out.append(r.cpu().numpy())

@@ -91,6 +91,8 @@ def _get(cfg, key, default=None):
 
 
 class MF(BaseModel):
+    _said_default_optimizer = False
+
     def __init__(self, dataset, hparams, device, kernels=None):
         super().__init__()
         self.num_users = dataset.num_users
@@ -98,7 +100,15 @@ class MF(BaseModel):
         self.hidden_dim = int(hparams["hidden_dim"])
         self.pointwise = bool(hparams["pointwise"])
         self.loss_func = "mse" if _get(hparams, "loss_func", "ce") == "mse" else "ce"          # models/MF.py:21
-        opt = _get(hparams, "optimizer", "sgd")
+        opt = _get(hparams, "optimizer", None)
+        if opt is None:
+            # conf/MF.yaml has no such key and the reference trains dense Adam, lr 1e-3 (models/MF.py:30): a maintainer who swaps the
+            # class and nothing else gets the north star's SGD -- said once, loudly, not silently
+            opt = "sgd"
+            if not MF._said_default_optimizer:
+                MF._said_default_optimizer = True
+                print(f"recsys_pytorch_amd.MF: hparams has no 'optimizer' key -> SGD, lr {float(_get(hparams, 'lr', 0.05))} (the MI355X step kernel; "
+                      "the reference's own models/MF.py:30 is dense Adam, lr 1e-3: pass hparams['optimizer'] = 'adam' for that)", flush=True)
         if opt not in ("sgd", "adam"):
             raise ValueError("optimizer must be 'sgd' (north star) or 'adam' (as shipped, models/MF.py:30)")
         self.optimizer_name = opt
@@ -313,7 +323,7 @@ class MF(BaseModel):
         for s in range(0, len(eval_users), chunk):
             users = self._idx(eval_users[s:s + chunk])
             if ws is None:
-                need = self._k.lib().rsx_score_topk_workspace(users.numel(), self.num_items) if hasattr(self._k, "lib") else 0
+                need = self._k.lib().rsx_score_topk_workspace_d(users.numel(), self.num_items, self._dpad) if hasattr(self._k, "lib") else 0
                 ws = torch.empty(max(need, 4) // 4 + 64, dtype=torch.float32, device=self.device)
             r = self._k.score_topk(self._P, self._Q, users, K, mask=mask, want_values=want_values, ws=ws)
             if want_values:

@@ -102,6 +102,7 @@ SIGNATURES = {
     "rsx_score": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P, _P, _P, _P]),
     "rsx_topk": (C.c_int, [_P, _I64, _I64, _I32, _P, _P, _P]),
     "rsx_score_topk_workspace": (_I64, [_I64, _I64]),
+    "rsx_score_topk_workspace_d": (_I64, [_I64, _I64, _I32]),
     "rsx_score_topk": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P, _P, _I32, _P, _P, _P, _I64, _P]),
 }
 
@@ -887,7 +888,7 @@ def topk(scores, K, want_values=False):
 
 def score_topk(P, Q, user_ids, K, mask=None, want_values=False, ws=None):
     rows, I = user_ids.numel(), Q.shape[0]
-    need = lib().rsx_score_topk_workspace(rows, I)
+    need = lib().rsx_score_topk_workspace_d(rows, I, Q.shape[1])
     if ws is None or ws.numel() * ws.element_size() < need:
         ws = torch.empty(max(need, 4) // 4, dtype=torch.float32, device=P.device)
     idx = torch.empty((rows, K), dtype=torch.int32, device=P.device)
