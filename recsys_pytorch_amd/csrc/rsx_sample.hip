@@ -1452,9 +1452,10 @@ RSX_API int64_t rsx_bpr_csc_workspace(int64_t nnz, int64_t num_items)
 RSX_API int rsx_bpr_build_csc(const int64_t *indptr_dev, const int32_t *indices_dev, int64_t num_users, int64_t num_items, int64_t nnz,
                               void *blob, int64_t blob_bytes, void *ws, int64_t ws_bytes, rsx_stream_t stream, rsx_csc **out)
 {
-    RSX_CHECK_ARG(indptr_dev && indices_dev && blob && ws && out, "null pointer");
+    RSX_CHECK_ARG(indptr_dev && blob && ws && out, "null pointer");
     RSX_CHECK_ARG(num_users > 0 && num_users < (1ll << 31) && num_items > 0 && num_items < (1ll << 31) && nnz >= 0 && nnz < (1ll << 32),
                   "table sizes must fit int32 (nnz: uint32)");
+    RSX_CHECK_ARG(indices_dev != nullptr || nnz == 0, "null pointer (indices may be null only when there is no interaction at all)");
     RSX_CHECK_ARG(blob_bytes >= rsx_bpr_csc_bytes(nnz, num_items), "blob smaller than rsx_bpr_csc_bytes(nnz, num_items)");
     RSX_CHECK_ARG(ws_bytes >= rsx_bpr_csc_workspace(nnz, num_items), "workspace smaller than rsx_bpr_csc_workspace(nnz, num_items)");
     hipStream_t st = (hipStream_t)stream;
@@ -1535,7 +1536,7 @@ RSX_API int rsx_bpr_sample_csc(const rsx_csc *csc, const int64_t *indptr_dev, co
                                uint64_t neg_key, void *ws, int64_t ws_bytes, const uint64_t *user_sig_dev, int32_t *u_out,
                                int32_t *i_out, int32_t *j_out, int64_t *chunk_pos_out, rsx_stream_t stream)
 {
-    RSX_CHECK_ARG(csc && indptr_dev && indices_dev && u_out && i_out && j_out && ws, "null pointer");
+    RSX_CHECK_ARG(csc && indptr_dev && (indices_dev || csc->a.nnz == 0) && u_out && i_out && j_out && ws, "null pointer");
     RSX_CHECK_ARG(rsx_csc_matches(csc, indptr_dev, indices_dev, num_users, num_items),
                   "the CSC was built from another CSR (rsx_bpr_build_csc takes the SAME indptr, indices, num_users, num_items)");
     RSX_CHECK_ARG(neg_block >= 0 && neg_block <= kMaxNegBlock, "neg_block must be in [0, 16]");

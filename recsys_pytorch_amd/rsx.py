@@ -432,7 +432,7 @@ class Csc:
         self._keep = (indptr, indices)
         self.num_items, self.nnz = int(num_items), nnz
         self._h = C.c_void_p()
-        _check(lib().rsx_bpr_build_csc(_dev(indptr, torch.int64, "indptr"), _dev(indices, torch.int32, "indices"), U, int(num_items), nnz,
+        _check(lib().rsx_bpr_build_csc(_dev(indptr, torch.int64, "indptr"), _dev(indices, torch.int32, "indices") if nnz else None, U, int(num_items), nnz,
                                        C.c_void_p(self.blob.data_ptr()), nb, C.c_void_p(ws.data_ptr()), nw, _stream(), C.byref(self._h)),
                "rsx_bpr_build_csc")
         torch.cuda.current_stream().synchronize()       # (the build scratch is released below)
@@ -487,7 +487,7 @@ def bpr_sample_csc(csc, indptr, indices, num_items, seed, step, u_out, i_out, j_
                    chunks=1, items_real=None, chunk_pos=None):
     """include/rsx.h:rsx_bpr_sample_csc -- a batch of EVERY user once, ordered by positive item by one walk over the CSC"""
     _check(lib().rsx_bpr_sample_csc(
-        csc.handle, _dev(indptr, torch.int64, "indptr"), _dev(indices, torch.int32, "indices"), indptr.numel() - 1, int(num_items),
+        csc.handle, _dev(indptr, torch.int64, "indptr"), _dev(indices, torch.int32, "indices") if indices.numel() else None, indptr.numel() - 1, int(num_items),
         int(items_real if items_real is not None else num_items), int(chunks), seed & (2**64 - 1), step, int(neg_block),
         int(neg_key) & (2**64 - 1), C.c_void_p(ws.data_ptr()), ws.numel() * ws.element_size(),
         _dev(user_sig, torch.int64, "user_sig") if user_sig is not None else None,
