@@ -271,7 +271,8 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     for _ in range(max(1, int(regions))):
         fence(world)
         t0 = time.perf_counter()
-        tr.run(steps, B, gb, time_every=1)     # exactly `steps` steps inside the timed region, every step kernel timed
+        # exactly `steps` steps inside the timed region, every step kernel timed (RSX_TIME_EVERY: development A/B of what the timing events cost)
+        tr.run(steps, B, gb, time_every=int(os.environ.get("RSX_TIME_EVERY", "1")))
         fence(world)
         elapsed = time.perf_counter() - t0
         el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -662,6 +663,8 @@ def main():
         rsx.set_option("step_waves", int(os.environ["RSX_STEP_WAVES"]))
     if os.environ.get("RSX_APPLY_STREAM"):      # experiment: the ranges' applies on a stream of their own (include/rsx.h: "apply_stream")
         rsx.set_option("apply_stream", int(os.environ["RSX_APPLY_STREAM"]))
+    if os.environ.get("RSX_MESH_BLOCKS"):
+        rsx.set_option("mesh_blocks", int(os.environ["RSX_MESH_BLOCKS"]))
     if os.environ.get("RSX_SCORE_LANES"):
         rsx.set_option("score_lanes", int(os.environ["RSX_SCORE_LANES"]))
 

@@ -107,6 +107,9 @@ int rsx_device_info_get(int device, rsx_device_info *out);
  *                     of its item ranges on a high-priority stream of their own instead of behind the collectives on the
  *                     collective stream (pays only where an exchange is longer than the whole step).  Read at
  *                     rsx_bpr_trainer_create.  The result does not depend on it.
+ *   "mesh_blocks"     0 (default: one per CU) .. 4096: workgroups of the two kernels of rsx_mesh_exchange_apply (like a collective's
+ *                     channels: over xGMI they are link-bound and a few dozen saturate the links; every workgroup more takes a wave slot
+ *                     from the other item ranges' step kernels it runs beside).  The result does not depend on it.
  * There is no option that skips work: the development ablation switches of the kernels exist only
  * in the separate dev build (librsx_dev.so, -DRSX_ABLATE), never in librsx.so.                    */
 int rsx_set_option(const char *name, int64_t value);

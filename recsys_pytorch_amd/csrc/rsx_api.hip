@@ -45,6 +45,7 @@ int g_rsx_score_lanes = 2;
 int g_rsx_sort_cap = 0;
 int g_rsx_apply_stream = 0;
 int g_rsx_step_waves = 0;
+int g_rsx_mesh_blocks = 0;
 
 RSX_API int rsx_set_option(const char *name, int64_t value)
 {
@@ -67,6 +68,11 @@ RSX_API int rsx_set_option(const char *name, int64_t value)
     if (strcmp(name, "apply_stream") == 0) {
         RSX_CHECK_ARG(value == 0 || value == 1, "apply_stream must be 0 or 1");
         g_rsx_apply_stream = (int)value;
+        return RSX_OK;
+    }
+    if (strcmp(name, "mesh_blocks") == 0) {
+        RSX_CHECK_ARG(value >= 0 && value <= 4096, "mesh_blocks must be in [0, 4096] (0 = one workgroup per CU)");
+        g_rsx_mesh_blocks = (int)value;
         return RSX_OK;
     }
     rsx_set_error("rsx_set_option: unknown option '%s'", name);

@@ -55,6 +55,7 @@ static __constant__ int c_rsx_ablate = 0;
 extern int g_rsx_score_lanes;   // passes of the fused scoring path in flight (1..4)
 extern int g_rsx_sort_cap;      // LDS sort capacity of the bucket sampler (test hook for the out-of-LDS path)
 extern int g_rsx_step_waves;    // resident wavefronts per SIMD the blocked step kernel is held to (0: the default of rsx_bpr.hip)
+extern int g_rsx_mesh_blocks;   // workgroups of the mesh's two exchange kernels (0: one per CU)
 extern int g_rsx_apply_stream;  // chunked + sharded trainer: the ranges' applies on a stream of their own (opt-in)
 
 // rsx_det.hip: the deterministic form of the step (RSX_DETERMINISTIC); arguments validated by rsx_bpr_step

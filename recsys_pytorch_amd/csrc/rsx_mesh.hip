@@ -106,13 +106,26 @@ __device__ __forceinline__ void mesh_wait(uint32_t *flags, int rank, int world, 
 }
 
 // phase 1: this rank's slice [lo4, hi4) (in float4 units from the table's base): sum the peers' partial sums onto mine, apply, clear
+// (development build's one-GPU traffic model only: `pace` > 0 spreads a kernel's trips evenly over `pace` ticks of the 100 MHz clock -- the
+//  time the wire would take -- so that the kernel's HBM traffic and the wire time overlap as they do when the rows really come over xGMI)
+__device__ __forceinline__ void mesh_pace(uint64_t t0, uint64_t pace, int64_t done, int64_t total)
+{
+#ifdef RSX_ABLATE
+    if (pace == 0) return;
+    const uint64_t due = (uint64_t)((double)pace * (double)done / (double)total);
+    while (wall_clock64() - t0 < due) __builtin_amdgcn_s_sleep(8);
+#endif
+}
+
 __global__ __launch_bounds__(kMeshBlock) void mesh_reduce_apply_kernel(PeerPtrs p, uint32_t *flags, int rank, int world, uint32_t seq,
                                                                        uint64_t limit, float4 *Q, float4 *G, int64_t lo4, int64_t hi4,
-                                                                       float lr)
+                                                                       float lr, uint64_t pace)
 {
     mesh_wait(flags, rank, world, kReady, seq, limit);
     const int64_t stride = (int64_t)gridDim.x * kMeshBlock;
+    const uint64_t t0 = pace ? wall_clock64() : 0;
     for (int64_t n = lo4 + (int64_t)blockIdx.x * kMeshBlock + threadIdx.x; n < hi4; n += stride) {
+        mesh_pace(t0, pace, n - lo4, hi4 - lo4);
         float4 s = G[n];
         float4 v[kMaxWorld];
         // the peers' quads are requested together (one per link), then added in rank order: the same order on whatever rank owns the row
@@ -132,13 +145,15 @@ __global__ __launch_bounds__(kMeshBlock) void mesh_reduce_apply_kernel(PeerPtrs 
 // phase 2: every other rank's slice: copy the updated rows from their owner, clear my partial sums of them (the owner has read them)
 __global__ __launch_bounds__(kMeshBlock) void mesh_gather_kernel(PeerPtrs p, uint32_t *flags, int rank, int world, uint32_t seq,
                                                                  uint64_t limit, float4 *Q, float4 *G, int64_t first4, int64_t slice4,
-                                                                 int64_t end4)
+                                                                 int64_t end4, uint64_t pace)
 {
     mesh_wait(flags, rank, world, kApplied, seq, limit);
     const int64_t stride = (int64_t)gridDim.x * kMeshBlock;
+    const uint64_t t0 = pace ? wall_clock64() : 0;
     // the slices of the other ranks, walked interleaved (thread t of a trip reads from owner (t / slice) -- consecutive workgroups hit
     // different links only through the grid stride; with N - 1 peers and hundreds of workgroups every link is busy)
     for (int64_t n = first4 + (int64_t)blockIdx.x * kMeshBlock + threadIdx.x; n < end4; n += stride) {
+        mesh_pace(t0, pace, n - first4, end4 - first4);
         const int owner = (int)((n - first4) / slice4);
         if (owner == rank) continue;
         Q[n] = reinterpret_cast<const float4 *>(p.Q[owner])[n];
@@ -308,7 +323,7 @@ RSX_API int rsx_mesh_connect(rsx_mesh *m, int rank, int world, const void *all_d
 // DEVELOPMENT BUILD ONLY: the HBM side of a world-W exchange on ONE GPU (tools/exchange_model_schedules.sh).  A mesh of one
 // rank then behaves as rank 0 of W: it sums ITS 1/W of the rows from W "peers" (all of them its own G: W reads of the slice, as when the
 // rank reads 7 peers and serves 7), applies that slice, and copies the other (W - 1)/W of the rows of Q onto themselves (the all-gather's
-// writes) while clearing G -- with `delay_us` of idle time in front of either phase for the wire.  TIMING ONLY: the sums are W times too
+// writes) while clearing G -- each of the two phases spread over `delay_us` (the wire's time), its HBM traffic under it.  TIMING ONLY: the sums are W times too
 // large (lr is divided by W to keep the tables finite).
 static int g_mesh_model_world = 0, g_mesh_model_delay_us = 0;
 RSX_API int rsx_debug_set_mesh_model(int world, int delay_us_per_phase)
@@ -316,11 +331,6 @@ RSX_API int rsx_debug_set_mesh_model(int world, int delay_us_per_phase)
     g_mesh_model_world = (world >= 2 && world <= kMaxWorld) ? world : 0;
     g_mesh_model_delay_us = delay_us_per_phase > 0 ? delay_us_per_phase : 0;
     return RSX_OK;
-}
-__global__ void mesh_model_delay_kernel(uint64_t ticks)
-{
-    const uint64_t t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
 }
 #endif
 
@@ -339,12 +349,9 @@ RSX_API int rsx_mesh_exchange_apply(rsx_mesh *m, int64_t first_row, int64_t rows
         world = g_mesh_model_world; rank = 0; limit = 0; lr /= (float)world;
         for (int q = 0; q < world; ++q) { peers.Q[q] = m->Q; peers.G[q] = m->G; peers.flags[q] = m->flags; }
     }
-    auto wire = [&]() {
-        if (model && g_mesh_model_delay_us > 0)
-            hipLaunchKernelGGL(mesh_model_delay_kernel, dim3(1), dim3(64), 0, st, (uint64_t)g_mesh_model_delay_us * 100ull * (uint64_t)rows / (uint64_t)m->rows);
-    };
+    const uint64_t pace = model ? (uint64_t)g_mesh_model_delay_us * 100ull * (uint64_t)rows / (uint64_t)m->rows : 0ull;
 #else
-    auto wire = []() {};
+    const uint64_t pace = 0;
 #endif
     const int64_t d4 = m->d / 4;
     const int64_t slice = ceil_div64(rows, world);                       // rows per owner (the last slices may be short or empty)
@@ -353,17 +360,15 @@ RSX_API int rsx_mesh_exchange_apply(rsx_mesh *m, int64_t first_row, int64_t rows
     if (lo4 > end4) lo4 = end4;
     if (hi4 > end4) hi4 = end4;
     // few workgroups, like a collective's channels: the exchange runs beside the other ranges' step kernels
-    const int cus = rsx_num_cus();
+    const int cus = g_rsx_mesh_blocks > 0 ? g_rsx_mesh_blocks : rsx_num_cus();
     auto grid = [&](int64_t n4) { int64_t g = ceil_div64(n4, (int64_t)kMeshBlock * 4); if (g > cus) g = cus; return (unsigned)(g < 1 ? 1 : g); };
     if (world > 1) hipLaunchKernelGGL(mesh_signal_kernel, dim3(1), dim3(64), 0, st, peers, rank, world, kReady, seq);
-    wire();
     hipLaunchKernelGGL(mesh_reduce_apply_kernel, dim3(grid(hi4 - lo4)), dim3(kMeshBlock), 0, st, peers, m->flags, rank, world, seq,
-                       limit, (float4 *)m->Q, (float4 *)m->G, lo4, hi4, lr);
+                       limit, (float4 *)m->Q, (float4 *)m->G, lo4, hi4, lr, pace);
     if (world > 1) {
         hipLaunchKernelGGL(mesh_signal_kernel, dim3(1), dim3(64), 0, st, peers, rank, world, kApplied, seq);
-        wire();
         hipLaunchKernelGGL(mesh_gather_kernel, dim3(grid(end4 - first4)), dim3(kMeshBlock), 0, st, peers, m->flags, rank, world, seq,
-                           limit, (float4 *)m->Q, (float4 *)m->G, first4, slice4, end4);
+                           limit, (float4 *)m->Q, (float4 *)m->G, first4, slice4, end4, pace);
     }
     RSX_CHECK_LAUNCH();
     return RSX_OK;

@@ -819,7 +819,6 @@ template <typename RD> struct RdBits;
 template <> struct RdBits<uint16_t> { static constexpr int shift = 8; static constexpr uint32_t mask = 0xFFu; };
 template <> struct RdBits<uint32_t> { static constexpr int shift = 16; static constexpr uint32_t mask = 0xFFFFu; };
 
-constexpr uint64_t kStatusAggregate = 1ull << 62, kStatusPrefix = 2ull << 62, kStatusValue = (1ull << 62) - 1;
 
 struct CscArgs {
     const int64_t *ptr;          // [I + 1] first entry of every item
@@ -830,21 +829,21 @@ struct CscArgs {
     int ntiles;
 };
 
+// pass 1 of the walk: one workgroup per tile of kCscTile entries.  No workgroup waits for another: the kept pairs of a tile go, in
+// order, to the tile's OWN slice of a staging buffer and its count to counts[tile]; a one-workgroup scan turns the counts into the
+// tiles' first positions and a copy pass moves the slices into place.  (The first form of this kernel compacted in ONE pass with a
+// decoupled look-back between the tiles: 85 us alone for the 120 MB of the headline shape -- a tile's look-back is a chain of
+// device-scope loads across the XCDs' L2s, ~1.5 us per 64 tiles, and the ~1 800 resident tiles of the first round all wait for it
+// while holding their wave slots.  profiles/r06_exp_csc_sampler.txt)
 template <typename RD>
-__global__ __launch_bounds__(kCscThreads) void csc_select_kernel(CscArgs a, uint32_t k0, uint32_t k1, uint64_t *__restrict__ status,
-                                                                 uint32_t *__restrict__ ticket, int32_t *__restrict__ u_out,
-                                                                 int32_t *__restrict__ i_out, int64_t *__restrict__ n_live_out,
-                                                                 int C, int64_t Ic, int64_t *__restrict__ chunk_pos_out)
+__global__ __launch_bounds__(kCscThreads) void csc_select_kernel(CscArgs a, uint32_t k0, uint32_t k1, uint2 *__restrict__ stage,
+                                                                 uint32_t *__restrict__ counts, int C, int64_t Ic,
+                                                                 uint32_t *__restrict__ border_tile, uint32_t *__restrict__ border_rank)
 {
-    __shared__ uint32_t s_tile;
     __shared__ uint32_t s_cnt[kCscCounts], s_ex[kCscCounts + 1];
-    __shared__ int64_t s_base;
     __shared__ uint16_t s_border[kCscItemsLds];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // tiles are numbered in the order their workgroups START: a tile only ever waits for tiles that are already running
-    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const int tile = (int)s_tile;
+    const int tile = blockIdx.x;
     const int64_t e0 = (int64_t)tile * kCscTile;
     // (non-temporal: 120 MB stream through once per step and must not push the item table out of the memory-side cache)
     const u32x4 *up = reinterpret_cast<const u32x4 *>(a.users) + e0 / 4;
@@ -906,43 +905,15 @@ __global__ __launch_bounds__(kCscThreads) void csc_select_kernel(CscArgs a, uint
             if (tid >= off) incl += v;
         }
         s_ex[tid] = incl - mine;
-        if (tid == kCscCounts - 1) s_ex[kCscCounts] = incl;
+        if (tid == kCscCounts - 1) { s_ex[kCscCounts] = incl; counts[tile] = incl; }
     }
     __syncthreads();
-    const uint32_t total = s_ex[kCscCounts];
-    // decoupled look-back: publish this tile's count, add up the tiles before it (the first wavefront, 64 tiles per trip)
-    if (wave == 0) {
-        int64_t excl = 0;
-        if (tile > 0) {
-            if (lane == 0) __hip_atomic_store(status + tile, kStatusAggregate | (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int look = tile - 1;;) {
-                const int idx = look - lane;
-                uint64_t v = kStatusPrefix;                        // (in front of tile 0: the prefix 0)
-                if (idx >= 0) v = __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint64_t m_prefix = __ballot((v >> 62) == 2ull), m_invalid = __ballot((v >> 62) == 0ull);
-                const int pl = m_prefix ? __builtin_ctzll(m_prefix) : 63;                   // nearest tile with a full prefix
-                const uint64_t span = pl == 63 ? ~0ull : ((2ull << pl) - 1ull);
-                if (m_invalid & span) { __builtin_amdgcn_s_sleep(8); continue; }            // a tile in between has not published yet
-                uint64_t part = lane <= pl ? (v & kStatusValue) : 0ull;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-                excl += (int64_t)part;
-                if (m_prefix) break;
-                look -= 64;
-            }
-        }
-        if (lane == 0) {
-            __hip_atomic_store(status + tile, kStatusPrefix | (uint64_t)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_base = excl;
-        }
-    }
-    __syncthreads();
-    const int64_t base = s_base;
     // rank (inside the tile) of the entry (k, j) of this thread
     auto rank_of = [&](int k, int j) -> uint32_t {
         return s_ex[k * 4 + wave] + before[k] + (uint32_t)__popc(keep & (((1u << j) - 1u) << (k * 4)));
     };
     if (keep) {
+        uint2 *mine = stage + e0;                                  // the tile's slice: room for every entry of the tile
 #pragma unroll
         for (int k = 0; k < kCscRounds; ++k) {
             if (!((keep >> (k * 4)) & 0xFu)) continue;
@@ -961,31 +932,71 @@ __global__ __launch_bounds__(kCscThreads) void csc_select_kernel(CscArgs a, uint
                     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.ptr[mid] <= e0 + x) lo = mid; else hi = mid - 1; }
                     item = lo;
                 }
-                const int64_t pos = base + rank_of(k, j);
-                u_out[pos] = (int32_t)uu[j];
-                i_out[pos] = item;
+                mine[rank_of(k, j)] = make_uint2(uu[j], (uint32_t)item);
             }
         }
     }
-    // where the item ranges start in the ordered batch (chunked layout) and how many positions are live
-    if (tile == 0 && tid == 0 && chunk_pos_out != nullptr) chunk_pos_out[0] = 0;
-    const bool last_tile = tile == a.ntiles - 1;
+    // where the item ranges start (chunked layout): the tile that holds the first entry of range ch says how many of its kept
+    // entries lie in front of it; the scan adds the tile's first position
     for (int ch = 1; ch < C; ++ch) {
         const int64_t eb = a.ptr[ch * Ic];
-        if (eb >= a.nnz) { if (last_tile && tid == 0) chunk_pos_out[ch] = base + total; continue; }
+        if (eb >= a.nnz) { if (tile == 0 && tid == 0) { border_tile[ch] = (uint32_t)a.ntiles; border_rank[ch] = 0u; } continue; }
         if (eb < e0 || eb >= e0 + kCscTile) continue;
         const int x = (int)(eb - e0), k = x / (kCscThreads * 4), t = (x / 4) % kCscThreads, j = x % 4;
         if (t == tid) {
             uint32_t r = 0;
 #pragma unroll
             for (int kk = 0; kk < kCscRounds; ++kk) if (kk == k) r = rank_of(kk, j);
-            chunk_pos_out[ch] = base + r;
+            border_tile[ch] = (uint32_t)tile; border_rank[ch] = r;
         }
     }
-    if (last_tile && tid == 0) {
-        *n_live_out = base + total;
-        if (chunk_pos_out != nullptr) chunk_pos_out[C] = base + total;
+}
+
+// pass 2: one workgroup scans the tiles' counts into their first positions; the number of live positions and the ranges' first positions
+constexpr int kCscScanThreads = 1024;
+__global__ __launch_bounds__(kCscScanThreads) void csc_scan_kernel(const uint32_t *__restrict__ counts, uint32_t *__restrict__ first_pos, int ntiles,
+                                                                   int64_t *__restrict__ n_live_out)
+{
+    __shared__ uint32_t wsum[kCscScanThreads / 64];
+    const int tid = threadIdx.x;
+    const int per = (ntiles + kCscScanThreads - 1) / kCscScanThreads;
+    const int q0 = tid * per < ntiles ? tid * per : ntiles, q1 = (q0 + per < ntiles) ? q0 + per : ntiles;
+    uint32_t mine = 0;
+    for (int q = q0; q < q1; ++q) mine += counts[q];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off);
+        if ((tid & 63) >= off) incl += v;
     }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t run = incl - mine;
+    for (int w = 0; w < (tid >> 6); ++w) run += wsum[w];
+    for (int q = q0; q < q1; ++q) { first_pos[q] = run; run += counts[q]; }
+    if (tid == kCscScanThreads - 1) { first_pos[ntiles] = run; *n_live_out = (int64_t)run; }
+}
+
+// pass 3: every tile moves its slice of the staging buffer into place (the ranges' first positions are finished here: they need the tiles' first positions)
+__global__ __launch_bounds__(kCscThreads) void csc_place_kernel(const uint2 *__restrict__ stage, const uint32_t *__restrict__ counts,
+                                                                const uint32_t *__restrict__ first_pos, int ntiles, int32_t *__restrict__ u_out,
+                                                                int32_t *__restrict__ i_out, int C, const uint32_t *__restrict__ border_tile,
+                                                                const uint32_t *__restrict__ border_rank, int64_t *__restrict__ chunk_pos_out)
+{
+    const int tile = blockIdx.x;
+    const uint32_t n = counts[tile], p0 = first_pos[tile];
+    const uint2 *mine = stage + (int64_t)tile * kCscTile;
+    for (uint32_t r = threadIdx.x; r < n; r += kCscThreads) {
+        const uint2 v = mine[r];
+        u_out[p0 + r] = (int32_t)v.x; i_out[p0 + r] = (int32_t)v.y;
+    }
+    if (chunk_pos_out != nullptr && threadIdx.x == 0)
+        for (int ch = 1; ch < C; ++ch) {
+            const uint32_t bt = border_tile[ch];
+            if (bt == (uint32_t)tile) chunk_pos_out[ch] = (int64_t)p0 + border_rank[ch];
+            else if (bt >= (uint32_t)ntiles && tile == 0) chunk_pos_out[ch] = (int64_t)first_pos[ntiles];
+        }
+    if (chunk_pos_out != nullptr && tile == 0 && threadIdx.x == 0) { chunk_pos_out[0] = 0; chunk_pos_out[C] = (int64_t)first_pos[ntiles]; }
 }
 
 // negatives of the ordered positions (the second half of bucket_sort_kernel on pairs that are already in place): a workgroup
@@ -1519,10 +1530,30 @@ RSX_API int rsx_csc_info(const rsx_csc *c, int64_t *nnz, int64_t *num_items, int
     return RSX_OK;
 }
 
+namespace {
+struct CscWs { int64_t *n_live; uint32_t *border_tile, *border_rank, *counts, *first_pos; uint2 *stage; int64_t bytes; };
+CscWs csc_ws_carve(void *ws, int64_t nnz)
+{
+    const int64_t ntiles = nnz > 0 ? (nnz + kCscTile - 1) / kCscTile : 1;
+    char *p = (char *)ws;
+    CscWs w;
+    w.n_live = (int64_t *)p;
+    w.border_tile = (uint32_t *)(p + 64);
+    w.border_rank = (uint32_t *)(p + 128);
+    int64_t off = 256;
+    w.counts = (uint32_t *)(p + off);     off += align256(ntiles * 4);
+    w.first_pos = (uint32_t *)(p + off);  off += align256((ntiles + 1) * 4);
+    w.stage = (uint2 *)(p + off);         off += ntiles * kCscTile * 8;      // a slice per tile with room for EVERY entry of the tile
+    w.bytes = off;
+    return w;
+}
+static_assert(RSX_MAX_CHUNKS * 4 <= 64, "the ranges' border words sit in two 64-byte slots of the workspace head");
+}  // namespace
+
 RSX_API int64_t rsx_bpr_sample_csc_workspace(int64_t nnz)
 {
     if (nnz < 0 || nnz >= (1ll << 32)) return RSX_E_INVALID;
-    return 256 + align256(((nnz > 0 ? (nnz + kCscTile - 1) / kCscTile : 1)) * 8);
+    return csc_ws_carve(nullptr, nnz).bytes;
 }
 
 // (internal, rsx_common.h) the native loop asks before it takes the CSC walk
@@ -1552,22 +1583,21 @@ RSX_API int rsx_bpr_sample_csc(const rsx_csc *csc, const int64_t *indptr_dev, co
     }
     const int64_t B = num_users;                                   // the batch IS one pass over the users
     hipStream_t st = (hipStream_t)stream;
-    int64_t *n_live = (int64_t *)ws;
-    uint32_t *ticket = (uint32_t *)((char *)ws + 64);
-    uint64_t *status = (uint64_t *)((char *)ws + 256);
-    if (hipMemsetAsync(ws, 0, (size_t)rsx_bpr_sample_csc_workspace(csc->a.nnz), st) != hipSuccess) {
-        rsx_set_error("rsx_bpr_sample_csc: memset failed");
-        return RSX_E_HIP;
-    }
+    const CscWs w = csc_ws_carve(ws, csc->a.nnz);
     const uint64_t k = csc_step_key(seed, step);
     const uint32_t k0 = (uint32_t)k, k1 = (uint32_t)(k >> 32);
     const ChunkArgs ca{chunked_layout ? chunks : 1, 0, g, chunked_layout ? chunk_pos_out : nullptr, whole};
+    // select (every tile on its own) -> scan of the tiles' counts (one workgroup) -> place -> negatives per ordered position
     if (csc->rd_bits == 16)
-        hipLaunchKernelGGL(csc_select_kernel<uint16_t>, dim3(csc->a.ntiles), dim3(kCscThreads), 0, st, csc->a, k0, k1, status, ticket, u_out, i_out,
-                           n_live, ca.C, g.Ic, ca.chunk_pos_out);
+        hipLaunchKernelGGL(csc_select_kernel<uint16_t>, dim3(csc->a.ntiles), dim3(kCscThreads), 0, st, csc->a, k0, k1, w.stage, w.counts, ca.C, g.Ic,
+                           w.border_tile, w.border_rank);
     else
-        hipLaunchKernelGGL(csc_select_kernel<uint32_t>, dim3(csc->a.ntiles), dim3(kCscThreads), 0, st, csc->a, k0, k1, status, ticket, u_out, i_out,
-                           n_live, ca.C, g.Ic, ca.chunk_pos_out);
+        hipLaunchKernelGGL(csc_select_kernel<uint32_t>, dim3(csc->a.ntiles), dim3(kCscThreads), 0, st, csc->a, k0, k1, w.stage, w.counts, ca.C, g.Ic,
+                           w.border_tile, w.border_rank);
+    hipLaunchKernelGGL(csc_scan_kernel, dim3(1), dim3(kCscScanThreads), 0, st, w.counts, w.first_pos, csc->a.ntiles, w.n_live);
+    hipLaunchKernelGGL(csc_place_kernel, dim3(csc->a.ntiles), dim3(kCscThreads), 0, st, w.stage, w.counts, w.first_pos, csc->a.ntiles, u_out, i_out,
+                       ca.C, w.border_tile, w.border_rank, ca.chunk_pos_out);
+    int64_t *n_live = w.n_live;
     const int64_t blocks = ceil_div64(B, kCscNegBlock) + ca.C + 1;
     hipLaunchKernelGGL(csc_neg_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, indptr_dev, indices_dev, user_sig_dev, num_items, B, seed, step,
                        neg_block, neg_key, n_live, u_out, i_out, j_out, ca);

@@ -154,7 +154,7 @@ def version():
 
 
 def set_option(name, value):
-    """include/rsx.h:rsx_set_option ("score_lanes", "sample_sort_cap", "apply_stream")"""
+    """include/rsx.h:rsx_set_option ("score_lanes", "sample_sort_cap", "step_waves", "apply_stream", "mesh_blocks")"""
     _check(lib().rsx_set_option(name.encode(), int(value)), "rsx_set_option")
 
 
