@@ -240,8 +240,8 @@ def step_leg(P, Q, indptr, indices, lr, B, want_nb, hot, hot_replicas, steps, wa
     eng = BPREngine(P, Q, lr, user_begin=rank * U, seed=2020, exchange=os.environ.get("RSX_EXCHANGE", "allreduce"),
                     force_sharded=SHARDED, comm=COMM)
     Q = eng.Q                                            # (scatter_gather may re-home the item table)
-    if os.environ.get("RSX_CSC_SAMPLER", "1") == "0":    # A/B: the bucket passes also for whole-pass batches
-        eng.use_csc = False
+    if os.environ.get("RSX_CSC_SAMPLER", "0") == "1":    # A/B (opt-in): whole-pass batches sampled by the CSC walk instead of the bucket passes
+        eng.use_csc = True
     if two_pass is not None:
         eng.overlap_exchange = bool(two_pass) and SHARDED and eng.exchange != "direct"      # (the mesh sums and applies in one go)
     # OPT-IN, never the default: RSX_STALE_EXCHANGE=1 lets a step's exchange travel under the NEXT step kernel (item

@@ -198,9 +198,11 @@ class BPREngine:
         self._sample_ws = {}        # sampler scratch, one per stream role ("main" / "side"): never shared
         self._csr = None            # the CSR tensors the static sampler tables below were built from
         self._sig = self._cdf = None
-        # whole-pass batches (batch == this rank's users) of an ordered layout are sampled by ONE walk over the transposed
-        # interaction matrix instead of the bucket passes (include/rsx.h: rsx_bpr_sample_csc); built on first use, per CSR
-        self.use_csc = True
+        # OPT-IN (round 6): whole-pass batches (batch == this rank's users) of an ordered layout sampled by ONE walk over the transposed
+        # interaction matrix instead of the bucket passes (include/rsx.h: rsx_bpr_sample_csc); built on first use, per CSR.  Exact and
+        # tested like the bucket passes; measured beside the step kernel it is a wash -- headline 339-344 vs 335-337 us per step, d = 64
+        # 213-218 vs 213-215, configs[3] slice 1149-1156 vs 1166-1169 (profiles/r06_exp_csc_sampler.txt) -- so the default stays
+        self.use_csc = False
         self._csc = None            # (rsx.Csc, indptr, indices)
         self._bufs = None           # double-buffered triplets for the overlapped sampler
         self._side = None           # ONE side stream for the engine's lifetime

@@ -274,6 +274,7 @@ def test_native_loop_through_the_walk_replays_through_the_oracle(oracle_mod, d, 
     P = torch.randn(U, d, device="cuda") * 0.1
     Q = torch.randn(I, d, device="cuda") * 0.1
     eng = BPREngine(P, Q, lr)
+    eng.use_csc = True                      # (opt-in: the default sampler of whole-pass batches stays the bucket passes)
     nb = eng.set_neg_block(U, c_max)
     if nb == 0:
         eng.sorted_min_batch = 1
@@ -317,6 +318,7 @@ def test_hand_driven_steps_take_the_walk_too():
         P = torch.randn(U, d, device="cuda") * 0.1
         Q = torch.randn(I, d, device="cuda") * 0.1
         eng = BPREngine(P, Q, resolvable_lr(U))
+        eng.use_csc = True
         eng.set_neg_block(U, 8)
         if native:
             tr = eng.native_trainer(ip, ix, U)
@@ -326,5 +328,6 @@ def test_hand_driven_steps_take_the_walk_too():
             for _ in range(3):
                 eng.sampled_step(ip, ix, U, want_loss=False)
         torch.cuda.synchronize()
+        assert eng._csc is not None                      # (both arms really sampled through the walk)
         outs.append((P.cpu().numpy(), Q.cpu().numpy()))
     assert np.allclose(outs[0][0], outs[1][0], rtol=0, atol=1e-6) and np.allclose(outs[0][1], outs[1][1], rtol=0, atol=1e-6)
