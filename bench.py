@@ -663,6 +663,8 @@ def main():
         rsx.set_option("step_waves", int(os.environ["RSX_STEP_WAVES"]))
     if os.environ.get("RSX_APPLY_STREAM"):      # experiment: the ranges' applies on a stream of their own (include/rsx.h: "apply_stream")
         rsx.set_option("apply_stream", int(os.environ["RSX_APPLY_STREAM"]))
+    if os.environ.get("RSX_TOUCHED_APPLY"):     # experiment: the row-marked apply of small batches never (0) / by the rule (1) / always (2)
+        rsx.set_option("touched_apply", int(os.environ["RSX_TOUCHED_APPLY"]))
     if os.environ.get("RSX_MESH_BLOCKS"):
         rsx.set_option("mesh_blocks", int(os.environ["RSX_MESH_BLOCKS"]))
     if os.environ.get("RSX_SCORE_LANES"):
@@ -711,7 +713,7 @@ def main():
                 legs["independent_uniform_negatives"] = leg(P, Q, indptr, indices, args.lr, B, 0, args.hot, args.hot_replicas,
                                                                  short, 3, 1, 0, args.popularity)
             sweep = []
-            for b in (4_096, 16_384, 262_144):
+            for b in (256, 4_096, 16_384, 262_144):      # (256: the reference's default batch, config.py)
                 if b < B:
                     r = leg(P, Q, indptr, indices, args.lr, b, args.neg_block, args.hot, args.hot_replicas, 100, 10, 1, 0,
                                  args.popularity)

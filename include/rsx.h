@@ -107,6 +107,8 @@ int rsx_device_info_get(int device, rsx_device_info *out);
  *                     of its item ranges on a high-priority stream of their own instead of behind the collectives on the
  *                     collective stream (pays only where an exchange is longer than the whole step).  Read at
  *                     rsx_bpr_trainer_create.  The result does not depend on it.
+ *   "touched_apply"   0 / 1 (default) / 2: the native loop's row-marked apply (rsx_bpr_trainer_config.touched) never / where
+ *                     2 * batch <= num_items / wherever the plain kernel runs.  The result does not depend on it.
  *   "mesh_blocks"     0 (default: one per CU) .. 4096: workgroups of the two kernels of rsx_mesh_exchange_apply (like a collective's
  *                     channels: over xGMI they are link-bound and a few dozen saturate the links; every workgroup more takes a wave slot
  *                     from the other item ranges' step kernels it runs beside).  The result does not depend on it.
@@ -498,6 +500,11 @@ void rsx_mesh_destroy(rsx_mesh *m);
  *                        user once (batch == num_users, starting a pass) and take an ordered layout (neg_block engaged, sort_min_batch,
  *                        or chunks > 1) are sampled by rsx_bpr_sample_csc instead of the bucket passes; sample_ws must also hold
  *                        rsx_bpr_sample_csc_workspace(nnz) bytes.  Other steps (short batches) sample as without it.
+ *   touched              (optional, unsharded trainers) device bytes [num_items], zero-filled by the caller once.  Where a step runs the
+ *                        plain kernel on a batch small against the catalog (2 * batch <= num_items; rsx_set_option "touched_apply"), the
+ *                        kernel marks the rows of G it adds to and the apply visits the marked (and the replicated) rows only instead of
+ *                        sweeping G -- at 100 000 x 128 the sweep costs 22-28 us whether the batch held 256 triplets (the reference's default
+ *                        batch, config.py) or 65 536.  Same arithmetic per element: the tables are bit-identical with and without it.
  *   stale_exchange / G_alt   OPT-IN, needs an exchange (callbacks or comm) and a second zeroed [num_items x d] buffer.
  *                        != 0: the exchange of step t's item gradients travels under the step kernel of
  *                        step t+1, which therefore reads an item table that lacks step t's update (ONE STEP
@@ -568,6 +575,7 @@ typedef struct rsx_bpr_trainer_config {
     rsx_exchange_range_fn exchange_range;   /* chunks > 1 without comm: the caller's all-reduce of one item range  */
     rsx_mesh *mesh;                         /* the library's own exchange over xGMI (see rsx_mesh_*), or NULL        */
     const rsx_csc *csc;                     /* the CSC walk for whole-pass batches (see rsx_bpr_sample_csc), or NULL  */
+    uint8_t *touched;                       /* row marks of the small-batch apply: [num_items] bytes, zero; or NULL   */
 } rsx_bpr_trainer_config;
 
 #define RSX_EXCHANGE_ALLREDUCE 1

@@ -46,6 +46,7 @@ int g_rsx_sort_cap = 0;
 int g_rsx_apply_stream = 0;
 int g_rsx_step_waves = 0;
 int g_rsx_mesh_blocks = 0;
+int g_rsx_touched_apply = 1;
 
 RSX_API int rsx_set_option(const char *name, int64_t value)
 {
@@ -68,6 +69,11 @@ RSX_API int rsx_set_option(const char *name, int64_t value)
     if (strcmp(name, "apply_stream") == 0) {
         RSX_CHECK_ARG(value == 0 || value == 1, "apply_stream must be 0 or 1");
         g_rsx_apply_stream = (int)value;
+        return RSX_OK;
+    }
+    if (strcmp(name, "touched_apply") == 0) {
+        RSX_CHECK_ARG(value >= 0 && value <= 2, "touched_apply must be 0, 1 or 2");
+        g_rsx_touched_apply = (int)value;
         return RSX_OK;
     }
     if (strcmp(name, "mesh_blocks") == 0) {

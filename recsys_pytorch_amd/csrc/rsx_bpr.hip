@@ -197,6 +197,9 @@ struct HotMap {
     const int32_t *slot;   // [num_items] hot slot of an item or -1
     float *ghot;           // [n_hot x replicas x D], zero between steps
     int replicas;          // power of two
+    // (the native loop's small batches, plain kernel only) [num_items] bytes, zero between steps: the kernel marks every row of G it adds
+    // to, and the apply that follows visits the marked rows only instead of sweeping the table (apply_item_grad_touched_kernel)
+    uint8_t *touched = nullptr;
 };
 
 // MODE 0: users unique in the batch -> P[u] updated in place by its owner group.
@@ -277,6 +280,10 @@ __global__ __launch_bounds__(kBlock) void bpr_step_kernel(
                         p.atomic_axpy_at(G, i_off, gi);
                 }
                 if (!RSX_ABL(2)) p.atomic_axpy_at(G, j_off, -gi);
+                if (hot.touched != nullptr && k == 0) {       // (replicated rows are always visited by the apply: no mark)
+                    if (!(has_hot && hs >= 0)) hot.touched[i] = 1;
+                    hot.touched[j] = 1;
+                }
             }
             // user row: P[u] -= lr * g * (qi - qj)
             const float s = -lr * g * (RSX_ABL(128) ? 1.01f : 1.0f);
@@ -880,6 +887,47 @@ __global__ __launch_bounds__(kBlock) void fold_hot_range_kernel(float *__restric
     *dst = g;
 }
 
+// Q -= lr*G ; G = 0 for the rows the step kernel MARKED (and the replicated rows, whose replicas are summed in here), one float4 per thread,
+// D / 4 threads per row; the marks are cleared.  A batch far below the catalog touches few rows: the streaming apply above reads all of G
+// to find them (51 MB at 100 000 x 128 -- 22-28 us whether the batch held 4 096 or 65 536 triplets), this one reads a byte per row.
+// Same arithmetic per quad as apply_item_grad_kernel: the tables come out bit-identical.
+template <int D>
+__global__ __launch_bounds__(kBlock) void apply_item_grad_touched_kernel(float4 *__restrict__ Q, float4 *__restrict__ G, int64_t num_items,
+                                                                         float lr, HotMap hot)
+{
+    constexpr int d4 = D / 4;
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t row = t / d4;
+    const int k = (int)(t % d4);
+    if (row >= num_items) return;
+    const int32_t hs = hot.slot != nullptr ? hot.slot[row] : -1;
+    if (hs < 0 && hot.touched[row] == 0) return;
+    const int64_t n = row * d4 + k;
+    float4 g = G[n];
+    bool cancel = false;
+    if (hs >= 0) {
+        cancel = g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f;
+        float4 *src = reinterpret_cast<float4 *>(hot.ghot) + ((size_t)hs * hot.replicas) * d4 + k;
+        for (int r = 0; r < hot.replicas; ++r) {
+            const float4 v = src[(size_t)r * d4];
+            g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+            src[(size_t)r * d4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if (g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f) {
+        float4 w = Q[n];
+        w.x = fmaf(-lr, g.x, w.x); w.y = fmaf(-lr, g.y, w.y);
+        w.z = fmaf(-lr, g.z, w.z); w.w = fmaf(-lr, g.w, w.w);
+        Q[n] = w;
+        G[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else if (cancel) {
+        G[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // (every thread of the row has read the mark above before any of them clears it: the row's threads are lanes of ONE wavefront -- d4 <= 64
+    //  divides the wavefront -- and execute in lockstep)
+    if (k == 0 && hs < 0) hot.touched[row] = 0;
+}
+
 // tables of 4 GB and more need 64-bit row offsets (see ADDRESSING above)
 bool wide_offsets(int64_t num_users, int64_t num_items, int d)
 {
@@ -999,7 +1047,22 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
                          unsigned flags, void *ws, int64_t ws_bytes, const int32_t *hot_slot_dev,
                          float *G_hot, int hot_replicas, int neg_block, uint64_t neg_key, rsx_stream_t stream)
 {
+    return rsx_bpr_step_ex(P, Q, G, num_users, num_items, u_dev, i_dev, j_dev, batch, d, lr, inv_batch, loss_acc, flags, ws, ws_bytes,
+                           hot_slot_dev, G_hot, hot_replicas, neg_block, neg_key, nullptr, stream);
+}
+
+// (internal, rsx_common.h) the same with the native loop's row marks: `touched_dev` (nullable, [num_items] bytes, zero) is written by the
+// plain in-place kernel only -- RSX_USERS_UNIQUE without neg_block / RSX_BATCH_SORTED / a split pass -- and must be NULL otherwise
+int rsx_bpr_step_ex(float *P, const float *Q, float *G, int64_t num_users, int64_t num_items,
+                    const int32_t *u_dev, const int32_t *i_dev, const int32_t *j_dev,
+                    int64_t batch, int d, float lr, float inv_batch, float *loss_acc,
+                    unsigned flags, void *ws, int64_t ws_bytes, const int32_t *hot_slot_dev,
+                    float *G_hot, int hot_replicas, int neg_block, uint64_t neg_key, uint8_t *touched_dev, rsx_stream_t stream)
+{
     RSX_CHECK_ARG(P && Q && (G || (flags & RSX_NO_UPDATE)), "null table pointer");
+    RSX_CHECK_ARG(touched_dev == nullptr || ((flags & RSX_USERS_UNIQUE) && neg_block == 0 &&
+                                             !(flags & (RSX_NO_UPDATE | RSX_DETERMINISTIC | RSX_ITEMS_ONLY | RSX_USERS_ONLY | RSX_BATCH_SORTED))),
+                  "row marks are written by the plain in-place kernel only");
     RSX_CHECK_ARG(rsx_dim_ok(d), "d must be 32, 64, 128 or 256");
     RSX_CHECK_ARG(batch >= 0 && num_users > 0 && num_items > 0, "negative size");
     if (batch == 0) return RSX_OK;
@@ -1012,6 +1075,7 @@ RSX_API int rsx_bpr_step(float *P, const float *Q, float *G, int64_t num_users, 
         RSX_CHECK_ARG(hot_replicas >= 1 && (hot_replicas & (hot_replicas - 1)) == 0, "hot_replicas must be a power of two");
         hot = HotMap{hot_slot_dev, G_hot, hot_replicas};
     }
+    hot.touched = touched_dev;
     if (flags & RSX_NO_UPDATE) {   // loss only: the in-place kernel with neither side written
         dispatch_step<0, 0>(d, wide, P, Q, G, u_dev, i_dev, j_dev, batch, lr, inv_batch, loss_acc, nullptr, nullptr,
                             HotMap{nullptr, nullptr, 1}, st);
@@ -1211,6 +1275,29 @@ int rsx_apply_item_grad_ex(float *Q, float *G, int64_t num_items, int d, float l
                                   (float4 *)Q, (float4 *)G, n4, lr, hot, d / 4);
     else hipLaunchKernelGGL(apply_item_grad_kernel<false>, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(kBlock), 0, stream,
                             (float4 *)Q, (float4 *)G, n4, lr, hot, d / 4);
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+}
+
+// (internal, rsx_common.h) the apply behind a step that marked its rows (rsx_bpr_step_ex with touched_dev): marked and replicated rows only
+int rsx_apply_item_grad_touched(float *Q, float *G, int64_t num_items, int d, float lr, const int32_t *hot_slot_dev, float *G_hot,
+                                int hot_replicas, uint8_t *touched_dev, hipStream_t stream)
+{
+    RSX_CHECK_ARG(Q && G && touched_dev, "null pointer");
+    RSX_CHECK_ARG(rsx_dim_ok(d) && num_items > 0, "bad shape");
+    HotMap hot{nullptr, nullptr, 1};
+    if (hot_slot_dev != nullptr) {
+        RSX_CHECK_ARG(G_hot != nullptr && hot_replicas >= 1, "hot_slot_dev given without G_hot");
+        hot = HotMap{hot_slot_dev, G_hot, hot_replicas};
+    }
+    hot.touched = touched_dev;
+    const unsigned blocks = (unsigned)ceil_div64(num_items * (d / 4), kBlock);
+    switch (d) {
+    case 32: hipLaunchKernelGGL(apply_item_grad_touched_kernel<32>, dim3(blocks), dim3(kBlock), 0, stream, (float4 *)Q, (float4 *)G, num_items, lr, hot); break;
+    case 64: hipLaunchKernelGGL(apply_item_grad_touched_kernel<64>, dim3(blocks), dim3(kBlock), 0, stream, (float4 *)Q, (float4 *)G, num_items, lr, hot); break;
+    case 128: hipLaunchKernelGGL(apply_item_grad_touched_kernel<128>, dim3(blocks), dim3(kBlock), 0, stream, (float4 *)Q, (float4 *)G, num_items, lr, hot); break;
+    default: hipLaunchKernelGGL(apply_item_grad_touched_kernel<256>, dim3(blocks), dim3(kBlock), 0, stream, (float4 *)Q, (float4 *)G, num_items, lr, hot); break;
+    }
     RSX_CHECK_LAUNCH();
     return RSX_OK;
 }

@@ -148,6 +148,15 @@ void rsx_mesh_tables(const rsx_mesh *m, const float **Q, const float **G, int64_
 int rsx_apply_item_grad_ex(float *Q, float *G, int64_t num_items, int d, float lr, const int32_t *hot_slot_dev, float *G_hot,
                            int hot_replicas, bool dense, hipStream_t stream);
 
+// rsx_bpr.hip: the step and its apply with the native loop's row marks (small batches: the apply visits the marked rows only)
+int rsx_bpr_step_ex(float *P, const float *Q, float *G, int64_t num_users, int64_t num_items, const int32_t *u_dev, const int32_t *i_dev,
+                    const int32_t *j_dev, int64_t batch, int d, float lr, float inv_batch, float *loss_acc, unsigned flags, void *ws,
+                    int64_t ws_bytes, const int32_t *hot_slot_dev, float *G_hot, int hot_replicas, int neg_block, uint64_t neg_key,
+                    uint8_t *touched_dev, rsx_stream_t stream);
+int rsx_apply_item_grad_touched(float *Q, float *G, int64_t num_items, int d, float lr, const int32_t *hot_slot_dev, float *G_hot,
+                                int hot_replicas, uint8_t *touched_dev, hipStream_t stream);
+extern int g_rsx_touched_apply;  // 0 never, 1 (default) where the batch is small against the catalog, 2 wherever the plain kernel runs
+
 // rsx_bpr.hip: pieces of the chunked step the native loop queues on its own stream
 int rsx_fold_hot_grad_range(float *G, float *G_hot, const int32_t *hot_items_dev, int n_hot, int hot_replicas, int d,
                             int64_t row_lo, int64_t row_hi, hipStream_t st);

@@ -588,8 +588,12 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
         if (stale) t->flip = !t->flip;
         float *const Gprev = (Gs == c.G) ? c.G_alt : c.G;
         const int which = (Gs == c.G) ? 0 : 1;
-        RSX_TRY(rsx_bpr_step(c.P, c.Q, Gs, c.num_users, c.num_items, u, i, j, batch, c.d, c.lr, inv_batch, c.loss_acc, f,
-                             nullptr, 0, c.hot_slot, c.G_hot, c.hot_replicas, nb, key, stream));
+        // small batches of an unsharded trainer: the plain kernel marks the rows of G it adds to and the apply visits those only
+        // (2 B <= items: at most ~2/3 of the rows are touched; "touched_apply" = 2: wherever the plain kernel runs)
+        uint8_t *const marks = (!sharded && c.touched != nullptr && nb == 0 && sorted_flag == 0u && !two_pass && g_rsx_touched_apply != 0 &&
+                                (g_rsx_touched_apply == 2 || 2 * batch <= c.num_items)) ? c.touched : nullptr;
+        RSX_TRY(rsx_bpr_step_ex(c.P, c.Q, Gs, c.num_users, c.num_items, u, i, j, batch, c.d, c.lr, inv_batch, c.loss_acc, f,
+                                nullptr, 0, c.hot_slot, c.G_hot, c.hot_replicas, nb, key, marks, stream));
         RSX_TRY(time_end(st));
         if (timed) ++t->timed;
 #if RSX_SAMPLER_BEHIND_KERNEL
@@ -600,6 +604,9 @@ RSX_API int rsx_bpr_trainer_run(rsx_bpr_trainer *t, int64_t n_steps, int64_t bat
         }
 #endif
         if (!sharded) {
+            if (marks != nullptr)
+                RSX_TRY(rsx_apply_item_grad_touched(c.Q, c.G, c.num_items, c.d, c.lr, c.hot_slot, c.G_hot, c.hot_replicas, marks, st));
+            else
             RSX_TRY(rsx_apply_item_grad_ex(c.Q, c.G, c.num_items, c.d, c.lr, c.hot_slot, c.G_hot, c.hot_replicas, batch >= c.num_items, st));
         } else if (meshed) {
             // one pass, the exchange exposed: the mesh sums, applies and redistributes the item rows (Q updated, G zero afterwards)

@@ -154,7 +154,7 @@ def version():
 
 
 def set_option(name, value):
-    """include/rsx.h:rsx_set_option ("score_lanes", "sample_sort_cap", "step_waves", "apply_stream", "mesh_blocks")"""
+    """include/rsx.h:rsx_set_option ("score_lanes", "sample_sort_cap", "step_waves", "apply_stream", "touched_apply", "mesh_blocks")"""
     _check(lib().rsx_set_option(name.encode(), int(value)), "rsx_set_option")
 
 
@@ -719,7 +719,7 @@ class TrainerConfig(C.Structure):
                 ("exchange_applies", C.c_int32), ("sort_min_batch", C.c_int32), ("step0", _I64), ("epoch_pos0", _I64),
                 ("G_alt", _P), ("stale_exchange", C.c_int32), ("exchange_kind", C.c_int32), ("comm", _P),
                 ("item_rows_padded", _I64), ("chunks", C.c_int32), ("reserved0", C.c_int32), ("items_real", _I64),
-                ("chunk_pos", _P), ("progress", _P), ("exchange_range", EXCHANGE_RANGE_FN), ("mesh", _P), ("csc", _P)]
+                ("chunk_pos", _P), ("progress", _P), ("exchange_range", EXCHANGE_RANGE_FN), ("mesh", _P), ("csc", _P), ("touched", _P)]
 
 
 class BPRTrainer:
@@ -750,6 +750,10 @@ class BPRTrainer:
                                              csc.sample_ws_bytes if csc is not None else 0), dtype=torch.uint8, device=dev)
         else:
             csc = None                                 # (the plain layout never takes the walk)
+        # row marks of the small-batch apply (include/rsx.h: touched): unsharded, unchunked trainers
+        self.touched = None
+        if exchange is None and comm is None and mesh is None and exchange_range is None and self.chunks <= 1:
+            self.touched = torch.zeros(int(num_items) if num_items is not None else Q.shape[0], dtype=torch.uint8, device=dev)
         self._keep = (P, Q, G, indptr, indices, hot, user_sig, item_cdf, loss_acc, G_alt, comm, mesh, csc)
         ptr = lambda t, dt, name: _dev(t, dt, name) if t is not None else None
         self._cb = (None, None)
@@ -799,7 +803,8 @@ class BPRTrainer:
             item_rows_padded=int(item_rows_padded), chunks=self.chunks, reserved0=0, items_real=int(items_real),
             chunk_pos=ptr(self.chunk_pos, torch.int64, "chunk_pos"), progress=ptr(self.progress, torch.int32, "progress"),
             exchange_range=self._cb_range or EXCHANGE_RANGE_FN(), mesh=mesh.handle if mesh is not None else None,
-            csc=csc.handle if csc is not None else None)
+            csc=csc.handle if csc is not None else None,
+            touched=C.c_void_p(self.touched.data_ptr()) if self.touched is not None else None)
         self._h = C.c_void_p()
         _check(lib().rsx_bpr_trainer_create(C.byref(cfg), C.byref(self._h)), "rsx_bpr_trainer_create")
 

@@ -48,7 +48,7 @@ def test_bench_json_contract_small_shape():
     assert 2 <= legs["base_batch_65536"]["neg_block"] <= 8 and legs["base_batch_65536"]["roofline"]["kernel_ms"] > 0     # 65536 >= 2 * 30000
     assert legs["independent_uniform_negatives"]["neg_block"] == 0
     assert legs["independent_uniform_negatives"]["roofline"]["kernel"] == "bpr_step_blocked_kernel<TILE=false>"   # 80000 >= 2 * 30000: ordered batch
-    assert [s["batch_per_gpu"] for s in legs["batch_sweep"]] == [4096, 16384] and legs["uniform_item_popularity"]["value"] > 0
+    assert [s["batch_per_gpu"] for s in legs["batch_sweep"]] == [256, 4096, 16384] and legs["uniform_item_popularity"]["value"] > 0
     assert legs["config1_d64"]["value"] > 0 and "config3_slice_1.25Mx1M" not in legs       # only beside the default shape
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["cpu_model"]

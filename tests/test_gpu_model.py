@@ -1092,3 +1092,57 @@ def test_synthetic_csr_shape_and_popularity():
     assert np.all(np.diff(rows, axis=1) > 0)                     # sorted, no duplicates per user
     cnt = np.bincount(rows.reshape(-1), minlength=10_000)
     assert cnt[0] > 20 * cnt[1000:1100].mean()                   # head is much more popular than the tail
+
+
+@pytest.mark.parametrize("d,B,hot,mode", [(128, 256, 64, 1), (64, 4096, 0, 1), (128, 20000, 64, 2), (32, 1, 8, 1)])
+def test_small_batches_apply_the_marked_rows_only(oracle_mod, d, B, hot, mode):
+    """batches small against the catalog (the reference's default batch of 256 among them, config.py) through the native loop with the
+    row-marked apply (include/rsx.h: rsx_bpr_trainer_config.touched -- the plain kernel marks the rows of G it adds to, the apply
+    visits those instead of sweeping G): every step replays through the CPU oracle (loss 1e-5, the update of P and Q to 1e-5 of its
+    size), popular rows with replicas included, and afterwards no mark and no gradient is left behind.  mode 2 = the marked apply
+    forced where the rule (2 B <= items) would sweep; the same steps with the option off (the sweep) agree"""
+    from recsys_pytorch_amd import rsx
+    from recsys_pytorch_amd.data import synthetic_csr
+    from recsys_pytorch_amd.sharded import BPREngine
+    U, I, steps = 30_000, 30_000, 5
+    ip, ix = synthetic_csr(U, I, 9, "cuda", seed=11, popularity="zipf")
+    lr = resolvable_lr(B)
+    outs = []
+    for option in (mode, 0):
+        rsx.set_option("touched_apply", option)
+        try:
+            torch.manual_seed(6)
+            P = torch.randn(U, d, device="cuda") * 0.1
+            Q = torch.randn(I, d, device="cuda") * 0.1
+            P0, Q0 = P.cpu().numpy().copy(), Q.cpu().numpy().copy()
+            orc = oracle_mod.MFOracle(P0, Q0, "sgd", lr)
+            eng = BPREngine(P, Q, lr)
+            assert eng.set_neg_block(B, 8) == 0                      # far below two triplets per item: the plain kernel
+            eng.sorted_min_batch = 0
+            if hot:
+                eng.set_hot_items(torch.bincount(ix.long(), minlength=I), hot, 4)
+            acc = torch.zeros(rsx.RSX_LOSS_SLOTS, device="cuda")
+            tr = eng.native_trainer(ip, ix, B, loss_acc=acc)
+            assert tr.touched is not None and tr.touched.numel() == I
+            for _ in range(steps):
+                acc.zero_()
+                tr.run(1)
+                torch.cuda.synchronize()
+                u, i, j = (x.cpu().numpy().astype(np.int64) for x in tr.last_batch()[:3])
+                assert abs(float(acc.sum()) / B - orc.step(u, i, j)) < 1e-5
+                assert int(tr.touched.sum()) == 0 and float(eng.G.abs().max()) == 0.0       # nothing left behind
+                if eng.hot is not None:
+                    assert float(eng.hot.ghot.abs().max()) == 0.0
+            assert_update(P.cpu().numpy(), P0, orc.P, "P")
+            assert_update(Q.cpu().numpy(), Q0, orc.Q, "Q")
+            tr.run(3)                                                 # ... and several steps queued by one call
+            torch.cuda.synchronize()
+            assert int(tr.touched.sum()) == 0 and float(eng.G.abs().max()) == 0.0
+            eng.adopt(tr)
+            outs.append((P.cpu().numpy(), Q.cpu().numpy()))
+            tr.close()
+        finally:
+            rsx.set_option("touched_apply", 1)
+    # the marked apply and the sweep took the same eight steps (same sampler draws): the tables agree to the atomics' summation order
+    assert_update(outs[0][0], P0, outs[1][0], "P (marked apply vs sweep)")
+    assert_update(outs[0][1], Q0, outs[1][1], "Q (marked apply vs sweep)")
