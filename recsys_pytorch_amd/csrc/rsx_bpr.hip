@@ -925,7 +925,7 @@ __global__ __launch_bounds__(kBlock) void apply_item_grad_touched_kernel(float4 
     }
     // (every thread of the row has read the mark above before any of them clears it: the row's threads are lanes of ONE wavefront -- d4 <= 64
     //  divides the wavefront -- and execute in lockstep)
-    if (k == 0 && hs < 0) hot.touched[row] = 0;
+    if (k == 0) hot.touched[row] = 0;          // (a replicated row carries a mark when it was somebody's NEGATIVE)
 }
 
 // tables of 4 GB and more need 64-bit row offsets (see ADDRESSING above)
