@@ -646,7 +646,8 @@ int rsx_score_topk(const float *P, const int32_t *user_ids_dev, int64_t num_rows
  * is the same product applied to the gradient.
  * rsx_spmm_plan (HOST): cuts rows into segments of <= max_seg non-zeros (item rows of a
  *   popularity-skewed graph have 10^5+ neighbours); call with NULL outputs for the count.
- * rsx_spmm_csr: Y = A X   (Y is overwritten -- every row must own at least one segment, as rsx_spmm_plan's plans do;
+ * rsx_spmm_csr: Y = A X   (Y is overwritten -- every row must own at least one segment, as rsx_spmm_plan's plans do, or be computed
+ *   by rsx_spmm_hot_rows below;
  *   X [N x d] must not alias Y or S_acc);
  *   if S_acc != NULL also S_acc += A X (the running layer sum).
  * rsx_scale: X *= alpha (the 1/(L+1) of the layer mean).                                   */
@@ -687,6 +688,28 @@ int rsx_spmm_csr_select_rows(const int32_t *seg_row_dev, const int64_t *seg_begi
                              const float *vals_dev, const float *X, const uint8_t *y_row_wanted_dev, float *Y,
                              float *S_acc, int64_t num_rows, int d, rsx_stream_t stream);
 int rsx_scale(float *X, int64_t n, float alpha, rsx_stream_t stream);
+/* rsx_spmm_hot_rows: the LONGEST rows of the product by scatter instead of gather.  A popularity-skewed graph puts half of all non-zeros
+ *   into a few hundred rows (the popular items); gathered, they re-read the source table once per row.  The caller takes the H <=
+ *   rsx_spmm_hot_capacity(d) longest rows OUT of the segment plan it hands to the four products above (a row without a segment is not
+ *   written by them) and describes them by SOURCE row: for every source row that has an entry in a hot row, the (hot slot, value) pairs.
+ *   rsx_spmm_hot_rows then reads every such source row ONCE, adds a * x into LDS accumulators of the hot rows (one workgroup per CU) and
+ *   adds the workgroups' partial rows to Y: Y[hot rows] = A[hot rows, :] X, and S_acc[hot rows] = (S_init or S_acc)[hot rows] + that --
+ *   the same sums as the gather, in another order.  x_row_nonzero_dev / y_row_wanted_dev / S_init: as in the products above (each NULL
+ *   or the same array the product call got).  Call it after the product over the reduced plan, on the same stream.                      */
+typedef struct rsx_spmm_hot {
+    int32_t num_hot;             /* H rows of Y computed here (<= rsx_spmm_hot_capacity(d))                       */
+    int32_t reserved;
+    int64_t num_src;             /* source rows with at least one entry in a hot row                               */
+    const int32_t *hot_rows;     /* device [H]: the row of Y behind every slot                                     */
+    const int32_t *src_rows;     /* device [num_src]: ascending row ids of X                                       */
+    const int64_t *src_ptr;      /* device [num_src + 1]: the entries of every source row                          */
+    const uint16_t *src_slot;    /* device [entries]: hot slot of an entry                                         */
+    const float *src_val;        /* device [entries]: its value A[hot_rows[slot], src_row]                         */
+} rsx_spmm_hot;
+int64_t rsx_spmm_hot_capacity(int d);
+int rsx_spmm_hot_rows(const rsx_spmm_hot *hot, const float *X, const uint8_t *x_row_nonzero_dev, const uint8_t *y_row_wanted_dev,
+                      const float *S_init, float *Y, float *S_acc, int64_t num_rows, int d, rsx_stream_t stream);
+
 /* rsx_spmm_mark_batch_rows: the row flags rsx_spmm_csr_sparse_rows takes, for the gradient of ONE batch of triplets on the
  *   stacked [users; items] table: flags (uint8 [num_rows]) = 0 everywhere, then 1 at u[b], item_offset + i[b], item_offset + j[b]
  *   (triplets with i[b] < 0 are skipped, as the step kernels skip them).                                             */

@@ -175,6 +175,77 @@ __global__ __launch_bounds__(kBlock) void zero_split_rows_kernel(const int32_t *
     }
 }
 
+// ---- the longest rows by SCATTER: each source row read once -----------------------------------------
+// A popularity-skewed interaction graph puts half of all non-zeros into a few hundred item rows (Zipf, 100 000 items: the 128 longest rows
+// hold 45 % of the entries).  As a gather those rows re-read the user table once per row: every user row is fetched ~10 times for them
+// (5 GB of the product's 10.6 GB at the configs[4] shape).  Turned round -- walk the SOURCE rows in order, read each once, and add a x into
+// the accumulators of the hot rows it belongs to -- the same entries cost one streaming pass over the source rows that have a hot
+// neighbour (0.5 GB).  The accumulators of H = 16 384 / d hot rows live in LDS (64 KB per workgroup, ds_add_f32), one workgroup per CU;
+// at the end every workgroup adds its partial rows to Y (pre-zeroed) with global atomics -- H x workgroups row updates, not one per entry.
+// The caller's plan (rsx_spmm_plan) simply owns no segment for the hot rows; rsx_spmm_hot_rows computes them.
+constexpr int kHotThreads = 1024;
+constexpr int kHotLdsFloats = 16384;          // 64 KB of accumulators: H * D <= 16 384
+
+template <int D>
+__global__ __launch_bounds__(kHotThreads) void spmm_hot_rows_kernel(rsx_spmm_hot h, const float *__restrict__ X, const uint8_t *__restrict__ nz,
+                                                                    const uint8_t *__restrict__ want, float *__restrict__ Y)
+{
+    __shared__ __attribute__((aligned(16))) float acc[kHotLdsFloats];
+    constexpr int LPR = D / 4;                 // lanes per row (a float4 each)
+    constexpr int GROUPS = kHotThreads / LPR;
+    const int tid = threadIdx.x, g = tid / LPR, k = tid % LPR;
+    const int H = h.num_hot;
+    for (int q = tid; q < H * D; q += kHotThreads) acc[q] = 0.f;
+    __syncthreads();
+    // a contiguous share of the source rows per workgroup (they ascend: the source table is streamed), the groups side by side inside it
+    const int64_t per = ceil_div64(h.num_src, gridDim.x), s0 = (int64_t)blockIdx.x * per, s1 = (s0 + per < h.num_src) ? s0 + per : h.num_src;
+    for (int64_t s = s0 + g; s < s1; s += GROUPS) {
+        const int32_t c = h.src_rows[s];
+        if (nz != nullptr && nz[c] == 0) continue;                  // (a * 0 adds nothing: the row is not fetched)
+        const float4 x = reinterpret_cast<const float4 *>(X + (size_t)c * D)[k];
+        const int64_t e0 = h.src_ptr[s], e1 = h.src_ptr[s + 1];
+        for (int64_t e = e0; e < e1; ++e) {
+            const float a = h.src_val[e];
+            float *dst = acc + (int)h.src_slot[e] * D + 4 * k;
+            __hip_atomic_fetch_add(dst, a * x.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(dst + 1, a * x.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(dst + 2, a * x.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(dst + 3, a * x.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    if (s0 >= s1) return;                                           // (a workgroup without a share adds nothing)
+    for (int q = tid; q < H * D; q += kHotThreads) {
+        const int slot = q / D;
+        const int32_t row = h.hot_rows[slot];
+        if (want != nullptr && want[row] == 0) continue;
+        const float v = acc[q];
+        if (v != 0.f) rsx_atomic_add(Y + (size_t)row * D + (q - slot * D), v);
+    }
+}
+
+// before: Y[hot rows] = 0 (they are summed into); after: the running layer sum S of the hot rows (S = S_init + Y or S += Y)
+template <int D, bool AFTER>
+__global__ __launch_bounds__(kBlock) void hot_rows_edge_kernel(rsx_spmm_hot h, const uint8_t *__restrict__ want, float *__restrict__ Y,
+                                                               float *__restrict__ S, const float *__restrict__ Sinit)
+{
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int slot = t / (D / 4), k = t % (D / 4);
+    if (slot >= h.num_hot) return;
+    const int32_t row = h.hot_rows[slot];
+    if (want != nullptr && want[row] == 0) return;                  // rsx_spmm_csr_select_rows' rule: an unwanted row is not written
+    float4 *y = reinterpret_cast<float4 *>(Y + (size_t)row * D) + k;
+    if constexpr (!AFTER) {
+        *y = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        float4 *sp = reinterpret_cast<float4 *>(S + (size_t)row * D) + k;
+        float4 t4 = Sinit != nullptr ? reinterpret_cast<const float4 *>(Sinit + (size_t)row * D)[k] : *sp;
+        const float4 v = *y;
+        t4.x += v.x; t4.y += v.y; t4.z += v.z; t4.w += v.w;
+        *sp = t4;
+    }
+}
+
 unsigned grid_for(int64_t threads)
 {
     int64_t blocks = (threads + kBlock - 1) / kBlock;
@@ -304,6 +375,42 @@ RSX_API int rsx_spmm_csr_select_rows(const int32_t *seg_row_dev, const int64_t *
     int rc = spmm_launch(seg_row_dev, seg_begin_dev, seg_len_dev, num_segs, indptr_dev, indices_dev, vals_dev, X, Y, S_acc, num_rows, d,
                          nullptr, y_row_wanted_dev, nullptr, (hipStream_t)stream);
     if (rc != RSX_OK) return rc;
+    RSX_CHECK_LAUNCH();
+    return RSX_OK;
+}
+
+RSX_API int64_t rsx_spmm_hot_capacity(int d)
+{
+    return rsx_dim_ok(d) ? kHotLdsFloats / d : RSX_E_INVALID;
+}
+
+RSX_API int rsx_spmm_hot_rows(const rsx_spmm_hot *hot, const float *X, const uint8_t *x_row_nonzero_dev, const uint8_t *y_row_wanted_dev,
+                              const float *S_init, float *Y, float *S_acc, int64_t num_rows, int d, rsx_stream_t stream)
+{
+    RSX_CHECK_ARG(hot != nullptr && X && Y, "null pointer");
+    RSX_CHECK_ARG(rsx_dim_ok(d) && num_rows > 0, "bad shape");
+    RSX_CHECK_ARG(hot->num_hot >= 0 && hot->num_hot <= rsx_spmm_hot_capacity(d) && hot->num_src >= 0,
+                  "num_hot must be in [0, rsx_spmm_hot_capacity(d)]");
+    RSX_CHECK_ARG(X != Y && X != S_acc, "X must not alias an output");
+    RSX_CHECK_ARG(S_init == nullptr || S_acc != nullptr, "S_init without S_acc");
+    if (hot->num_hot == 0) return RSX_OK;
+    RSX_CHECK_ARG(hot->hot_rows && (hot->num_src == 0 || (hot->src_rows && hot->src_ptr && hot->src_slot && hot->src_val)), "null plan array");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned eb = (unsigned)ceil_div64((int64_t)hot->num_hot * (d / 4), kBlock);
+    int64_t wgs = rsx_num_cus();
+    if (wgs > hot->num_src) wgs = hot->num_src;
+#define RSX_HOT(D_) do { \
+        hipLaunchKernelGGL((hot_rows_edge_kernel<D_, false>), dim3(eb), dim3(kBlock), 0, st, *hot, y_row_wanted_dev, Y, S_acc, S_init); \
+        if (wgs > 0) hipLaunchKernelGGL(spmm_hot_rows_kernel<D_>, dim3((unsigned)wgs), dim3(kHotThreads), 0, st, *hot, X, x_row_nonzero_dev, y_row_wanted_dev, Y); \
+        if (S_acc != nullptr) hipLaunchKernelGGL((hot_rows_edge_kernel<D_, true>), dim3(eb), dim3(kBlock), 0, st, *hot, y_row_wanted_dev, Y, S_acc, S_init); \
+    } while (0)
+    switch (d) {
+    case 32: RSX_HOT(32); break;
+    case 64: RSX_HOT(64); break;
+    case 128: RSX_HOT(128); break;
+    default: RSX_HOT(256); break;
+    }
+#undef RSX_HOT
     RSX_CHECK_LAUNCH();
     return RSX_OK;
 }

@@ -83,7 +83,8 @@ class LightGCN(BaseModel):
     def getSparseGraph(self, rating_matrix, adjacency=None):
         """models/LightGCN.py:228-266; `adjacency` lets a caller hand in a prebuilt A_hat"""
         A = normalized_adjacency(rating_matrix) if adjacency is None else adjacency
-        self.Graph = self._k.SpmmGraph(A, self.device)
+        # (d: the row width of the products -- lets the longest rows of a popularity-skewed graph go by scatter, rsx_spmm_hot_rows)
+        self.Graph = self._k.SpmmGraph(A, self.device, d=self._dpad) if hasattr(self._k, "lib") else self._k.SpmmGraph(A, self.device)
         return self.Graph
 
     def _idx(self, t):

@@ -56,6 +56,8 @@ SIGNATURES = {
     "rsx_spmm_csr_init": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
     "rsx_spmm_scale_rows": (C.c_int, [_P, _P, _I64, _I32, _F, _P]),
     "rsx_scale": (C.c_int, [_P, _I64, _F, _P]),
+    "rsx_spmm_hot_capacity": (_I64, [_I32]),
+    "rsx_spmm_hot_rows": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
     "rsx_spmm_mark_batch_rows": (C.c_int, [_P, _I64, _P, _P, _P, _I64, _I64, _P]),
     "rsx_pair_score": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P]),
     "rsx_eval_holdout": (C.c_int, [_I64, _P, _I32, _P, _I32, _P, _P, _P]),
@@ -262,10 +264,19 @@ def adam_apply(W, M, V, G, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):
            "rsx_adam_apply")
 
 
-class SpmmGraph:
-    """device CSR of a (square) sparse matrix + its segment plan (include/rsx.h:rsx_spmm_plan)"""
+class SpmmHot(C.Structure):
+    """include/rsx.h: rsx_spmm_hot, field for field"""
+    _fields_ = [("num_hot", C.c_int32), ("reserved", C.c_int32), ("num_src", _I64), ("hot_rows", _P), ("src_rows", _P), ("src_ptr", _P),
+                ("src_slot", _P), ("src_val", _P)]
 
-    def __init__(self, csr, device, max_seg=None):
+
+class SpmmGraph:
+    """device CSR of a (square) sparse matrix + its segment plan (include/rsx.h:rsx_spmm_plan).  d (the row width the products will
+    run at) lets the LONGEST rows be computed by scatter (include/rsx.h: rsx_spmm_hot_rows) when they hold a worthwhile share of the
+    non-zeros -- hot = None: when the rsx_spmm_hot_capacity(d) longest rows hold at least 10 % of at least a million non-zeros;
+    True / False: always / never (RSX_SPMM_HOT=1 / 0 overrides the default)"""
+
+    def __init__(self, csr, device, max_seg=None, d=None, hot=None):
         import numpy as np
         if max_seg is None:
             # rows above max_seg non-zeros are cut and combined with atomics.  Measured at the configs[4] shape (ms per product /
@@ -281,6 +292,30 @@ class SpmmGraph:
             raise RsxError("rsx_spmm_plan failed")
         row, beg, ln = np.empty(cnt, np.int32), np.empty(cnt, np.int64), np.empty(cnt, np.int32)
         lib().rsx_spmm_plan(indptr.ctypes.data, n, max_seg, row.ctypes.data, beg.ctypes.data, ln.ctypes.data)
+        # the longest rows by scatter: taken out of the plan, described by source row (include/rsx.h: rsx_spmm_hot)
+        self.hot = None
+        if hot is None and os.environ.get("RSX_SPMM_HOT") in ("0", "1"):
+            hot = os.environ["RSX_SPMM_HOT"] == "1"
+        if d is not None and hot is not False and csr.nnz > 0:
+            H = int(lib().rsx_spmm_hot_capacity(int(d)))
+            lens = np.diff(indptr)
+            top = np.argsort(-lens, kind="stable")[:H]
+            top = np.sort(top[lens[top] > 0])
+            share = float(lens[top].sum()) / float(csr.nnz)
+            if len(top) and (hot is True or (share >= 0.10 and csr.nnz >= 1_000_000)):
+                sub = csr[top].tocsc()                    # [H x N]: column c = the (slot, value) pairs of source row c
+                sub.sort_indices()
+                cols = np.flatnonzero(np.diff(sub.indptr)).astype(np.int32)
+                ptr = np.concatenate([sub.indptr[cols], [sub.indptr[-1]]]).astype(np.int64)
+                self._hot_keep = [torch.from_numpy(a).to(device).contiguous() for a in
+                                  (top.astype(np.int32), cols, ptr, sub.indices.astype(np.uint16).view(np.int16), sub.data.astype(np.float32))]
+                self.hot = SpmmHot(num_hot=len(top), reserved=0, num_src=len(cols), hot_rows=self._hot_keep[0].data_ptr(),
+                                   src_rows=self._hot_keep[1].data_ptr(), src_ptr=self._hot_keep[2].data_ptr(),
+                                   src_slot=self._hot_keep[3].data_ptr(), src_val=self._hot_keep[4].data_ptr())
+                self.hot_share = share
+                keep = ~np.isin(row, top)                 # the plan owns no segment for them
+                row, beg, ln = row[keep], beg[keep], ln[keep]
+                cnt = int(keep.sum())
         # longest segments first (the long item rows of a popularity-skewed graph would otherwise start last and finish alone)
         order = np.argsort(-ln.astype(np.int64), kind="stable")
         row, beg, ln = row[order].copy(), beg[order].copy(), ln[order].copy()
@@ -299,6 +334,15 @@ def spmm(graph, X, Y, S_acc=None, x_nonzero=None, y_wanted=None, S_init=None):
     overwritten: the first product of a propagation, without the copy of the source into the running sum)"""
     if (x_nonzero is not None or S_init is not None) and y_wanted is not None:
         raise RsxError("spmm: y_wanted does not combine with x_nonzero / S_init (different products)")
+    _spmm_planned(graph, X, Y, S_acc, x_nonzero, y_wanted, S_init)
+    if getattr(graph, "hot", None) is not None:          # the longest rows, which the plan leaves out: by scatter
+        ptr = lambda t, dt, name: _dev(t, dt, name) if t is not None else None
+        _check(lib().rsx_spmm_hot_rows(C.byref(graph.hot), _dev(X, torch.float32, "X"), ptr(x_nonzero, torch.uint8, "x_nonzero"),
+                                       ptr(y_wanted, torch.uint8, "y_wanted"), ptr(S_init, torch.float32, "S_init"), _dev(Y, torch.float32, "Y"),
+                                       ptr(S_acc, torch.float32, "S_acc"), graph.n, X.shape[1], _stream()), "rsx_spmm_hot_rows")
+
+
+def _spmm_planned(graph, X, Y, S_acc, x_nonzero, y_wanted, S_init):
     if S_init is not None:
         _check(lib().rsx_spmm_csr_init(
             _dev(graph.seg_row, torch.int32, "seg_row"), _dev(graph.seg_begin, torch.int64, "seg_begin"),

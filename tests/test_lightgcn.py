@@ -188,7 +188,7 @@ def test_hip_spmm_long_rows_vs_oracle(oracle_mod, max_seg):
 def test_hip_spmm_on_random_graphs():
     """20 random square sparse matrices (empty rows, rows of one entry, heavy tails, rows holding every column; any segment length from 1
     up; every row width) through every form of the product -- plain, with the running sum, started from S_init, with row flags on X,
-    with only some rows wanted -- against scipy in fp64"""
+    with only some rows wanted -- against scipy in fp64; every other graph with its longest rows computed by scatter"""
     from conftest import fuzz
     from recsys_pytorch_amd import rsx
     rng, trials = fuzz(2024, 20)
@@ -205,8 +205,11 @@ def test_hip_spmm_on_random_graphs():
         vals = rng.standard_normal(len(indices)).astype(np.float32)
         A = sp.csr_matrix((vals, indices, indptr), shape=(N, N))
         max_seg = [None, 1, 3, 64, 1000][int(rng.integers(0, 5))]
-        ctx = f"trial {trial}: N={N} d={d} kind={kind} nnz={len(indices)} max_seg={max_seg}"
-        G = rsx.SpmmGraph(A, "cuda", max_seg=max_seg)
+        # every other graph with its longest rows by scatter (include/rsx.h: rsx_spmm_hot_rows), forced (these graphs are small)
+        hot = bool(trial % 2)
+        ctx = f"trial {trial}: N={N} d={d} kind={kind} nnz={len(indices)} max_seg={max_seg} hot={hot}"
+        G = rsx.SpmmGraph(A, "cuda", max_seg=max_seg, d=d, hot=hot)
+        assert (G.hot is not None) == (hot and len(indices) > 0), ctx
         X = rng.standard_normal((N, d)).astype(np.float32)
         A64 = A.astype(np.float64)
         Y64 = A64 @ X.astype(np.float64)

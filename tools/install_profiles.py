@@ -27,6 +27,15 @@ for meta_path in sorted(glob.glob(os.path.join(dst, f"{tag}_pmc_*.meta.json"))):
     if not ks or "TCC_EA0_RDREQ_sum" not in d[ks[0]] or "WRITE_SIZE" not in d[ks[0]]:
         print("no counters for", prof, meta["kernel"], list(d)); continue
     v = d[ks[0]]
+    if meta["key"].startswith("lightgcn"):
+        # one propagation product is several kernels since round 6 (the plan's segments, the longest rows by scatter, their two edge
+        # kernels, the clearing of split rows): the product's traffic is the SUM of their per-launch traffic (each runs once per product)
+        v = dict(v)
+        for kname, kv in d.items():
+            if kname != ks[0] and "TCC_EA0_RDREQ_sum" in kv and "WRITE_SIZE" in kv:
+                for c_ in ("TCC_EA0_RDREQ_sum", "WRITE_SIZE", "FETCH_SIZE", "TCC_EA0_ATOMIC_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"):
+                    if c_ in kv:
+                        v[c_] = v.get(c_, 0.0) + kv[c_]
     # a chunked step launches the kernel once per item range: the leg's figure is the STEP's (sum over its launches)
     per_step = int(meta.get("env", {}).get("CHUNKS", 1)) if "_c" in meta["key"].rsplit("_nb", 1)[-1] else 1
     v = {k_: (x * per_step if isinstance(x, (int, float)) and k_ not in ("launches",) else x) for k_, x in v.items()}

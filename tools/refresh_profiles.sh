@@ -50,10 +50,10 @@ leg B1M_ranges3   "$T" "CHUNKS=3" 1000000 8 12
 leg B1M_ranges2   "$T" "CHUNKS=2" 1000000 8 12
 leg config3_ranges2 "$T" "USERS=1250000 ITEMS=1000000 DEG=10 CHUNKS=2" 1250000 8 8
 ( export STEP_PROF_META="$out/${tag}_pmc_spmm.meta.json"
-  PMC_GROUPS="$T;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" python3 tools/pmc_groups.py "$out/${tag}_pmc_spmm.json" spmm_csr -- python3 tools/spmm_prof.py > /dev/null 2>&1 )
+  PMC_GROUPS="$T;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" python3 tools/pmc_groups.py "$out/${tag}_pmc_spmm.json" spmm_csr,spmm_hot,hot_rows_edge,zero_split -- python3 tools/spmm_prof.py > /dev/null 2>&1 )
 for half in users items; do
 ( export SPMM_HALF=$half
-  PMC_GROUPS="$T;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" python3 tools/pmc_groups.py "$out/${tag}_pmc_spmm_${half}.json" spmm_csr -- python3 tools/spmm_prof.py > /dev/null 2>&1 )
+  PMC_GROUPS="$T;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" python3 tools/pmc_groups.py "$out/${tag}_pmc_spmm_${half}.json" spmm_csr,spmm_hot,hot_rows_edge,zero_split -- python3 tools/spmm_prof.py > /dev/null 2>&1 )
 done
 S="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU_MFMA_MOPS_F32;SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS;FETCH_SIZE;WRITE_SIZE"
 PMC_GROUPS="$S" LANES=2 python3 tools/pmc_groups.py "$out/${tag}_pmc_scoring.json" score_,merge_cand,topk_rows,sample_tau,permute_items -- python3 tools/score_prof.py 16 > /dev/null 2>&1

@@ -22,9 +22,10 @@ if os.environ.get("STEP_PROF_META"):
 half = os.environ.get("SPMM_HALF")
 if half:
     keep = (g.seg_row < U) if half == "users" else (g.seg_row >= U)
+    g0 = g                                      # (keeps the hot plan's tensors alive)
     g = types.SimpleNamespace(seg_row=g.seg_row[keep].contiguous(), seg_begin=g.seg_begin[keep].contiguous(),
                               seg_len=g.seg_len[keep].contiguous(), num_segs=int(keep.sum()), indptr=g.indptr, indices=g.indices,
-                              vals=g.vals, n=g.n)
+                              vals=g.vals, n=g.n, hot=(g.hot if half == "items" else None))   # (the rows that go by scatter are item rows)
     print(half, "segments", g.num_segs, "non-zeros", int(g.seg_len.sum()))
 for _ in range(6):
     rsx.spmm(g, m._E0, m._ta, S_acc=m._out)
