@@ -689,24 +689,38 @@ int rsx_spmm_csr_select_rows(const int32_t *seg_row_dev, const int64_t *seg_begi
                              float *S_acc, int64_t num_rows, int d, rsx_stream_t stream);
 int rsx_scale(float *X, int64_t n, float alpha, rsx_stream_t stream);
 /* rsx_spmm_hot_rows: the LONGEST rows of the product by scatter instead of gather.  A popularity-skewed graph puts half of all non-zeros
- *   into a few hundred rows (the popular items); gathered, they re-read the source table once per row.  The caller takes the H <=
- *   rsx_spmm_hot_capacity(d) longest rows OUT of the segment plan it hands to the four products above (a row without a segment is not
- *   written by them) and describes them by SOURCE row: for every source row that has an entry in a hot row, the (hot slot, value) pairs.
- *   rsx_spmm_hot_rows then reads every such source row ONCE, adds a * x into LDS accumulators of the hot rows (one workgroup per CU) and
- *   adds the workgroups' partial rows to Y: Y[hot rows] = A[hot rows, :] X, and S_acc[hot rows] = (S_init or S_acc)[hot rows] + that --
- *   the same sums as the gather, in another order.  x_row_nonzero_dev / y_row_wanted_dev / S_init: as in the products above (each NULL
- *   or the same array the product call got).  Call it after the product over the reduced plan, on the same stream.                      */
+ *   into a few hundred rows (the popular items); gathered, they re-read the source table once per row.  The caller takes those rows OUT of
+ *   the segment plan it hands to the four products above (a row without a segment is not written by them) and describes them by SOURCE
+ *   row.  rsx_spmm_hot_rows then stages every source row that has an entry in a hot row through LDS ONCE, adds a * x into register
+ *   accumulators -- each of a workgroup's 16 wavefronts owns num_slots / 16 SLOTS -- and adds the wavefronts' rows to Y:
+ *   Y[hot rows] = A[hot rows, :] X, and S_acc[hot rows] = (S_init or S_acc)[hot rows] + that: the same sums as the gather, in another
+ *   order.  x_row_nonzero_dev / y_row_wanted_dev / S_init: as in the products above (each NULL or the same array the product call got).
+ *   Call it after the product over the reduced plan, on the same stream.
+ *   The plan (all arrays on the device; recsys_pytorch_amd/rsx.py: SpmmGraph builds it):
+ *     num_slots = rsx_spmm_hot_capacity(d) = 16 384 / d; slot s belongs to wavefront s / (num_slots / 16); hot_rows[s] = the row of Y
+ *       behind it, or -1; a very long row may own several slots (its entries dealt round) so that no wavefront carries it alone;
+ *       uniq_rows = the distinct hot rows;
+ *     src_rows: ascending rows of X with at least one hot entry, cut into CHUNKS of chunk_rows = rsx_spmm_hot_chunk_rows(d) rows;
+ *     entries grouped by (chunk, wavefront): cw_ptr[chunk * 16 + w] .. cw_ptr[chunk * 16 + w + 1], and inside such a group SORTED BY
+ *       SLOT: rw_off[(chunk * 16 + w) * (R + 1) + r] .. [.. + r + 1] (R = num_slots / 16, relative to the group's first entry) are the
+ *       entries of the wavefront's slot r; an entry is  ent_code = (row inside the chunk) | (slot inside the wavefront) << 8  and
+ *       ent_val = A[hot row, source row].                                                                                         */
 typedef struct rsx_spmm_hot {
-    int32_t num_hot;             /* H rows of Y computed here (<= rsx_spmm_hot_capacity(d))                       */
+    int32_t num_slots;           /* rsx_spmm_hot_capacity(d)                                                        */
+    int32_t chunk_rows;          /* rsx_spmm_hot_chunk_rows(d)                                                      */
+    int32_t num_uniq;            /* distinct hot rows                                                               */
     int32_t reserved;
-    int64_t num_src;             /* source rows with at least one entry in a hot row                               */
-    const int32_t *hot_rows;     /* device [H]: the row of Y behind every slot                                     */
-    const int32_t *src_rows;     /* device [num_src]: ascending row ids of X                                       */
-    const int64_t *src_ptr;      /* device [num_src + 1]: the entries of every source row                          */
-    const uint16_t *src_slot;    /* device [entries]: hot slot of an entry                                         */
-    const float *src_val;        /* device [entries]: its value A[hot_rows[slot], src_row]                         */
+    int64_t num_src;             /* source rows with at least one entry in a hot row                                */
+    const int32_t *hot_rows;     /* [num_slots]: the row of Y behind every slot, or -1                              */
+    const int32_t *uniq_rows;    /* [num_uniq]                                                                      */
+    const int32_t *src_rows;     /* [num_src] ascending                                                             */
+    const int64_t *cw_ptr;       /* [ceil(num_src / chunk_rows) * 16 + 1]                                           */
+    const uint16_t *rw_off;      /* [ceil(num_src / chunk_rows) * 16 * (num_slots / 16 + 1)]                        */
+    const uint16_t *ent_code;    /* [entries]                                                                       */
+    const float *ent_val;        /* [entries]                                                                       */
 } rsx_spmm_hot;
 int64_t rsx_spmm_hot_capacity(int d);
+int64_t rsx_spmm_hot_chunk_rows(int d);
 int rsx_spmm_hot_rows(const rsx_spmm_hot *hot, const float *X, const uint8_t *x_row_nonzero_dev, const uint8_t *y_row_wanted_dev,
                       const float *S_init, float *Y, float *S_acc, int64_t num_rows, int d, rsx_stream_t stream);
 

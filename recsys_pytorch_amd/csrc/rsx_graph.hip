@@ -178,61 +178,148 @@ __global__ __launch_bounds__(kBlock) void zero_split_rows_kernel(const int32_t *
 // ---- the longest rows by SCATTER: each source row read once -----------------------------------------
 // A popularity-skewed interaction graph puts half of all non-zeros into a few hundred item rows (Zipf, 100 000 items: the 128 longest rows
 // hold 45 % of the entries).  As a gather those rows re-read the user table once per row: every user row is fetched ~10 times for them
-// (5 GB of the product's 10.6 GB at the configs[4] shape).  Turned round -- walk the SOURCE rows in order, read each once, and add a x into
-// the accumulators of the hot rows it belongs to -- the same entries cost one streaming pass over the source rows that have a hot
-// neighbour (0.5 GB).  The accumulators of H = 16 384 / d hot rows live in LDS (64 KB per workgroup, ds_add_f32), one workgroup per CU;
-// at the end every workgroup adds its partial rows to Y (pre-zeroed) with global atomics -- H x workgroups row updates, not one per entry.
-// The caller's plan (rsx_spmm_plan) simply owns no segment for the hot rows; rsx_spmm_hot_rows computes them.
-constexpr int kHotThreads = 1024;
-constexpr int kHotLdsFloats = 16384;          // 64 KB of accumulators: H * D <= 16 384
+// (5 GB of the product's 10.6 GB at the configs[4] shape; 0.68 ms of its 2.33 ms).  Turned round -- walk the SOURCE rows in order, read
+// each once, add a x into the accumulators of the hot rows it belongs to -- the same entries cost one streaming pass over the source rows
+// that have a hot neighbour (0.5 GB).
+//   * the accumulators live in REGISTERS: each of a workgroup's 16 wavefronts owns H / 16 hot slots (16 registers per lane), and the
+//     caller's plan hands every wavefront ITS entries per chunk of source rows.  (First form: accumulators in LDS, ds_add_f32 from every
+//     lane group: 4.3 ms -- LDS float atomics retire about half a lane per clock and CU; profiles/r06_exp_spmm_hot_rows.txt.)
+//   * the source rows of a chunk are staged through LDS once per workgroup (the only HBM read of them) and read from there per entry;
+//   * a very long row is given several slots by the plan (its entries dealt round), so that no wavefront carries it alone; at the end
+//     every wavefront adds its rows to Y (pre-zeroed) with global atomics -- slots x workgroups row updates, not one per entry.
+// The caller's segment plan (rsx_spmm_plan) simply owns no segment for the hot rows; rsx_spmm_hot_rows computes them.
+constexpr int kHotThreads = 1024, kHotWaves = kHotThreads / 64;
+constexpr int kHotSlotFloats = 16384;         // H * D: 16 accumulator registers per lane in each of the 16 wavefronts
+constexpr int kHotTileFloats = 8192;          // LDS tile of source rows: chunk_rows * D <= 8192 (32 KB)
 
 template <int D>
-__global__ __launch_bounds__(kHotThreads) void spmm_hot_rows_kernel(rsx_spmm_hot h, const float *__restrict__ X, const uint8_t *__restrict__ nz,
+__global__ __launch_bounds__(kHotThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void spmm_hot_rows_kernel(rsx_spmm_hot h, const float *__restrict__ X, const uint8_t *__restrict__ nz,
                                                                     const uint8_t *__restrict__ want, float *__restrict__ Y)
 {
-    __shared__ __attribute__((aligned(16))) float acc[kHotLdsFloats];
-    constexpr int LPR = D / 4;                 // lanes per row (a float4 each)
-    constexpr int GROUPS = kHotThreads / LPR;
-    const int tid = threadIdx.x, g = tid / LPR, k = tid % LPR;
-    const int H = h.num_hot;
-    for (int q = tid; q < H * D; q += kHotThreads) acc[q] = 0.f;
-    __syncthreads();
-    // a contiguous share of the source rows per workgroup (they ascend: the source table is streamed), the groups side by side inside it
-    const int64_t per = ceil_div64(h.num_src, gridDim.x), s0 = (int64_t)blockIdx.x * per, s1 = (s0 + per < h.num_src) ? s0 + per : h.num_src;
-    for (int64_t s = s0 + g; s < s1; s += GROUPS) {
-        const int32_t c = h.src_rows[s];
-        if (nz != nullptr && nz[c] == 0) continue;                  // (a * 0 adds nothing: the row is not fetched)
-        const float4 x = reinterpret_cast<const float4 *>(X + (size_t)c * D)[k];
-        const int64_t e0 = h.src_ptr[s], e1 = h.src_ptr[s + 1];
-        for (int64_t e = e0; e < e1; ++e) {
-            const float a = h.src_val[e];
-            float *dst = acc + (int)h.src_slot[e] * D + 4 * k;
-            __hip_atomic_fetch_add(dst, a * x.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(dst + 1, a * x.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(dst + 2, a * x.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(dst + 3, a * x.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __shared__ __attribute__((aligned(16))) float tile[kHotTileFloats];
+    constexpr int R = kHotSlotFloats / D / kHotWaves;               // hot slots per wavefront
+    constexpr int NX = D >= 64 ? D / 64 : 1;                        // registers a source row takes per lane
+    constexpr int NACC = R * D / 64;                                // = 16
+    static_assert(NACC == 16, "16 accumulator registers per lane");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = h.chunk_rows;
+    float acc[NACC];
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) acc[j] = 0.f;
+    const int64_t nchunks = ceil_div64(h.num_src, K);
+    // TWO chunks ahead.  A chunk's loads are two dependent levels (row id -> row of X; pointer -> entries): the ids and pointers of chunk
+    // n + 2 and the rows and entries of chunk n + 1 travel while chunk n is added, each level a whole iteration old when it is needed --
+    // per chunk the loop itself only stores the tile, meets at two barriers and computes.
+    static_assert(kHotTileFloats / 4 == 2 * kHotThreads, "two float4 of the tile per thread");
+    int32_t ia[2] = {-1, -1};                                       // stage A: my two rows' ids (-1: nothing / flagged off) ...
+    int64_t pa0 = 0, pa1 = 0;                                       // ... and this wavefront's entry range
+    float4 tr[2];                                                   // stage B: my two float4 of the tile ...
+    uint32_t pcode = 0u; float pval = 0.f; int64_t pe0 = 0, pe1 = 0;   // ... and the wavefront's first 64 entries
+    auto fetch_ids = [&](int64_t ch) __attribute__((always_inline)) {
+        ia[0] = ia[1] = -1; pa0 = pa1 = 0;
+        if (ch >= nchunks) return;
+        const int rows = (int)((h.num_src - ch * K < K) ? h.num_src - ch * K : K);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int q = tid + t * kHotThreads;
+            if (q < rows * (D / 4)) {
+                const int32_t c = h.src_rows[ch * K + q / (D / 4)];
+                ia[t] = (nz != nullptr && nz[c] == 0) ? -1 : c;     // (a row whose flag is off is staged as zeros)
+            }
         }
+        pa0 = h.cw_ptr[ch * kHotWaves + wave]; pa1 = h.cw_ptr[ch * kHotWaves + wave + 1];
+    };
+    auto fetch_data = [&]() __attribute__((always_inline)) {       // from stage A's registers
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int c4 = (tid + t * kHotThreads) % (D / 4);
+            const float *src = ia[t] < 0 ? g_zero_row : X + (size_t)ia[t] * D;
+            tr[t] = reinterpret_cast<const float4 *>(src)[c4];
+        }
+        pe0 = pa0; pe1 = pa1; pcode = 0u; pval = 0.f;
+        if (pe0 + lane < pe1) { pcode = h.ent_code[pe0 + lane]; pval = h.ent_val[pe0 + lane]; }
+    };
+    fetch_ids(blockIdx.x);
+    fetch_data();
+    fetch_ids((int64_t)blockIdx.x + gridDim.x);
+    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        reinterpret_cast<float4 *>(tile)[tid] = tr[0];
+        reinterpret_cast<float4 *>(tile)[tid + kHotThreads] = tr[1];
+        const int64_t e0 = pe0, e1 = pe1;
+        uint32_t codev = pcode; float valv = pval;
+        __syncthreads();
+        fetch_data();                                               // chunk ch + G (its ids arrived an iteration ago)
+        fetch_ids(ch + 2 * (int64_t)gridDim.x);
+        // the wavefront's entries of this chunk are SORTED BY SLOT, rw_off[0 .. R] cutting them (relative to e0): the slot of an entry is a
+        // compile-time constant inside each of the R unrolled sections below, so its accumulator registers are addressed statically.  (A
+        // jump on the slot per entry made the compiler carry all 16 accumulators through every branch: ~50 register moves per entry,
+        // 533 us; profiles/r06_exp_spmm_hot_rows.txt)
+        const uint32_t offv = (lane <= R) ? (uint32_t)h.rw_off[(ch * kHotWaves + wave) * (R + 1) + lane] : 0u;
+        for (int64_t base = e0; base < e1; base += 64) {
+            const int n = __builtin_amdgcn_readfirstlane((int)((e1 - base < 64) ? e1 - base : 64));
+            if (base > e0) {                                        // (more than 64 entries for this wavefront in one chunk: rare)
+                codev = 0u; valv = 0.f;
+                if (lane < n) { codev = h.ent_code[base + lane]; valv = h.ent_val[base + lane]; }
+            }
+            const int w0 = __builtin_amdgcn_readfirstlane((int)(base - e0));   // this window holds the entries [w0, w0 + n) of the chunk
+            // (scalar loop control and two entries per trip: the first form of this loop spent 10 vector instructions per entry -- lane reads,
+            //  the loop counter in a vector register, address arithmetic -- on one useful multiply-add: 92M wave instructions per launch)
+#pragma unroll
+            for (int r_ = 0; r_ < R; ++r_) {
+                int q0 = (int)__builtin_amdgcn_readlane((int)offv, r_) - w0, q1 = (int)__builtin_amdgcn_readlane((int)offv, r_ + 1) - w0;
+                q0 = q0 < 0 ? 0 : q0; q1 = q1 > n ? n : q1;
+                q0 = __builtin_amdgcn_readfirstlane(q0); q1 = __builtin_amdgcn_readfirstlane(q1);     // (wave-uniform: say so)
+                auto entry_off = [&](int q) __attribute__((always_inline)) { return (int)((uint32_t)__builtin_amdgcn_readlane((int)codev, q) & 0xFFu) * D; };
+                auto entry_val = [&](int q) __attribute__((always_inline)) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, valv), q)); };
+                auto load_row = [&](int off, float (&x)[NX]) __attribute__((always_inline)) {
+                    if constexpr (D >= 64) {
+#pragma unroll
+                        for (int m = 0; m < NX; ++m) x[m] = tile[off + m * 64 + lane];
+                    } else {
+                        x[0] = tile[off + (lane & (D - 1))];
+                    }
+                };
+                auto add_row = [&](float a, const float (&x)[NX]) __attribute__((always_inline)) {
+                    if constexpr (D >= 64) {
+#pragma unroll
+                        for (int m = 0; m < NX; ++m) acc[r_ * NX + m] = fmaf(a, x[m], acc[r_ * NX + m]);
+                    } else {
+                        acc[r_ / 2] = fmaf(((lane >> 5) == (r_ & 1)) ? a : 0.f, x[0], acc[r_ / 2]);
+                    }
+                };
+                int q = q0;
+                for (; q + 2 <= q1; q += 2) {                       // both rows requested from LDS before either is used
+                    float xa[NX], xb[NX];
+                    load_row(entry_off(q), xa);
+                    load_row(entry_off(q + 1), xb);
+                    add_row(entry_val(q), xa);
+                    add_row(entry_val(q + 1), xb);
+                }
+                if (q < q1) { float xa[NX]; load_row(entry_off(q), xa); add_row(entry_val(q), xa); }
+            }
+        }
+        __syncthreads();                                            // (the tile is overwritten by the next chunk)
     }
-    __syncthreads();
-    if (s0 >= s1) return;                                           // (a workgroup without a share adds nothing)
-    for (int q = tid; q < H * D; q += kHotThreads) {
-        const int slot = q / D;
-        const int32_t row = h.hot_rows[slot];
-        if (want != nullptr && want[row] == 0) continue;
-        const float v = acc[q];
-        if (v != 0.f) rsx_atomic_add(Y + (size_t)row * D + (q - slot * D), v);
+    // the wavefront's slots -> Y: register j of lane l holds element (j * 64 + l) of its [R x D] block
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) {
+        const int f = j * 64 + lane, r = f / D, el = f % D;
+        const int32_t row = h.hot_rows[wave * R + r];
+        if (row < 0 || (want != nullptr && want[row] == 0)) continue;
+        if (acc[j] != 0.f) rsx_atomic_add(Y + (size_t)row * D + el, acc[j]);
     }
 }
 
-// before: Y[hot rows] = 0 (they are summed into); after: the running layer sum S of the hot rows (S = S_init + Y or S += Y)
+// before: Y[hot rows] = 0 (they are summed into); after: the running layer sum S of the hot rows (S = S_init + Y or S += Y).  Over the
+// DISTINCT hot rows (a row with several slots appears once in uniq_rows)
 template <int D, bool AFTER>
 __global__ __launch_bounds__(kBlock) void hot_rows_edge_kernel(rsx_spmm_hot h, const uint8_t *__restrict__ want, float *__restrict__ Y,
                                                                float *__restrict__ S, const float *__restrict__ Sinit)
 {
     const int t = blockIdx.x * kBlock + threadIdx.x;
     const int slot = t / (D / 4), k = t % (D / 4);
-    if (slot >= h.num_hot) return;
-    const int32_t row = h.hot_rows[slot];
+    if (slot >= h.num_uniq) return;
+    const int32_t row = h.uniq_rows[slot];
     if (want != nullptr && want[row] == 0) return;                  // rsx_spmm_csr_select_rows' rule: an unwanted row is not written
     float4 *y = reinterpret_cast<float4 *>(Y + (size_t)row * D) + k;
     if constexpr (!AFTER) {
@@ -381,7 +468,14 @@ RSX_API int rsx_spmm_csr_select_rows(const int32_t *seg_row_dev, const int64_t *
 
 RSX_API int64_t rsx_spmm_hot_capacity(int d)
 {
-    return rsx_dim_ok(d) ? kHotLdsFloats / d : RSX_E_INVALID;
+    return rsx_dim_ok(d) ? kHotSlotFloats / d : RSX_E_INVALID;
+}
+
+RSX_API int64_t rsx_spmm_hot_chunk_rows(int d)
+{
+    if (!rsx_dim_ok(d)) return RSX_E_INVALID;
+    const int k = kHotTileFloats / d;
+    return k < 64 ? k : 64;
 }
 
 RSX_API int rsx_spmm_hot_rows(const rsx_spmm_hot *hot, const float *X, const uint8_t *x_row_nonzero_dev, const uint8_t *y_row_wanted_dev,
@@ -389,16 +483,19 @@ RSX_API int rsx_spmm_hot_rows(const rsx_spmm_hot *hot, const float *X, const uin
 {
     RSX_CHECK_ARG(hot != nullptr && X && Y, "null pointer");
     RSX_CHECK_ARG(rsx_dim_ok(d) && num_rows > 0, "bad shape");
-    RSX_CHECK_ARG(hot->num_hot >= 0 && hot->num_hot <= rsx_spmm_hot_capacity(d) && hot->num_src >= 0,
-                  "num_hot must be in [0, rsx_spmm_hot_capacity(d)]");
+    RSX_CHECK_ARG(hot->num_slots == rsx_spmm_hot_capacity(d) && hot->chunk_rows == rsx_spmm_hot_chunk_rows(d),
+                  "the plan was built for another row width: num_slots = rsx_spmm_hot_capacity(d), chunk_rows = rsx_spmm_hot_chunk_rows(d)");
+    RSX_CHECK_ARG(hot->num_src >= 0 && hot->num_uniq >= 0 && hot->num_uniq <= hot->num_slots, "bad plan sizes");
     RSX_CHECK_ARG(X != Y && X != S_acc, "X must not alias an output");
     RSX_CHECK_ARG(S_init == nullptr || S_acc != nullptr, "S_init without S_acc");
-    if (hot->num_hot == 0) return RSX_OK;
-    RSX_CHECK_ARG(hot->hot_rows && (hot->num_src == 0 || (hot->src_rows && hot->src_ptr && hot->src_slot && hot->src_val)), "null plan array");
+    if (hot->num_uniq == 0) return RSX_OK;
+    RSX_CHECK_ARG(hot->hot_rows && hot->uniq_rows && (hot->num_src == 0 || (hot->src_rows && hot->cw_ptr && hot->rw_off && hot->ent_code && hot->ent_val)),
+                  "null plan array");
     hipStream_t st = (hipStream_t)stream;
-    const unsigned eb = (unsigned)ceil_div64((int64_t)hot->num_hot * (d / 4), kBlock);
-    int64_t wgs = rsx_num_cus();
-    if (wgs > hot->num_src) wgs = hot->num_src;
+    const unsigned eb = (unsigned)ceil_div64((int64_t)hot->num_uniq * (d / 4), kBlock);
+    const int64_t nchunks = ceil_div64(hot->num_src, hot->chunk_rows);
+    int64_t wgs = 2 * (int64_t)rsx_num_cus();           // (1024 threads, 32 KB of LDS: two workgroups fill a CU's wave slots)
+    if (wgs > nchunks) wgs = nchunks;
 #define RSX_HOT(D_) do { \
         hipLaunchKernelGGL((hot_rows_edge_kernel<D_, false>), dim3(eb), dim3(kBlock), 0, st, *hot, y_row_wanted_dev, Y, S_acc, S_init); \
         if (wgs > 0) hipLaunchKernelGGL(spmm_hot_rows_kernel<D_>, dim3((unsigned)wgs), dim3(kHotThreads), 0, st, *hot, X, x_row_nonzero_dev, y_row_wanted_dev, Y); \

@@ -57,6 +57,7 @@ SIGNATURES = {
     "rsx_spmm_scale_rows": (C.c_int, [_P, _P, _I64, _I32, _F, _P]),
     "rsx_scale": (C.c_int, [_P, _I64, _F, _P]),
     "rsx_spmm_hot_capacity": (_I64, [_I32]),
+    "rsx_spmm_hot_chunk_rows": (_I64, [_I32]),
     "rsx_spmm_hot_rows": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
     "rsx_spmm_mark_batch_rows": (C.c_int, [_P, _I64, _P, _P, _P, _I64, _I64, _P]),
     "rsx_pair_score": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P]),
@@ -266,8 +267,66 @@ def adam_apply(W, M, V, G, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):
 
 class SpmmHot(C.Structure):
     """include/rsx.h: rsx_spmm_hot, field for field"""
-    _fields_ = [("num_hot", C.c_int32), ("reserved", C.c_int32), ("num_src", _I64), ("hot_rows", _P), ("src_rows", _P), ("src_ptr", _P),
-                ("src_slot", _P), ("src_val", _P)]
+    _fields_ = [("num_slots", C.c_int32), ("chunk_rows", C.c_int32), ("num_uniq", C.c_int32), ("reserved", C.c_int32), ("num_src", _I64),
+                ("hot_rows", _P), ("uniq_rows", _P), ("src_rows", _P), ("cw_ptr", _P), ("rw_off", _P), ("ent_code", _P), ("ent_val", _P)]
+
+
+def spmm_hot_plan(csr, d, waves=16):
+    """host plan of include/rsx.h: rsx_spmm_hot for the longest rows of `csr` at row width d: (dict of numpy arrays, share of the non-zeros
+    it covers), or (None, 0.0) for an empty matrix.  The longest rows get the rsx_spmm_hot_capacity(d) slots; a row that would load one
+    wavefront with more than ~1.5 average slots' worth of entries gets several slots (its entries dealt round); the slots are dealt to
+    the 16 wavefronts longest first, to the least loaded wavefront that still has a free slot."""
+    import numpy as np
+    H, K = int(lib().rsx_spmm_hot_capacity(int(d))), int(lib().rsx_spmm_hot_chunk_rows(int(d)))
+    R = H // waves
+    indptr = np.asarray(csr.indptr, dtype=np.int64)
+    lens = np.diff(indptr)
+    cand = np.argsort(-lens, kind="stable")[:H]
+    cand = cand[lens[cand] > 0]
+    if len(cand) == 0:
+        return None, 0.0
+    cap = max(1.0, 1.5 * float(lens[cand].sum()) / H)
+    items, reps, used = [], [], 0
+    for it in cand:                                     # (H <= 512: a Python loop)
+        n = min(waves, max(1, int(np.ceil(lens[it] / cap))))
+        if used + n > H:
+            n = H - used if not items else 0
+            if n <= 0:
+                break
+        items.append(int(it)); reps.append(n); used += n
+    items, reps = np.asarray(items, np.int64), np.asarray(reps, np.int64)
+    # slots -> wavefronts (longest processing time first, at most R slots per wavefront)
+    slot_item = np.repeat(np.arange(len(items)), reps)
+    slot_rep = np.concatenate([np.arange(n) for n in reps])
+    slot_load = (lens[items] / reps)[slot_item]
+    wave_load, wave_used = np.zeros(waves), np.zeros(waves, np.int64)
+    slot_id = np.empty(len(slot_item), np.int64)
+    for q in np.argsort(-slot_load, kind="stable"):
+        free = np.flatnonzero(wave_used < R)
+        w = free[np.argmin(wave_load[free])]
+        slot_id[q] = w * R + wave_used[w]
+        wave_used[w] += 1; wave_load[w] += slot_load[q]
+    hot_rows = np.full(H, -1, np.int32)
+    hot_rows[slot_id] = items[slot_item]
+    first_slot = np.concatenate([[0], np.cumsum(reps)[:-1]])                # index into slot_id of every item's replica 0
+    sub = csr[items].tocsr()                                                # [items x N], columns ascending inside a row
+    sub.sort_indices()
+    row_of = np.repeat(np.arange(len(items)), np.diff(sub.indptr))
+    rank = np.arange(sub.nnz) - sub.indptr[row_of]                          # position of the entry inside its hot row
+    slot = slot_id[first_slot[row_of] + rank % reps[row_of]]
+    src_rows = np.unique(sub.indices).astype(np.int32)
+    pos = np.searchsorted(src_rows, sub.indices)
+    key = ((pos // K) * waves + slot // R) * R + slot % R                  # (chunk, wavefront, slot inside the wavefront)
+    order = np.argsort(key, kind="stable")
+    nchunks = -(-len(src_rows) // K)
+    per_slot = np.bincount(key, minlength=nchunks * waves * R).reshape(nchunks * waves, R)
+    cw_ptr = np.concatenate([[0], np.cumsum(per_slot.sum(1))]).astype(np.int64)
+    rw_off = np.concatenate([np.zeros((nchunks * waves, 1), np.int64), np.cumsum(per_slot, 1)], 1)
+    assert rw_off.max(initial=0) < 65536
+    code = ((pos % K) | ((slot % R) << 8)).astype(np.uint16)[order]
+    plan = {"num_slots": H, "chunk_rows": K, "hot_rows": hot_rows, "uniq_rows": np.sort(items).astype(np.int32), "src_rows": src_rows,
+            "cw_ptr": cw_ptr, "rw_off": rw_off.astype(np.uint16).ravel(), "ent_code": code, "ent_val": sub.data.astype(np.float32)[order]}
+    return plan, float(lens[items].sum()) / max(1, csr.nnz)
 
 
 class SpmmGraph:
@@ -297,23 +356,15 @@ class SpmmGraph:
         if hot is None and os.environ.get("RSX_SPMM_HOT") in ("0", "1"):
             hot = os.environ["RSX_SPMM_HOT"] == "1"
         if d is not None and hot is not False and csr.nnz > 0:
-            H = int(lib().rsx_spmm_hot_capacity(int(d)))
-            lens = np.diff(indptr)
-            top = np.argsort(-lens, kind="stable")[:H]
-            top = np.sort(top[lens[top] > 0])
-            share = float(lens[top].sum()) / float(csr.nnz)
-            if len(top) and (hot is True or (share >= 0.10 and csr.nnz >= 1_000_000)):
-                sub = csr[top].tocsc()                    # [H x N]: column c = the (slot, value) pairs of source row c
-                sub.sort_indices()
-                cols = np.flatnonzero(np.diff(sub.indptr)).astype(np.int32)
-                ptr = np.concatenate([sub.indptr[cols], [sub.indptr[-1]]]).astype(np.int64)
-                self._hot_keep = [torch.from_numpy(a).to(device).contiguous() for a in
-                                  (top.astype(np.int32), cols, ptr, sub.indices.astype(np.uint16).view(np.int16), sub.data.astype(np.float32))]
-                self.hot = SpmmHot(num_hot=len(top), reserved=0, num_src=len(cols), hot_rows=self._hot_keep[0].data_ptr(),
-                                   src_rows=self._hot_keep[1].data_ptr(), src_ptr=self._hot_keep[2].data_ptr(),
-                                   src_slot=self._hot_keep[3].data_ptr(), src_val=self._hot_keep[4].data_ptr())
+            plan, share = spmm_hot_plan(csr, d) if (hot is True or csr.nnz >= 1_000_000) else (None, 0.0)
+            if plan is not None and (hot is True or share >= 0.10):
+                dev = lambda a, view=None: torch.from_numpy(a if view is None else a.view(view)).to(device).contiguous()
+                self._hot_keep = {k: dev(plan[k], np.int16 if k in ("ent_code", "rw_off") else None)
+                                  for k in ("hot_rows", "uniq_rows", "src_rows", "cw_ptr", "rw_off", "ent_code", "ent_val")}
+                self.hot = SpmmHot(num_slots=plan["num_slots"], chunk_rows=plan["chunk_rows"], num_uniq=len(plan["uniq_rows"]), reserved=0,
+                                   num_src=len(plan["src_rows"]), **{k: v.data_ptr() for k, v in self._hot_keep.items()})
                 self.hot_share = share
-                keep = ~np.isin(row, top)                 # the plan owns no segment for them
+                keep = ~np.isin(row, plan["uniq_rows"])   # the plan owns no segment for them
                 row, beg, ln = row[keep], beg[keep], ln[keep]
                 cnt = int(keep.sum())
         # longest segments first (the long item rows of a popularity-skewed graph would otherwise start last and finish alone)
