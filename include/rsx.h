@@ -411,9 +411,18 @@ int rsx_comm_all_reduce_f32(rsx_comm *c, float *buf_dev, int64_t n, rsx_stream_t
  *   rsx_mesh_destroy   the caller makes sure (host barrier) that no peer still reads this rank's buffers, and -- before any
  *                      rank exports the same allocations again -- that every rank has returned from rsx_mesh_destroy
  *                      (a second host barrier: recsys_pytorch_amd/rsx.py Mesh.close).
- * Handed to rsx_bpr_trainer_create as config.mesh, the native loop issues it per step or per item range.            */
+ * Handed to rsx_bpr_trainer_create as config.mesh, the native loop issues it per step or per item range.
+ *   rsx_mesh_alloc     device memory FOR the exchanged tables: plain hipMalloc'ed, zero-filled, and exported at allocation -- an
+ *                      allocation the runtime refuses to export is set aside and another one taken (up to 8), so what comes back HAS
+ *                      an IPC handle, which the library keeps: rsx_mesh_local over such memory makes no export call at all.  Twice (the
+ *                      driver's round-5 box, a round-6 box) the runtime refused to export a POOLED allocation of the caller's allocator
+ *                      -- persistently, "invalid argument" -- in a process that had mapped and unmapped peers' memory before; tables that
+ *                      live in rsx_mesh_alloc memory cannot meet that.  rsx_mesh_free releases it (after rsx_mesh_destroy on every rank). */
 #define RSX_MESH_DESC_BYTES 512
 typedef struct rsx_mesh rsx_mesh;
+int rsx_mesh_alloc(int64_t bytes, void **out);
+int rsx_mesh_free(void *p);
+int rsx_mesh_alloc_refused(void);                                        /* allocations set aside because they could not be exported */
 int rsx_mesh_local(float *Q, float *G, int64_t rows, int d, void *desc_out, rsx_mesh **out);
 int rsx_mesh_connect(rsx_mesh *m, int rank, int world, const void *all_desc);
 int rsx_mesh_exchange_apply(rsx_mesh *m, int64_t first_row, int64_t rows, float lr, rsx_stream_t stream);

@@ -31,6 +31,8 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "rsx_common.h"
@@ -179,8 +181,28 @@ struct Exported {
 
 constexpr int kExportAttempts = 4;
 
+// Memory the library allocated FOR exchange (rsx_mesh_alloc): its IPC handle was taken when it was allocated -- an allocation the runtime
+// refuses to export never leaves rsx_mesh_alloc -- and is kept, so a mesh over it makes no export call at all.
+struct Owned { size_t size; hipIpcMemHandle_t handle; };
+std::mutex g_owned_mu;
+std::map<void *, Owned> g_owned;              // by allocation base
+std::vector<void *> g_refused;                // allocations the runtime would not export: kept (their addresses are not handed out again)
+
+bool owned_lookup(const void *ptr, size_t bytes_needed, Exported *x)
+{
+    std::lock_guard<std::mutex> lock(g_owned_mu);
+    auto it = g_owned.upper_bound(const_cast<void *>(ptr));
+    if (it == g_owned.begin()) return false;
+    --it;
+    const char *base = (const char *)it->first;
+    if ((const char *)ptr < base || (const char *)ptr + bytes_needed > base + it->second.size) return false;
+    x->base = it->first; x->size = it->second.size; x->handle = it->second.handle; x->attempts = 1;
+    return true;
+}
+
 int export_allocation(const char *what, const void *ptr, size_t bytes_needed, int device, Exported *x)
 {
+    if (owned_lookup(ptr, bytes_needed, x)) return RSX_OK;     // (allocated by rsx_mesh_alloc: proven exportable, handle cached)
     hipPointerAttribute_t at;
     memset(&at, 0, sizeof(at));
     hipError_t e = hipPointerGetAttributes(&at, ptr);
@@ -217,12 +239,74 @@ int export_allocation(const char *what, const void *ptr, size_t bytes_needed, in
         usleep(50000 * x->attempts);
     }
     rsx_set_error("rsx_mesh_local: hipIpcGetMemHandle(allocation of %s: base %p, %zu bytes; table at offset %zu, %zu bytes) failed %d "
-                  "times: %s (HSA_ENABLE_IPC_MODE_LEGACY=%s)", what, x->base, x->size, off, bytes_needed, x->attempts, hipGetErrorString(e),
-                  getenv("HSA_ENABLE_IPC_MODE_LEGACY") ? getenv("HSA_ENABLE_IPC_MODE_LEGACY") : "unset");
+                  "times: %s (HSA_ENABLE_IPC_MODE_LEGACY=%s).  The runtime refuses to export THIS allocation (seen for pooled allocations of "
+                  "the caller's allocator in processes that had mapped and unmapped peers' memory before): keep the tables in memory from "
+                  "rsx_mesh_alloc, which hands out only allocations it has exported", what, x->base, x->size, off, bytes_needed, x->attempts,
+                  hipGetErrorString(e), getenv("HSA_ENABLE_IPC_MODE_LEGACY") ? getenv("HSA_ENABLE_IPC_MODE_LEGACY") : "unset");
     return RSX_E_HIP;
 }
 
 }  // namespace
+
+// (uncached: the mailbox -- polled by this rank while the peers store into it -- in uncached device memory where the runtime has it)
+static int mesh_alloc_impl(int64_t bytes, bool uncached, void **out)
+{
+    RSX_CHECK_ARG(out != nullptr && bytes > 0, "bad size");
+    *out = nullptr;
+    constexpr int kTries = 8;
+    hipError_t last = hipSuccess;
+    for (int t = 0; t < kTries; ++t) {
+        void *p = nullptr;
+        hipError_t e = hipErrorUnknown;
+        if (uncached) {
+            e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached);
+            if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+        }
+        if (e != hipSuccess) e = hipMalloc(&p, (size_t)bytes);
+        if (e != hipSuccess) { rsx_set_error("rsx_mesh_alloc: hipMalloc(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(e)); (void)hipGetLastError(); return RSX_E_HIP; }
+        Owned o;
+        o.size = (size_t)bytes;
+        e = hipIpcGetMemHandle(&o.handle, p);
+        if (e == hipSuccess) {
+            e = hipMemset(p, 0, (size_t)bytes);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            if (e != hipSuccess) { (void)hipFree(p); rsx_set_error("rsx_mesh_alloc: clearing %lld bytes failed: %s", (long long)bytes, hipGetErrorString(e)); (void)hipGetLastError(); return RSX_E_HIP; }
+            std::lock_guard<std::mutex> lock(g_owned_mu);
+            g_owned[p] = o;
+            *out = p;
+            return RSX_OK;
+        }
+        // the runtime will not export this allocation: keep it (so that the next hipMalloc returns ANOTHER address) and try again
+        (void)hipGetLastError();
+        last = e;
+        std::lock_guard<std::mutex> lock(g_owned_mu);
+        g_refused.push_back(p);
+    }
+    rsx_set_error("rsx_mesh_alloc: hipIpcGetMemHandle refused %d fresh allocations of %lld bytes in a row: %s (HSA_ENABLE_IPC_MODE_LEGACY=%s)", kTries,
+                  (long long)bytes, hipGetErrorString(last), getenv("HSA_ENABLE_IPC_MODE_LEGACY") ? getenv("HSA_ENABLE_IPC_MODE_LEGACY") : "unset");
+    return RSX_E_HIP;
+}
+
+RSX_API int rsx_mesh_alloc(int64_t bytes, void **out) { return mesh_alloc_impl(bytes, false, out); }
+
+RSX_API int rsx_mesh_free(void *p)
+{
+    if (p == nullptr) return RSX_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_owned_mu);
+        auto it = g_owned.find(p);
+        if (it == g_owned.end()) { rsx_set_error("rsx_mesh_free: invalid argument: not an allocation of rsx_mesh_alloc"); return RSX_E_INVALID; }
+        g_owned.erase(it);
+    }
+    (void)hipDeviceSynchronize();
+    return hipFree(p) == hipSuccess ? RSX_OK : RSX_E_HIP;
+}
+
+RSX_API int rsx_mesh_alloc_refused(void)      /* allocations rsx_mesh_alloc had to set aside because the runtime would not export them */
+{
+    std::lock_guard<std::mutex> lock(g_owned_mu);
+    return (int)g_refused.size();
+}
 
 RSX_API int rsx_mesh_local(float *Q, float *G, int64_t rows, int d, void *desc_out, rsx_mesh **out)
 {
@@ -234,17 +318,14 @@ RSX_API int rsx_mesh_local(float *Q, float *G, int64_t rows, int d, void *desc_o
     m->Q = Q; m->G = G; m->rows = rows; m->d = d;
     hipError_t e = hipGetDevice(&m->device);
     if (e != hipSuccess) { const int rc = mesh_fail("rsx_mesh_local: hipGetDevice", e); rsx_mesh_destroy(m); return rc; }
-    // the mailbox: polled by this rank's kernels while the peers store into it -- uncached device memory where the runtime has it
-    e = hipExtMallocWithFlags((void **)&m->flags, kMailboxBytes, hipDeviceMallocUncached);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        m->flags = nullptr;
-        e = hipMalloc((void **)&m->flags, kMailboxBytes);
-        if (e != hipSuccess) { m->flags = nullptr; const int rc = mesh_fail("rsx_mesh_local: hipMalloc(mailbox)", e); rsx_mesh_destroy(m); return rc; }
+    // the mailbox: polled by this rank's kernels while the peers store into it (their stores and this rank's loads are system-scope
+    // atomics).  From rsx_mesh_alloc like the tables should be: an allocation that has been exported already, zero-filled.
+    {
+        void *mb = nullptr;
+        const int rc = mesh_alloc_impl((int64_t)kMailboxBytes, true, &mb);
+        if (rc != RSX_OK) { rsx_mesh_destroy(m); return rc; }
+        m->flags = (uint32_t *)mb;
     }
-    e = hipMemset(m->flags, 0, kMailboxBytes);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e != hipSuccess) { const int rc = mesh_fail("rsx_mesh_local: clearing the mailbox (hipMemset + hipDeviceSynchronize)", e); rsx_mesh_destroy(m); return rc; }
     const size_t table_bytes = (size_t)rows * (size_t)d * sizeof(float);
     Exported xQ, xG, xF;
     int rc = export_allocation("Q", Q, table_bytes, m->device, &xQ);
@@ -422,6 +503,6 @@ RSX_API void rsx_mesh_destroy(rsx_mesh *m)
     if (m == nullptr) return;
     (void)hipDeviceSynchronize();
     for (void *p : m->opened) (void)hipIpcCloseMemHandle(p);
-    if (m->flags) (void)hipFree(m->flags);
+    if (m->flags) (void)rsx_mesh_free(m->flags);
     delete m;
 }

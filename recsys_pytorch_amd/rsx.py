@@ -94,6 +94,9 @@ SIGNATURES = {
     "rsx_comm_destroy": (None, [_P]),
     "rsx_comm_info": (C.c_int, [_P, _P, _P]),
     "rsx_comm_all_reduce_f32": (C.c_int, [_P, _P, _I64, _P]),
+    "rsx_mesh_alloc": (C.c_int, [_I64, _P]),
+    "rsx_mesh_free": (C.c_int, [_P]),
+    "rsx_mesh_alloc_refused": (C.c_int, []),
     "rsx_mesh_local": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "rsx_mesh_connect": (C.c_int, [_P, _I32, _I32, _P]),
     "rsx_mesh_exchange_apply": (C.c_int, [_P, _I64, _I64, _F, _P]),
@@ -692,6 +695,42 @@ class Comm:
             self.close()
         except Exception:                              # noqa: BLE001 -- interpreter shutdown
             pass
+
+
+class _MeshMemory:
+    """one allocation of rsx_mesh_alloc, freed with its last tensor view (include/rsx.h: memory that HAS been exported already)"""
+
+    def __init__(self, nbytes, shape):
+        self.ptr = C.c_void_p()
+        _check(lib().rsx_mesh_alloc(int(nbytes), C.byref(self.ptr)), "rsx_mesh_alloc")
+        self.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": "<f4", "data": (int(self.ptr.value), False),
+                                         "version": 2, "strides": None}
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None) is not None and self.ptr.value:
+                lib().rsx_mesh_free(self.ptr)
+                self.ptr = C.c_void_p()
+        except Exception:                              # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+def mesh_tensor(rows, d, device=None):
+    """a zero-filled fp32 [rows x d] device tensor in memory from rsx_mesh_alloc: plain hipMalloc'ed memory that the library has already
+    exported for the peers (an allocation the runtime refuses to export never comes back from there) -- where the tables of a
+    BPREngine(exchange="direct") live.  Freed when the last view of it is dropped (after Mesh.close() on every rank)."""
+    if device is not None and torch.device(device).index is not None:
+        assert torch.device(device).index == torch.cuda.current_device(), "mesh memory is allocated on the CURRENT device"
+    mem = _MeshMemory(int(rows) * int(d) * 4, (rows, d))
+    t = torch.as_tensor(mem, device=torch.device("cuda", torch.cuda.current_device()))
+    assert t.data_ptr() == mem.ptr.value and t.dtype == torch.float32 and tuple(t.shape) == (rows, d)
+    t._rsx_mesh_memory = mem                            # (torch holds the exporter too; this names it for the reader)
+    return t
+
+
+def mesh_alloc_refused():
+    """allocations rsx_mesh_alloc set aside in this process because the runtime would not export them"""
+    return int(lib().rsx_mesh_alloc_refused())
 
 
 class Mesh:

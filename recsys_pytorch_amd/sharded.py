@@ -114,6 +114,13 @@ class BPREngine:
         self.k = kernels
         self.P, self.Q = P_local, Q
         self.G = torch.zeros_like(Q)
+        if exchange == "direct" and hasattr(self.k, "mesh_tensor") and Q.is_cuda:
+            # the tables the peers will map live in memory the library has ALREADY exported (include/rsx.h: rsx_mesh_alloc) -- a pooled
+            # allocation of torch's allocator was refused by the runtime twice.  Like "scatter_gather": a caller that allocated Q goes on
+            # with ENGINE.Q
+            Qm = self.k.mesh_tensor(*Q.shape)
+            Qm.copy_(Q)
+            self.Q, self.G = Qm, self.k.mesh_tensor(*Q.shape)
         self.lr = float(lr)
         self.group = group
         self.world = dist.get_world_size(group) if (group is not None or dist.is_initialized()) else 1
@@ -363,8 +370,12 @@ class BPREngine:
             cm = torch.zeros(C * Ic, dtype=cnt.dtype)
             cm[rank_of_pos] = cnt.cpu()[perm]
             hot = self.k.HotItems(cm, num_hot, replicas, d, dev)
+        direct = self.exchange == "direct" and hasattr(self.k, "mesh_tensor") and Qm.is_cuda
+        if direct:                                       # (the relabelled tables are what the peers map: memory from rsx_mesh_alloc)
+            self.close_mesh()                            # (collective: the mesh over the last round's tables, before they are dropped)
+            Qm = self.k.mesh_tensor(C * Ic, d)
         r = {"csr": (indptr, indices), "nb": nb, "C": C, "Ic": Ic, "round": self._relabel_round, "item_rank": item_rank, "rank_item": rank_item, "real": real,
-             "indices": indices_m, "Q": Qm, "G": torch.zeros_like(Qm), "hot": hot,
+             "indices": indices_m, "Q": Qm, "G": self.k.mesh_tensor(C * Ic, d) if direct else torch.zeros_like(Qm), "hot": hot,
              "sig": self.k.build_signature(indptr, indices_m, nb) if nb else None,
              "cdf": self.k.build_item_cdf(indptr, indices_m, C * Ic)}
         self._relabel = r

@@ -94,7 +94,9 @@ sys.path.insert(0, %r)
 from recsys_pytorch_amd import rsx
 L = rsx.lib()
 sizing = {"rsx_bpr_item_cdf_workspace", "rsx_bpr_sample_workspace", "rsx_bpr_step_det_workspace", "rsx_bpr_step_workspace", "rsx_chunk_rows",
-          "rsx_score_topk_workspace"}
+          "rsx_score_topk_workspace",
+          # (queries / no-ops by contract: a counter, and free(NULL))
+          "rsx_mesh_alloc_refused", "rsx_mesh_free"}
 bad = []
 for name, (res, args) in sorted(rsx.SIGNATURES.items()):
     if name in ("rsx_last_error", "rsx_version"):

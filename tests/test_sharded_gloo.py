@@ -677,8 +677,8 @@ def _mesh_timeout_worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from recsys_pytorch_amd import rsx
     dev = torch.device("cuda", 0)
-    Q = torch.ones(1000, 64, device=dev)
-    G = torch.full((1000, 64), float(rank + 1), device=dev)
+    Q, G = rsx.mesh_tensor(1000, 64), rsx.mesh_tensor(1000, 64)       # (memory the library has already exported: include/rsx.h rsx_mesh_alloc)
+    Q.fill_(1.0); G.fill_(float(rank + 1))
     mesh = rsx.Mesh(Q, G)
     mesh.set_wait_limit(0.5)
     # a healthy exchange first: Q -= 0.5 * (1 + 2) on both ranks, G cleared
@@ -725,8 +725,13 @@ def _mesh_shapes_worker(rank, world, port, out):
         gen = torch.Generator().manual_seed(1000 * rows + d)
         Q0 = torch.randn(rows, d, generator=gen)
         Gs = [torch.randn(rows, d, generator=gen) for _ in range(world)]      # every rank's partial sums (the same draws on all ranks)
-        Q, G = Q0.clone().to(dev), Gs[rank].clone().to(dev)
+        # the exchanged tables live in memory the library has already exported (rsx_mesh_alloc): twice the runtime refused to export a
+        # pooled allocation of torch's allocator in a process that had mapped peers' memory before (GPUTEST_r05, profiles/r06_mesh_stress.txt);
+        # the borrowed-memory path has a test of its own below
+        Q, G = rsx.mesh_tensor(rows, d), rsx.mesh_tensor(rows, d)
+        Q.copy_(Q0); G.copy_(Gs[rank])
         mesh = rsx.Mesh(Q, G)
+        assert mesh.export_retries() == 0
         mesh.set_wait_limit(20.0)                                               # (a lost peer fails the test, it does not hang the box)
         # two exchanges over parts of the table, then the whole: rows [0, rows / 2), [rows / 2, rows) -- like item ranges -- and a second
         # step over everything with fresh partial sums
@@ -747,6 +752,48 @@ def _mesh_shapes_worker(rank, world, port, out):
     out[rank] = res
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _mesh_borrowed_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from recsys_pytorch_amd import rsx
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator().manual_seed(5)
+    Q0 = torch.randn(300, 64, generator=gen)
+    Gs = [torch.randn(300, 64, generator=gen) for _ in range(world)]
+    Q, G = Q0.clone().to(dev), Gs[rank].clone().to(dev)            # torch's own (pooled) memory
+    res = None
+    try:
+        mesh = rsx.Mesh(Q, G)
+    except rsx.RsxError as e:                                        # (collective outcome: every rank raises the same list)
+        res = ("refused", str(e))
+    else:
+        mesh.exchange_apply(0, 300, 0.5)
+        mesh.check()
+        res = ("ok", bool(torch.allclose(Q.cpu(), Q0 - 0.5 * sum(Gs), rtol=1e-5, atol=1e-5)) and float(G.abs().max()) == 0.0)
+        mesh.close()
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_mesh_over_borrowed_memory_works_or_says_exactly_why():
+    """rsx_mesh_local over tables in the CALLER's memory (torch's pooled allocations): validated, exported with bounded retries.  On this
+    runtime the export of such an allocation has been refused twice, persistently, in processes that had mapped peers' memory before --
+    then every rank must get the same error, and it must name the call, the allocation and the way out (rsx_mesh_alloc); otherwise the
+    exchange must be right"""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    spawn(_mesh_borrowed_worker, args=(2, 29500 + (os.getpid() + 211) % 2000, out), nprocs=2, join=True)
+    assert out[0][0] == out[1][0]
+    if out[0][0] == "refused":
+        for r in (0, 1):
+            assert "hipIpcGetMemHandle(allocation of" in out[r][1] and "rsx_mesh_alloc" in out[r][1], out[r][1]
+    else:
+        assert out[0][1] and out[1][1]
 
 
 @pytest.mark.gpu

@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 SHAPES = ((1, 32), (5, 64), (257, 128), (1000, 256))
 
 
-def worker(rank, world, port, loops, post_barrier, own_memory, out):
+def worker(rank, world, port, loops, post_barrier, own_memory, out, empty_cache=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from recsys_pytorch_amd import rsx
@@ -41,10 +41,13 @@ def worker(rank, world, port, loops, post_barrier, own_memory, out):
             gen = torch.Generator().manual_seed(1000 * rows + d + 7 * loop)
             Q0 = torch.randn(rows, d, generator=gen)
             Gs = [torch.randn(rows, d, generator=gen) for _ in range(world)]
-            if own_memory:                       # > 20 MB: an allocation of its own, not a piece of a pooled segment
+            if own_memory == 1:                  # > 20 MB: an allocation of its own, not a piece of a pooled segment
                 pad = (24 << 20) // (4 * d) + 1
                 Qb = torch.zeros(pad, d, device=dev); Gb = torch.zeros(pad, d, device=dev)
                 Q, G = Qb[:rows], Gb[:rows]
+                Q.copy_(Q0); G.copy_(Gs[rank])
+            elif own_memory == 2:                # memory from rsx_mesh_alloc (exported at allocation, handle cached)
+                Q, G = rsx.mesh_tensor(rows, d), rsx.mesh_tensor(rows, d)
                 Q.copy_(Q0); G.copy_(Gs[rank])
             else:
                 Q, G = Q0.clone().to(dev), Gs[rank].clone().to(dev)
@@ -93,6 +96,9 @@ def worker(rank, world, port, loops, post_barrier, own_memory, out):
                 mesh.timings.update(barrier_before=td - tb, destroy=time.time() - td)
             for k, v in mesh.timings.items():
                 phases[k] = phases.get(k, 0.0) + v
+            if empty_cache:
+                del mesh, Q, G
+                torch.cuda.empty_cache()
     out[rank] = {"fails": fails, "retries": retries, "meshes": meshes, "seconds": round(time.time() - t0, 2),
                  "phase_seconds": {k: round(v, 3) for k, v in phases.items()}}
     dist.barrier()
@@ -105,6 +111,9 @@ def main():
     ap.add_argument("--loops", type=int, default=20)
     ap.add_argument("--no-post-barrier", action="store_true")
     ap.add_argument("--own-memory", action="store_true")
+    ap.add_argument("--mesh-memory", action="store_true", help="tables in memory from rsx_mesh_alloc (rsx.mesh_tensor)")
+    ap.add_argument("--empty-cache", action="store_true", help="torch.cuda.empty_cache() after every mesh (segments freed and re-allocated: "
+                    "new allocations may land where a peer's memory was mapped before)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     mgr = mp.Manager()
@@ -112,10 +121,12 @@ def main():
     port = 29500 + (os.getpid() + 31 * a.world) % 2000
     status = "ok"
     try:
-        mp.spawn(worker, args=(a.world, port, a.loops, not a.no_post_barrier, a.own_memory, out), nprocs=a.world, join=True)
+        mp.spawn(worker, args=(a.world, port, a.loops, not a.no_post_barrier, 2 if a.mesh_memory else int(a.own_memory), out, a.empty_cache),
+                 nprocs=a.world, join=True)
     except Exception as e:                       # noqa: BLE001
         status = "crashed: " + repr(e)[:2000]
-    res = {"world": a.world, "loops": a.loops, "post_barrier": not a.no_post_barrier, "own_memory": a.own_memory, "status": status,
+    res = {"world": a.world, "loops": a.loops, "post_barrier": not a.no_post_barrier, "own_memory": a.own_memory, "mesh_memory": a.mesh_memory, "empty_cache": a.empty_cache,
+           "status": status,
            "ranks": {int(k): v for k, v in out.items()}}
     res["failures"] = sum(len(v["fails"]) for v in res["ranks"].values())
     res["retries"] = sum(v["retries"] for v in res["ranks"].values())
