@@ -417,7 +417,10 @@ int rsx_comm_all_reduce_f32(rsx_comm *c, float *buf_dev, int64_t n, rsx_stream_t
  *                      an IPC handle, which the library keeps: rsx_mesh_local over such memory makes no export call at all.  Twice (the
  *                      driver's round-5 box, a round-6 box) the runtime refused to export a POOLED allocation of the caller's allocator
  *                      -- persistently, "invalid argument" -- in a process that had mapped and unmapped peers' memory before; tables that
- *                      live in rsx_mesh_alloc memory cannot meet that.  rsx_mesh_free releases it (after rsx_mesh_destroy on every rank). */
+ *                      live in rsx_mesh_alloc memory cannot meet that.  rsx_mesh_free (after rsx_mesh_destroy on every rank) hands the
+ *                      block back to the LIBRARY, which keeps it -- allocation and handle -- for the next rsx_mesh_alloc of that size:
+ *                      an exporter that really frees memory its peers had mapped and gets the same address again hands out a handle the
+ *                      peers resolve to the old, freed memory (measured: wrong sums; tools/mesh_stress.py --empty-cache).              */
 #define RSX_MESH_DESC_BYTES 512
 typedef struct rsx_mesh rsx_mesh;
 int rsx_mesh_alloc(int64_t bytes, void **out);

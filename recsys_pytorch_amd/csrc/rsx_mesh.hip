@@ -183,7 +183,11 @@ constexpr int kExportAttempts = 4;
 
 // Memory the library allocated FOR exchange (rsx_mesh_alloc): its IPC handle was taken when it was allocated -- an allocation the runtime
 // refuses to export never leaves rsx_mesh_alloc -- and is kept, so a mesh over it makes no export call at all.
-struct Owned { size_t size; hipIpcMemHandle_t handle; };
+// rsx_mesh_free does NOT return the memory to the runtime: the block (with its handle) waits for the next rsx_mesh_alloc of its size.  An
+// exporter that frees an allocation its peers had mapped and then gets the SAME address back from hipMalloc hands out a handle the peers
+// resolve to the OLD, freed memory (round 6, tools/mesh_stress.py --empty-cache: wrong sums in every mesh after the first) -- or is refused
+// the export outright (the driver's round-5 run; a round-6 suite run).  A block that never dies keeps one valid handle for good.
+struct Owned { size_t size; hipIpcMemHandle_t handle; bool in_use; };
 std::mutex g_owned_mu;
 std::map<void *, Owned> g_owned;              // by allocation base
 std::vector<void *> g_refused;                // allocations the runtime would not export: kept (their addresses are not handed out again)
@@ -195,7 +199,7 @@ bool owned_lookup(const void *ptr, size_t bytes_needed, Exported *x)
     if (it == g_owned.begin()) return false;
     --it;
     const char *base = (const char *)it->first;
-    if ((const char *)ptr < base || (const char *)ptr + bytes_needed > base + it->second.size) return false;
+    if (!it->second.in_use || (const char *)ptr < base || (const char *)ptr + bytes_needed > base + it->second.size) return false;
     x->base = it->first; x->size = it->second.size; x->handle = it->second.handle; x->attempts = 1;
     return true;
 }
@@ -253,6 +257,21 @@ static int mesh_alloc_impl(int64_t bytes, bool uncached, void **out)
 {
     RSX_CHECK_ARG(out != nullptr && bytes > 0, "bad size");
     *out = nullptr;
+    {   // a block of this size that an earlier rsx_mesh_free handed back: the same allocation, the same handle
+        void *reuse = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(g_owned_mu);
+            for (auto &kv : g_owned)
+                if (!kv.second.in_use && kv.second.size == (size_t)bytes) { kv.second.in_use = true; reuse = kv.first; break; }
+        }
+        if (reuse != nullptr) {
+            hipError_t e = hipMemset(reuse, 0, (size_t)bytes);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            if (e != hipSuccess) { rsx_set_error("rsx_mesh_alloc: clearing %lld bytes failed: %s", (long long)bytes, hipGetErrorString(e)); (void)hipGetLastError(); return RSX_E_HIP; }
+            *out = reuse;
+            return RSX_OK;
+        }
+    }
     constexpr int kTries = 8;
     hipError_t last = hipSuccess;
     for (int t = 0; t < kTries; ++t) {
@@ -265,7 +284,7 @@ static int mesh_alloc_impl(int64_t bytes, bool uncached, void **out)
         if (e != hipSuccess) e = hipMalloc(&p, (size_t)bytes);
         if (e != hipSuccess) { rsx_set_error("rsx_mesh_alloc: hipMalloc(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(e)); (void)hipGetLastError(); return RSX_E_HIP; }
         Owned o;
-        o.size = (size_t)bytes;
+        o.size = (size_t)bytes; o.in_use = true;
         e = hipIpcGetMemHandle(&o.handle, p);
         if (e == hipSuccess) {
             e = hipMemset(p, 0, (size_t)bytes);
@@ -292,14 +311,12 @@ RSX_API int rsx_mesh_alloc(int64_t bytes, void **out) { return mesh_alloc_impl(b
 RSX_API int rsx_mesh_free(void *p)
 {
     if (p == nullptr) return RSX_OK;
-    {
-        std::lock_guard<std::mutex> lock(g_owned_mu);
-        auto it = g_owned.find(p);
-        if (it == g_owned.end()) { rsx_set_error("rsx_mesh_free: invalid argument: not an allocation of rsx_mesh_alloc"); return RSX_E_INVALID; }
-        g_owned.erase(it);
-    }
     (void)hipDeviceSynchronize();
-    return hipFree(p) == hipSuccess ? RSX_OK : RSX_E_HIP;
+    std::lock_guard<std::mutex> lock(g_owned_mu);
+    auto it = g_owned.find(p);
+    if (it == g_owned.end() || !it->second.in_use) { rsx_set_error("rsx_mesh_free: invalid argument: not a live allocation of rsx_mesh_alloc"); return RSX_E_INVALID; }
+    it->second.in_use = false;                       // (kept for the next rsx_mesh_alloc of this size: see Owned)
+    return RSX_OK;
 }
 
 RSX_API int rsx_mesh_alloc_refused(void)      /* allocations rsx_mesh_alloc had to set aside because the runtime would not export them */

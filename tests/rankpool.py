@@ -41,8 +41,9 @@ def _serve(conn, paths):
             if "torch" in sys.modules:
                 import torch
                 if torch.cuda.is_available() and torch.cuda.is_initialized():
+                    # (NO torch.cuda.empty_cache() here: a rank that frees segments its peers had mapped over HIP IPC and gets the same
+                    #  addresses back hands out handles the peers resolve to the old memory -- profiles/r06_mesh_stress.txt)
                     torch.cuda.synchronize()
-                    torch.cuda.empty_cache()
             conn.send(("ok", None))
         except BaseException:                       # noqa: BLE001 -- reported to the parent, which restarts the pool
             try:
