@@ -270,6 +270,94 @@ __global__ __launch_bounds__(512, 2) void shape_4x2db(float *o, int c, const flo
 __global__ __launch_bounds__(1024, 1) void shape_4x4(float *o, int c, const float *t, int r, int d) { shape_body<4, 4, false>(o, c, t, r, d); }
 __global__ __launch_bounds__(1024, 1) void shape_4x4db(float *o, int c, const float *t, int r, int d) { shape_body<4, 4, true>(o, c, t, r, d); }
 
+// Round 6 (the review's item 7): "a feed that is not LDS-DMA pieces of 1 KiB for BOTH operands" -- the A operand (the user tile: it is the same
+// for every item tile of a pass and lives in L2) comes by DIRECT global loads in MFMA layout, only B through the LDS-DMA: half the DMA pieces per
+// MFMA (4 per wavefront and chunk instead of 8).  A lane holds its two rows' 16 contraction values of the chunk: lane (l31, hi) takes k = 16 hi ..
+// 16 hi + 15 (four dwordx4 per row block = 32 VGPRs per chunk; B's fragment reads follow the same k mapping), and the NEXT chunk's A travels while
+// this chunk's MFMAs run (DOUBLE: 64 VGPRs of A) or is fetched at the top of the chunk (SINGLE: 32).
+template <bool DOUBLE>
+__device__ __forceinline__ void mfma_adirect_body(float *out, int chunks, const float *table, int rows, int d)
+{
+    constexpr int TS = 128 * 32 + 16;
+    __shared__ __attribute__((aligned(16))) float Bs[TS];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wr = wid >> 1, wc = wid & 1, hi = lane >> 5, l31 = lane & 31;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    const int xs = (l31 & 7) << 2, hb = (16 * hi) ^ xs;
+    const float *bp = Bs + (wc * 64 + l31) * 32 + ((wc * 64 + l31) >> 3);
+    const int kq = tid & 7, srow = tid >> 3, gq = kq ^ (srow & 7);
+    unsigned base = blockIdx.x * 2654435761u;
+    unsigned abase = base;
+    auto dma_b = [&](int c) __attribute__((always_inline)) {
+        const int k0 = (c * 32) % d;
+        if (k0 == 0) base = base * 1664525u + 1013904223u;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const unsigned rb = (base * 7u + (unsigned)(srow + 32 * n)) % (unsigned)rows;
+            __builtin_amdgcn_global_load_lds(table + (size_t)rb * d + k0 + 4 * gq, Bs + (32 * n + 8 * wid) * 32 + (4 * n + wid), 16, 0, 0);
+        }
+    };
+    auto load_a = [&](int c, float4 (&a)[2][4]) __attribute__((always_inline)) {
+        const int k0 = (c * 32) % d;
+        if (k0 == 0) abase = abase * 1664525u + 1013904223u;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const unsigned ra = (abase + (unsigned)(wr * 64 + 32 * blk + l31)) % (unsigned)rows;
+            const float4 *src = reinterpret_cast<const float4 *>(table + (size_t)ra * d + k0 + 16 * hi);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[blk][q] = src[q];
+        }
+    };
+    float4 acur[2][4], anext[2][4];
+    if (DOUBLE) load_a(0, anext);
+    for (int c = 0; c < chunks; ++c) {
+        dma_b(c);
+        if (DOUBLE) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acur[blk][q] = anext[blk][q];
+        } else {
+            load_a(c, acur);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (DOUBLE && c + 1 < chunks) load_a(c + 1, anext);
+        float b0 = bp[hb], b1 = bp[32 * 32 + 4 + hb];
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) {
+            float nb0 = 0.f, nb1 = 0.f;
+            if (s_ + 1 < 16) {
+                const int o = (hb ^ ((s_ + 1) & ~3)) | ((s_ + 1) & 3);
+                nb0 = bp[o]; nb1 = bp[32 * 32 + 4 + o];
+            }
+            const float a0 = reinterpret_cast<const float *>(&acur[0][s_ >> 2])[s_ & 3], a1 = reinterpret_cast<const float *>(&acur[1][s_ >> 2])[s_ & 3];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            b0 = nb0; b1 = nb1;
+        }
+        __syncthreads();
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[m][n][r];
+    if (s == 12345.678f) out[tid] = s;
+}
+__global__ __launch_bounds__(256, 4) void mfma_adirect_single(float *o, int c, const float *t, int r, int d) { mfma_adirect_body<false>(o, c, t, r, d); }
+__global__ __launch_bounds__(256, 3) void mfma_adirect_double3(float *o, int c, const float *t, int r, int d) { mfma_adirect_body<true>(o, c, t, r, d); }
+__global__ __launch_bounds__(256, 4) void mfma_adirect_double4(float *o, int c, const float *t, int r, int d) { mfma_adirect_body<true>(o, c, t, r, d); }
+
 template <int ACCS>
 void run(int waves_per_simd, int cus, int iters = 2000)
 {
@@ -295,11 +383,46 @@ void run(int waves_per_simd, int cus, int iters = 2000)
     hipFree(out);
 }
 
-int main()
+int main(int argc, char **argv)
 {
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
     printf("%s, %d CUs, clock %d MHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate / 1000);
+    if (argc > 1 && argv[1][0] == 'a') {        // `tools/mfma_peak adirect`: only round 6's A-by-direct-loads feed against the kernel's own structure
+        float *out;
+        (void)hipMalloc(&out, 4096);
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        for (int rows : {24576, 1000000}) {
+            float *table;
+            (void)hipMalloc(&table, (size_t)rows * 128 * 4);
+            (void)hipMemset(table, 0x3d, (size_t)rows * 128 * 4);
+            struct { const char *name; void (*k)(float *, int, const float *, int, int); int per_cu; } ks[] = {
+                {"LDS-DMA for A and B + two barriers per chunk (the kernel's structure), 4 workgroups per CU", mfma_dma_loop0, 4},
+                {"A by direct loads at the top of the chunk (32 VGPRs), B by LDS-DMA, 4 per CU", mfma_adirect_single, 4},
+                {"A by direct loads one chunk ahead (64 VGPRs), B by LDS-DMA, 3 per CU", mfma_adirect_double3, 3},
+                {"A by direct loads one chunk ahead, compiled for 4 per CU", mfma_adirect_double4, 4}};
+            for (auto &kk : ks) {
+                dim3 grid(p.multiProcessorCount * kk.per_cu), block(256);
+                const int chunks = 500;
+                const double flop = (double)grid.x * 4 * chunks * 16.0 * 4 * 4096.0;
+                printf("table of %d rows x 128, %s:", rows, kk.name);
+                for (int rep = 0; rep < 8; ++rep) {
+                    (void)hipEventRecord(e0);
+                    kk.k<<<grid, block>>>(out, chunks, table, rows, 128);
+                    (void)hipEventRecord(e1);
+                    if (rep % 2 == 1) {
+                        (void)hipEventSynchronize(e1);
+                        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+                        printf(" %.1f", flop / ms / 1e9);
+                    }
+                }
+                printf(" TFLOP/s  [%s]\n", hipGetErrorString(hipGetLastError()));
+            }
+            (void)hipFree(table);
+        }
+        return 0;
+    }
     for (int w : {1, 2, 4}) { run<1>(w, p.multiProcessorCount); run<2>(w, p.multiProcessorCount); run<4>(w, p.multiProcessorCount); }
     // the shape of the scoring product is 4 accumulators x 4 wavefronts per SIMD: which of the two makes 0.80 of it?  (launches of equal length)
     printf("--- equal work per launch (~3.4 ms at full rate)\n");
