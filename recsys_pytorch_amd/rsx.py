@@ -388,7 +388,8 @@ def spmm(graph, X, Y, S_acc=None, x_nonzero=None, y_wanted=None, S_init=None):
     overwritten: the first product of a propagation, without the copy of the source into the running sum)"""
     if (x_nonzero is not None or S_init is not None) and y_wanted is not None:
         raise RsxError("spmm: y_wanted does not combine with x_nonzero / S_init (different products)")
-    _spmm_planned(graph, X, Y, S_acc, x_nonzero, y_wanted, S_init)
+    if graph.num_segs > 0:                               # (a small graph whose every non-empty row goes by scatter has no segment left)
+        _spmm_planned(graph, X, Y, S_acc, x_nonzero, y_wanted, S_init)
     if getattr(graph, "hot", None) is not None:          # the longest rows, which the plan leaves out: by scatter
         ptr = lambda t, dt, name: _dev(t, dt, name) if t is not None else None
         _check(lib().rsx_spmm_hot_rows(C.byref(graph.hot), _dev(X, torch.float32, "X"), ptr(x_nonzero, torch.uint8, "x_nonzero"),

@@ -210,6 +210,7 @@ def test_hip_spmm_on_random_graphs():
         ctx = f"trial {trial}: N={N} d={d} kind={kind} nnz={len(indices)} max_seg={max_seg} hot={hot}"
         G = rsx.SpmmGraph(A, "cuda", max_seg=max_seg, d=d, hot=hot)
         assert (G.hot is not None) == (hot and len(indices) > 0), ctx
+        # (found by the campaign, seed 6: a graph with no empty row and fewer non-empty rows than hot slots has NO segment left)
         X = rng.standard_normal((N, d)).astype(np.float32)
         A64 = A.astype(np.float64)
         Y64 = A64 @ X.astype(np.float64)
@@ -237,6 +238,26 @@ def test_hip_spmm_on_random_graphs():
         Yw, Sw = Yw.cpu().numpy(), Sw.cpu().numpy()
         assert not want.any() or (np.abs(Yw[want] - Y64[want]).max() <= bound and np.abs(Sw[want] - (Y64[want] - 3.0)).max() <= bound + 3e-6), ctx
         assert want.all() or (bool((Yw[~want] == 7.0).all()) and bool((Sw[~want] == -3.0).all())), ctx
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,d", [(50, 128), (120, 32), (7, 256)])
+def test_hip_spmm_when_every_row_goes_by_scatter(N, d):
+    """a graph with no empty row and fewer rows than hot slots: the segment plan is left EMPTY and the whole product is the scatter
+    (found by the random-shape campaign, seed 6: the planned product was called with no segment)"""
+    from recsys_pytorch_amd import rsx
+    rng = np.random.default_rng(N + d)
+    A = sp.random(N, N, density=0.3, format="csr", random_state=rng, dtype=np.float32)
+    A = (A + sp.identity(N, dtype=np.float32, format="csr")).tocsr()          # every row owns an entry
+    G = rsx.SpmmGraph(A, "cuda", d=d, hot=True)
+    assert G.hot is not None and G.num_segs == 0
+    X = rng.standard_normal((N, d)).astype(np.float32)
+    Xd = torch.from_numpy(X).cuda()
+    Y, S = torch.full_like(Xd, 7.0), Xd.clone()
+    rsx.spmm(G, Xd, Y, S_acc=S)
+    Y64 = A.astype(np.float64) @ X.astype(np.float64)
+    bound = 4e-6 * np.maximum(abs(A.astype(np.float64)) @ np.abs(X).astype(np.float64), 1e-30).max()
+    assert np.abs(Y.cpu().numpy() - Y64).max() <= bound and np.abs(S.cpu().numpy() - (X + Y64)).max() <= bound + 1e-6 * np.abs(X).max()
 
 
 @pytest.mark.gpu

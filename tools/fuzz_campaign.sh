@@ -14,6 +14,8 @@ for seed in $(seq ${1:-1} ${2:-4}); do
         "tests/test_gpu_chunks.py::test_native_loop_on_random_shapes" "tests/test_gpu_parity.py::test_dense_gradient_paths_on_random_shapes" \
         "tests/test_gpu_parity.py::test_deterministic_step_on_random_shapes" "tests/test_gpu_model.py::test_model_on_random_shapes" \
         "tests/test_lightgcn.py::test_hip_lightgcn_on_random_graphs" \
+        "tests/test_gpu_csc.py::test_csc_blob_is_the_transposed_matrix" "tests/test_gpu_csc.py::test_csc_sampler_on_random_shapes" \
+        "tests/test_gpu_csc.py::test_csc_sampler_with_item_ranges_on_random_shapes" \
         2>&1 | grep -v "amdgpu.ids" | tail -40 >> $out
 done
 grep -c passed $out
