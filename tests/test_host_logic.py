@@ -253,3 +253,80 @@ def test_item_range_redraw_moves_heavy_items_and_keeps_the_balance(I, C, pop):
     together = lambda x, y: sum(int(a[x] == a[y]) for a in rounds)
     pairs = [(heavy[k], heavy[k + 1]) for k in range(0, 64, 2)]
     assert np.mean([together(x, y) > 0 for x, y in pairs]) > 0.8
+
+
+def _replay_hot_plan(plan, X, waves=16):
+    """the scatter of include/rsx.h: rsx_spmm_hot_rows restated on the host: per (chunk of source rows, wavefront) a run of entries,
+    ordered by the wavefront's slot (rw_off), each adding val * X[source] to its slot's accumulator; a row's result is the sum of
+    the slots that name it (hot_rows)"""
+    H, K = plan["num_slots"], plan["chunk_rows"]
+    R = H // waves
+    acc = np.zeros((H, X.shape[1]))
+    rw = plan["rw_off"].astype(np.int64).reshape(-1, R + 1)
+    nchunks = -(-len(plan["src_rows"]) // K)
+    assert rw.shape[0] == nchunks * waves and len(plan["cw_ptr"]) == nchunks * waves + 1
+    assert (np.diff(plan["cw_ptr"]) == rw[:, -1]).all() and (np.diff(rw, axis=1) >= 0).all() and (rw[:, 0] == 0).all()
+    for cw in range(nchunks * waves):
+        c, w = divmod(cw, waves)
+        base = int(plan["cw_ptr"][cw])
+        for r in range(R):
+            e = np.arange(base + rw[cw, r], base + rw[cw, r + 1])
+            if len(e) == 0:
+                continue
+            code = plan["ent_code"][e].astype(np.int64)
+            assert ((code >> 8) == r).all()                       # the slot the entry carries is the slot its position says
+            src = c * K + (code & 0xFF)
+            assert (src < len(plan["src_rows"])).all()
+            acc[w * R + r] += (plan["ent_val"][e, None].astype(np.float64) * X[plan["src_rows"][src]]).sum(0)
+    return acc
+
+
+@pytest.mark.parametrize("d", [32, 128, 256])
+def test_hot_row_plan_covers_every_entry_of_its_rows_once(d):
+    """recsys_pytorch_amd/rsx.py: spmm_hot_plan (host side of include/rsx.h: rsx_spmm_hot) on popularity-skewed graphs: the plan's rows
+    are the longest ones, every slot belongs to one wavefront's share, and replaying the plan gives A[rows] @ X (models/LightGCN.py:188-197
+    is the product it is part of)"""
+    import scipy.sparse as sp
+    from recsys_pytorch_amd import rsx
+    rng = np.random.default_rng(600 + d)
+    for trial in range(4):
+        n = int(rng.integers(300, 3000))
+        nnz = int(rng.integers(n, 30 * n))
+        pop = rng.zipf(1.3, nnz) % n                                   # a few very long rows
+        A = sp.csr_matrix((rng.standard_normal(nnz).astype(np.float32), (pop, rng.integers(0, n, nnz))), shape=(n, n))
+        A.sum_duplicates(); A.sort_indices()
+        plan, share = rsx.spmm_hot_plan(A, d)
+        H = plan["num_slots"]
+        assert H == int(rsx.lib().rsx_spmm_hot_capacity(d)) and plan["chunk_rows"] == int(rsx.lib().rsx_spmm_hot_chunk_rows(d))
+        rows = plan["uniq_rows"]
+        lens = np.diff(A.indptr)
+        assert len(np.unique(rows)) == len(rows) and (lens[rows] > 0).all()
+        assert lens[rows].min() >= np.sort(lens)[::-1][min(H, n) - 1]   # none of them shorter than the H-th longest row
+        assert abs(share - lens[rows].sum() / A.nnz) < 1e-12
+        named = plan["hot_rows"][plan["hot_rows"] >= 0]
+        assert set(named.tolist()) == set(rows.tolist())
+        assert len(plan["ent_code"]) == len(plan["ent_val"]) == int(plan["cw_ptr"][-1]) == int(lens[rows].sum())
+        assert (np.diff(plan["src_rows"]) > 0).all()
+        X = rng.standard_normal((n, 3))
+        acc = _replay_hot_plan(plan, X)
+        got = np.zeros((n, 3))
+        np.add.at(got, plan["hot_rows"][plan["hot_rows"] >= 0], acc[plan["hot_rows"] >= 0])
+        want = np.zeros((n, 3)); want[rows] = A[rows].astype(np.float64) @ X
+        assert np.abs(got - want).max() <= 1e-9 * max(1.0, np.abs(want).max()), (d, trial, n, nnz)
+    assert rsx.spmm_hot_plan(sp.csr_matrix((50, 50), dtype=np.float32), d) == (None, 0.0)
+
+
+def test_csc_walk_rank_is_in_range_and_uniform():
+    """recsys_pytorch_amd/rsx.py: csc_positive_rank (the host restatement the device walk is compared with): 0 <= rank < deg, a different
+    draw every step, every rank of a row about equally often (data/generators.py:160-166 draws the positive uniformly in the row)"""
+    from recsys_pytorch_amd import rsx
+    users = np.arange(200_000)
+    deg = (users % 7 + 1).astype(np.int64)
+    r0, r1 = rsx.csc_positive_rank(users, deg, 2020, 0), rsx.csc_positive_rank(users, deg, 2020, 1)
+    assert (r0 >= 0).all() and (r0 < deg).all() and (r1 < deg).all()
+    assert (r0[deg > 1] != r1[deg > 1]).mean() > 0.5
+    assert (rsx.csc_positive_rank(users, deg, 2020, 0) == r0).all() and (rsx.csc_positive_rank(users, deg, 2021, 0)[deg > 1] != r0[deg > 1]).any()
+    for k in (2, 5, 7):
+        cnt = np.bincount(r0[deg == k], minlength=k)
+        n = cnt.sum()
+        assert np.abs(cnt / n - 1.0 / k).max() < 5 * np.sqrt((1.0 / k) / n), (k, cnt)
