@@ -34,6 +34,8 @@ Prints ONE JSON line (rank 0).
   value         the MEDIAN of three back-to-back timed regions of --steps steps each (`timed_regions`: every region, min, max).
   hbm_utilisation_end_to_end   everything a step moves at the fabric side (step kernel + apply + the sampler beside them, PMC) over the
                 whole step, as a fraction of the 8 TB/s peak: how busy the loop as a whole keeps HBM.
+                roofline.achieved_over_copy_rate / hbm_utilisation_e2e_over_copy_rate: the same against 6.29 TB/s, what a float4 copy
+                measures on this part (MI355X_MICROARCH.md) -- a second reference point; `peak` and `frac` stay on the 8 TB/s spec.
   legs          the other section-8d measurements, each with its own roofline: SURVEY's base batch
                 B = 65 536, independent uniform negatives, uniform item popularity, a batch sweep, the
                 configs[1] (d=64) shape, and the configs[3] one-rank slice (1.25M users x 1M items).
@@ -56,6 +58,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_COPY_GBS = 6290.0          # MI355X_MICROARCH.md: what a float4 copy measures on this part (79 % of the spec): NOT the roofline's `peak`,
+                               # a second reference point only (`*_over_copy_rate`): how far from what HBM delivers to a pure stream
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: matrix FP32 peak
 
 
@@ -848,7 +852,12 @@ def main():
             out["roofline"] = {**out["roofline"], "configs": cfgs}
         # ... and the same figures once more as FLAT scalars (the driver's record keeps the scalars of `roofline` / `config` and
         # drops nested objects): every BASELINE config readable from BENCH_rNN.parsed alone
-        flat = {"frac_e2e": sig(head["frac_end_to_end"])}
+        flat = {"frac_e2e": sig(head["frac_end_to_end"]), "hbm_utilisation_e2e": sig(head["hbm_utilisation_end_to_end"]),
+                # the same two figures against the float4-copy rate the guide measured (6.29 TB/s), beside -- never instead of -- the 8 TB/s peak
+                "copy_rate_GBs": HBM_COPY_GBS,
+                "achieved_over_copy_rate": sig(head["roofline"]["achieved"] / HBM_COPY_GBS) if head["roofline"].get("achieved") else None,
+                "hbm_utilisation_e2e_over_copy_rate": sig(head["hbm_utilisation_end_to_end"] * HBM_PEAK_GBS / HBM_COPY_GBS)
+                if head.get("hbm_utilisation_end_to_end") else None}
         for pre, name in (("base65536", "base_batch_65536"), ("d64", "config1_d64"), ("config3", "config3_slice")):
             if name in cfgs:
                 flat.update({f"{pre}_value": cfgs[name]["value"], f"{pre}_ms_per_step": cfgs[name]["ms_per_step"],

@@ -66,10 +66,13 @@ def test_bench_json_contract_small_shape():
         assert set(v) == {"value", "ms_per_step", "kernel_ms", "frac", "frac_end_to_end"} and v["value"] > 0
     # ... and flat: the driver's record keeps scalars of `roofline` / `config` only
     for k in ("base65536_value", "base65536_frac", "base65536_frac_e2e", "d64_value", "d64_frac", "d64_frac_e2e", "scoring_value",
-              "scoring_frac", "traffic_stale", "traffic_commit", "frac_e2e"):
+              "scoring_frac", "traffic_stale", "traffic_commit", "frac_e2e", "hbm_utilisation_e2e", "copy_rate_GBs", "achieved_over_copy_rate",
+              "hbm_utilisation_e2e_over_copy_rate"):
         assert k in r and not isinstance(r[k], (dict, list)), k
         assert d["config"]["roofline_" + k] == r[k]
     assert r["base65536_value"] == cf["base_batch_65536"]["value"] and r["scoring_frac"] == cf["scoring"]["frac"]
+    # the guide's measured float4-copy rate is a second reference point; the roofline's `peak` stays the 8 TB/s spec
+    assert r["copy_rate_GBs"] == 6290.0 and r["achieved_over_copy_rate"] is None      # (no PMC profile of this small shape)
 
 
 @pytest.mark.gpu
