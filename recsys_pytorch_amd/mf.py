@@ -19,6 +19,10 @@ Divergences from the reference, all documented in DESIGN.md:
   * hparams['neg_block'] (default 8; 0 = off): when a batch holds >= 2 triplets per item the sampler
     orders it by positive item and stratifies the negatives by item block so that the step kernel can
     sum item gradients on chip; tests/test_gpu_model.py checks it trains as well.
+    hparams['neg_block_min'] (default 2): the smallest block the engine may pick.  Same expectation as independent negatives, more
+    variance per step the smaller the block: measured on a planted-factor dataset (profiles/r06_sampler_quality.txt) NDCG@10 falls short
+    of independent negatives' by 2.4 % at block 2 and 0.8 % at block 8 with a LARGE step size (0.1 per triplet), by nothing measurable
+    at the step size where that model is best (0.02); larger blocks cost a few percent of speed (sharded.py: pick_neg_block).
   * hparams['pointwise'] = True (MF.py:48-51,101-102): the pointwise branch, hparams['loss_func'] 'mse' or anything
     else = binary cross entropy with logits (MF.py:21).  Batches are the reference generator's (data/generators.py:
     105-130: batch_size interactions of a per-epoch permutation PLUS one uniformly drawn negative, rating 0, for EVERY
@@ -116,6 +120,7 @@ class MF(BaseModel):
         self.seed = int(_get(hparams, "seed", 2020))
         # item block of the stratified negatives; 0 = independent uniform negatives always
         self.neg_block = int(_get(hparams, "neg_block", 8))
+        self.neg_block_min = int(_get(hparams, "neg_block_min", 2))
         self.chunks = int(_get(hparams, "chunks", 0))
         self.hot_items = int(_get(hparams, "hot_items", 256))
         self.device = torch.device(device)
@@ -196,7 +201,7 @@ class MF(BaseModel):
         n_data = self.num_users
         num_batches = int(np.ceil(n_data / batch_size))
         if self.optimizer_name == "sgd":     # on-chip gradient summation when batch >= 2 * items
-            nb = self._engine.set_neg_block(batch_size if self.neg_block > 0 else 0, max(self.neg_block, 1))
+            nb = self._engine.set_neg_block(batch_size if self.neg_block > 0 else 0, max(self.neg_block, 1), self.neg_block_min)
             if self.hot_items > 0 and hasattr(self._k, "HotItems"):
                 self._engine.set_hot_items(torch.bincount(indices.long(), minlength=self.num_items),
                                            min(self.hot_items, self.num_items))

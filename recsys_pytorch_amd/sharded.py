@@ -26,29 +26,40 @@ def user_block(num_users, rank, world):
     return begin, min(begin + per, num_users)
 
 
-def pick_neg_block(num_items, max_block, wave_slots, batch=None, min_block=2):
+def pick_neg_block(num_items, max_block, wave_slots, batch=None, min_block=3, floor=2):
     """item block c of the stratified negatives.  The blocked step kernel runs one wavefront per block over
     ~c * batch / num_items positions.
 
-    * many triplets per item (batch / num_items >= 10): the SMALLEST c that still gives a wavefront 20 positions.  Short
+    * many triplets per item (batch / num_items >= 10): the SMALLEST c >= min_block that still gives a wavefront 20 positions.  Short
       wavefronts retire often, and the sampler of the next step -- which time-shares the CUs with this kernel, whose
       wavefronts hold nearly all VGPRs -- finds room continuously instead of at the end of each round.  Measured at
-      I = 100K, B = 2**20 (profiles/r03_exp_sampler_placement.txt): c = 2 -> 341 us per step, 3 -> 345, 6 -> 362.
+      I = 100K, B = 2**20: c = 2 -> 341 us per step, 3 -> 345, 6 -> 362 (round 3, profiles/r03_exp_sampler_placement.txt); alternating on
+      one box in round 6: c = 2: 307 / 329 / 321, c = 3: 303 / 322 / 322, c = 4: 327 / 336 / 337, c = 5: 341 / 343 / 356; d = 64: 2 / 3 / 4 alike.
     * fewer: a wavefront needs its positions to amortise its start, and the kernel's duration is ceil(waves / resident
       slots) ROUNDS (12 500 wavefronts on 6 144 slots take three rounds for two rounds' worth of work): the c in
       [2, max_block] whose last round is fullest; ties go to the larger block.  (B = 262 144 at I = 100K: c = 6 -> 1.54e9
       triplets/s, 3 -> 1.36e9, 2 -> 1.12e9.)
 
-    min_block: lower bound of the first rule.  The item-range pipelines (set_chunks) use 3: two ranges on one GPU take
-    358 us per step with c = 3, 432-442 with c = 2, 396-409 with c = 6 (same file, block F)."""
+    min_block: lower bound of the first rule, 3.  That is the QUALITY side of the choice: the negatives of one block all come from the
+    ~c batch / num_items consecutive positions of ONE wavefront, i.e. from users who share c or so positive items -- the same expectation
+    as independent draws, more variance per step.  On a planted-factor dataset in the headline's proportions (tools/sampler_quality.py,
+    profiles/r06_sampler_quality.txt) NDCG@10 at the plateau falls short of independent negatives' by 2.4 / 1.4 / 1.4 / 0.9 / 0.8 / 0.45 %
+    at c = 2 / 3 / 4 / 6 / 8 / 16 with a step size of 0.1 per triplet, by 0.7 % (c = 2) at 0.05 and by nothing measurable (16 seeds) at 0.02,
+    where that model is best.  c = 3 costs nothing on the clock and closes 40 % of that gap, so it is the floor since round 6 (it was 2);
+    the item-range pipelines (set_chunks) were at 3 already: two ranges on one GPU take 358 us per step with c = 3, 432-442 with c = 2,
+    396-409 with c = 6 (round 3, block F; round 6: c = 3 / 4 / 5 alike, 340 us).  max_block = 2 still gives 2.
+
+    floor: the caller's lower bound of BOTH rules (hparams['neg_block_min']): larger blocks for a large step size, at ~4 % of the
+    step per block size from 4 on."""
     if max_block < 2:
         return max(1, int(max_block))
+    floor = max(2, min(int(floor), int(max_block)))
     if batch is not None and batch >= 10 * num_items:
-        for c in range(min(min_block, max_block), max_block + 1):
+        for c in range(max(min(min_block, max_block), floor), max_block + 1):
             if c * batch >= 20 * num_items:
                 return c
-    best, best_eff = 2, -1.0
-    for c in range(2, max_block + 1):
+    best, best_eff = floor, -1.0
+    for c in range(floor, max_block + 1):
         waves = -(-num_items // c)
         eff = waves / (-(-waves // wave_slots) * wave_slots)
         if eff >= best_eff - 1e-9:
@@ -214,13 +225,15 @@ class BPREngine:
         self._bufs = None           # double-buffered triplets for the overlapped sampler
         self._side = None           # ONE side stream for the engine's lifetime
 
-    def set_neg_block(self, batch, max_block=8):
+    def set_neg_block(self, batch, max_block=8, min_block=2):
         """enable the on-chip gradient summation (blocked negatives + batch sorted by positive
         item, include/rsx.h: neg_block / RSX_SAMPLE_SORT_POS) when every item row gets >= 2
-        updates per step; below that there is nothing to combine.  The block size c <= max_block
-        is `pick_neg_block`'s choice for this batch size."""
-        self._nb_args = (int(batch), int(max_block))
-        nb = pick_neg_block(self.Q.shape[0], int(max_block), self._wave_slots(), int(batch), 3 if self.chunks > 1 else 2) if batch >= 2 * self.Q.shape[0] else 0
+        updates per step; below that there is nothing to combine.  The block size c in [min_block, max_block]
+        is `pick_neg_block`'s choice for this batch size (min_block: the caller's floor -- larger blocks mix the
+        negatives of more positive items, see pick_neg_block)."""
+        self._nb_args = (int(batch), int(max_block), int(min_block))
+        nb = pick_neg_block(self.Q.shape[0], int(max_block), self._wave_slots(), int(batch), 3,
+                            floor=int(min_block)) if batch >= 2 * self.Q.shape[0] else 0
         if nb != self.neg_block:
             self._csr = None        # the user signatures depend on neg_block: rebuild on next use
         self.neg_block = nb

@@ -93,18 +93,22 @@ def test_pick_neg_block_follows_the_batch_density():
     fullest-last-round rule below, never above max_block, item ranges from 3 up"""
     from recsys_pytorch_amd.sharded import pick_neg_block
     slots = 256 * 24
-    assert pick_neg_block(100_000, 8, slots, 1 << 20) == 2            # the headline shape: 10.5 triplets per item
-    assert pick_neg_block(100_000, 8, slots, 1 << 20, 3) == 3         # ... as item ranges
-    assert pick_neg_block(100_000, 8, slots, 1_000_000) == 2
+    assert pick_neg_block(100_000, 8, slots, 1 << 20) == 3            # the headline shape: 10.5 triplets per item; blocks of 3 since round 6
+    assert pick_neg_block(100_000, 8, slots, 1 << 20, 2) == 2         # ... (2 gave the 20 positions; 3 is free on the clock and mixes more positives)
+    assert pick_neg_block(100_000, 8, slots, 1_000_000) == 3
     assert pick_neg_block(100_000, 8, slots, 262_144) == 6            # 2.6 per item: whole rounds of wavefronts
     assert pick_neg_block(100_000, 8, slots) == 6                     # no batch given: the round rule
     assert pick_neg_block(100_000, 4, slots, 1 << 20, 3) == 3
     assert pick_neg_block(100_000, 2, slots, 1 << 20, 3) == 2         # min_block never exceeds max_block
     assert pick_neg_block(100_000, 1, slots, 1 << 20) == 1
-    assert pick_neg_block(1_000, 8, slots, 100_000) == 2              # 100 per item: c = 2 gives 200 positions
-    for I, B in ((50_000, 600_000), (7_777, 90_000), (100_000, 3_000_000)):
+    assert pick_neg_block(1_000, 8, slots, 100_000) == 3              # 100 per item: the floor
+    for I, B in ((50_000, 600_000), (7_777, 90_000), (100_000, 3_000_000), (100_000, 1_000_001)):
         c = pick_neg_block(I, 8, slots, B)
-        assert 2 <= c <= 8 and c * B >= 20 * I and (c == 2 or (c - 1) * B < 20 * I)
+        assert 3 <= c <= 8 and c * B >= 20 * I and (c == 3 or (c - 1) * B < 20 * I)
+    # the caller's floor (hparams['neg_block_min']: larger blocks mix the negatives of more positive items) bounds BOTH rules from below
+    assert pick_neg_block(100_000, 8, slots, 1 << 20, floor=8) == 8 and pick_neg_block(100_000, 8, slots, 1 << 20, 3, floor=4) == 4
+    assert pick_neg_block(100_000, 8, slots, 1 << 20, 3, floor=2) == 3 and pick_neg_block(100_000, 8, slots, 1 << 20, 2, floor=2) == 2 and pick_neg_block(100_000, 4, slots, 1 << 20, floor=16) == 4
+    assert pick_neg_block(100_000, 16, slots, 262_144, floor=7) >= 7 and pick_neg_block(100_000, 8, slots, floor=1) == 6
 
 
 def test_user_block_partition():
