@@ -920,6 +920,31 @@ def test_fit_runs_twice_with_different_csrs(ml100k):
         assert dense[un, inn].all() and not dense[un, jn].any()
 
 
+def test_item_block_floor_is_a_hyper_parameter():
+    """hparams['neg_block_min'] (round 6): the smallest item block of the stratified negatives the engine may pick -- larger blocks mix
+    the negatives of more positive items (profiles/r06_sampler_quality.txt).  Default: blocks of 3 from ten triplets per item on; the
+    floor raises it up to hparams['neg_block']; every sampled negative still is a true negative of its user"""
+    import scipy.sparse as sp
+    import recsys_pytorch_amd as pkg
+    rng = np.random.default_rng(5)
+    U, I = 6000, 300
+    dense = rng.random((U, I)) < 0.03
+    dense[np.arange(U), rng.integers(0, I, U)] = True
+    mat = sp.csr_matrix(dense.astype(np.float32))
+    ds = pkg.InteractionData(mat)
+    cfg = types.SimpleNamespace(batch_size=U, num_epochs=2, verbose=0, test_from=1, test_step=1)      # 20 triplets per item
+    for extra, want in (({}, 3), ({"neg_block_min": 6}, 6), ({"neg_block_min": 12}, 8), ({"neg_block": 2}, 2), ({"neg_block": 16, "neg_block_min": 16}, 16)):
+        m = pkg.MF(ds, dict(HP, hidden_dim=32, lr=0.5, **extra), "cuda")
+        Q0 = m._Q.clone()
+        m.fit(ds, cfg)
+        eng = m._engine
+        assert eng.neg_block == want, (extra, eng.neg_block)
+        assert float((m._Q - Q0).abs().max()) > 0
+        u, i, j = eng.sample(eng._csr[0], eng._csr[1], U)
+        un, inn, jn = u.cpu().numpy(), i.cpu().numpy(), j.cpu().numpy()
+        assert dense[un, inn].all() and not dense[un, jn].any() and len(np.unique(un)) == U
+
+
 def test_fit_with_and_without_popular_row_replicas_trains_the_same_model():
     """MF.fit engages the replicas of the most popular items' gradient rows (hparams['hot_items'], default 256): the same
     triplets, the same sums in another order -- the tables after two epochs agree with a fit without replicas to 1e-5 of the
