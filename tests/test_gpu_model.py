@@ -920,6 +920,46 @@ def test_fit_runs_twice_with_different_csrs(ml100k):
         assert dense[un, inn].all() and not dense[un, jn].any()
 
 
+def test_whole_epoch_batches_keep_the_sampler_ahead(monkeypatch):
+    """MF.fit with batch = users (one step per epoch: the headline shape as a user runs it): the loop does not seek a trainer that already
+    is where the next epoch starts -- a seek drops the batches sampled ahead -- and trains the same model as the loop that seeks every
+    epoch (the sampler is a function of (seed, step, position): data/generators.py:206-224 is the epoch it mirrors)"""
+    import scipy.sparse as sp
+    import recsys_pytorch_amd as pkg
+    from recsys_pytorch_amd import rsx
+    rng = np.random.default_rng(9)
+    U, I = 5000, 400
+    dense = rng.random((U, I)) < 0.03
+    dense[np.arange(U), rng.integers(0, I, U)] = True
+    ds = pkg.InteractionData(sp.csr_matrix(dense.astype(np.float32)))
+
+    class NeverEqual(tuple):          # the trainer's true state, which the loop's comparison nevertheless finds "elsewhere": the old loop
+        __eq__ = lambda self, other: False
+        __ne__ = lambda self, other: True
+        __hash__ = tuple.__hash__
+    seeks = []
+    real_seek, real_state = rsx.BPRTrainer.seek, rsx.BPRTrainer.state
+    monkeypatch.setattr(rsx.BPRTrainer, "seek", lambda self, step, pos: (seeks.append((step, pos)), real_seek(self, step, pos))[1])
+    tables = []
+    for always_seek, batch in ((False, U), (True, U), (False, 1800), (True, 1800)):      # one step per epoch; two full batches and a short one
+        monkeypatch.setattr(rsx.BPRTrainer, "state", (lambda self: NeverEqual(real_state(self))) if always_seek else real_state)
+        del seeks[:]
+        torch.manual_seed(21)
+        m = pkg.MF(ds, dict(HP, hidden_dim=32, lr=0.05 * batch, seed=5), "cuda")
+        P0, Q0 = m._P.clone(), m._Q.clone()
+        m.fit(ds, types.SimpleNamespace(batch_size=batch, num_epochs=6, verbose=0, test_from=1, test_step=1))
+        spe = -(-U // batch)
+        assert seeks == ([(e * spe, e * U) for e in range(6)] if always_seek else []), (always_seek, batch, seeks)
+        assert (m._engine.step_count, m._engine.epoch_pos) == (6 * spe, 6 * U)
+        tables.append((m._P.clone(), m._Q.clone(), P0, Q0))
+    for a, b in ((0, 1), (2, 3)):
+        (Pa, Qa, P0, Q0), (Pb, Qb, P0b, Q0b) = tables[a], tables[b]
+        assert torch.equal(P0, P0b) and torch.equal(Q0, Q0b)
+        for x, y, z in ((Pa, Pb, P0), (Qa, Qb, Q0)):
+            upd = float((x - z).abs().max())
+            assert upd > 1e-3 and float((x - y).abs().max()) <= 2e-5 * upd, (a, upd, float((x - y).abs().max()))
+
+
 def test_item_block_floor_is_a_hyper_parameter():
     """hparams['neg_block_min'] (round 6): the smallest item block of the stratified negatives the engine may pick -- larger blocks mix
     the negatives of more positive items (profiles/r06_sampler_quality.txt).  Default: blocks of 3 from ten triplets per item on; the

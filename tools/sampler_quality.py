@@ -17,6 +17,7 @@ import argparse
 import json
 import os
 import sys
+import time
 import types
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -46,13 +47,22 @@ def planted(U, I, k_true, n_pos, n_held, seed, dev="cuda"):
 
 
 class Recorder:
-    """an evaluator that keeps every score dictionary it returned"""
+    """an evaluator that keeps every score dictionary it returned, and the seconds of TRAINING in front of it (wall clock since
+    start() minus the time spent inside evaluate)"""
     def __init__(self, ev):
-        self.ev, self.hist = ev, []
+        self.ev, self.hist, self.t0, self.eval_s = ev, [], None, 0.0
+
+    def start(self):
+        torch.cuda.synchronize()
+        self.t0, self.eval_s = time.perf_counter(), 0.0
 
     def evaluate(self, model):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
         s = self.ev.evaluate(model)
-        self.hist.append({k: float(v) for k, v in s.items()})
+        torch.cuda.synchronize()
+        self.eval_s += time.perf_counter() - t
+        self.hist.append({**{k: float(v) for k, v in s.items()}, "train_s": time.perf_counter() - self.t0 - self.eval_s})
         return s
 
 
@@ -61,6 +71,7 @@ def main():
     ap.add_argument("--users", type=int, default=100_000)
     ap.add_argument("--items", type=int, default=5_000)
     ap.add_argument("--dim", type=int, default=32)
+    ap.add_argument("--rank", type=int, default=16, help="rank of the planted factors")
     ap.add_argument("--seeds", type=int, default=6)
     ap.add_argument("--epochs", type=int, default=150)
     ap.add_argument("--every", type=int, default=50)
@@ -70,7 +81,7 @@ def main():
     ap.add_argument("--force-block", type=int, default=0, help="the item block c itself instead of the engine's choice: hparams neg_block = neg_block_min = c")
     a = ap.parse_args()
     U, I = a.users, a.items
-    tr, held = planted(U, I, 16, 20, 5, seed=42)
+    tr, held = planted(U, I, a.rank, 20, 5, seed=42)
     ds = pkg.InteractionData(tr, held, held)
     ev = pkg.Evaluator(ds.valid_input, ds.valid_target, "holdout", [10])
     cfg = types.SimpleNamespace(batch_size=U, num_epochs=a.epochs, verbose=0, test_from=a.every, test_step=a.every)
@@ -88,6 +99,7 @@ def main():
             rec = Recorder(ev)
             if seed == 1 and "untrained" not in res:
                 res["untrained"] = {k: float(v) for k, v in ev.evaluate(m).items()}
+            rec.start()
             m.fit(ds, cfg, evaluator=rec)
             eng = m._engine
             assert not (a.force_block and arm != "iid") or eng.neg_block == a.force_block, (eng.neg_block, a.force_block)
@@ -107,6 +119,9 @@ def main():
                 v = np.array([res[(arm, s)][t][mt] for s in range(1, a.seeds + 1)])
                 cols.append(f"{v.mean():.4f} +- {v.std(ddof=1) if len(v) > 1 else 0.0:.4f}")
             print(f"#   {arm:8s} " + "   ".join(cols))
+    print(f"# seconds of training (evaluation excluded; includes the fit's set-up: sampler tables, trainer) in front of each evaluation, mean over the seeds")
+    for arm in a.arms.split(","):
+        print(f"#   {arm:8s} " + "   ".join(f"{np.mean([res[(arm, s)][t]['train_s'] for s in range(1, a.seeds + 1)]):8.3f}" for t in range(len(res[(arm, 1)]))))
 
 
 if __name__ == "__main__":
