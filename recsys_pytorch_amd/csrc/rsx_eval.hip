@@ -4,11 +4,34 @@
 // (Prec / Recall / NDCG @K per user, float accumulators, result layout
 // [user][metric*K_len + k]).  Own implementation: the truth row is sorted once
 // and probed by binary search instead of building a std::set per user.
+// The users are independent, so the loop is cut into contiguous ranges over host threads (round 6: at a million users the one-thread
+// loop was a third of an evaluation -- 310 ms beside 250 ms of scoring on the device); every user's numbers are what one thread computes.
 #include <algorithm>
 #include <cmath>
+#include <thread>
 #include <vector>
 
 #include "rsx_common.h"
+
+namespace {
+// body(first user, one past the last) over [0, n) on up to 64 host threads, 4096 users per thread at least
+template <typename F>
+void over_users(int64_t n, F body)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    int64_t T = std::min<int64_t>(std::min<int64_t>(hw ? hw : 1, 64), n / 4096);
+    if (T <= 1) { body((int64_t)0, n); return; }
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)T - 1);
+    const int64_t per = (n + T - 1) / T;
+    for (int64_t k = 1; k < T; ++k) {
+        const int64_t lo = std::min(n, k * per), hi = std::min(n, lo + per);
+        if (lo < hi) pool.emplace_back([=] { body(lo, hi); });
+    }
+    body((int64_t)0, std::min(n, per));
+    for (auto &th : pool) th.join();
+}
+}  // namespace
 
 RSX_API int rsx_eval_holdout(int64_t users_num, const int32_t *rankings, int max_k,
                              const int32_t *Ks, int K_len, const int64_t *truth_indptr,
@@ -19,8 +42,9 @@ RSX_API int rsx_eval_holdout(int64_t users_num, const int32_t *rankings, int max
     for (int q = 0; q < K_len; ++q) RSX_CHECK_ARG(Ks[q] >= 1 && Ks[q] <= max_k, "K outside [1, max_k]");
     std::vector<float> discount(max_k);
     for (int p = 0; p < max_k; ++p) discount[p] = (float)(1.0 / std::log2((double)p + 2.0));
+    over_users(users_num, [&](int64_t first, int64_t last) {
     std::vector<int32_t> truth;
-    for (int64_t uid = 0; uid < users_num; ++uid) {
+    for (int64_t uid = first; uid < last; ++uid) {
         const int32_t *rk = rankings + uid * max_k;
         const int64_t lo = truth_indptr[uid], hi = truth_indptr[uid + 1];
         const int truth_len = (int)(hi - lo);
@@ -40,6 +64,7 @@ RSX_API int rsx_eval_holdout(int64_t users_num, const int32_t *rankings, int max
             }
         }
     }
+    });
     return RSX_OK;
 }
 
@@ -49,7 +74,8 @@ RSX_API int rsx_eval_loo(int64_t users_num, const int32_t *rankings, int max_k, 
     RSX_CHECK_ARG(rankings && Ks && truth && results, "null pointer");
     RSX_CHECK_ARG(users_num >= 0 && max_k > 0 && K_len > 0, "bad shape");
     for (int q = 0; q < K_len; ++q) RSX_CHECK_ARG(Ks[q] >= 1 && Ks[q] <= max_k, "K outside [1, max_k]");
-    for (int64_t uid = 0; uid < users_num; ++uid) {
+    over_users(users_num, [&](int64_t first, int64_t last) {
+    for (int64_t uid = first; uid < last; ++uid) {
         const int32_t *rk = rankings + uid * max_k;
         int hit_at = max_k + 1;                                   // 1-based position of the held-out item
         for (int p = 0; p < max_k; ++p)
@@ -62,5 +88,6 @@ RSX_API int rsx_eval_loo(int64_t users_num, const int32_t *rankings, int max_k, 
             res[K_len + q] = hit ? gain : 0.0f;
         }
     }
+    });
     return RSX_OK;
 }

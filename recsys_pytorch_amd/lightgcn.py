@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from .data import csr_to_device
-from .mf import BaseModel, _get, _pad_dim, end_of_epoch
+from .mf import BaseModel, _get, _pad_dim, device_mask, end_of_epoch
 
 
 def normalized_adjacency(train_csr):
@@ -221,14 +221,15 @@ class LightGCN(BaseModel):
     def predict_topk(self, eval_users, eval_pos, K, test_batch_size=1024, want_values=False):
         self.update_lightgcn_embedding()
         eval_users = np.asarray(eval_users)
-        mask = csr_to_device(eval_pos, self.device) if eval_pos is not None else None
+        mask = device_mask(self, eval_pos)
         U = self.num_users
         out = []
         # large catalogs take the fused path, which wants many 8 192-row passes per call (like MF.predict_topk)
         chunk = max(int(test_batch_size), 65536) if self.num_items >= 32768 else int(test_batch_size)
         ws = None
+        users_dev = self._idx(eval_users)           # once (mf.py: predict_topk)
         for s in range(0, len(eval_users), chunk):
-            users = self._idx(eval_users[s:s + chunk])
+            users = users_dev[s:s + chunk]
             if ws is None and hasattr(self._k, "lib"):
                 need = self._k.lib().rsx_score_topk_workspace_d(users.numel(), self.num_items, self._dpad)
                 ws = torch.empty(max(need, 4) // 4 + 64, dtype=torch.float32, device=self.device)

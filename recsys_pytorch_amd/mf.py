@@ -78,6 +78,21 @@ def end_of_epoch(model, epoch, epoch_summary, scores, evaluator, early_stop, log
     return scores, stop
 
 
+def device_mask(model, eval_pos):
+    """the seen-items matrix of an evaluation on the device.  An Evaluator hands in the SAME matrix at every evaluation
+    (evaluation/evaluator.py:16-17 keeps eval_input): the device copy of the last one is kept on the model -- by identity of the object,
+    its shape and its number of entries -- instead of 40 ms of slicing, sorting and uploading 20 M entries per evaluation at a million users"""
+    if eval_pos is None:
+        return None
+    c = getattr(model, "_mask_cache", None)
+    key = (tuple(eval_pos.shape), int(getattr(eval_pos, "nnz", -1)))
+    if c is not None and c[0] is eval_pos and c[1] == key:
+        return c[2]
+    mask = csr_to_device(eval_pos, model.device)
+    model._mask_cache = (eval_pos, key, mask)
+    return mask
+
+
 def _pad_dim(d):
     """the kernels are instantiated for rows of 32, 64, 128 and 256 floats; any other hidden_dim (the reference takes any,
     models/MF.py:19,23-24; conf/MF.yaml ships 50) is stored with zero columns behind it, which provably stay zero"""
@@ -325,14 +340,17 @@ class MF(BaseModel):
     # -- the large-catalog twin: only [n x K] indices leave the device -----------------------------
     def predict_topk(self, eval_users, eval_pos, K, test_batch_size=1024, want_values=False):
         eval_users = np.asarray(eval_users)
-        mask = csr_to_device(eval_pos, self.device) if eval_pos is not None else None
+        mask = device_mask(self, eval_pos)
         out_i, out_v = [], []
         # large catalogs take the fused path, which wants many 8 192-row passes per call (two are in
         # flight at a time); small ones score a dense [test_batch_size x I] tile like the reference
         chunk = max(int(test_batch_size), 65536) if self.num_items >= 32768 else int(test_batch_size)
         ws = None
+        # (the user ids go to the device ONCE: a pageable host-to-device copy per pass -- 512 KB out of the middle of a numpy array --
+        #  stalled every third scoring call of a million-user evaluation by 45 ms, tools/eval_time.py)
+        users_dev = self._idx(eval_users)
         for s in range(0, len(eval_users), chunk):
-            users = self._idx(eval_users[s:s + chunk])
+            users = users_dev[s:s + chunk]
             if ws is None:
                 need = self._k.lib().rsx_score_topk_workspace_d(users.numel(), self.num_items, self._dpad) if hasattr(self._k, "lib") else 0
                 ws = torch.empty(max(need, 4) // 4 + 64, dtype=torch.float32, device=self.device)

@@ -960,6 +960,39 @@ def test_whole_epoch_batches_keep_the_sampler_ahead(monkeypatch):
             assert upd > 1e-3 and float((x - y).abs().max()) <= 2e-5 * upd, (a, upd, float((x - y).abs().max()))
 
 
+def test_evaluation_mask_is_uploaded_once_per_matrix(monkeypatch):
+    """predict_topk keeps the device copy of the seen-items matrix of the last evaluation (evaluation/evaluator.py:16-17 hands in the same
+    eval_input every time): one upload for repeated evaluations, a new one for ANOTHER matrix -- also one of the same shape and size --
+    and the same top-k as the dense predict + the oracle's argsort either way"""
+    import scipy.sparse as sp
+    import recsys_pytorch_amd as pkg
+    import recsys_pytorch_amd.mf as mf_mod
+    rng = np.random.default_rng(31)
+    U, I = 3000, 700
+    mk = lambda: sp.csr_matrix((rng.random((U, I)) < 0.02).astype(np.float32))
+    A, B = mk(), mk()
+    B = B[:, :].copy()
+    m = pkg.MF(pkg.InteractionData(A), dict(HP, hidden_dim=32), "cuda")
+    uploads = []
+    real = mf_mod.csr_to_device
+    monkeypatch.setattr(mf_mod, "csr_to_device", lambda mat, dev, *a, **k: (uploads.append(id(mat)), real(mat, dev, *a, **k))[1])
+    users = np.arange(U)
+    t1 = m.predict_topk(users, A, 10); t2 = m.predict_topk(users, A, 10)
+    assert len(uploads) == 1 and np.array_equal(t1, t2)
+    t3 = m.predict_topk(users, B, 10)
+    assert len(uploads) == 2
+    C2 = A.copy()                                        # same shape, same entries, another object: not served from the cache
+    t4 = m.predict_topk(users, C2, 10)
+    assert len(uploads) == 3 and np.array_equal(t4, t1)
+    for top, mat in ((t1, A), (t3, B)):
+        dense = m.predict(users, mat, 1024)
+        want = np.argsort(-dense, axis=1, kind="stable")[:, :10]
+        agree = np.mean([len(set(a) & set(b)) == 10 for a, b in zip(top, want)])
+        assert agree > 0.999, agree
+        seen = np.asarray(mat.todense()) > 0
+        assert not seen[np.arange(U)[:, None], top].any()                    # nothing seen is recommended
+
+
 def test_item_block_floor_is_a_hyper_parameter():
     """hparams['neg_block_min'] (round 6): the smallest item block of the stratified negatives the engine may pick -- larger blocks mix
     the negatives of more positive items (profiles/r06_sampler_quality.txt).  Default: blocks of 3 from ten triplets per item on; the

@@ -82,6 +82,29 @@ def test_eval_metrics_on_random_shapes_match_reference_native(oracle_mod):
                 assert np.allclose(b, oracle_mod.loo(rk, ks, t, use_ref=True), atol=1e-6), ctx
 
 
+def test_eval_metrics_over_host_threads_equal_one_thread():
+    """rsx_eval_holdout / rsx_eval_loo cut the users into ranges over host threads from 8 192 users on (csrc/rsx_eval.hip; holdout.h:20-103
+    and loo.h:19-85 are per-user loops): every user's numbers are the ones a single thread computes -- compared with the same call over
+    slices below the threshold, bit for bit, at sizes that leave a ragged last range"""
+    from recsys_pytorch_amd import rsx
+    rng = np.random.default_rng(77)
+    for n in (8_191, 8_192, 50_001, 131_072 + 5):
+        K = 20
+        rk = rng.integers(0, 500, (n, K)).astype(np.int32)
+        deg = rng.integers(0, 9, n)
+        deg[rng.integers(0, n, 50)] = 0                                       # users without targets stay in the call (evaluator.py skips them in the mean)
+        ip = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+        ix = rng.integers(0, 500, int(ip[-1])).astype(np.int32)
+        whole = rsx.eval_holdout(rk, [1, 5, 20], ip, ix)
+        parts = np.concatenate([rsx.eval_holdout(rk[s:s + 3000], [1, 5, 20], ip[s:s + 3001] - ip[s], ix[ip[s]:ip[min(s + 3000, n)]]) for s in range(0, n, 3000)])
+        has = deg > 0
+        assert whole.shape == (n, 9) and np.array_equal(whole[has], parts[has])
+        truth = rng.integers(0, 500, n).astype(np.int32)
+        whole = rsx.eval_loo(rk, [1, 5, 20], truth)
+        parts = np.concatenate([rsx.eval_loo(rk[s:s + 3000], [1, 5, 20], truth[s:s + 3000]) for s in range(0, n, 3000)])
+        assert np.array_equal(whole, parts)
+
+
 def test_eval_holdout_rejects_bad_k():
     from recsys_pytorch_amd import rsx
     with pytest.raises(rsx.RsxError):
