@@ -78,18 +78,20 @@ def end_of_epoch(model, epoch, epoch_summary, scores, evaluator, early_stop, log
     return scores, stop
 
 
-def device_mask(model, eval_pos):
+def device_mask(model, eval_pos, slot="_mask_cache"):
     """the seen-items matrix of an evaluation on the device.  An Evaluator hands in the SAME matrix at every evaluation
     (evaluation/evaluator.py:16-17 keeps eval_input): the device copy of the last one is kept on the model -- by identity of the object,
-    its shape and its number of entries -- instead of 40 ms of slicing, sorting and uploading 20 M entries per evaluation at a million users"""
+    its shape and its number of entries -- instead of 40 ms of slicing, sorting and uploading 20 M entries per evaluation at a million users.
+    slot = "_train_cache": the same for the train matrix of `fit` (a caller's own loop of one-epoch fits hands in the same matrix every
+    time; the SAME device tensors also let the engine keep its sampler tables, which it files under their identity)"""
     if eval_pos is None:
         return None
-    c = getattr(model, "_mask_cache", None)
+    c = getattr(model, slot, None)
     key = (tuple(eval_pos.shape), int(getattr(eval_pos, "nnz", -1)))
     if c is not None and c[0] is eval_pos and c[1] == key:
         return c[2]
     mask = csr_to_device(eval_pos, model.device)
-    model._mask_cache = (eval_pos, key, mask)
+    setattr(model, slot, (eval_pos, key, mask))
     return mask
 
 
@@ -202,7 +204,7 @@ class MF(BaseModel):
     # -- models/MF.py:44-97 ----------------------------------------------------------------
     def fit(self, dataset, exp_config, evaluator=None, early_stop=None, loggers=None):
         train_matrix = dataset.train_data
-        indptr, indices = csr_to_device(train_matrix, self.device)
+        indptr, indices = device_mask(self, train_matrix, "_train_cache")
         batch_size = int(_get(exp_config, "batch_size"))
         num_epochs = int(_get(exp_config, "num_epochs"))
         verbose = _get(exp_config, "verbose", 0)
@@ -218,8 +220,11 @@ class MF(BaseModel):
         if self.optimizer_name == "sgd":     # on-chip gradient summation when batch >= 2 * items
             nb = self._engine.set_neg_block(batch_size if self.neg_block > 0 else 0, max(self.neg_block, 1), self.neg_block_min)
             if self.hot_items > 0 and hasattr(self._k, "HotItems"):
-                self._engine.set_hot_items(torch.bincount(indices.long(), minlength=self.num_items),
-                                           min(self.hot_items, self.num_items))
+                hot_for = getattr(self, "_hot_for", None)           # (the same matrix, the same kernel family: the replica tables of the last fit stand)
+                if not (hot_for is not None and hot_for[0] is indices and hot_for[1] == bool(nb) and self._engine.hot is not None):
+                    self._engine.set_hot_items(torch.bincount(indices.long(), minlength=self.num_items),
+                                               min(self.hot_items, self.num_items))
+                    self._hot_for = (indices, bool(nb))
             self._engine.set_chunks(self.chunks if nb else 0)
         scores = None
         # SGD on the HIP library: the batch loop itself is native (include/rsx.h: rsx_bpr_trainer_run),

@@ -991,6 +991,22 @@ def test_evaluation_mask_is_uploaded_once_per_matrix(monkeypatch):
         assert agree > 0.999, agree
         seen = np.asarray(mat.todense()) > 0
         assert not seen[np.arange(U)[:, None], top].any()                    # nothing seen is recommended
+    # the train matrix of fit likewise: a caller's own loop of one-epoch fits uploads it once (and the engine keeps its sampler tables)
+    del uploads[:]
+    dsA, dsB = pkg.InteractionData(A), pkg.InteractionData(B)
+    cfg = types.SimpleNamespace(batch_size=U, num_epochs=1, verbose=0, test_from=1, test_step=1)
+    for _ in range(3):
+        m.fit(dsA, cfg)
+    assert len(uploads) == 1 and m._engine.step_count == 3
+    csr_a = m._engine._csr
+    m.fit(dsB, cfg)
+    assert len(uploads) == 2 and m._engine._csr is not csr_a
+    u, i, j = m._engine.sample(m._engine._csr[0], m._engine._csr[1], U)
+    seenB = np.asarray(B.todense()) > 0
+    ok = np.diff(B.indptr) > 0
+    un, inn, jn = u.cpu().numpy(), i.cpu().numpy(), j.cpu().numpy()
+    live = inn >= 0
+    assert seenB[un[live], inn[live]].all() and not seenB[un[live], jn[live]].any() and live.sum() == ok.sum()    # THIS fit's matrix
 
 
 def test_item_block_floor_is_a_hyper_parameter():
