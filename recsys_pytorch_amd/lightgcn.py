@@ -184,17 +184,17 @@ class LightGCN(BaseModel):
         scores = None
         for epoch in range(1, num_epochs + 1):
             self.train()
-            epoch_loss = 0.0
+            epoch_loss = torch.zeros((), dtype=torch.float32, device=self.device)
             sampler.epoch_pos = (epoch - 1) * n_data
             for b in range(num_batches):
                 bsz = min(batch_size, n_data - b * batch_size)
                 u, i, j = sampler.sample(indptr, indices, bsz)
                 sampler.step_count += 1
-                batch_loss = float(self.train_step(u, i, j))
+                batch_loss = self.train_step(u, i, j)          # (stays on the device: read back for the progress line and the loggers only)
                 epoch_loss += batch_loss
                 if verbose and b % 50 == 0:
-                    print('(%3d / %3d) loss = %.4f' % (b, num_batches, batch_loss))
-            scores, stop = end_of_epoch(self, epoch, {'loss': epoch_loss}, scores, evaluator, early_stop,
+                    print('(%3d / %3d) loss = %.4f' % (b, num_batches, float(batch_loss)))
+            scores, stop = end_of_epoch(self, epoch, {'loss': float(epoch_loss)} if loggers is not None else {}, scores, evaluator, early_stop,
                                         loggers, test_from, test_step)
             if stop:
                 break
