@@ -88,6 +88,9 @@ def device_mask(model, eval_pos, slot="_mask_cache"):
         return None
     c = getattr(model, slot, None)
     key = (tuple(eval_pos.shape), int(getattr(eval_pos, "nnz", -1)))
+    if hasattr(eval_pos, "indices") and hasattr(eval_pos, "indptr"):      # ... and a strided sample of its arrays: an edit in place re-uploads
+        ix, ip = eval_pos.indices, eval_pos.indptr
+        key += (int(ix[::max(1, len(ix) // 4096)].astype(np.int64).sum()), int(ip[::max(1, len(ip) // 4096)].astype(np.int64).sum()))
     if c is not None and c[0] is eval_pos and c[1] == key:
         return c[2]
     mask = csr_to_device(eval_pos, model.device)
