@@ -29,6 +29,9 @@ echo "## 6 seeds, 150 steps (the first run)"; grep "^#" $O/sampler_quality.txt
 for n in long lr05 lr02 lr02_16 d128 big; do echo "## sweep: $n"; grep "^#" $O/sq_$n.txt; done
 for c in 2 3 4 6 8 16; do echo "## item block forced to $c (1000 steps, 8 seeds, 0.1 per triplet)"; grep "^#" $O/sq_c$c.txt | tail -4; done
 echo "## independent negatives, the same 1000 steps"; grep "^#" $O/sq_iid1000.txt | tail -4
+echo "## AT THE HEADLINE SHAPE (tools/r06_quality_headline.sh: 1M users x 100K items, d = 128, batch = users, item blocks of 3, 0.05 per triplet, 3 seeds), with the clock:"
+echo "## same NDCG@10 step for step; 400 steps take 0.24 s of training blocked, 0.44 s with independent negatives -- the same quality 1.86x sooner"
+grep "^#" $O/sq_headline_lr05.txt
 echo "## headline step time against the item block, first box (RSX_NEG_BLOCK_EXACT, bench.py --no-legs)"; cat $O/block_speed.txt
 echo "## ... alternating on a second box: headline, d = 64, two item ranges"; cat $O/block_speed2.txt
 } > profiles/r06_sampler_quality.txt
