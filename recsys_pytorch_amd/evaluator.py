@@ -42,7 +42,9 @@ class Evaluator:
         num_users = self.eval_target.shape[0]
         eval_users = np.arange(num_users)                      # sparse_to_dict keys (utils/types.py:13-21)
         if hasattr(model, "predict_topk"):
-            pred = model.predict_topk(eval_users, self.eval_input, self.max_k, self.batch_size)
+            # (the package's models hand the ids back in a pinned buffer they keep -- consumed right here, before their next call)
+            kw = {"reuse_host": True} if getattr(model, "topk_reuse_host", False) else {}
+            pred = model.predict_topk(eval_users, self.eval_input, self.max_k, self.batch_size, **kw)
         else:   # any reference-style model: dense predict, top-k on the device
             import torch
             output = model.predict(eval_users, self.eval_input, self.batch_size)

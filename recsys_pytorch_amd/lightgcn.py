@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from .data import csr_to_device
-from .mf import BaseModel, _get, _pad_dim, device_mask, end_of_epoch
+from .mf import BaseModel, IdsToHost, _get, _pad_dim, device_mask, end_of_epoch
 
 
 def normalized_adjacency(train_csr):
@@ -218,12 +218,15 @@ class LightGCN(BaseModel):
             pred_matrix[batch_users] = S.cpu().numpy()
         return pred_matrix
 
-    def predict_topk(self, eval_users, eval_pos, K, test_batch_size=1024, want_values=False):
+    topk_reuse_host = True          # predict_topk takes reuse_host (evaluator.py)
+
+    def predict_topk(self, eval_users, eval_pos, K, test_batch_size=1024, want_values=False, reuse_host=False):
         self.update_lightgcn_embedding()
         eval_users = np.asarray(eval_users)
         mask = device_mask(self, eval_pos)
         U = self.num_users
         out = []
+        to_host = IdsToHost(self, len(eval_users), K) if (reuse_host and self.device.type == "cuda" and len(eval_users)) else None
         # large catalogs take the fused path, which wants many 8 192-row passes per call (like MF.predict_topk)
         chunk = max(int(test_batch_size), 65536) if self.num_items >= 32768 else int(test_batch_size)
         ws = None
@@ -234,5 +237,10 @@ class LightGCN(BaseModel):
                 need = self._k.lib().rsx_score_topk_workspace_d(users.numel(), self.num_items, self._dpad)
                 ws = torch.empty(max(need, 4) // 4 + 64, dtype=torch.float32, device=self.device)
             r = self._k.score_topk(self._out[:U], self._out[U:], users, K, mask=mask, want_values=False, ws=ws)
-            out.append(r.cpu().numpy())
+            if to_host is not None:
+                to_host.put(s, r)
+            else:
+                out.append(r.cpu().numpy())
+        if to_host is not None:
+            return to_host.done()
         return np.concatenate(out) if out else np.zeros((0, K), np.int32)

@@ -991,6 +991,21 @@ def test_evaluation_mask_is_uploaded_once_per_matrix(monkeypatch):
         assert agree > 0.999, agree
         seen = np.asarray(mat.todense()) > 0
         assert not seen[np.arange(U)[:, None], top].any()                    # nothing seen is recommended
+    # the Evaluator's way of receiving the ids (a view of a pinned buffer the model keeps, filled by copies on a side stream): the same ids;
+    # the view is only valid until the model's next such call
+    for n in (U, 1, 777):
+        a = m.predict_topk(users[:n], A, 10)
+        b = m.predict_topk(users[:n], A, 10, reuse_host=True)
+        assert b.shape == (n, 10) and b.dtype == np.int32 and np.array_equal(a, b)
+    keep = b.copy()
+    c = m.predict_topk(users[:777][::-1].copy(), A, 10, reuse_host=True)
+    assert np.array_equal(c, keep[::-1]) and np.shares_memory(b, c)
+    ev = pkg.Evaluator(A, B, "holdout", [5, 10])
+    s1 = ev.evaluate(m)
+    monkeypatch.setattr(type(m), "topk_reuse_host", False)
+    s2 = ev.evaluate(m)
+    monkeypatch.setattr(type(m), "topk_reuse_host", True)
+    assert s1 == s2 and set(s1) == {"Prec@5", "Prec@10", "Recall@5", "Recall@10", "NDCG@5", "NDCG@10"}
     # the train matrix of fit likewise: a caller's own loop of one-epoch fits uploads it once (and the engine keeps its sampler tables)
     del uploads[:]
     dsA, dsB = pkg.InteractionData(A), pkg.InteractionData(B)
