@@ -750,7 +750,9 @@ int rsx_spmm_mark_batch_rows(uint8_t *flags_dev, int64_t num_rows, const int32_t
  * the host); truth as CSR (indptr int64 [users_num+1], indices int32, any order);
  * results: float [users_num x 3*K_len], layout [user][metric*K_len + k] with metrics
  * Prec, Recall, NDCG (holdout.h:72-102).  Users with an empty truth row get NaN for
- * Recall/NDCG exactly like the reference header (0/0).                                  */
+ * Recall/NDCG exactly like the reference header (0/0).  From 8 192 users on the users are cut
+ * into contiguous ranges over up to 64 host threads (rsx_eval_loo likewise): every user's numbers
+ * are the ones one thread computes; the call returns when all ranges are done.            */
 int rsx_eval_holdout(int64_t users_num, const int32_t *rankings, int max_k, const int32_t *Ks,
                      int K_len, const int64_t *truth_indptr, const int32_t *truth_indices,
                      float *results);
