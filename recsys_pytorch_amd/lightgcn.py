@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from .data import csr_to_device
-from .mf import BaseModel, IdsToHost, _get, _pad_dim, device_mask, end_of_epoch
+from .mf import BaseModel, IdsToHost, _get, _pad_dim, device_mask, end_of_epoch, kept_for_matrix
 
 
 def normalized_adjacency(train_csr):
@@ -172,8 +172,9 @@ class LightGCN(BaseModel):
     def fit(self, dataset, exp_config, evaluator=None, early_stop=None, loggers=None):
         from .sharded import BPREngine
         train_matrix = dataset.train_data
-        self.getSparseGraph(train_matrix)
-        indptr, indices = csr_to_device(train_matrix, self.device)
+        # (the graph -- 1.9 s of host work at 1M x 100K -- and the device copy of the matrix are kept while the caller hands in the same matrix)
+        self.Graph = kept_for_matrix(self, "_graph_cache", train_matrix, lambda: self.getSparseGraph(train_matrix))
+        indptr, indices = device_mask(self, train_matrix, "_train_cache")
         batch_size = int(_get(exp_config, "batch_size"))
         num_epochs = int(_get(exp_config, "num_epochs"))
         verbose = _get(exp_config, "verbose", 0)

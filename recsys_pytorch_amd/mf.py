@@ -86,16 +86,22 @@ def device_mask(model, eval_pos, slot="_mask_cache"):
     time; the SAME device tensors also let the engine keep its sampler tables, which it files under their identity)"""
     if eval_pos is None:
         return None
+    return kept_for_matrix(model, slot, eval_pos, lambda: csr_to_device(eval_pos, model.device))
+
+
+def kept_for_matrix(model, slot, mat, make):
+    """make() once per matrix: the result is kept on the model under `slot` while the caller hands in the SAME scipy object -- identity,
+    shape, number of entries and a strided sample of its arrays are compared (an edit in place that the sample sees makes it again)"""
     c = getattr(model, slot, None)
-    key = (tuple(eval_pos.shape), int(getattr(eval_pos, "nnz", -1)))
-    if hasattr(eval_pos, "indices") and hasattr(eval_pos, "indptr"):      # ... and a strided sample of its arrays: an edit in place re-uploads
-        ix, ip = eval_pos.indices, eval_pos.indptr
+    key = (tuple(mat.shape), int(getattr(mat, "nnz", -1)))
+    if hasattr(mat, "indices") and hasattr(mat, "indptr"):
+        ix, ip = mat.indices, mat.indptr
         key += (int(ix[::max(1, len(ix) // 4096)].astype(np.int64).sum()), int(ip[::max(1, len(ip) // 4096)].astype(np.int64).sum()))
-    if c is not None and c[0] is eval_pos and c[1] == key:
+    if c is not None and c[0] is mat and c[1] == key:
         return c[2]
-    mask = csr_to_device(eval_pos, model.device)
-    setattr(model, slot, (eval_pos, key, mask))
-    return mask
+    made = make()
+    setattr(model, slot, (mat, key, made))
+    return made
 
 
 class IdsToHost:

@@ -327,6 +327,22 @@ def test_hip_lightgcn_fit_and_topk_end_to_end():
     for r in range(64):
         kth = np.sort(pred[r])[::-1][9]
         assert np.all(pred[r][top[r]] >= kth) and np.all(np.isfinite(pred[r][top[r]]))
+    # a further fit on the SAME matrix keeps the graph (models/LightGCN.py:70 builds it in every fit; 1.9 s of host work at 1M x 100K) and
+    # the device copy of the matrix; another matrix builds both again
+    built = []
+    real = m.getSparseGraph
+    m.getSparseGraph = lambda R, adjacency=None: (built.append(R.shape), real(R, adjacency))[1]
+    one = types.SimpleNamespace(batch_size=256, num_epochs=1, verbose=0, test_from=1, test_step=1)
+    g0 = m.Graph
+    m.fit(ds, one); m.fit(ds, one)
+    assert built == [] and m.Graph is g0
+    import scipy.sparse as sp
+    other = sp.csr_matrix(ds.train_data, copy=True)
+    other.data[:] = 1.0
+    other[0, :5] = 1.0
+    ds2 = pkg.InteractionData(sp.csr_matrix(other), ds.valid_target, ds.test_target)
+    m.fit(ds2, one)
+    assert built == [ds.train_data.shape] and m.Graph is not g0
 
 
 @pytest.mark.gpu
